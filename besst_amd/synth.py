@@ -1,0 +1,176 @@
+"""Seeded synthetic read-pair streams shaped like the BASELINE.json configs.
+
+Implements the generator described in SURVEY.md section 8(d) / BASELINE.md section 3:
+a genome of ``nc`` contigs (log-normal lengths, clipped to [500, 200000]) laid end
+to end with U[0,500] gaps; fragments start uniformly on the genome; a pair is kept
+only if both 100-bp reads lie fully inside contigs; PE libraries are ``fr`` with
+N(mean, sd) inserts, MP libraries are ``rf`` with an optional opposite-orientation
+(PE contamination) sub-population; mapq is 60 / 0 / U[1,59] with probability
+0.8 / 0.1 / 0.1 (same for both mates); 1 % of pairs are exact duplicates
+(adjacent after sorting); 0.1 % of contig-spanning pairs get a read1 record that is
+flagged unmapped while keeping its own placement (the BWA quirk the reference
+guards against, CreateGraph.py:141-163); every pair emits two records and the
+stream is sorted by (tid, pos) like a coordinate-sorted BAM.
+
+Everything is numpy on the host: this is test/bench scaffolding, not the product.
+"""
+import numpy as np
+
+from .records import (FLAG_MATE_REVERSE, FLAG_MATE_UNMAPPED, FLAG_PAIRED, FLAG_PROPER, FLAG_READ1,
+                      FLAG_READ2, FLAG_REVERSE, FLAG_UNMAPPED, RecordBatch)
+
+BASE_SEED = 20240929
+
+
+class Assembly(object):
+    def __init__(self, names, lengths, gaps):
+        self.names = list(names)
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.gaps = np.asarray(gaps, dtype=np.int64)
+        self.starts = np.concatenate(([0], np.cumsum(self.lengths + self.gaps)[:-1]))
+        self.total = int(self.starts[-1] + self.lengths[-1])
+
+    @property
+    def nc(self):
+        return len(self.names)
+
+
+def make_assembly(nc, median_len, seed, sigma_log=1.0, min_len=500, max_len=200000):
+    rng = np.random.default_rng(seed)
+    lengths = np.exp(rng.normal(np.log(median_len), sigma_log, nc))
+    lengths = np.clip(lengths, min_len, max_len).astype(np.int64)
+    gaps = rng.integers(0, 501, nc)
+    names = ['ctg%07d' % i for i in range(nc)]
+    return Assembly(names, lengths, gaps)
+
+
+class LibrarySpec(object):
+    def __init__(self, orientation='fr', mean=500.0, sd=50.0, contam_frac=0.0, contam_mean=350.0,
+                 contam_sd=60.0, read_len=100, dup_frac=0.01, fishy_frac=0.001, softclip_frac=0.05):
+        self.orientation = orientation
+        self.mean = mean
+        self.sd = sd
+        self.contam_frac = contam_frac
+        self.contam_mean = contam_mean
+        self.contam_sd = contam_sd
+        self.read_len = read_len
+        self.dup_frac = dup_frac
+        self.fishy_frac = fishy_frac
+        self.softclip_frac = softclip_frac
+
+
+def simulate_library(asm, spec, n_pairs, seed, chunk=4_000_000):
+    """Generate exactly ``n_pairs`` placed read pairs (2 records each) -> RecordBatch.
+
+    Candidate fragments whose reads are not both fully inside contigs are dropped and
+    replaced by further draws, so the stream holds ``n_pairs`` pairs, duplicates included.
+    """
+    rng = np.random.default_rng(seed)
+    r = spec.read_len
+    cols = {k: [] for k in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen')}
+    done = 0
+    while done < n_pairs:
+        m = min(chunk, max(1024, int((n_pairs - done) * 1.3)))
+        start = rng.integers(0, asm.total, m)
+        contam = rng.random(m) < spec.contam_frac
+        x = np.where(contam, rng.normal(spec.contam_mean, spec.contam_sd, m),
+                     rng.normal(spec.mean, spec.sd, m))
+        x = np.maximum(np.rint(x).astype(np.int64), 2 * r)
+        lpos = start                       # left read  [lpos, lpos + r)
+        rpos = start + x - r               # right read [rpos, rpos + r)
+        lt = np.searchsorted(asm.starts, lpos, side='right') - 1
+        rt = np.searchsorted(asm.starts, rpos, side='right') - 1
+        ok = (lpos + r <= asm.starts[lt] + asm.lengths[lt]) & (rpos + r <= asm.starts[rt] + asm.lengths[rt])
+        lt, rt, lpos, rpos, x, contam = lt[ok], rt[ok], lpos[ok], rpos[ok], x[ok], contam[ok]
+        k = lt.shape[0]
+        lp = (lpos - asm.starts[lt]).astype(np.int64)
+        rp = (rpos - asm.starts[rt]).astype(np.int64)
+        # innie: left forward / right reverse; outie: left reverse / right forward
+        innie = (spec.orientation == 'fr') ^ contam
+        l_rev = ~innie
+        r_rev = innie
+        first_is_left = rng.random(k) < 0.5
+        u = rng.random(k)
+        mapq = np.where(u < 0.8, 60, np.where(u < 0.9, 0, rng.integers(1, 60, k))).astype(np.int64)
+        same = lt == rt
+        tl = np.where(same, x, 0)
+        ql = np.full(k, r, dtype=np.int64)
+        qr = np.full(k, r, dtype=np.int64)
+        sc = rng.random(k) < spec.softclip_frac
+        ql[sc] = rng.integers(r // 2, r, int(sc.sum()))
+        sc = rng.random(k) < spec.softclip_frac
+        qr[sc] = rng.integers(r // 2, r, int(sc.sum()))
+        base = FLAG_PAIRED + np.where(same, FLAG_PROPER, 0)
+        fl = base + np.where(l_rev, FLAG_REVERSE, 0) + np.where(r_rev, FLAG_MATE_REVERSE, 0) \
+            + np.where(first_is_left, FLAG_READ1, FLAG_READ2)
+        fr_ = base + np.where(r_rev, FLAG_REVERSE, 0) + np.where(l_rev, FLAG_MATE_REVERSE, 0) \
+            + np.where(first_is_left, FLAG_READ2, FLAG_READ1)
+        # BWA quirk: read1 flagged unmapped but keeping its placement, on contig-spanning pairs
+        fishy = (~same) & (rng.random(k) < spec.fishy_frac * 20)
+        l_is_r1 = first_is_left
+        fl = np.where(fishy & l_is_r1, fl | FLAG_UNMAPPED, fl)
+        fr_ = np.where(fishy & ~l_is_r1, fr_ | FLAG_UNMAPPED, fr_)
+        fl = np.where(fishy & ~l_is_r1, fl | FLAG_MATE_UNMAPPED, fl)
+        fr_ = np.where(fishy & l_is_r1, fr_ | FLAG_MATE_UNMAPPED, fr_)
+        # exact duplicates: repeat a subset of pairs verbatim
+        base_n = min(k, int(np.ceil((n_pairs - done) / (1.0 + spec.dup_frac))))
+        dup = np.nonzero(rng.random(base_n) < spec.dup_frac)[0]
+        sel = np.concatenate((np.arange(base_n), dup))[:n_pairs - done]
+        done += sel.shape[0]
+        for name, left, right in (('tid', lt, rt), ('mtid', rt, lt), ('pos', lp, rp), ('mpos', rp, lp),
+                                  ('tlen', tl, -tl), ('flag', fl, fr_), ('mapq', mapq, mapq),
+                                  ('qlen', ql, qr)):
+            cols[name].append(np.concatenate((left[sel], right[sel])))
+    cat = {name: np.concatenate(parts) for name, parts in cols.items()}
+    order = np.argsort((cat['tid'].astype(np.int64) << 32) | cat['pos'].astype(np.int64), kind='stable')
+    cat = {name: v[order] for name, v in cat.items()}
+    n = cat['tid'].shape[0]
+    return RecordBatch(asm.names, asm.lengths.tolist(), rlen=np.full(n, r, dtype=np.int32),
+                       alen=cat['qlen'].astype(np.int32), **cat)
+
+
+def chain_scaffolds(asm, seed, max_run=5, first_scaffold_id=1):
+    """Contig table as left by a previous pass (MakeScaffolds.py:362-414): random runs of 1..max_run
+    adjacent contigs chained into scaffolds with random per-contig direction, cumulative position
+    (+ true gap) and scaffold length.  Returns dict of int arrays indexed by tid."""
+    rng = np.random.default_rng(seed)
+    nc = asm.nc
+    scaf_id = np.zeros(nc, dtype=np.int64)
+    position = np.zeros(nc, dtype=np.int64)
+    direction = rng.random(nc) < 0.5
+    scaf_len = np.zeros(nc, dtype=np.int64)
+    i = 0
+    sid = first_scaffold_id
+    while i < nc:
+        run = int(rng.integers(1, max_run + 1))
+        j = min(nc, i + run)
+        cur = 0
+        for c in range(i, j):
+            position[c] = cur
+            cur += int(asm.lengths[c])
+            if c + 1 < j:
+                cur += int(asm.gaps[c])
+        scaf_id[i:j] = sid
+        scaf_len[i:j] = cur
+        sid += 1
+        i = j
+    return dict(scaf_id=scaf_id, scaf_len=scaf_len, position=position, direction=direction,
+                next_scaffold_id=sid)
+
+
+# (contigs, median contig length, candidate pairs, [library specs]) per BASELINE.json config
+CONFIGS = {
+    'C1': dict(nc=1836, median=1000, pairs=1_000_000, libs=[LibrarySpec('fr', 4000.0, 500.0)]),
+    'C2': dict(nc=10_000, median=4000, pairs=10_000_000, libs=[LibrarySpec('fr', 500.0, 50.0)]),
+    'C3': dict(nc=100_000, median=8000, pairs=200_000_000,
+               libs=[LibrarySpec('rf', 5000.0, 500.0, contam_frac=0.22)]),
+    'C4': dict(nc=500_000, median=8000, pairs=1_000_000_000,
+               libs=[LibrarySpec('fr', 500.0, 50.0), LibrarySpec('rf', 5000.0, 500.0, contam_frac=0.22)]),
+    'C5': dict(nc=2_000_000, median=8000, pairs=4_000_000_000,
+               libs=[LibrarySpec('fr', 500.0, 50.0), LibrarySpec('rf', 5000.0, 500.0, contam_frac=0.22),
+                     LibrarySpec('rf', 10000.0, 1000.0, contam_frac=0.2)]),
+}
+
+
+def config_seed(name):
+    return BASE_SEED + int(name[1:])

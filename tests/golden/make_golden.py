@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference modules are imported in place through tests/refharness (no reference source is
+copied).  Each scenario stores its INPUTS (record columns, header, parameters, initial object
+state) and the reference's OUTPUTS (library metrics, the raw edge tables right after the record
+loop, counters, coverage, and the final filtered/scored graphs).  `gap`/`score` values involve the
+mathstats shim (tests/refharness/stubs/mathstats -> besst_amd.mathstats_compat) and therefore pin
+plumbing only; every other number is produced by reference code alone.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from besst_amd import synth  # noqa: E402
+from besst_amd.records import RecordBatch  # noqa: E402
+from tests.refharness import driver, loader  # noqa: E402
+
+COLS = ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen', 'rlen', 'alen')
+
+
+def save_batch(name, batch):
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **{c: getattr(batch, c) for c in COLS})
+
+
+def jsonable(o):
+    if isinstance(o, dict):
+        return {str(k): jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [jsonable(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    return o
+
+
+def scenario(mods, name, stream, batch, overrides, fasta_names=None, layout=None, layout_threshold=None):
+    param = driver.make_param(mods, **overrides)
+    metrics = driver.run_get_metrics(mods, batch, param)
+    state = None
+    if layout is not None:
+        thr = layout_threshold if layout_threshold is not None else param.contig_threshold
+        state = driver.build_state(mods, layout, batch.references, batch.lengths, thr)
+        param.scaffold_indexer = int(layout['next_scaffold_id'])
+        param.tot_assembly_length = int(sum(batch.lengths))
+    fasta = list(batch.references) if fasta_names is None else list(fasta_names)
+    snap, final, _ = driver.run_pe(mods, batch, param, fasta, state)
+    doc = dict(name=name, stream=stream, references=list(batch.references), lengths=list(batch.lengths),
+               fasta_names=fasta, overrides=overrides, metrics=metrics, after_loop=snap, final=final,
+               layout=None if layout is None else {k: np.asarray(v).tolist() for k, v in layout.items()},
+               layout_threshold=layout_threshold)
+    with open(os.path.join(HERE, name + '.json'), 'w') as fh:
+        json.dump(jsonable(doc), fh)
+    print('%-14s records=%d G=%d Gp=%d counters=%s' % (
+        name, len(batch), len(final['G']), len(final['G_prime']), snap and snap['counter']))
+
+
+def edgecase_stream(asm, spec, seed):
+    """Stream with unknown tids, a zero-length header entry, a repeat and an unsampled contig."""
+    b = synth.simulate_library(asm, spec, 14000, seed)
+    rng = np.random.default_rng(seed + 1)
+    cols = {c: getattr(b, c).copy() for c in COLS}
+    n = len(b)
+    # unplaced reads (tid -1) and an out-of-range mate id
+    idx = rng.choice(n, 60, replace=False)
+    cols['tid'][idx[:30]] = -1
+    cols['mtid'][idx[30:]] = len(b.references) + 3
+    # mapq exactly at / just below the default --min_mapq 11
+    idx = rng.choice(n, 400, replace=False)
+    cols['mapq'][idx[:200]] = 10
+    cols['mapq'][idx[200:]] = 11
+    # secondary alignments and mate-unmapped flags sprinkled in
+    idx = rng.choice(n, 200, replace=False)
+    cols['flag'][idx[:100]] |= 0x100
+    cols['flag'][idx[100:]] |= 0x8
+    # a repeat: pile extra multi-mapping (mapq 0) reads on one long contig
+    big = int(np.argsort(asm.lengths)[-5])
+    extra = 4000
+    add = dict(tid=np.full(extra, big), mtid=np.full(extra, big),
+               pos=rng.integers(0, asm.lengths[big] - 100, extra), mpos=rng.integers(0, asm.lengths[big] - 100, extra),
+               tlen=np.zeros(extra, int), flag=np.full(extra, 0x1 | 0x40), mapq=np.zeros(extra, int),
+               qlen=np.full(extra, 100), rlen=np.full(extra, 100), alen=np.full(extra, 100))
+    # drop every record touching one mid-sized contig so its coverage is 0 (< -z_min)
+    quiet = int(np.argsort(asm.lengths)[len(asm.lengths) // 2])
+    keep = (cols['tid'] != quiet) & (cols['mtid'] != quiet)
+    cat = {c: np.concatenate((cols[c][keep], add[c])) for c in COLS}
+    order = np.argsort((cat['tid'].astype(np.int64) << 32) | (cat['pos'].astype(np.int64) & 0xffffffff), kind='stable')
+    cat = {c: v[order] for c, v in cat.items()}
+    refs = list(b.references) + ['zero_len_ctg']
+    lens = list(b.lengths) + [0]
+    return RecordBatch(refs, lens, **cat)
+
+
+def main():
+    mods = loader.load()
+
+    # ---- PE library, short contigs: many contig-spanning pairs --------------------------------
+    asm = synth.make_assembly(300, 1500, 101)
+    fr = synth.simulate_library(asm, synth.LibrarySpec('fr', 500.0, 50.0), 15000, 102)
+    save_batch('stream_fr', fr)
+    scenario(mods, 'fr_infer', 'stream_fr', fr, {})
+    scenario(mods, 'fr_noscore', 'stream_fr', fr, dict(no_score=True))
+    scenario(mods, 'fr_noextend', 'stream_fr', fr, dict(extend_paths=False))
+    scenario(mods, 'fr_nodup', 'stream_fr', fr, dict(detect_duplicate=False))
+    # user-given -m -s -T -k -r -e, mapq threshold 0, tight -T so that long inserts are rejected
+    scenario(mods, 'fr_given', 'stream_fr', fr,
+             dict(mean_ins_size=480.0, std_dev_ins_size=55.0, ins_size_threshold=430, contig_threshold=900,
+                  read_len=100, edgesupport=3, min_mapq=0))
+
+    # ---- MP library with PE contamination, fractional inferred read length ---------------------
+    asm2 = synth.make_assembly(250, 5000, 201)
+    rf = synth.simulate_library(asm2, synth.LibrarySpec('rf', 2500.0, 250.0, contam_frac=0.25), 16000, 202)
+    rf.rlen[:1000:7] = 99          # first-1000-records mean read length becomes fractional
+    rf.rlen[5:1000:11] = 0         # rlen == 0 falls back to alen (libmetrics.py:258-263)
+    save_batch('stream_rf', rf)
+    scenario(mods, 'rf_contam', 'stream_rf', rf, dict(orientation='rf'))
+
+    # ---- later-library state: chained scaffolds with mixed directions --------------------------
+    layout = synth.chain_scaffolds(asm2, 301, max_run=4)
+    scenario(mods, 'rf_second_lib', 'stream_rf', rf, dict(orientation='rf', first_lib=False),
+             layout=layout, layout_threshold=3000)
+    scenario(mods, 'rf_second_lib_nodup_noext', 'stream_rf', rf,
+             dict(orientation='rf', first_lib=False, detect_duplicate=False, extend_paths=False),
+             layout=layout, layout_threshold=3000)
+
+    # ---- edge cases: unknown tids, contig missing from FASTA, zero-length contig, repeat, low coverage
+    asm3 = synth.make_assembly(200, 1500, 401)
+    ec = edgecase_stream(asm3, synth.LibrarySpec('fr', 500.0, 50.0, fishy_frac=0.01), 402)
+    save_batch('stream_edge', ec)
+    fasta = [n for i, n in enumerate(ec.references) if i % 37 != 5]
+    scenario(mods, 'fr_edgecases', 'stream_edge', ec, {}, fasta_names=fasta)
+
+
+if __name__ == '__main__':
+    main()
