@@ -1,0 +1,116 @@
+"""ctypes binding of libbesst_amd.so (the C ABI declared in include/besst_amd.h).
+
+The reference reaches its one native helper the same way - ``ctypes.CDLL`` plus a
+caller-allocated result struct (BESST/diploid/wrapper_sw.py:12-24).  There is no CPU
+fallback: if the shared library is missing or no MI355X is visible, loading or context
+creation raises :class:`BesstDeviceError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbesst_amd.so')
+
+
+class BesstDeviceError(RuntimeError):
+    pass
+
+
+class LibParams(C.Structure):
+    _fields_ = [('read_len', C.c_double), ('ins_size_threshold', C.c_double), ('min_mapq', C.c_int32),
+                ('orientation', C.c_int32), ('detect_duplicate', C.c_int32), ('extend_paths', C.c_int32),
+                ('no_score', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [('count', C.c_int64), ('non_unique', C.c_int64), ('non_unique_for_scaf', C.c_int64),
+                ('nr_of_duplicates', C.c_int64), ('reads_with_too_long_insert', C.c_int64),
+                ('fishy_reads', C.c_int64), ('n_tuples', C.c_int64), ('n_reach', C.c_int64),
+                ('prev_obs1', C.c_int32), ('prev_obs2', C.c_int32)]
+
+
+class MetricsCounts(C.Structure):
+    _fields_ = [('n_isize', C.c_int64), ('n_contam', C.c_int64), ('counter_total', C.c_int64),
+                ('sample_counter', C.c_int64), ('records_scanned', C.c_int64)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    'besst_abi_version': (C.c_int, []),
+    'besst_last_error': (C.c_char_p, []),
+    'besst_device_count': (C.c_int, []),
+    'besst_ctx_create': (_P, [C.c_int]),
+    'besst_ctx_destroy': (None, [_P]),
+    'besst_ctx_set_contigs': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    'besst_ctx_set_library': (C.c_int, [_P, C.POINTER(LibParams)]),
+    'besst_ctx_clear_records': (C.c_int, [_P]),
+    'besst_ctx_push_records': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_ctx_metrics_sample': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P,
+                                           C.POINTER(MetricsCounts)]),
+    'besst_ctx_value_histogram': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
+    'besst_ctx_build_graph': (C.c_int, [_P]),
+    'besst_ctx_edge_count': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'besst_ctx_fetch_edges': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int32)]),
+    'besst_ctx_fetch_observations': (C.c_int, [_P, _P, _P]),
+    'besst_ctx_fetch_coverage': (C.c_int, [_P, _P]),
+    'besst_ctx_fetch_counters': (C.c_int, [_P, C.POINTER(Counters)]),
+    'besst_ctx_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
+                                        _P, _P, _P, _P]),
+    'besst_dev_classify_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_reduce_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_pack_contigs': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_dev_classify': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
+                                     C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t]),
+    'besst_dev_reduce': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, C.c_size_t]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libbesst_amd.so (no GPU needed for loading; needed for any compute call)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise BesstDeviceError(
+            '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(besst_amd has no CPU fallback)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.besst_abi_version() != 1:
+        raise BesstDeviceError('libbesst_amd.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().besst_last_error().decode('utf-8', 'replace')
+
+
+def check(status, what):
+    if status != 0:
+        raise BesstDeviceError('%s failed (status %d): %s' % (what, status, last_error()))
+
+
+def ptr(arr):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    if not arr.flags['C_CONTIGUOUS']:
+        raise ValueError('array must be C-contiguous')
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def as_col(arr, dtype):
+    return np.ascontiguousarray(arr, dtype=dtype)

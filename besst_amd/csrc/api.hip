@@ -1,0 +1,464 @@
+// C ABI of libbesst_amd.so: argument checking, the HBM-owning context, and the host-side float
+// finishing that must replay the reference's operation order.  See include/besst_amd.h.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace besst {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return BESST_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+            return BESST_ERR_NOMEM;
+        }
+        cap = want;
+        return BESST_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int bits_for(uint64_t v) {
+    int b = 1;
+    while ((v >> b) != 0) ++b;
+    return b;
+}
+
+}  // namespace
+
+}  // namespace besst
+
+using namespace besst;
+
+struct besst_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // contig table
+    int64_t n_contigs = 0;
+    int32_t node_bits = 1;
+    DevBuf<ContigRow> table;
+    DevBuf<int64_t> aligned;
+    // library
+    bool have_lib = false;
+    besst_lib_params lib{};
+    // resident records
+    int64_t n_records = 0;
+    DevBuf<int32_t> tid, mtid, pos, mpos, tlen;
+    DevBuf<uint16_t> flag, qlen;
+    DevBuf<uint8_t> mapq;
+    // tuple stream + edge table
+    DevBuf<uint64_t> keys, payload, row_key;
+    DevBuf<uint32_t> row_mask, row_n, row_first, row_offset;
+    DevBuf<int64_t> row_sum, row_sum_sq;
+    DevBuf<int32_t> obs_lo, obs_hi;
+    DevBuf<char> ws;
+    DevBuf<char> small;      // counters + carry + n_out + n_rows
+    bool built = false;
+    int64_t n_rows = 0, n_tuples = 0;
+    // misc scratch for metrics / scoring
+    DevBuf<uint8_t> top_mask;
+    DevBuf<int32_t> sample_a, sample_b;
+    DevBuf<char> aux;
+};
+
+namespace {
+
+struct SmallBlock {
+    besst_counters counters;
+    int32_t carry[2];
+    uint32_t n_out;
+    uint32_t n_rows;
+};
+
+int use_device(besst_ctx* c) {
+    BESST_HIP_TRY(hipSetDevice(c->device));
+    return BESST_OK;
+}
+
+template <typename T>
+int grow_copy(besst_ctx* c, DevBuf<T>& buf, int64_t have, const T* src, int64_t n) {
+    if ((size_t)(have + n) > buf.cap) {
+        DevBuf<T> bigger;
+        int rc = bigger.ensure((size_t)(have + n) * 3 / 2 + 1024);
+        if (rc) return rc;
+        if (have) BESST_HIP_TRY(hipMemcpyAsync(bigger.p, buf.p, (size_t)have * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+        buf.release();
+        buf = bigger;
+    }
+    BESST_HIP_TRY(hipMemcpyAsync(buf.p + have, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return BESST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int besst_abi_version(void) { return BESST_ABI_VERSION; }
+
+const char* besst_last_error(void) { return g_error; }
+
+int besst_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return -BESST_ERR_HIP;
+    }
+    return n;
+}
+
+besst_ctx* besst_ctx_create(int device) {
+    int n = besst_device_count();
+    if (n <= 0) {
+        if (n == 0) set_error("no HIP device visible");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return nullptr;
+    }
+    besst_ctx* c = new besst_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        set_error("could not create a stream on device %d", device);
+        delete c;
+        return nullptr;
+    }
+    if (c->small.ensure(sizeof(SmallBlock)) != BESST_OK) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void besst_ctx_destroy(besst_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->table.release(); c->aligned.release();
+    c->tid.release(); c->mtid.release(); c->pos.release(); c->mpos.release(); c->tlen.release();
+    c->flag.release(); c->qlen.release(); c->mapq.release();
+    c->keys.release(); c->payload.release(); c->row_key.release();
+    c->row_mask.release(); c->row_n.release(); c->row_first.release(); c->row_offset.release();
+    c->row_sum.release(); c->row_sum_sq.release(); c->obs_lo.release(); c->obs_hi.release();
+    c->ws.release(); c->small.release(); c->top_mask.release(); c->sample_a.release();
+    c->sample_b.release(); c->aux.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int besst_dev_pack_contigs(void* stream, int64_t n, const int32_t* scaf_id, const int32_t* scaf_len,
+                           const int32_t* ctg_pos, const int32_t* ctg_len, const uint8_t* direction,
+                           const uint8_t* cls, void* d_table) {
+    BESST_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "pack_contigs: n_contigs out of range");
+    BESST_REQUIRE(n == 0 || (scaf_id && scaf_len && ctg_pos && ctg_len && direction && cls && d_table),
+                  "pack_contigs: null pointer");
+    std::vector<ContigRow> rows((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        BESST_REQUIRE(cls[i] <= BESST_CLS_SMALL, "pack_contigs: class must be 0, 1 or 2");
+        if (cls[i] != BESST_CLS_ABSENT)
+            BESST_REQUIRE(scaf_id[i] >= 1 && (uint32_t)scaf_id[i] <= kScafIdMask,
+                          "pack_contigs: scaffold id must be in [1, 2^28)");
+        rows[(size_t)i].w0 = ((uint32_t)scaf_id[i] & kScafIdMask) | ((direction[i] ? 1u : 0u) << 28) |
+                             ((uint32_t)cls[i] << 29);
+        rows[(size_t)i].scaf_len = scaf_len[i];
+        rows[(size_t)i].ctg_pos = ctg_pos[i];
+        rows[(size_t)i].ctg_len = ctg_len[i];
+    }
+    if (n) {
+        BESST_HIP_TRY(hipMemcpyAsync(d_table, rows.data(), (size_t)n * sizeof(ContigRow), hipMemcpyHostToDevice,
+                                     static_cast<hipStream_t>(stream)));
+        BESST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // rows is a local
+    }
+    return BESST_OK;
+}
+
+int besst_ctx_set_contigs(besst_ctx* c, int64_t n, const int32_t* scaf_id, const int32_t* scaf_len,
+                          const int32_t* ctg_pos, const int32_t* ctg_len, const uint8_t* direction,
+                          const uint8_t* cls) {
+    BESST_REQUIRE(c, "null context");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = c->table.ensure((size_t)n + 1))) return rc;
+    if ((rc = c->aligned.ensure((size_t)n + 1))) return rc;
+    if ((rc = besst_dev_pack_contigs(c->stream, n, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls, c->table.p)))
+        return rc;
+    uint32_t max_id = 1;
+    for (int64_t i = 0; i < n; ++i)
+        if (cls[i] != BESST_CLS_ABSENT && (uint32_t)scaf_id[i] > max_id) max_id = (uint32_t)scaf_id[i];
+    c->node_bits = bits_for((uint64_t)max_id * 2 + 1);
+    c->n_contigs = n;
+    c->built = false;
+    return BESST_OK;
+}
+
+int besst_ctx_set_library(besst_ctx* c, const besst_lib_params* p) {
+    BESST_REQUIRE(c && p, "null pointer");
+    BESST_REQUIRE(p->orientation == 0 || p->orientation == 1, "orientation must be 0 (fr) or 1 (rf)");
+    BESST_REQUIRE(p->ins_size_threshold < 1073741824.0, "ins_size_threshold must be below 2^30");
+    BESST_REQUIRE(p->read_len == p->read_len && p->ins_size_threshold == p->ins_size_threshold, "NaN parameter");
+    c->lib = *p;
+    c->have_lib = true;
+    c->built = false;
+    return BESST_OK;
+}
+
+int besst_ctx_clear_records(besst_ctx* c) {
+    BESST_REQUIRE(c, "null context");
+    c->n_records = 0;
+    c->built = false;
+    return BESST_OK;
+}
+
+int besst_ctx_push_records(besst_ctx* c, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                           const int32_t* mpos, const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq,
+                           const uint16_t* qlen) {
+    BESST_REQUIRE(c, "null context");
+    BESST_REQUIRE(n >= 0, "negative record count");
+    if (n == 0) return BESST_OK;
+    BESST_REQUIRE(tid && mtid && pos && mpos && tlen && flag && mapq && qlen, "null column");
+    BESST_REQUIRE(c->n_records + n < ((int64_t)1 << 32), "more than 2^32-1 records in one context");
+    int rc = use_device(c);
+    if (rc) return rc;
+    const int64_t have = c->n_records;
+    if ((rc = grow_copy(c, c->tid, have, tid, n))) return rc;
+    if ((rc = grow_copy(c, c->mtid, have, mtid, n))) return rc;
+    if ((rc = grow_copy(c, c->pos, have, pos, n))) return rc;
+    if ((rc = grow_copy(c, c->mpos, have, mpos, n))) return rc;
+    if ((rc = grow_copy(c, c->tlen, have, tlen, n))) return rc;
+    if ((rc = grow_copy(c, c->flag, have, flag, n))) return rc;
+    if ((rc = grow_copy(c, c->mapq, have, mapq, n))) return rc;
+    if ((rc = grow_copy(c, c->qlen, have, qlen, n))) return rc;
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));   // caller may reuse its host buffers
+    c->n_records += n;
+    c->built = false;
+    return BESST_OK;
+}
+
+size_t besst_dev_classify_workspace_bytes(int64_t n_records) { return classify_workspace_bytes(n_records); }
+size_t besst_dev_reduce_workspace_bytes(int64_t n_tuples) { return reduce_workspace_bytes(n_tuples); }
+
+int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                       const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                       int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
+                       int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
+                       besst_counters* counters, void* workspace, size_t workspace_bytes) {
+    BESST_REQUIRE(p, "classify: null params");
+    BESST_REQUIRE(n >= 0, "classify: negative record count");
+    BESST_REQUIRE(n == 0 || (tid && mtid && pos && mpos && flag && mapq && qlen), "classify: null column");
+    BESST_REQUIRE(aligned16(tid) && aligned16(mtid) && aligned16(pos) && aligned16(mpos) && aligned16(flag) &&
+                      aligned16(mapq) && aligned16(qlen),
+                  "classify: record columns must be 16-byte aligned");
+    BESST_REQUIRE(contig_table && aligned16(contig_table), "classify: contig table null or misaligned");
+    BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
+    BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "classify: n_contigs out of range");
+    BESST_REQUIRE(node_bits >= 1 && node_bits <= 29, "classify: node_bits must be in [1, 29]");
+    BESST_REQUIRE(p->orientation == 0 || p->orientation == 1, "classify: orientation must be 0 or 1");
+    BESST_REQUIRE(p->ins_size_threshold < 1073741824.0, "classify: ins_size_threshold must be below 2^30");
+    ClassifyArgs a;
+    a.tid = tid; a.mtid = mtid; a.pos = pos; a.mpos = mpos; a.flag = flag; a.mapq = mapq; a.qlen = qlen;
+    a.table = static_cast<const ContigRow*>(contig_table);
+    a.n = n;
+    a.n_contigs = (int32_t)n_contigs;
+    a.node_bits = node_bits;
+    a.read_len = p->read_len;
+    a.ins_size_threshold = p->ins_size_threshold;
+    a.min_mapq = p->min_mapq;
+    a.rf = p->orientation;
+    a.detect_dup = p->detect_duplicate;
+    a.extend_paths = p->extend_paths;
+    a.no_score = p->no_score;
+    return launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
+                           workspace, workspace_bytes);
+}
+
+int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
+                     const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
+                     int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes) {
+    BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
+    BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
+                                    row_first && row_offset && obs_lo && obs_hi),
+                  "reduce: null buffer");
+    return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
+                              row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
+                              workspace, workspace_bytes);
+}
+
+int besst_ctx_build_graph(besst_ctx* c) {
+    BESST_REQUIRE(c, "null context");
+    if (!c->have_lib || c->n_contigs <= 0) {
+        set_error("build_graph: set_contigs and set_library must be called first");
+        return BESST_ERR_STATE;
+    }
+    int rc = use_device(c);
+    if (rc) return rc;
+    const int64_t n = c->n_records;
+    auto* sb = reinterpret_cast<SmallBlock*>(c->small.p);
+    SmallBlock init;
+    memset(&init, 0, sizeof(init));
+    init.carry[0] = -1;   // counters(0, 0, 0, 0, -1, -1, 0): CreateGraph.py:98
+    init.carry[1] = -1;
+    BESST_HIP_TRY(hipMemcpyAsync(sb, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemsetAsync(c->aligned.p, 0, (size_t)c->n_contigs * sizeof(int64_t), c->stream));
+    const size_t cap1 = (size_t)(n > 0 ? n : 1);
+    if ((rc = c->keys.ensure(cap1))) return rc;
+    if ((rc = c->payload.ensure(cap1))) return rc;
+    if ((rc = c->ws.ensure(classify_workspace_bytes(n)))) return rc;
+    besst_lib_params lp = c->lib;
+    rc = besst_dev_classify(c->stream, n, c->tid.p, c->mtid.p, c->pos.p, c->mpos.p, c->flag.p, c->mapq.p, c->qlen.p,
+                            c->n_contigs, c->table.p, &lp, c->node_bits, sb->carry, c->aligned.p, c->keys.p,
+                            c->payload.p, &sb->n_out, &sb->counters, c->ws.p, c->ws.cap);
+    if (rc) return rc;
+    SmallBlock host;
+    BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t L = host.n_out;
+    c->n_tuples = L;
+    const size_t cap2 = (size_t)(L > 0 ? L : 1);
+    if ((rc = c->row_key.ensure(cap2))) return rc;
+    if ((rc = c->row_mask.ensure(cap2))) return rc;
+    if ((rc = c->row_n.ensure(cap2))) return rc;
+    if ((rc = c->row_first.ensure(cap2))) return rc;
+    if ((rc = c->row_offset.ensure(cap2))) return rc;
+    if ((rc = c->row_sum.ensure(cap2))) return rc;
+    if ((rc = c->row_sum_sq.ensure(cap2))) return rc;
+    if ((rc = c->obs_lo.ensure(cap2))) return rc;
+    if ((rc = c->obs_hi.ensure(cap2))) return rc;
+    if ((rc = c->ws.ensure(reduce_workspace_bytes(L)))) return rc;
+    rc = besst_dev_reduce(c->stream, L, &sb->n_out, 2 * c->node_bits + 1, c->keys.p, c->payload.p, c->row_key.p,
+                          c->row_mask.p, c->row_n.p, c->row_sum.p, c->row_sum_sq.p, c->row_first.p, c->row_offset.p,
+                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap);
+    if (rc) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_rows = host.n_rows;
+    c->built = true;
+    return BESST_OK;
+}
+
+#define BESST_NEED_BUILT(c)                                                   \
+    do {                                                                      \
+        BESST_REQUIRE(c, "null context");                                     \
+        if (!(c)->built) {                                                    \
+            set_error("no edge table: call besst_ctx_build_graph first");     \
+            return BESST_ERR_STATE;                                           \
+        }                                                                     \
+    } while (0)
+
+int besst_ctx_edge_count(besst_ctx* c, int64_t* n_rows, int64_t* n_tuples) {
+    BESST_NEED_BUILT(c);
+    if (n_rows) *n_rows = c->n_rows;
+    if (n_tuples) *n_tuples = c->n_tuples;
+    return BESST_OK;
+}
+
+int besst_ctx_fetch_edges(besst_ctx* c, uint64_t* key, uint32_t* mask, uint32_t* n, int64_t* sum_obs,
+                          int64_t* sum_obs_sq, uint32_t* first_idx, uint32_t* offset, int32_t* node_bits) {
+    BESST_NEED_BUILT(c);
+    int rc = use_device(c);
+    if (rc) return rc;
+    const size_t r = (size_t)c->n_rows;
+    if (node_bits) *node_bits = c->node_bits;
+    if (r) {
+        BESST_REQUIRE(key && mask && n && sum_obs && sum_obs_sq && first_idx && offset, "fetch_edges: null buffer");
+        BESST_HIP_TRY(hipMemcpyAsync(key, c->row_key.p, r * 8, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(mask, c->row_mask.p, r * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(n, c->row_n.p, r * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(sum_obs, c->row_sum.p, r * 8, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(sum_obs_sq, c->row_sum_sq.p, r * 8, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(first_idx, c->row_first.p, r * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(offset, c->row_offset.p, r * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return BESST_OK;
+}
+
+int besst_ctx_fetch_observations(besst_ctx* c, int32_t* obs_lo, int32_t* obs_hi) {
+    BESST_NEED_BUILT(c);
+    int rc = use_device(c);
+    if (rc) return rc;
+    const size_t L = (size_t)c->n_tuples;
+    if (L) {
+        BESST_REQUIRE(obs_lo && obs_hi, "fetch_observations: null buffer");
+        BESST_HIP_TRY(hipMemcpyAsync(obs_lo, c->obs_lo.p, L * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipMemcpyAsync(obs_hi, c->obs_hi.p, L * 4, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return BESST_OK;
+}
+
+int besst_ctx_fetch_coverage(besst_ctx* c, int64_t* aligned) {
+    BESST_NEED_BUILT(c);
+    BESST_REQUIRE(aligned, "fetch_coverage: null buffer");
+    int rc = use_device(c);
+    if (rc) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(aligned, c->aligned.p, (size_t)c->n_contigs * 8, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
+}
+
+int besst_ctx_fetch_counters(besst_ctx* c, besst_counters* out) {
+    BESST_NEED_BUILT(c);
+    BESST_REQUIRE(out, "fetch_counters: null buffer");
+    int rc = use_device(c);
+    if (rc) return rc;
+    SmallBlock host;
+    BESST_HIP_TRY(hipMemcpyAsync(&host, c->small.p, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = host.counters;
+    out->prev_obs1 = host.carry[0];
+    out->prev_obs2 = host.carry[1];
+    return BESST_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+int besst_ctx_metrics_sample(besst_ctx*, const uint8_t*, int32_t, int32_t, double, int32_t, int32_t*, int32_t*,
+                             besst_metrics_counts*) {
+    set_error("metrics_sample: not built yet");
+    return BESST_ERR_STATE;
+}
+int besst_ctx_value_histogram(besst_ctx*, const int32_t*, int64_t, int64_t, int64_t*, int64_t*) {
+    set_error("value_histogram: not built yet");
+    return BESST_ERR_STATE;
+}
+int besst_ctx_score_edges(besst_ctx*, int64_t, const uint32_t*, const uint8_t*, const int32_t*, const int32_t*, double,
+                          double, double, double*, double*, int32_t*, uint8_t*) {
+    set_error("score_edges: not built yet");
+    return BESST_ERR_STATE;
+}
+}

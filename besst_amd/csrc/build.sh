@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build libbesst_amd.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off : the fp64 paths (PosDir truncation, KS centring, gap estimator) must round
+#                       exactly like the reference's Python floats - no fused multiply-adds.
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="${here}/../libbesst_amd.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
+    -Wall -Wno-unused-result \
+    "${here}/api.hip" "${here}/classify.hip" "${here}/sortreduce.hip" "${here}/metrics.hip" "${here}/score.hip" \
+    -o "${out}"
+echo "built ${out}"

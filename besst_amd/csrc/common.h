@@ -1,0 +1,148 @@
+// Shared declarations for the gfx950 kernels of libbesst_amd.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/besst_amd.h"
+
+namespace besst {
+
+// ---- error plumbing -----------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define BESST_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            besst::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                      \
+            return BESST_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+
+#define BESST_REQUIRE(cond, msg)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            besst::set_error("%s", msg);         \
+            return BESST_ERR_ARG;                \
+        }                                        \
+    } while (0)
+
+// ---- record flag bits (SAM) -----------------------------------------------------------------------
+constexpr uint32_t kFlagUnmapped = 0x4, kFlagMateUnmapped = 0x8, kFlagReverse = 0x10,
+                   kFlagMateReverse = 0x20, kFlagRead1 = 0x40, kFlagRead2 = 0x80,
+                   kFlagSecondary = 0x100;
+
+// ---- contig table row: one 16-byte gather per lookup ---------------------------------------------
+// w0 = scaffold id (bits 0..27) | direction << 28 | class << 29
+struct __attribute__((aligned(16))) ContigRow {
+    uint32_t w0;
+    int32_t scaf_len;
+    int32_t ctg_pos;
+    int32_t ctg_len;
+};
+constexpr uint32_t kScafIdMask = (1u << 28) - 1;
+
+// ---- classify kernel geometry ----------------------------------------------------------------------
+constexpr int kClsThreads = 256;
+constexpr int kClsVec = 4;                                   // records per thread per sub-tile
+constexpr int kClsSubTile = kClsThreads * kClsVec;           // 1024 records
+constexpr int kClsSubTiles = 4;
+constexpr int kClsTile = kClsSubTile * kClsSubTiles;         // 4096 records per block
+
+// Per-block summary of the classify kernel, resolved by the single-block "stitch" kernel.
+struct __attribute__((aligned(16))) BlockSummary {
+    uint32_t n_emit;      // tuples written to the block's local segment (head tuple included)
+    uint32_t has_reach;   // block holds >= 1 record that reached CreateEdge
+    int32_t first_o1, first_o2;   // head = first reaching record of the block
+    int32_t last_o1, last_o2;     // last reaching record of the block
+    uint32_t head_info;   // bit0 accept, bit1 double call, bit2 mapq == 0, bit3 has slot
+    uint32_t head_slot;   // local slot of the head's tuple
+};
+
+// Launch-time constants of the record loop.
+struct ClassifyArgs {
+    const int32_t* tid;
+    const int32_t* mtid;
+    const int32_t* pos;
+    const int32_t* mpos;
+    const uint16_t* flag;
+    const uint8_t* mapq;
+    const uint16_t* qlen;
+    const ContigRow* table;
+    int64_t n;
+    int32_t n_contigs;
+    int32_t node_bits;
+    double read_len;
+    double ins_size_threshold;
+    int32_t min_mapq;
+    int32_t rf;            // orientation == 'rf'
+    int32_t detect_dup;
+    int32_t extend_paths;
+    int32_t no_score;
+};
+
+// ---- sort / reduce geometry -------------------------------------------------------------------------
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortThreads * kSortItems;   // 4096 keys per block
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+
+constexpr int kRedThreads = 256;
+constexpr int kRedItems = 8;
+constexpr int kRedTile = kRedThreads * kRedItems;      // 2048 tuples per block
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- stage launchers (defined in the .hip files) -----------------------------------------------------
+size_t classify_workspace_bytes(int64_t n);
+int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned,
+                    uint64_t* keys, uint64_t* payload, uint32_t* n_out, besst_counters* counters,
+                    void* ws, size_t ws_bytes);
+
+size_t reduce_workspace_bytes(int64_t cap);
+int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
+                       const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
+                       uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                       uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                       uint32_t* n_rows, void* ws, size_t ws_bytes);
+
+struct MetricsArgs {
+    const int32_t* tid;
+    const int32_t* mtid;
+    const int32_t* tlen;
+    const uint16_t* flag;
+    const uint8_t* mapq;
+    const uint8_t* top_mask;   // device, n_contigs bytes
+    int64_t n;
+    int32_t n_contigs;
+    int32_t rf;
+    int32_t min_mapq;
+    double read_len;
+};
+size_t metrics_workspace_bytes(int64_t n);
+int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t count,
+                   int32_t* isize_out, int32_t* contam_out, int64_t* state, void* ws, size_t ws_bytes);
+int launch_value_histogram(hipStream_t s, const int32_t* values, int64_t n, int64_t n_bins,
+                           unsigned long long* hist, unsigned long long* overflow);
+
+struct ScoreArgs {
+    const uint32_t* row;       // edge-table row per scored edge
+    const uint8_t* swap;
+    const int32_t* len1;
+    const int32_t* len2;
+    const uint32_t* row_n;
+    const int64_t* row_sum;
+    const uint32_t* row_offset;
+    const int32_t* obs_lo;
+    const int32_t* obs_hi;
+    double mean, sigma, read_len;
+    int64_t n_edges;
+};
+size_t score_workspace_bytes(int64_t n_edges, int64_t n_tuples);
+int launch_score(hipStream_t s, const ScoreArgs& a, double* gap, double* sd0, int32_t* ks_h,
+                 uint8_t* flags, void* ws, size_t ws_bytes);
+
+}  // namespace besst

@@ -1,0 +1,399 @@
+// Stage 2 of the scaffold-graph build: edge table from the ordered tuple stream.
+//
+//   keys[i]    = ((min_node << node_bits) | max_node) << 1 | is_fishy      (CreateGraph.py:842-843 keys
+//                the edge by the unordered node pair; fishy_edges :161-162 likewise)
+//   payload[i] = obs_of_min_node | (obs_of_max_node | mask << 30) << 32
+//
+// 1. Stable LSD radix sort (8-bit digits, only the significant key bits) of (key, stream index).
+//    Stability keeps every edge's observations in BAM order, which is the order the reference appends
+//    them in (CreateGraph.py:845,856,862), and makes the first tuple of a row its first occurrence.
+//    Ranking is wave-native: a 64-lane match-any built from 8 ballots gives each key its rank among
+//    equal digits of the same wave; waves are stitched through a 4 x 256 LDS table.
+// 2. Segmented reduction of the sorted stream into edge rows: nr_links, sum obs, sum obs^2
+//    (int64, exact), first stream index, slice offset; observations are gathered once through the
+//    sorted index and written grouped by row.
+//
+// All sizes are read from device memory (n_tuples), so the whole stage is enqueued without a host
+// round trip; grids are sized by the caller's capacity bound and surplus workgroups exit at once.
+#include "common.h"
+
+namespace besst {
+
+namespace {
+
+__device__ __forceinline__ uint32_t nblocks_of(uint32_t n, uint32_t tile) { return (n + tile - 1) / tile; }
+
+// ---------------------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ n_ptr,
+                                                                  int shift, uint32_t* __restrict__ table,
+                                                                  uint32_t stride) {
+    const uint32_t n = *n_ptr;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks_of(n, kSortTile)) return;
+    __shared__ uint32_t s_hist[kRadix];
+    const int t = threadIdx.x;
+    s_hist[t] = 0;
+    __syncthreads();
+    const uint32_t base = b * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = base + r * kSortThreads + t;
+        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    table[(uint32_t)t * stride + b] = s_hist[t];
+}
+
+// one workgroup per digit: exclusive scan of that digit's per-block counts, total to row_total[d]
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ n_ptr,
+                                                            uint32_t* __restrict__ table, uint32_t stride,
+                                                            uint32_t* __restrict__ row_total) {
+    const uint32_t nb = nblocks_of(*n_ptr, kSortTile);
+    uint32_t* row = table + (size_t)blockIdx.x * stride;
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nb; c0 += 256) {
+        const uint32_t i = c0 + t;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < nb) row[i] = pre + x - v;
+        __syncthreads();
+        if (t == 255) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (t == 0) row_total[blockIdx.x] = s_carry;
+}
+
+template <bool kFirst>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+    const uint32_t* __restrict__ n_ptr, int shift, const uint32_t* __restrict__ table, uint32_t stride,
+    const uint32_t* __restrict__ row_total, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ idx_out) {
+    const uint32_t n = *n_ptr;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks_of(n, kSortTile)) return;
+    __shared__ uint32_t s_whist[4][kRadix];
+    __shared__ uint32_t s_base[kRadix];
+    __shared__ uint32_t s_w[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_whist[w][t] = 0;
+    // exclusive scan of the 256 digit totals -> global start of each digit
+    {
+        const uint32_t v = row_total[t];
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        s_base[t] = pre + x - v + table[(uint32_t)t * stride + b];
+    }
+    __syncthreads();
+
+    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint64_t key[kSortItems];
+    uint32_t idx[kSortItems];
+    uint32_t dig_rank[kSortItems];   // digit | rank << 8
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keys_in[i] : ~0ull;
+        idx[r] = kFirst ? i : (valid ? idx_in[i] : 0u);
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadix - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < kRadixBits; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const unsigned long long bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        uint32_t pre = 0;
+        const int leader = __ffsll((long long)peers) - 1;
+        if (valid && lane == leader) {
+            // volatile: another lane of this wave may have updated the counter in an earlier round
+            volatile uint32_t* slot = &s_whist[wave][d];
+            pre = *slot;
+            *slot = pre + (uint32_t)__popcll(peers);
+        }
+        pre = __shfl(pre, leader < 0 ? 0 : leader, 64);
+        dig_rank[r] = d | ((pre + (uint32_t)__popcll(peers & lt_mask)) << 8);
+    }
+    __syncthreads();
+    {   // per-digit start of each wave inside this block's range of the digit
+        uint32_t run = s_base[t];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_whist[w][t];
+            s_whist[w][t] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) {
+            const uint32_t dst = s_whist[wave][dig_rank[r] & 0xffu] + (dig_rank[r] >> 8);
+            keys_out[dst] = key[r];
+            idx_out[dst] = idx[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// segmented reduction into edge rows
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRedThreads) void row_heads_kernel(const uint64_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ n_ptr,
+                                                                uint32_t* __restrict__ blk_heads) {
+    const uint32_t n = *n_ptr;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks_of(n, kRedTile)) return;
+    __shared__ int s_w[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t i0 = b * kRedTile + t * kRedItems;
+    int cnt = 0;
+    uint64_t prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < kRedItems; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < n) {
+            const uint64_t key = keys[i];
+            cnt += (i == 0 || key != prev) ? 1 : 0;
+            prev = key;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0) s_w[wave] = cnt;
+    __syncthreads();
+    if (t == 0) blk_heads[b] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(1024) void row_scan_kernel(const uint32_t* __restrict__ n_ptr,
+                                                        const uint32_t* __restrict__ blk_heads,
+                                                        uint32_t* __restrict__ blk_base,
+                                                        uint32_t* __restrict__ n_rows) {
+    const uint32_t nb = nblocks_of(*n_ptr, kRedTile);
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
+        const uint32_t i = c0 + t;
+        const uint32_t v = i < nb ? blk_heads[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_w[w];
+        if (i < nb) blk_base[i] = pre + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (t == 0) *n_rows = s_carry;
+}
+
+__global__ __launch_bounds__(256) void row_zero_kernel(const uint32_t* __restrict__ n_rows,
+                                                       uint32_t* __restrict__ row_n,
+                                                       unsigned long long* __restrict__ row_sum,
+                                                       unsigned long long* __restrict__ row_sum_sq) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *n_rows) {
+        row_n[i] = 0;
+        row_sum[i] = 0;
+        row_sum_sq[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
+    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+    const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
+    const uint32_t* __restrict__ blk_base, uint64_t* __restrict__ row_key,
+    uint32_t* __restrict__ row_mask, uint32_t* __restrict__ row_n,
+    unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
+    uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo,
+    int32_t* __restrict__ obs_hi) {
+    const uint32_t n = *n_ptr;
+    const uint32_t b = blockIdx.x;
+    if (b >= nblocks_of(n, kRedTile)) return;
+    __shared__ int s_w[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t i0 = b * kRedTile + t * kRedItems;
+    uint64_t key[kRedItems];
+    bool head[kRedItems];
+    int cnt = 0;
+    uint64_t prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < kRedItems; ++k) {
+        const uint32_t i = i0 + k;
+        key[k] = i < n ? keys[i] : 0;
+        head[k] = i < n && (i == 0 || key[k] != prev);
+        cnt += head[k] ? 1 : 0;
+        prev = key[k];
+    }
+    int x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d, 64);
+        if (lane >= d) x += o;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int pre = 0;
+    for (int w = 0; w < wave; ++w) pre += s_w[w];
+    // index of the row the thread's first item belongs to (rows are numbered by their heads)
+    int64_t row = (int64_t)blk_base[b] + pre + x - cnt - 1;
+    uint32_t run_n = 0;
+    unsigned long long run_s = 0, run_s2 = 0;
+#pragma unroll
+    for (int k = 0; k < kRedItems; ++k) {
+        const uint32_t i = i0 + k;
+        if (i >= n) break;
+        if (head[k]) {
+            if (run_n) {
+                atomicAdd(&row_n[row], run_n);
+                atomicAdd(&row_sum[row], run_s);
+                atomicAdd(&row_sum_sq[row], run_s2);
+                run_n = 0; run_s = 0; run_s2 = 0;
+            }
+            row++;
+        }
+        const uint32_t src = idx[i];
+        const uint64_t p = payload[src];
+        const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32);
+        const int32_t o_lo = (int32_t)lo, o_hi = (int32_t)(hi & 0x3fffffffu);
+        obs_lo[i] = o_lo;
+        obs_hi[i] = o_hi;
+        if (head[k]) {
+            row_key[row] = key[k];
+            row_mask[row] = hi >> 30;
+            row_first[row] = src;
+            row_offset[row] = i;
+        }
+        const unsigned long long o = (unsigned long long)((long long)o_lo + o_hi);
+        run_n += 1;
+        run_s += o;
+        run_s2 += o * o;
+    }
+    if (run_n) {
+        atomicAdd(&row_n[row], run_n);
+        atomicAdd(&row_sum[row], run_s);
+        atomicAdd(&row_sum_sq[row], run_s2);
+    }
+}
+
+struct RedWorkspace {
+    uint64_t* keys[2];
+    uint32_t* idx[2];
+    uint32_t* table;
+    uint32_t* row_total;
+    uint32_t* blk_heads;
+    uint32_t* blk_base;
+    uint32_t stride;
+    size_t total;
+};
+
+RedWorkspace carve(void* ws, int64_t cap) {
+    RedWorkspace w;
+    char* p = static_cast<char*>(ws);
+    size_t off = 0;
+    const size_t nb_sort = (size_t)((cap + kSortTile - 1) / kSortTile);
+    const size_t nb_red = (size_t)((cap + kRedTile - 1) / kRedTile);
+    for (int j = 0; j < 2; ++j) { w.keys[j] = reinterpret_cast<uint64_t*>(p + off); off += align_up((size_t)cap * 8, 256); }
+    for (int j = 0; j < 2; ++j) { w.idx[j] = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)cap * 4, 256); }
+    w.stride = (uint32_t)nb_sort;
+    w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_sort * kRadix * 4, 256);
+    w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kRadix * 4, 256);
+    w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
+    w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+size_t reduce_workspace_bytes(int64_t cap) {
+    if (cap < 1) cap = 1;
+    return carve(nullptr, cap).total;
+}
+
+int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
+                       const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
+                       uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                       uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                       uint32_t* n_rows, void* ws, size_t ws_bytes) {
+    BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
+    BESST_REQUIRE(key_bits >= 1 && key_bits <= 64, "reduce: key_bits out of range");
+    if (cap == 0) {
+        BESST_HIP_TRY(hipMemsetAsync(n_rows, 0, sizeof(uint32_t), s));
+        return BESST_OK;
+    }
+    const RedWorkspace w = carve(ws, cap);
+    BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: workspace too small");
+    const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
+    const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
+    const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
+    const uint64_t* kin = keys;
+    const uint32_t* iin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        uint64_t* kout = w.keys[p & 1];
+        uint32_t* iout = w.idx[p & 1];
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples,
+                           shift, w.table, w.stride);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table,
+                           w.stride, w.row_total);
+        if (p == 0)
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb_sort), dim3(kSortThreads), 0, s, kin,
+                               iin, n_tuples, shift, w.table, w.stride, w.row_total, kout, iout);
+        else
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb_sort), dim3(kSortThreads), 0, s, kin,
+                               iin, n_tuples, shift, w.table, w.stride, w.row_total, kout, iout);
+        kin = kout;
+        iin = iout;
+    }
+    hipLaunchKernelGGL(row_heads_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, n_tuples, w.blk_heads);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_tuples, w.blk_heads, w.blk_base, n_rows);
+    hipLaunchKernelGGL(row_zero_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, n_rows, row_n,
+                       reinterpret_cast<unsigned long long*>(row_sum),
+                       reinterpret_cast<unsigned long long*>(row_sum_sq));
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, iin, payload, n_tuples,
+                       w.blk_base, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
+                       reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset, obs_lo,
+                       obs_hi);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+}  // namespace besst

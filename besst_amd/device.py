@@ -1,0 +1,157 @@
+"""Thin Python handle on a ``besst_ctx`` (host-buffer layer of the C ABI).
+
+Everything here is marshalling: numpy columns in, numpy result tables out.  The arithmetic
+lives in the HIP kernels behind libbesst_amd.so; nothing in this module computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BesstDeviceError, Counters, LibParams, MetricsCounts
+
+CLS_ABSENT, CLS_LARGE, CLS_SMALL = 0, 1, 2
+MASK_G, MASK_GPRIME = 1, 2
+SAMPLE_CAP = 1000000
+
+
+class EdgeTable(object):
+    """Edge rows as returned by the device, sorted by key.
+
+    ``u``/``v`` are node codes (``scaffold_id * 2 + (side == 'R')``) with ``u < v``;
+    ``is_fishy`` rows carry the BWA-quirk counts of CreateGraph.py:141-163, the other rows the
+    link statistics of CreateEdge (:842-862).  ``obs_lo``/``obs_hi`` hold per-link observations
+    grouped by row (slice ``offset[i] : offset[i] + n[i]``), in BAM order.
+    """
+
+    def __init__(self, key, mask, n, sum_obs, sum_obs_sq, first_idx, offset, node_bits, obs_lo, obs_hi):
+        self.key, self.mask, self.n = key, mask, n
+        self.sum_obs, self.sum_obs_sq = sum_obs, sum_obs_sq
+        self.first_idx, self.offset = first_idx, offset
+        self.node_bits = node_bits
+        self.obs_lo, self.obs_hi = obs_lo, obs_hi
+        pair = key >> np.uint64(1)
+        self.is_fishy = (key & np.uint64(1)).astype(bool)
+        self.u = (pair >> np.uint64(node_bits)).astype(np.int64)
+        self.v = (pair & np.uint64((1 << node_bits) - 1)).astype(np.int64)
+
+    def __len__(self):
+        return int(self.key.shape[0])
+
+
+class GraphContext(object):
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = self._lib.besst_ctx_create(int(device))
+        if not self._ctx:
+            raise BesstDeviceError('besst_ctx_create(%d) failed: %s' % (device, _lib.last_error()))
+        self.n_contigs = 0
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.besst_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    # ---- inputs ----------------------------------------------------------------------------------
+    def set_contigs(self, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls):
+        cols = [_lib.as_col(scaf_id, np.int32), _lib.as_col(scaf_len, np.int32), _lib.as_col(ctg_pos, np.int32),
+                _lib.as_col(ctg_len, np.int32), _lib.as_col(direction, np.uint8), _lib.as_col(cls, np.uint8)]
+        n = cols[0].shape[0]
+        if any(c.shape != (n,) for c in cols):
+            raise ValueError('contig table columns differ in length')
+        _lib.check(self._lib.besst_ctx_set_contigs(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'set_contigs')
+        self.n_contigs = n
+
+    def set_library(self, read_len, ins_size_threshold, min_mapq, orientation, detect_duplicate, extend_paths,
+                    no_score):
+        p = LibParams(float(read_len), float(ins_size_threshold), int(min_mapq),
+                      {'fr': 0, 'rf': 1}[orientation], int(bool(detect_duplicate)), int(bool(extend_paths)),
+                      int(bool(no_score)), 0)
+        _lib.check(self._lib.besst_ctx_set_library(self._ctx, C.byref(p)), 'set_library')
+
+    def clear_records(self):
+        _lib.check(self._lib.besst_ctx_clear_records(self._ctx), 'clear_records')
+
+    def push_records(self, batch):
+        """``batch``: a RecordBatch (or anything with the eight SoA columns)."""
+        cols = [_lib.as_col(batch.tid, np.int32), _lib.as_col(batch.mtid, np.int32),
+                _lib.as_col(batch.pos, np.int32), _lib.as_col(batch.mpos, np.int32),
+                _lib.as_col(batch.tlen, np.int32), _lib.as_col(batch.flag, np.uint16),
+                _lib.as_col(batch.mapq, np.uint8), _lib.as_col(batch.qlen, np.uint16)]
+        n = cols[0].shape[0]
+        _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
+
+    # ---- library statistics ----------------------------------------------------------------------
+    def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):
+        top = _lib.as_col(top_mask, np.uint8)
+        isize = np.empty(SAMPLE_CAP, dtype=np.int32)
+        contam = np.empty(SAMPLE_CAP, dtype=np.int32)
+        counts = MetricsCounts()
+        _lib.check(self._lib.besst_ctx_metrics_sample(
+            self._ctx, _lib.ptr(top), {'fr': 0, 'rf': 1}[orientation], int(min_mapq), float(read_len),
+            int(bool(want_isize)), _lib.ptr(isize), _lib.ptr(contam), C.byref(counts)), 'metrics_sample')
+        return isize[:counts.n_isize], contam[:counts.n_contam], counts
+
+    def value_histogram(self, values, n_bins):
+        vals = _lib.as_col(values, np.int32)
+        hist = np.zeros(int(n_bins), dtype=np.int64)
+        overflow = np.zeros(1, dtype=np.int64)
+        _lib.check(self._lib.besst_ctx_value_histogram(self._ctx, _lib.ptr(vals), vals.shape[0], int(n_bins),
+                                                       _lib.ptr(hist), _lib.ptr(overflow)), 'value_histogram')
+        return hist, int(overflow[0])
+
+    # ---- graph build -----------------------------------------------------------------------------
+    def build_graph(self):
+        _lib.check(self._lib.besst_ctx_build_graph(self._ctx), 'build_graph')
+        rows, tuples = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.besst_ctx_edge_count(self._ctx, C.byref(rows), C.byref(tuples)), 'edge_count')
+        r, L = rows.value, tuples.value
+        key = np.empty(r, dtype=np.uint64)
+        mask = np.empty(r, dtype=np.uint32)
+        n = np.empty(r, dtype=np.uint32)
+        s1 = np.empty(r, dtype=np.int64)
+        s2 = np.empty(r, dtype=np.int64)
+        first = np.empty(r, dtype=np.uint32)
+        off = np.empty(r, dtype=np.uint32)
+        nb = C.c_int32()
+        _lib.check(self._lib.besst_ctx_fetch_edges(self._ctx, _lib.ptr(key), _lib.ptr(mask), _lib.ptr(n),
+                                                   _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(first), _lib.ptr(off),
+                                                   C.byref(nb)), 'fetch_edges')
+        lo = np.empty(L, dtype=np.int32)
+        hi = np.empty(L, dtype=np.int32)
+        _lib.check(self._lib.besst_ctx_fetch_observations(self._ctx, _lib.ptr(lo), _lib.ptr(hi)),
+                   'fetch_observations')
+        aligned = np.empty(self.n_contigs, dtype=np.int64)
+        _lib.check(self._lib.besst_ctx_fetch_coverage(self._ctx, _lib.ptr(aligned)), 'fetch_coverage')
+        ctr = Counters()
+        _lib.check(self._lib.besst_ctx_fetch_counters(self._ctx, C.byref(ctr)), 'fetch_counters')
+        return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, lo, hi), aligned, ctr
+
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+        rows = _lib.as_col(rows, np.uint32)
+        swap = _lib.as_col(swap, np.uint8)
+        len1 = _lib.as_col(len1, np.int32)
+        len2 = _lib.as_col(len2, np.int32)
+        m = rows.shape[0]
+        gap = np.empty(m, dtype=np.float64)
+        sd0 = np.empty(m, dtype=np.float64)
+        ks_h = np.empty(m, dtype=np.int32)
+        flags = np.empty(m, dtype=np.uint8)
+        _lib.check(self._lib.besst_ctx_score_edges(self._ctx, m, _lib.ptr(rows), _lib.ptr(swap), _lib.ptr(len1),
+                                                   _lib.ptr(len2), float(mean), float(sigma), float(read_len),
+                                                   _lib.ptr(gap), _lib.ptr(sd0), _lib.ptr(ks_h), _lib.ptr(flags)),
+                   'score_edges')
+        return gap, sd0, ks_h, flags

@@ -1,0 +1,223 @@
+/*
+ * besst_amd.h - C ABI of the MI355X scaffold-graph construction library (libbesst_amd.so)
+ *
+ * This is the drop-in boundary for BESST's hot path
+ *     bam_parser -> libmetrics/find_bimodality -> CreateGraph/e_nr_links
+ * The reference has no plugin registry: the seam is two Python calls per library,
+ *     libmetrics.get_metrics(bam_file, param, Information)          runBESST:168
+ *     CreateGraph.PE(Contigs, Scaffolds, Information, C_dict, param,
+ *                    small_contigs, small_scaffolds, bam_file)      runBESST:182
+ * and its only native precedent is a ctypes call with a caller-allocated result struct and
+ * an int return (BESST/diploid/wrapper_sw.py:12-24, swmodule.cpp:20-28,44).  The entry points
+ * below follow that convention: extern "C", plain pointers and sizes, int status (0 = ok),
+ * never throw, never exit.  besst_amd/_lib.py binds them with ctypes; INTEGRATION.md shows
+ * the stub a BESST maintainer would add.
+ *
+ * Two layers:
+ *   besst_ctx_*  host-buffer API.  The context owns all device memory; inputs are host
+ *                (numpy) buffers, results come back in caller-allocated host buffers sized by
+ *                a preceding *_count call.  This is what the Python drop-in uses.
+ *   besst_dev_*  device-pointer API.  Every pointer is an HBM pointer owned by the caller
+ *                (e.g. a torch tensor's data_ptr()), work is enqueued on the given hipStream_t
+ *                and nothing is allocated or synchronised.  Used by bench.py and by the
+ *                multi-GPU path, where the RCCL exchange sits between two besst_dev_ stages.
+ *
+ * Threading: one caller thread per context (like the reference's single-threaded loop).
+ */
+#ifndef BESST_AMD_H
+#define BESST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BESST_ABI_VERSION 1
+
+/* status codes */
+#define BESST_OK 0
+#define BESST_ERR_ARG 1     /* bad argument (null pointer, misaligned column, size out of range) */
+#define BESST_ERR_HIP 2     /* a HIP runtime call failed; see besst_last_error() */
+#define BESST_ERR_STATE 3   /* call order violated (e.g. build before set_library) */
+#define BESST_ERR_NOMEM 4
+
+/* contig classes (membership in Contigs / small_contigs, CreateGraph.py:127-130) */
+#define BESST_CLS_ABSENT 0
+#define BESST_CLS_LARGE 1
+#define BESST_CLS_SMALL 2
+
+/* edge-table membership bits: which graph(s) CreateEdge was called for (CreateGraph.py:170-206) */
+#define BESST_MASK_G 1u
+#define BESST_MASK_GPRIME 2u
+
+/* Per-library constants of the record loop.  Mirrors the fields CreateGraph.PE / CreateEdge read
+ * from Parameter.parameter (CreateGraph.py:138,169,175-184,830-840). */
+typedef struct besst_lib_params {
+    double read_len;           /* param.read_len: may be fractional when inferred (libmetrics.py:265) */
+    double ins_size_threshold; /* param.ins_size_threshold (-T), float when inferred                 */
+    int32_t min_mapq;          /* param.min_mapq (--min_mapq, default 11)                            */
+    int32_t orientation;       /* 0 = 'fr' (PosDirCalculatorPE), 1 = 'rf' (PosDirCalculatorMP)       */
+    int32_t detect_duplicate;  /* param.detect_duplicate (-d, default on)                            */
+    int32_t extend_paths;      /* param.extend_paths (-y, default on)                                */
+    int32_t no_score;          /* param.no_score (--no_score)                                        */
+    int32_t reserved;
+} besst_lib_params;
+
+/* Tallies of the record loop: Parameter.counters (Parameter.py:113-124) plus the fishy-read count
+ * `ctr` of CreateGraph.py:100,163 and the sizes of the emitted tuple stream. */
+typedef struct besst_counters {
+    int64_t count;                      /* counter.count ("USEFUL READS", per CreateEdge call)      */
+    int64_t non_unique;                 /* counter.non_unique                                        */
+    int64_t non_unique_for_scaf;        /* counter.non_unique_for_scaf                               */
+    int64_t nr_of_duplicates;           /* counter.nr_of_duplicates                                  */
+    int64_t reads_with_too_long_insert; /* counter.reads_with_too_long_insert                        */
+    int64_t fishy_reads;                /* ctr                                                       */
+    int64_t n_tuples;                   /* link + fishy tuples written to the sort buffer            */
+    int64_t n_reach;                    /* records that reached CreateEdge                           */
+    int32_t prev_obs1;                  /* counter.prev_obs1 after the last record                   */
+    int32_t prev_obs2;                  /* counter.prev_obs2                                         */
+} besst_counters;
+
+/* Library-statistics sampling pass (libmetrics.py:49-131,283-304).  All counts are over the scanned
+ * prefix of the stream, honouring the reference's 1,000,000-sample cut-offs in stream order. */
+typedef struct besst_metrics_counts {
+    int64_t n_isize;        /* observations collected for the insert-size sample (<= 1,000,000)     */
+    int64_t n_contam;       /* opposite-orientation fragments collected (contamination_reads)       */
+    int64_t counter_total;  /* mapped records on the 1000 longest contigs within the cut-off       */
+    int64_t sample_counter; /* records on the 1000 longest contigs within the cut-off (<= 1,000,000) */
+    int64_t records_scanned;
+} besst_metrics_counts;
+
+typedef struct besst_ctx besst_ctx;
+
+/* ------------------------------------------------------------------------------------------------
+ * library
+ * ---------------------------------------------------------------------------------------------- */
+int besst_abi_version(void);
+/* Last error text of the calling thread's most recent failing call (never NULL). */
+const char* besst_last_error(void);
+/* Number of visible HIP devices, or a negative status. */
+int besst_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * host-buffer API (context owns HBM)
+ * ---------------------------------------------------------------------------------------------- */
+besst_ctx* besst_ctx_create(int device);
+void besst_ctx_destroy(besst_ctx* ctx);
+
+/* Contig table, one row per BAM header entry (tid order).  Replaces the Contigs / small_contigs /
+ * Scaffolds / small_scaffolds lookups of the record loop (CreateGraph.py:127-130,144-174,819-829).
+ * scaf_id must be in [1, 2^28). */
+int besst_ctx_set_contigs(besst_ctx* ctx, int64_t n_contigs, const int32_t* scaf_id,
+                          const int32_t* scaf_len, const int32_t* ctg_pos, const int32_t* ctg_len,
+                          const uint8_t* direction, const uint8_t* cls);
+
+int besst_ctx_set_library(besst_ctx* ctx, const besst_lib_params* params);
+
+/* Drop all records held by the context (start of a new library). */
+int besst_ctx_clear_records(besst_ctx* ctx);
+
+/* Append a batch of alignment records (SoA columns = the pysam attributes the hot path reads:
+ * rname mrnm pos mpos tlen flag mapq qlen).  Records stay resident in HBM. */
+int besst_ctx_push_records(besst_ctx* ctx, int64_t n, const int32_t* tid, const int32_t* mtid,
+                           const int32_t* pos, const int32_t* mpos, const int32_t* tlen,
+                           const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen);
+
+/* libmetrics sampling (replaces the three `for read in bam_file` scans, libmetrics.py:63,257,293).
+ * top_mask[tid] != 0 marks the 1000 longest references.  orientation/min_mapq/read_len as in
+ * besst_lib_params.  isize_out / contam_out receive |tlen| of the qualifying records in stream order
+ * (capacity 1,000,000 each); the host adds 2*read_len where the reference does. */
+int besst_ctx_metrics_sample(besst_ctx* ctx, const uint8_t* top_mask, int32_t orientation,
+                             int32_t min_mapq, double read_len, int32_t want_isize,
+                             int32_t* isize_out, int32_t* contam_out, besst_metrics_counts* counts);
+
+/* Count-per-value histogram of a sample on the device (input to find_bimodality.split_distribution,
+ * find_bimodality.py:109-132).  hist_out has n_bins entries; values >= n_bins are counted in
+ * *overflow. */
+int besst_ctx_value_histogram(besst_ctx* ctx, const int32_t* values, int64_t n, int64_t n_bins,
+                              int64_t* hist_out, int64_t* overflow);
+
+/* Record loop + CreateEdge + edge-table reduction (CreateGraph.py:111-211,812-871) over every record
+ * pushed so far. */
+int besst_ctx_build_graph(besst_ctx* ctx);
+
+/* Sizes of the result: edge rows (distinct (node pair, fishy) keys) and link/fishy tuples. */
+int besst_ctx_edge_count(besst_ctx* ctx, int64_t* n_rows, int64_t* n_tuples);
+
+/* Edge rows sorted by key.  key = ((min_node << node_bits) | max_node) << 1 | is_fishy with
+ * node = scaffold_id * 2 + (side == 'R').  For link rows: n = nr_links, sum_obs = obs,
+ * sum_obs_sq = obs_sq, mask = BESST_MASK_* bits; for fishy rows n = fishy count.  first_idx is the
+ * position of the row's first tuple in the emitted tuple stream (monotone in BAM order), offset the
+ * start of the row's slice in the observation arrays. */
+int besst_ctx_fetch_edges(besst_ctx* ctx, uint64_t* key, uint32_t* mask, uint32_t* n,
+                          int64_t* sum_obs, int64_t* sum_obs_sq, uint32_t* first_idx,
+                          uint32_t* offset, int32_t* node_bits);
+
+/* Per-tuple observations grouped by edge row, BAM order inside a row: obs_lo belongs to the row's
+ * min node, obs_hi to its max node; observations[i] = obs_lo[i] + obs_hi[i] (CreateGraph.py:842-862). */
+int besst_ctx_fetch_observations(besst_ctx* ctx, int32_t* obs_lo, int32_t* obs_hi);
+
+/* cont_aligned_len numerators (CreateGraph.py:138-139), one int64 per tid. */
+int besst_ctx_fetch_coverage(besst_ctx* ctx, int64_t* aligned);
+
+int besst_ctx_fetch_counters(besst_ctx* ctx, besst_counters* out);
+
+/* GiveScoreOnEdges, normal-distribution branch (CreateGraph.py:498-614), for n_edges rows of the
+ * table built by the last besst_ctx_build_graph.  row[i] indexes the edge table; swap[i] != 0 means
+ * the graph iterates the edge as (max_node, min_node), i.e. l1 comes from obs_hi; len1/len2 are the
+ * scaffold lengths of the first/second endpoint in that orientation.  Outputs per edge:
+ *   gap      int(gap)                      (CreateGraph.py:511-541)
+ *   sd0      expected std-dev tr_sk_std_dev or 2^32 (:548-558)
+ *   ks_h     integer h with KS statistic = h / n (:582-606)
+ *   flags    bit0: both scaffolds > 2 sigma (ML gap used), bit1: -gap > len (score forced to 0) */
+int besst_ctx_score_edges(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                          const int32_t* len1, const int32_t* len2, double mean, double sigma,
+                          double read_len, double* gap, double* sd0, int32_t* ks_h, uint8_t* flags);
+
+/* ------------------------------------------------------------------------------------------------
+ * device-pointer API (caller owns HBM; all pointers are device pointers unless noted)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Scratch bytes needed by besst_dev_classify / besst_dev_reduce for up to n records / tuples. */
+size_t besst_dev_classify_workspace_bytes(int64_t n_records);
+size_t besst_dev_reduce_workspace_bytes(int64_t n_tuples);
+
+/* Pack the contig table into the 16-byte rows the kernels gather from (host pointers in,
+ * device pointer out; table must hold n_contigs * 16 bytes). */
+int besst_dev_pack_contigs(void* stream, int64_t n_contigs, const int32_t* h_scaf_id,
+                           const int32_t* h_scaf_len, const int32_t* h_ctg_pos,
+                           const int32_t* h_ctg_len, const uint8_t* h_direction,
+                           const uint8_t* h_cls, void* d_table);
+
+/* Stage 1: per-record classification, coverage accumulation, CreateEdge semantics (duplicate
+ * chain, acceptance), ordered emission of link/fishy tuples.
+ *   carry   int32[2] device: counter.prev_obs1/2 entering the batch, updated on exit
+ *   aligned int64[n_contigs] device, accumulated into (zero it before the first batch)
+ *   keys / payload  uint64[capacity >= n] device: emitted tuples in BAM order
+ *   n_out   uint32 device: number of tuples emitted by this call
+ *   counters  besst_counters device struct, accumulated into
+ * Columns must be 16-byte aligned. */
+int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                       const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
+                       const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
+                       const void* contig_table, const besst_lib_params* h_params, int32_t node_bits,
+                       int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload,
+                       uint32_t* n_out, besst_counters* counters, void* workspace,
+                       size_t workspace_bytes);
+
+/* Stage 2: stable radix sort of the tuples by key and segmented reduction into edge rows.
+ *   n_tuples  uint32 device: number of valid tuples in keys/payload (<= capacity)
+ *   key_bits  number of significant key bits (2 * node_bits + 1)
+ * Outputs (capacity entries each): row_* arrays, obs_lo/obs_hi grouped by row, n_rows (uint32). */
+int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
+                     const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
+                     uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                     uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BESST_AMD_H */
