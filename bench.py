@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py - read-pairs/s into the scaffold graph on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one resident batch: record loop (classify), duplicate
+chain, ordered tuple emission, radix sort and edge-table reduction, all enqueued on one HIP stream
+through the besst_dev_* C ABI with the record columns already in HBM.  No host round trip happens
+inside a step.  At N > 1 every rank owns a contiguous slice of the (tid,pos)-sorted stream
+(weak scaling: one C2-sized slice per GPU); see besst_amd/distributed.py.
+
+Prints ONE JSON line on rank 0 (see the repo prompt for the contract) with two extra objects:
+  roofline     - dominant kernel (classify_kernel): algorithmic bytes per launch / mean launch
+                 duration from HIP events recorded on the launch stream inside the timed region
+  cpu_baseline - the pure-Python oracle (port of the reference's record loop) timed on this box's
+                 host cores over a bounded sample of the same stream
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+CLASSIFY_SLOT = 0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='C2')
+    ap.add_argument('--pairs', type=int, default=None, help='override pairs per GPU (smoke runs)')
+    ap.add_argument('--contigs', type=int, default=None)
+    ap.add_argument('--cpu-sample-records', type=int, default=6_000_000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown-steps', type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, table, lib, n_sample):
+    """Time the oracle's record loop (single thread) on the first n_sample records."""
+    from oracle import py_oracle as O
+    n = min(len(batch), n_sample)
+    rec = {k: getattr(batch, k)[:n].tolist() for k in ('tid', 'mtid', 'pos', 'mpos', 'flag', 'mapq', 'qlen')}
+    tab = dict(cls=table['cls'].tolist(), scaf=table['scaf_id'].tolist(), slen=table['scaf_len'].tolist(),
+               cpos=table['ctg_pos'].tolist(), clen=table['ctg_len'].tolist(),
+               cdir=[bool(x) for x in table['direction'].tolist()])
+    p = O.LibParams(read_len=lib['read_len'], ins_size_threshold=lib['ins_size_threshold'], min_mapq=lib['min_mapq'],
+                    orientation=lib['orientation'])
+    t0 = time.perf_counter()
+    res = O.record_loop(rec, tab, p)
+    dt = time.perf_counter() - t0
+    return dict(value=(n / 2.0) / dt, unit='read-pairs/s', cores=1, kind='port',
+                sample='first %d records (%d pairs) of the same stream, oracle/py_oracle.record_loop, %.1f s'
+                       % (n, n // 2, dt)), res
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from besst_amd import _lib, pipeline, workload
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no GPU visible; besst_amd has no CPU path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+
+    # ---- workload: one C2-sized slice per rank (weak scaling) -------------------------------------------
+    wl = workload.make(args.config, 0, pairs=args.pairs, nc=args.contigs, seed_offset=rank)
+    batch, table, lib = wl['batch'], wl['table'], wl['lib']
+    n_rec = len(batch)
+    pairs = n_rec // 2
+
+    if world > 1:
+        from besst_amd import distributed
+        runner = distributed.ShardedGraphBuild(device, wl, rank, world)
+    else:
+        runner = SingleGpu(device, wl)
+
+    lib_h = _lib.load()
+    for _ in range(args.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    runner.check_capacity()
+
+    lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = pipeline.prof_collect()
+    lib_h.besst_prof_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel breakdown (untimed extra steps, every slot) ------------------------------------------
+    lib_h.besst_prof_enable(0xffffffff)
+    for _ in range(args.breakdown_steps):
+        runner.step()
+    torch.cuda.synchronize()
+    breakdown = {k: round(v[0] / args.breakdown_steps, 4) for k, v in pipeline.prof_collect().items()}
+    lib_h.besst_prof_enable(0)
+
+    n_tuples, n_rows = runner.sizes()
+    f = n_tuples / float(pairs)
+    cls_ms, cls_launches = prof.get('classify_kernel', (0.0, 0))
+    cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
+    # algorithmic bytes of one classify launch: 19 B per record read + each emitted tuple written once
+    alg_bytes = n_rec * 19.0 + n_tuples * 16.0
+    achieved = alg_bytes / cls_avg_s / 1e9 if cls_avg_s > 0 else 0.0
+
+    if rank == 0:
+        total_pairs = pairs * world
+        out = {
+            'metric': 'read-pairs/sec into scaffold graph; edge-set match + gap MAE vs CPU ref',
+            'value': total_pairs / (elapsed / args.steps),
+            'unit': 'read-pairs/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'int32/int64 (fp64 for read_len truncation)',
+            'data': 'synthetic',
+            'config': {'workload': '%s: %d contigs / %d PE read-pairs per GPU, one fr library, records resident in HBM'
+                                   % (args.config, wl['asm'].nc, pairs),
+                       'records_per_gpu': n_rec, 'link_tuples_per_pair': round(f, 5), 'edge_rows': n_rows,
+                       'parallelism': 'stream-slice x%d + key-owner all-to-all' % world if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'kernel': 'classify_kernel', 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': None, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
+                         'algorithmic_bytes_per_launch': alg_bytes},
+            'kernel_ms': breakdown,
+        }
+        if not args.no_cpu_baseline:
+            base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
+            out['cpu_baseline'] = base
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class SingleGpu(object):
+    def __init__(self, device, wl):
+        from besst_amd import pipeline
+        self.rec = pipeline.DeviceRecords(wl['batch'], device)
+        # tuple capacity: every record may emit one tuple; sized down after the first measured pass
+        probe = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n, 1)
+        probe.set_contigs(**wl['table'])
+        probe.reset()
+        probe.classify(self.rec)
+        n_tuples, _ = probe.read_sizes()
+        del probe
+        self.cap = int(n_tuples * 1.25) + 4096
+        self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n, self.cap)
+        self.gb.set_contigs(**wl['table'])
+
+    def step(self):
+        self.gb.step(self.rec)
+
+    def sizes(self):
+        return self.gb.read_sizes()
+
+    def check_capacity(self):
+        n, _ = self.gb.read_sizes()
+        if n > self.cap:
+            raise SystemExit('tuple capacity exceeded')
+
+
+if __name__ == '__main__':
+    main()

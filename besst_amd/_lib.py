@@ -41,6 +41,10 @@ _SIGNATURES = {
     'besst_abi_version': (C.c_int, []),
     'besst_last_error': (C.c_char_p, []),
     'besst_device_count': (C.c_int, []),
+    'besst_prof_enable': (None, [C.c_uint32]),
+    'besst_prof_slots': (C.c_int, []),
+    'besst_prof_slot_name': (C.c_char_p, [C.c_int]),
+    'besst_prof_collect': (C.c_int, [C.c_int, _P, _P]),
     'besst_ctx_create': (_P, [C.c_int]),
     'besst_ctx_destroy': (None, [_P]),
     'besst_ctx_set_contigs': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),

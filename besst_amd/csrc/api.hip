@@ -20,6 +20,27 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+struct ProfRec {
+    int slot;
+    hipEvent_t a, b;
+};
+static uint32_t g_prof_mask = 0;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(hipStream_t stream, int slot) : s(stream), idx(-1) {
+    if (!((g_prof_mask >> slot) & 1u)) return;
+    ProfRec r;
+    r.slot = slot;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof[(size_t)idx].b, s);
+}
+
 namespace {
 
 template <typename T>
@@ -128,6 +149,38 @@ extern "C" {
 int besst_abi_version(void) { return BESST_ABI_VERSION; }
 
 const char* besst_last_error(void) { return g_error; }
+
+void besst_prof_enable(uint32_t slot_mask) { g_prof_mask = slot_mask; }
+
+int besst_prof_slots(void) { return kProfSlots; }
+
+const char* besst_prof_slot_name(int slot) {
+    static const char* names[kProfSlots] = {"classify_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
+                                            "radix_rowscan_kernel", "radix_scatter_kernel", "row_heads_kernel",
+                                            "row_scan_kernel", "row_zero_kernel", "row_reduce_kernel",
+                                            "metrics_kernels", "score_kernels"};
+    return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
+}
+
+int besst_prof_collect(int n_slots, double* ms, int64_t* launches) {
+    BESST_REQUIRE(ms && launches && n_slots >= kProfSlots, "prof_collect: need kProfSlots entries");
+    for (int i = 0; i < n_slots; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    int rc = BESST_OK;
+    for (ProfRec& r : g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.slot] += (double)t;
+            launches[r.slot] += 1;
+        } else {
+            rc = BESST_ERR_HIP;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    if (rc) set_error("prof_collect: an event could not be read");
+    return rc;
+}
 
 int besst_device_count(void) {
     int n = 0;

@@ -543,13 +543,22 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
     auto* ctr = reinterpret_cast<unsigned long long*>(counters);
-    hipLaunchKernelGGL(classify_kernel, dim3(nblocks), dim3(kClsThreads), 0, s, a,
-                       reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload,
-                       w.summ, ctr);
-    hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry,
-                       a.detect_dup, w.offsets, w.skip, n_out, ctr);
-    hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip,
-                       w.seg_keys, w.seg_payload, keys, payload);
+    {
+        ProfScope ps(s, kProfClassify);
+        hipLaunchKernelGGL(classify_kernel, dim3(nblocks), dim3(kClsThreads), 0, s, a,
+                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload,
+                           w.summ, ctr);
+    }
+    {
+        ProfScope ps(s, kProfStitch);
+        hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry,
+                           a.detect_dup, w.offsets, w.skip, n_out, ctr);
+    }
+    {
+        ProfScope ps(s, kProfCompact);
+        hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip,
+                           w.seg_keys, w.seg_payload, keys, payload);
+    }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

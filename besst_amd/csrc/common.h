@@ -29,6 +29,18 @@ void set_error(const char* fmt, ...);
         }                                        \
     } while (0)
 
+// ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
+enum ProfSlot {
+    kProfClassify = 0, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter,
+    kProfRowHeads, kProfRowScan, kProfRowZero, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
+};
+struct ProfScope {
+    hipStream_t s;
+    int idx;
+    ProfScope(hipStream_t stream, int slot);
+    ~ProfScope();
+};
+
 // ---- record flag bits (SAM) -----------------------------------------------------------------------
 constexpr uint32_t kFlagUnmapped = 0x4, kFlagMateUnmapped = 0x8, kFlagReverse = 0x10,
                    kFlagMateReverse = 0x20, kFlagRead1 = 0x40, kFlagRead2 = 0x80,

@@ -370,10 +370,17 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         const int shift = p * kRadixBits;
         uint64_t* kout = w.keys[p & 1];
         uint32_t* iout = w.idx[p & 1];
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples,
-                           shift, w.table, w.stride);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table,
-                           w.stride, w.row_total);
+        {
+            ProfScope ps(s, kProfSortHist);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples,
+                               shift, w.table, w.stride);
+        }
+        {
+            ProfScope ps(s, kProfSortScan);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table,
+                               w.stride, w.row_total);
+        }
+        ProfScope ps(s, kProfSortScatter);
         if (p == 0)
             hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb_sort), dim3(kSortThreads), 0, s, kin,
                                iin, n_tuples, shift, w.table, w.stride, w.row_total, kout, iout);
@@ -383,11 +390,21 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         kin = kout;
         iin = iout;
     }
-    hipLaunchKernelGGL(row_heads_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, n_tuples, w.blk_heads);
-    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_tuples, w.blk_heads, w.blk_base, n_rows);
+    {
+        ProfScope ps(s, kProfRowHeads);
+        hipLaunchKernelGGL(row_heads_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, n_tuples, w.blk_heads);
+    }
+    {
+        ProfScope ps(s, kProfRowScan);
+        hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_tuples, w.blk_heads, w.blk_base, n_rows);
+    }
+    {
+    ProfScope ps(s, kProfRowZero);
     hipLaunchKernelGGL(row_zero_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, n_rows, row_n,
                        reinterpret_cast<unsigned long long*>(row_sum),
                        reinterpret_cast<unsigned long long*>(row_sum_sq));
+    }
+    ProfScope ps(s, kProfRowReduce);
     hipLaunchKernelGGL(row_reduce_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, iin, payload, n_tuples,
                        w.blk_base, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                        reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset, obs_lo,

@@ -1,0 +1,172 @@
+"""Device-resident graph build on caller-owned HBM (torch tensors) through the besst_dev_* layer.
+
+torch is used for what it is good at here - device memory, streams and (in distributed.py)
+the RCCL process group.  Every kernel is a hand-written HIP kernel behind the C ABI; tensors
+only lend their ``data_ptr()``.  Used by bench.py, the multi-GPU path and the GPU tests; the
+ctypes drop-in (CreateGraph.PE) uses the host-buffer layer in device.py instead.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Counters, LibParams
+
+COUNTER_BYTES = C.sizeof(Counters)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _from_np(arr, device):
+    """Upload a numpy column; 16-bit unsigned columns travel as int16 bit patterns."""
+    if arr.dtype == np.uint16:
+        arr = arr.view(np.int16)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(device, non_blocking=False)
+
+
+class DeviceRecords(object):
+    """Record columns resident in HBM."""
+
+    def __init__(self, batch, device):
+        self.n = len(batch)
+        self.tid = _from_np(batch.tid, device)
+        self.mtid = _from_np(batch.mtid, device)
+        self.pos = _from_np(batch.pos, device)
+        self.mpos = _from_np(batch.mpos, device)
+        self.tlen = _from_np(batch.tlen, device)
+        self.flag = _from_np(batch.flag, device)
+        self.mapq = _from_np(batch.mapq, device)
+        self.qlen = _from_np(batch.qlen, device)
+
+    @property
+    def graph_bytes(self):
+        return self.n * 19
+
+
+class DeviceGraphBuilder(object):
+    """classify -> (optional exchange) -> sort/reduce on one GPU, no host round trip inside."""
+
+    def __init__(self, device, n_contigs, node_bits, lib, record_capacity, tuple_capacity):
+        self.lib = _lib.load()
+        self.device = device
+        self.n_contigs = int(n_contigs)
+        self.node_bits = int(node_bits)
+        self.params = LibParams(float(lib['read_len']), float(lib['ins_size_threshold']), int(lib['min_mapq']),
+                                {'fr': 0, 'rf': 1}[lib['orientation']], int(bool(lib['detect_duplicate'])),
+                                int(bool(lib['extend_paths'])), int(bool(lib['no_score'])), 0)
+        self.rec_cap = int(max(1, record_capacity))
+        self.tup_cap = int(max(1, tuple_capacity))
+        u8 = dict(dtype=torch.uint8, device=device)
+        i64 = dict(dtype=torch.int64, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.table = torch.zeros(self.n_contigs * 16, **u8)
+        self.aligned = torch.zeros(self.n_contigs, **i64)
+        self.small = torch.zeros(COUNTER_BYTES + 32, **u8)        # counters | carry[2] | n_out | n_rows
+        self.keys = torch.empty(self.rec_cap, **i64)
+        self.payload = torch.empty(self.rec_cap, **i64)
+        self.ws1 = torch.empty(self.lib.besst_dev_classify_workspace_bytes(self.rec_cap), **u8)
+        self.ws2 = torch.empty(self.lib.besst_dev_reduce_workspace_bytes(self.tup_cap), **u8)
+        c = self.tup_cap
+        self.row_key = torch.empty(c, **i64)
+        self.row_mask = torch.empty(c, **i32)
+        self.row_n = torch.empty(c, **i32)
+        self.row_sum = torch.empty(c, **i64)
+        self.row_sum_sq = torch.empty(c, **i64)
+        self.row_first = torch.empty(c, **i32)
+        self.row_offset = torch.empty(c, **i32)
+        self.obs_lo = torch.empty(c, **i32)
+        self.obs_hi = torch.empty(c, **i32)
+        self._init = torch.zeros(COUNTER_BYTES + 32, dtype=torch.uint8)
+        self._init[COUNTER_BYTES:COUNTER_BYTES + 8] = torch.from_numpy(np.array([-1, -1], dtype=np.int32).view(np.uint8))
+        self._init = self._init.to(device)
+
+    # device addresses inside the small block
+    def _small(self, off):
+        return C.c_void_p(self.small.data_ptr() + off)
+
+    @property
+    def _carry(self):
+        return self._small(COUNTER_BYTES)
+
+    @property
+    def _n_out(self):
+        return self._small(COUNTER_BYTES + 8)
+
+    @property
+    def _n_rows(self):
+        return self._small(COUNTER_BYTES + 12)
+
+    def set_contigs(self, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls):
+        cols = [_lib.as_col(scaf_id, np.int32), _lib.as_col(scaf_len, np.int32), _lib.as_col(ctg_pos, np.int32),
+                _lib.as_col(ctg_len, np.int32), _lib.as_col(direction, np.uint8), _lib.as_col(cls, np.uint8)]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.besst_dev_pack_contigs(C.c_void_p(stream), self.n_contigs, *[_lib.ptr(c) for c in cols],
+                                                   _p(self.table)), 'pack_contigs')
+
+    def reset(self):
+        """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
+        self.aligned.zero_()
+        self.small.copy_(self._init)
+
+    def classify(self, rec):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.besst_dev_classify(
+            C.c_void_p(stream), rec.n, _p(rec.tid), _p(rec.mtid), _p(rec.pos), _p(rec.mpos), _p(rec.flag),
+            _p(rec.mapq), _p(rec.qlen), self.n_contigs, _p(self.table), C.byref(self.params), self.node_bits,
+            self._carry, _p(self.aligned), _p(self.keys), _p(self.payload), self._n_out, self._small(0),
+            _p(self.ws1), self.ws1.numel()), 'dev_classify')
+
+    def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        keys = self.keys if keys is None else keys
+        payload = self.payload if payload is None else payload
+        cap = self.tup_cap if capacity is None else int(capacity)
+        _lib.check(self.lib.besst_dev_reduce(
+            C.c_void_p(stream), cap, n_tuples_ptr or self._n_out, 2 * self.node_bits + 1, _p(keys), _p(payload),
+            _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
+            _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
+            _p(self.ws2), self.ws2.numel()), 'dev_reduce')
+
+    def step(self, rec):
+        self.reset()
+        self.classify(rec)
+        self.reduce()
+
+    def read_sizes(self):
+        """(n_tuples, n_rows) - synchronises."""
+        raw = self.small.cpu().numpy()
+        n_out, n_rows = np.frombuffer(raw[COUNTER_BYTES + 8:COUNTER_BYTES + 16].tobytes(), dtype=np.uint32)
+        return int(n_out), int(n_rows)
+
+    def read_counters(self):
+        raw = self.small.cpu().numpy().tobytes()
+        ctr = Counters.from_buffer_copy(raw[:COUNTER_BYTES])
+        carry = np.frombuffer(raw[COUNTER_BYTES:COUNTER_BYTES + 8], dtype=np.int32)
+        ctr.prev_obs1, ctr.prev_obs2 = int(carry[0]), int(carry[1])
+        return ctr
+
+    def fetch_table(self):
+        """EdgeTable on the host (synchronises)."""
+        from .device import EdgeTable
+        L, r = self.read_sizes()
+        if L > self.tup_cap:
+            raise _lib.BesstDeviceError('tuple capacity %d exceeded (%d tuples)' % (self.tup_cap, L))
+
+        def h(t, n, dt):
+            return t[:n].cpu().numpy().view(dt)
+        return EdgeTable(h(self.row_key, r, np.uint64), h(self.row_mask, r, np.uint32), h(self.row_n, r, np.uint32),
+                         h(self.row_sum, r, np.int64), h(self.row_sum_sq, r, np.int64),
+                         h(self.row_first, r, np.uint32), h(self.row_offset, r, np.uint32), self.node_bits,
+                         h(self.obs_lo, L, np.int32), h(self.obs_hi, L, np.int32))
+
+
+def prof_collect():
+    lib = _lib.load()
+    n = lib.besst_prof_slots()
+    ms = np.zeros(n, dtype=np.float64)
+    cnt = np.zeros(n, dtype=np.int64)
+    _lib.check(lib.besst_prof_collect(n, _lib.ptr(ms), _lib.ptr(cnt)), 'prof_collect')
+    return {lib.besst_prof_slot_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i]}

@@ -1,0 +1,42 @@
+"""Synthetic workloads for bench.py and the full-size property tests.
+
+A workload = one library of one BASELINE.json config: the record stream, the contig table as
+InitializeObjects would build it for a first library (CreateGraph.py:729-786: scaffold ids are a
+running index in header order, contigs >= contig_threshold are 'large', the rest 'small') and the
+per-library constants the record loop needs.
+"""
+import numpy as np
+
+from . import synth
+
+
+def first_library_table(lengths, contig_threshold, first_scaffold_id=1):
+    lengths = np.asarray(lengths, dtype=np.int64)
+    nc = lengths.shape[0]
+    present = lengths > 0
+    scaf = np.zeros(nc, dtype=np.int64)
+    scaf[present] = first_scaffold_id + np.arange(int(present.sum()))
+    cls = np.where(lengths >= contig_threshold, 1, np.where(present, 2, 0))
+    return dict(scaf_id=scaf.astype(np.int32), scaf_len=lengths.astype(np.int32), ctg_pos=np.zeros(nc, dtype=np.int32),
+                ctg_len=lengths.astype(np.int32), direction=np.ones(nc, dtype=np.uint8), cls=cls.astype(np.uint8))
+
+
+def node_bits_for(table):
+    max_id = int(table['scaf_id'].max()) if len(table['scaf_id']) else 1
+    return max(1, int(max_id * 2 + 1).bit_length())
+
+
+def make(config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, tid_offset=0):
+    cfg = synth.CONFIGS[config]
+    spec = cfg['libs'][lib_index]
+    n_pairs = int(pairs if pairs is not None else cfg['pairs'] // len(cfg['libs']))
+    n_ctg = int(nc if nc is not None else cfg['nc'])
+    seed = synth.config_seed(config) + 1000 * seed_offset
+    asm = synth.make_assembly(n_ctg, cfg['median'], seed)
+    batch = synth.simulate_library(asm, spec, n_pairs, seed + 100 + lib_index)
+    lib = dict(read_len=float(spec.read_len), ins_size_threshold=spec.mean + 6 * spec.sd, min_mapq=11,
+               orientation=spec.orientation, detect_duplicate=True, extend_paths=True, no_score=False,
+               mean=spec.mean, sd=spec.sd)
+    table = first_library_table(asm.lengths, spec.mean + 4 * spec.sd)
+    return dict(config=config, asm=asm, batch=batch, table=table, lib=lib, node_bits=node_bits_for(table),
+                pairs=n_pairs, spec=spec)

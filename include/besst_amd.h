@@ -101,6 +101,15 @@ const char* besst_last_error(void);
 /* Number of visible HIP devices, or a negative status. */
 int besst_device_count(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline numbers).
+ * Off by default; slot_mask selects the kernels to time (bit i = slot i, 0 = off).
+ * besst_prof_collect synchronises the recorded events, sums elapsed milliseconds and
+ * launch counts per slot (besst_prof_slots() entries, names from besst_prof_slot_name) and resets. */
+void besst_prof_enable(uint32_t slot_mask);
+int besst_prof_slots(void);
+const char* besst_prof_slot_name(int slot);
+int besst_prof_collect(int n_slots, double* ms, int64_t* launches);
+
 /* ------------------------------------------------------------------------------------------------
  * host-buffer API (context owns HBM)
  * ---------------------------------------------------------------------------------------------- */
