@@ -1,0 +1,526 @@
+"""Scaffold-graph construction: drop-in for ``BESST/CreateGraph.py`` with the record loop on the MI355X.
+
+``PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file)``
+keeps the reference signature (CreateGraph.py:45) and contract: it returns
+``(G, G_prime)`` as networkx-1.x compatible graphs with nodes ``(scaffold_id, 'L'|'R')`` and link-edge
+attributes ``nr_links, obs, obs_sq, observations, gap, score``, mutates the four object dicts and
+``param`` in place, and writes repeats.fa / repeats_log.tsv / low_coverage_contigs.fa.
+
+Split of work:
+  * device (libbesst_amd.so): the per-record loop (CreateGraph.py:111-211) including coverage sums,
+    fishy-read counts, PosDir calculators, the CreateEdge duplicate chain and acceptance rule, then the
+    radix sort + segmented reduction that turns link tuples into edge rows, and the per-edge ML gap /
+    expected sigma / KS statistic of GiveScoreOnEdges (:498-614);
+  * host (this file): object initialisation, assembling the graphs from the edge rows in first-occurrence
+    order (= dict insertion order of the reference), the O(#contigs) coverage statistics and the
+    O(#edges) filters whose semantics depend on graph iteration order (:355-404).
+"""
+from __future__ import print_function
+
+import os
+import sys
+from collections import Counter
+from time import time
+
+import numpy as np
+
+from . import Contig, Scaffold, e_nr_links, session
+from . import GenerateOutput as GO
+from .Parameter import counters
+from .device import CLS_ABSENT, CLS_LARGE, CLS_SMALL, MASK_G, MASK_GPRIME
+from .mathstats_compat import MaxObsDistr
+from .nxcompat import Graph
+
+
+def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file):
+    G = Graph()
+    G_prime = Graph()
+    print('Parsing BAM file...', file=Information)
+    sess = session.open_session(bam_file)
+    batch = sess.batch
+
+    if param.first_lib:
+        start_init = time()
+        InitializeObjects(batch, Contigs, Scaffolds, param, Information, G_prime, small_contigs, small_scaffolds, C_dict)
+        print('Time initializing BESST objects: ', time() - start_init, file=Information)
+    else:
+        start_clean = time()
+        CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_scaffolds)
+        print('Time cleaning BESST objects for next library: ', time() - start_clean, file=Information)
+
+    if len(Scaffolds) == 0:
+        if param.output_directory and not os.path.isfile(param.output_directory + '/repeats.fa'):
+            open(param.output_directory + '/repeats.fa', 'w').close()
+        return (G, G_prime)
+
+    tot_start = time()
+    if param.no_score:
+        InitializeGraph(small_scaffolds, G_prime, Information)
+        InitializeGraph(Scaffolds, G_prime, Information)
+    elif param.extend_paths:
+        InitializeGraph(Scaffolds, G, Information)
+        InitializeGraph(small_scaffolds, G_prime, Information)
+        InitializeGraph(Scaffolds, G_prime, Information)
+    else:
+        InitializeGraph(Scaffolds, G, Information)
+    print('Total time elapsed for initializing Graph: ', time() - tot_start, file=Information)
+
+    # ---- record loop on the device ------------------------------------------------------------------------
+    print('Reading bam file and creating scaffold graph...', file=Information)
+    staart = time()
+    table_cols, tid_of = contig_table(batch.references, Contigs, small_contigs, Scaffolds, small_scaffolds)
+    ctx = sess.ctx
+    ctx.set_contigs(**table_cols)
+    ctx.set_library(param.read_len, param.ins_size_threshold, param.min_mapq, param.orientation,
+                    param.detect_duplicate, param.extend_paths, param.no_score)
+    table, aligned, ctr = ctx.build_graph()
+    counter = counters(ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates,
+                       ctr.prev_obs1, ctr.prev_obs2, ctr.reads_with_too_long_insert)
+    fishy_rows = add_link_edges(table, G, G_prime)
+
+    print('ELAPSED reading file:', time() - staart, file=Information)
+    print('NR OF FISHY READ LINKS: ', ctr.fishy_reads, file=Information)
+    print('Number of USEFUL READS (reads mapping to different contigs uniquly): ', counter.count, file=Information)
+    print('Number of non unique reads (at least one read non-unique in read pair) that maps to different contigs '
+          '(filtered out from scaffolding): ', counter.non_unique, file=Information)
+    print('Reads with too large insert size from "USEFUL READS" (filtered out): ',
+          counter.reads_with_too_long_insert, file=Information)
+    print('Initial number of edges in G (the graph with large contigs): ', len(G.edges()), file=Information)
+    print('Initial number of edges in G_prime (the full graph of all contigs before removal of repats): ',
+          len(G_prime.edges()), file=Information)
+    if param.detect_duplicate:
+        print('Number of duplicated reads indicated and removed: ', counter.nr_of_duplicates, file=Information)
+
+    # ---- coverage (CreateGraph.py:237-246) -----------------------------------------------------------------
+    aligned = aligned.tolist()
+    for name, cont in Contigs.items():
+        cont.coverage = aligned[tid_of[name]] / float(cont.length)
+    for name, cont in small_contigs.items():
+        cont.coverage = aligned[tid_of[name]] / float(cont.length)
+
+    if param.first_lib and param.lower_cov_cutoff:
+        filter_low_coverage_contigs(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information)
+
+    mean_cov, std_dev_cov = CalculateMeanCoverage(Contigs, Information, param)
+    param.mean_coverage = mean_cov
+    param.std_dev_coverage = std_dev_cov
+
+    if param.first_lib:
+        Contigs, Scaffolds, G = RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs,
+                                               small_scaffolds, Information)
+    print('Number of edges in G (after repeat removal): ', len(G.edges()), file=Information)
+    print('Number of edges in G_prime (after repeat removal): ', len(G_prime.edges()), file=Information)
+
+    RemoveBugEdges(G, G_prime, fishy_rows, param, Information)
+    print('Number of edges in G (after filtering for buggy flag stats reporting): ', len(G.edges()), file=Information)
+    print('Number of edges in G_prime  (after filtering for buggy flag stats reporting): ', len(G_prime.edges()),
+          file=Information)
+
+    infer_spurious_link_count_threshold(G_prime, param)
+    if not param.edgesupport:
+        param.edgesupport = 5
+        print('Letting -e be {0} for this library.'.format(param.edgesupport), file=Information)
+    else:
+        print('User has set -e to be {0} for this library.'.format(param.edgesupport), file=Information)
+
+    counter_low_support = 0
+    for u, v in G.edges():
+        nr = G[u][v]['nr_links']
+        if nr is not None and nr < param.edgesupport:
+            G.remove_edge(u, v)
+            counter_low_support += 1
+    print('Removed {0} edges from graph G of border contigs.'.format(counter_low_support), file=Information)
+    remove_edges_below_threshold(G_prime, param)
+
+    if not param.no_score:
+        GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, 'G', ctx)
+    print('Number of edges in G_prime  (after removing edges under -e threshold (if not specified, default is '
+          '-e 3): ', len(G_prime.edges()), file=Information)
+    print('\n -------------------------------------------------------------\n', file=Information)
+    print('Nr of contigs/scaffolds included in this pass: ' + str(len(Scaffolds) + len(small_scaffolds)),
+          file=Information)
+    print('Out of which {0} acts as border contigs.'.format(len(Scaffolds)), file=Information)
+    return (G, G_prime)
+
+
+# -----------------------------------------------------------------------------------------------------------
+# device boundary helpers
+# -----------------------------------------------------------------------------------------------------------
+def contig_table(references, Contigs, small_contigs, Scaffolds, small_scaffolds):
+    """Flatten the object dicts into the per-tid table the kernels gather from."""
+    n = len(references)
+    cols = dict(scaf_id=np.zeros(n, np.int32), scaf_len=np.zeros(n, np.int32), ctg_pos=np.zeros(n, np.int32),
+                ctg_len=np.zeros(n, np.int32), direction=np.zeros(n, np.uint8), cls=np.zeros(n, np.uint8))
+    tid_of = {}
+    for tid, name in enumerate(references):
+        if name in tid_of:
+            continue
+        tid_of[name] = tid
+        if name in Contigs:
+            c, scaf, k = Contigs[name], Scaffolds, CLS_LARGE
+        elif name in small_contigs:
+            c, scaf, k = small_contigs[name], small_scaffolds, CLS_SMALL
+        else:
+            continue
+        cols['cls'][tid] = k
+        cols['scaf_id'][tid] = c.scaffold
+        cols['scaf_len'][tid] = scaf[c.scaffold].s_length
+        cols['ctg_pos'][tid] = c.position
+        cols['ctg_len'][tid] = c.length
+        cols['direction'][tid] = 1 if c.direction else 0
+    return cols, tid_of
+
+
+def _node(code):
+    return (code >> 1, 'R' if code & 1 else 'L')
+
+
+def add_link_edges(table, G, G_prime):
+    """Insert the device's edge rows into the graphs in first-occurrence order.
+
+    The reference creates an edge the first time CreateEdge accepts a link for it (CreateGraph.py:842-849),
+    so adjacency order = order of first occurrence in the BAM; ``first_idx`` is monotone in that order.
+    Returns the fishy rows as {(node_a, node_b): count} for RemoveBugEdges.
+    """
+    n_rows = len(table)
+    fishy = {}
+    link_rows = []
+    is_fishy = table.is_fishy.tolist()
+    u_l, v_l, n_l = table.u.tolist(), table.v.tolist(), table.n.tolist()
+    for i in range(n_rows):
+        if is_fishy[i]:
+            fishy[(_node(u_l[i]), _node(v_l[i]))] = n_l[i]
+        else:
+            link_rows.append(i)
+    first = table.first_idx.tolist()
+    link_rows.sort(key=lambda i: first[i])
+    mask, off = table.mask.tolist(), table.offset.tolist()
+    s1, s2 = table.sum_obs.tolist(), table.sum_obs_sq.tolist()
+    obs_all = (table.obs_lo.astype(np.int64) + table.obs_hi.astype(np.int64))
+    for i in link_rows:
+        u, v = _node(u_l[i]), _node(v_l[i])
+        lo, hi = off[i], off[i] + n_l[i]
+        observations = obs_all[lo:hi].tolist()
+        if mask[i] & MASK_G:
+            # device_row lets GiveScoreOnEdges find the per-end observation lists without copying them
+            G.add_edge(u, v, nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=list(observations), device_row=i,
+                       device_min_node=u)
+        if mask[i] & MASK_GPRIME:
+            G_prime.add_edge(u, v, nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=observations)
+    return fishy
+
+
+# -----------------------------------------------------------------------------------------------------------
+# host-side stages, same names as the reference
+# -----------------------------------------------------------------------------------------------------------
+def InitializeGraph(dict_with_scaffolds, graph, Information):
+    for scaffold_ in dict_with_scaffolds:
+        graph.add_edge((scaffold_, 'L'), (scaffold_, 'R'), nr_links=None)
+        graph.node[(scaffold_, 'L')]['length'] = dict_with_scaffolds[scaffold_].s_length
+        graph.node[(scaffold_, 'R')]['length'] = dict_with_scaffolds[scaffold_].s_length
+    return ()
+
+
+def CalculateStats(sorted_contig_lengths, sorted_contig_lengths_small, param, Information):
+    cur_length, nr_conts, L50, N50 = 0, 0, 0, 0
+    half = param.tot_assembly_length / 2.0
+    for group in (sorted_contig_lengths, sorted_contig_lengths_small):
+        for contig_length in group:
+            cur_length += contig_length
+            nr_conts += 1
+            if cur_length >= half:
+                N50, L50 = contig_length, nr_conts
+                break
+        if N50 != 0:
+            break
+    print('L50: ', L50, 'N50: ', N50, 'Initial contig assembly length: ', param.tot_assembly_length, file=Information)
+    return (N50, L50)
+
+
+def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime, small_contigs, small_scaffolds, C_dict):
+    contig_threshold = param.contig_threshold
+    cont_lengths = [int(nr) for nr in bam_file.lengths]
+    cont_names = bam_file.references
+    contig_lengths = [len(c_seq) for c_seq in C_dict.values()]
+    param.tot_assembly_length = sum(contig_lengths)
+    N50, L50 = CalculateStats(sorted(contig_lengths, reverse=True), [], param, Information)
+    param.current_L50 = L50
+    param.current_N50 = N50
+    for i in range(len(cont_names)):
+        name = cont_names[i]
+        if name not in C_dict:
+            continue
+        if cont_lengths[i] >= contig_threshold:
+            target_c, target_s = Contigs, Scaffolds
+        elif cont_lengths[i] > 0:
+            target_c, target_s = small_contigs, small_scaffolds
+        else:
+            continue
+        C = Contig.contig(name)
+        C.length = cont_lengths[i]
+        C.sequence = C_dict[name]
+        del C_dict[name]
+        C.direction = True
+        C.position = 0
+        target_c[C.name] = C
+        S = Scaffold.scaffold(param.scaffold_indexer, [C], C.length)
+        target_s[S.name] = S
+        C.scaffold = S.name
+        param.scaffold_indexer += 1
+    return ()
+
+
+def CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_scaffolds):
+    singeled_out = 0
+    sorted_lengths = sorted((Scaffolds[s].s_length for s in Scaffolds), reverse=True)
+    sorted_lengths_small = sorted((small_scaffolds[s].s_length for s in small_scaffolds), reverse=True)
+    N50, L50 = CalculateStats(sorted_lengths, sorted_lengths_small, param, Information)
+    param.current_L50 = L50
+    param.current_N50 = N50
+    for scaffold_ in list(Scaffolds.keys()):
+        if Scaffolds[scaffold_].s_length < param.contig_threshold:
+            S_obj = Scaffolds[scaffold_]
+            GO.ChangeToSmallContigs(Contigs, S_obj.contigs, small_contigs)
+            small_scaffolds[scaffold_] = S_obj
+            del Scaffolds[scaffold_]
+            singeled_out += 1
+    print('Nr of contigs/scaffolds that was singeled out due to length constraints ' + str(singeled_out),
+          file=Information)
+    return ()
+
+
+def filter_low_coverage_contigs(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information):
+    low_coverage_contigs = []
+    print('Removing low coverage contigs if -z_min specified..', file=Information)
+    for contig in Contigs:
+        if Contigs[contig].coverage < param.lower_cov_cutoff:
+            low_coverage_contigs.append(Contigs[contig])
+            scaf_ = Contigs[contig].scaffold
+            del Scaffolds[scaf_]
+            G.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+            if param.extend_paths:
+                G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+    for contig in small_contigs:
+        if small_contigs[contig].coverage < param.lower_cov_cutoff:
+            low_coverage_contigs.append(small_contigs[contig])
+            scaf_ = small_contigs[contig].scaffold
+            del small_scaffolds[scaf_]
+            G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+    GO.PrintOut_low_cowerage_contigs(low_coverage_contigs, Contigs, param.output_directory, small_contigs)
+    print('Removed a total of: ', len(low_coverage_contigs), ' low coverage contigs. With coverage lower than ',
+          param.lower_cov_cutoff, file=Information)
+
+
+def _acc(values):
+    total = 0
+    for v in values:
+        total = total + v
+    return total
+
+
+def _mean_and_std(xs):
+    n = float(len(xs))
+    mean = _acc(xs) / n
+    sq = 0
+    for x in xs:
+        sq = sq + (x ** 2 - 2 * x * mean + mean ** 2)
+    return mean, (sq / (n - 1)) ** 0.5
+
+
+def RemoveOutliers(mean_cov, std_dev, cov_list):
+    k = MaxObsDistr(len(cov_list), 0.95)
+    filtered_list = [x for x in cov_list if (x < mean_cov + k * std_dev and x < 2 * mean_cov)]
+    return len(cov_list) > len(filtered_list), filtered_list
+
+
+def CalculateMeanCoverage(Contigs, Information, param):
+    by_length = sorted(((Contigs[c].length, c) for c in Contigs), key=lambda tup: tup[0], reverse=True)[:50000]
+    cov_of_longest_contigs = [Contigs[c].coverage for _, c in by_length if Contigs[c].coverage > 0]
+    if len(cov_of_longest_contigs) <= 1:
+        sys.exit('Too few contigs to calculate coverage on. Got: {0} contigs. If you have specified  -z_min or '
+                 '--min_mapq, consider lower them. If not, check the BAM file for proper alignments. Exiting here '
+                 'before scaffolding...'.format(len(cov_of_longest_contigs)))
+    mean_cov, std_dev = _mean_and_std(cov_of_longest_contigs)
+    n = float(len(cov_of_longest_contigs))
+    print('Mean coverage before filtering out extreme observations = ', mean_cov, file=Information)
+    print('Std dev of coverage before filtering out extreme observations= ', std_dev, file=Information)
+    print('Number of contigs used in calc of coverage before filtering: ', n, file=Information)
+    extreme_obs_occur = True
+    while extreme_obs_occur:
+        extreme_obs_occur, filtered_list = RemoveOutliers(mean_cov, std_dev, cov_of_longest_contigs)
+        n = float(len(filtered_list))
+        if n == 0 or _acc(filtered_list) == 0:
+            break
+        mean_cov, std_dev = _mean_and_std(filtered_list)
+        cov_of_longest_contigs = filtered_list
+    print('Mean coverage after filtering = ', mean_cov, file=Information)
+    print('Std coverage after filtering = ', std_dev, file=Information)
+    print('Number of contigs used in calc of coverage after filtering: ', n, file=Information)
+    print('Length of longest contig in calc of coverage: ', by_length[0][0], file=Information)
+    print('Length of shortest contig in calc of coverage: ', by_length[-1][0], file=Information)
+    return (mean_cov, std_dev)
+
+
+def RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information):
+    mean_cov, std_dev = param.mean_coverage, param.std_dev_coverage
+    Repeats = []
+    count_hapl = 0
+    k = MaxObsDistr(len(Contigs), 0.95)
+    if param.cov_cutoff:
+        repeat_thresh = param.cov_cutoff
+    else:
+        repeat_thresh = max(mean_cov + k * std_dev, 2 * mean_cov - 3 * std_dev)
+    print('Detecting repeats..', file=Information)
+    for contig in Contigs:
+        if Contigs[contig].coverage > repeat_thresh:
+            Repeats.append(Contigs[contig])
+            scaf_ = Contigs[contig].scaffold
+            del Scaffolds[scaf_]
+            G.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+            if param.extend_paths:
+                G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+        if param.detect_haplotype and Contigs[contig].coverage < mean_cov / 2.0 + param.hapl_threshold * std_dev:
+            count_hapl += 1
+            Contigs[contig].is_haplotype = True
+    for contig in small_contigs:
+        if small_contigs[contig].coverage > repeat_thresh:
+            Repeats.append(small_contigs[contig])
+            scaf_ = small_contigs[contig].scaffold
+            del small_scaffolds[scaf_]
+            G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+        if param.detect_haplotype and small_contigs[contig].coverage < mean_cov / 2.0 + param.hapl_threshold * std_dev:
+            count_hapl += 1
+            small_contigs[contig].is_haplotype = True
+    GO.repeat_contigs_logger(Repeats, Contigs, param.output_directory, small_contigs, param)
+    GO.PrintOutRepeats(Repeats, Contigs, param.output_directory, small_contigs)
+    print('Removed a total of: ', len(Repeats), ' repeats. With coverage larger than ', repeat_thresh, file=Information)
+    if param.detect_haplotype:
+        print('Marked a total of: ', count_hapl, ' potential haplotypes.', file=Information)
+    return (Contigs, Scaffolds, G)
+
+
+def RemoveBugEdges(G, G_prime, fishy_edges, param, Information):
+    """Drop an edge when the BWA-quirk read count reaches its link count (CreateGraph.py:690-708)."""
+    edges_removed = 0
+    for (a, b), nr_links in list(fishy_edges.items()):
+        if param.extend_paths:
+            if b in G_prime and a in G_prime[b] and nr_links >= G_prime[a][b]['nr_links']:
+                G_prime.remove_edge(a, b)
+                edges_removed += 1
+            if b in G and a in G[b] and nr_links >= G[a][b]['nr_links']:
+                G.remove_edge(a, b)
+        else:
+            if b in G and a in G[b] and nr_links >= G[a][b]['nr_links']:
+                G.remove_edge(a, b)
+                edges_removed += 1
+    print('Number of BWA buggy edges removed: ', edges_removed, file=Information)
+    return ()
+
+
+def infer_spurious_link_count_threshold(G_prime, param):
+    nr_nodes = G_prime.number_of_nodes() / 2
+    contamination_ratio = param.contamination_ratio if param.contamination_ratio else 0
+    cov = param.mean_coverage * (1 - contamination_ratio)
+    link_params = e_nr_links.Param(param.mean_ins_size, param.std_dev_ins_size, cov, param.read_len, 0)
+    gap = param.mean_ins_size + param.std_dev_ins_size - 2 * param.read_len
+    expected = e_nr_links.ExpectedLinks(100000, 100000, gap, link_params)
+    link_counter = Counter(G_prime[u][v]['nr_links'] for u, v in G_prime.edges()
+                           if G_prime[u][v]['nr_links'] is not None)
+    total_included_edges = 0
+    for link_number in sorted(link_counter, reverse=True):
+        total_included_edges += link_counter[link_number]
+        print('Nodes: {0}.\t Total edges with over {1} links:{2}. \tAverage density: {3}'.format(
+            nr_nodes, link_number, total_included_edges, total_included_edges / float(nr_nodes)),
+            file=param.information_file)
+    param.expected_links_over_mean_plus_stddev = 5 if expected < 5 else int(expected)
+    print('Letting filtering threshold in high complexity regions be {0} for this library.'.format(
+        param.expected_links_over_mean_plus_stddev), file=param.information_file)
+
+
+def remove_edges_below_threshold(graph, param):
+    """Dense-region pruning; order dependent, so it runs on the host in graph iteration order (:355-404)."""
+    print('Remove edges in high complexity areas.', file=param.information_file)
+    limit = param.expected_links_over_mean_plus_stddev
+    thin = [(u, v) for u, v in graph.edges()
+            if graph[u][v]['nr_links'] is not None and graph[u][v]['nr_links'] < limit]
+    removed = 0
+    for u, v in thin:
+        if len(graph.neighbors(u)) > 4 and len(graph.neighbors(v)) > 4:
+            graph.remove_edge(u, v)
+            removed += 1
+    print('Removed total of {0} edges in high density areas.'.format(removed), file=param.information_file)
+    counter_low_support = 0
+    for u, v in graph.edges():
+        nr = graph[u][v]['nr_links']
+        if nr is not None and nr < param.edgesupport:
+            graph.remove_edge(u, v)
+            counter_low_support += 1
+    print('Removed an additional of {0} edges with low support from full graph G_prime of all contigs.'.format(
+        counter_low_support), file=param.information_file)
+
+
+def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, plot, ctx):
+    """Score every link edge of G (normal-distribution branch of CreateGraph.py:498-614).
+
+    The device returns per edge the ML gap, the expected std-dev and the integer KS numerator h; the
+    remaining scalar arithmetic below is evaluated with the reference's expressions so the floats agree.
+    """
+    if param.lognormal:
+        raise NotImplementedError('log-normal scoring branch (CreateGraph.py:485-531) is not provided: the reference '
+                                  'itself fails there on Python 3 (float range step, :490)')
+    score_file = None
+    if param.print_scores:
+        score_file = open(os.path.join(param.output_directory, 'score_file_pass_{0}.tsv'.format(param.pass_number)), 'w')
+        print('scf1/ctg1\to1\tscf2/ctg2\to2\tgap\tlink_variation_score\tlink_dispersity_score\tnumber_of_links',
+              file=score_file)
+
+    def s_length(sid):
+        try:
+            return Scaffolds[sid].s_length
+        except KeyError:
+            return small_scaffolds[sid].s_length
+
+    edges, rows, swap, len1, len2 = [], [], [], [], []
+    for u, v in G.edges():
+        data = G[u][v]
+        if data['nr_links'] is None:
+            continue
+        edges.append((u, v))
+        rows.append(data['device_row'])
+        swap.append(0 if u == data['device_min_node'] else 1)    # l1 belongs to the first endpoint (:568-579)
+        len1.append(s_length(u[0]))
+        len2.append(s_length(v[0]))
+    gap_d, sd0_d, ks_h, flags = ctx.score_edges(rows, swap, len1, len2, param.mean_ins_size, param.std_dev_ins_size,
+                                                param.read_len)
+    gap_d, sd0_d, ks_h, flags = gap_d.tolist(), sd0_d.tolist(), ks_h.tolist(), flags.tolist()
+    for j, (u, v) in enumerate(edges):
+        data = G[u][v]
+        data.pop('device_row')
+        data.pop('device_min_node')
+        n = data['nr_links']
+        mean_ = data['obs'] / float(n)
+        # integer-valued when the ML estimator was used (int in the reference), float otherwise
+        gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
+        data['gap'] = int(gap)
+        if flags[j] & 2:                      # -gap > len1 or -gap > len2
+            data['score'] = 0
+            continue
+        std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
+        try:
+            std_dev = ((data['obs_sq'] - n * mean_ ** 2) / (n - 1)) ** 0.5
+        except ZeroDivisionError:
+            std_dev = 2 ** 32
+        span_score = 0 if n < 5 else 1 - ks_h[j] * 1.0 / n
+        try:
+            std_dev_score = min(std_dev / std_dev_d_eq_0, std_dev_d_eq_0 / std_dev)
+        except ZeroDivisionError:
+            std_dev_score = 0
+            sys.stderr.write(str(std_dev) + ' ' + str(std_dev_d_eq_0) + ' ' + str(span_score) + '\n')
+        data['score'] = std_dev_score + span_score if std_dev_score > 0.5 and span_score > 0.5 else 0
+        if score_file is not None:
+            print('{0}\t{1}\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}'.format(u[0], u[1], v[0], v[1], gap, std_dev_score,
+                                                                   span_score, n), file=score_file)
+    if score_file is not None:
+        score_file.close()
+    print('Number of significantly spurious edges:', 0, file=Information)
+    return ()

@@ -500,18 +500,138 @@ int besst_ctx_fetch_counters(besst_ctx* c, besst_counters* out) {
 }  // extern "C"
 
 extern "C" {
-int besst_ctx_metrics_sample(besst_ctx*, const uint8_t*, int32_t, int32_t, double, int32_t, int32_t*, int32_t*,
-                             besst_metrics_counts*) {
-    set_error("metrics_sample: not built yet");
-    return BESST_ERR_STATE;
+
+int besst_ctx_metrics_sample(besst_ctx* c, const uint8_t* top_mask, int32_t orientation, int32_t min_mapq,
+                             double read_len, int32_t want_isize, int32_t* isize_out, int32_t* contam_out,
+                             besst_metrics_counts* counts) {
+    BESST_REQUIRE(c && top_mask && contam_out && counts, "metrics_sample: null pointer");
+    BESST_REQUIRE(!want_isize || isize_out, "metrics_sample: isize_out is null");
+    BESST_REQUIRE(orientation == 0 || orientation == 1, "metrics_sample: orientation must be 0 or 1");
+    if (c->n_contigs <= 0) {
+        set_error("metrics_sample: set_contigs must be called first (defines the reference count)");
+        return BESST_ERR_STATE;
+    }
+    int rc = use_device(c);
+    if (rc) return rc;
+    constexpr int64_t kCap = 1000000;
+    constexpr int64_t kChunk = 4 << 20;
+    if ((rc = c->top_mask.ensure((size_t)c->n_contigs))) return rc;
+    if ((rc = c->sample_a.ensure((size_t)kCap))) return rc;
+    if ((rc = c->sample_b.ensure((size_t)kCap))) return rc;
+    if ((rc = c->aux.ensure(metrics_workspace_bytes(kChunk) + 64))) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(c->top_mask.p, top_mask, (size_t)c->n_contigs, hipMemcpyHostToDevice, c->stream));
+    int64_t* state = reinterpret_cast<int64_t*>(c->aux.p);
+    char* ws = c->aux.p + 64;
+    BESST_HIP_TRY(hipMemsetAsync(state, 0, 64, c->stream));
+    MetricsArgs a;
+    a.tid = c->tid.p; a.mtid = c->mtid.p; a.tlen = c->tlen.p; a.flag = c->flag.p; a.mapq = c->mapq.p;
+    a.top_mask = c->top_mask.p;
+    a.n = c->n_records;
+    a.n_contigs = (int32_t)c->n_contigs;
+    a.rf = orientation;
+    a.min_mapq = min_mapq;
+    a.read_len = read_len;
+    int64_t host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t start = 0; start < c->n_records; start += kChunk) {
+        const int64_t cnt = c->n_records - start < kChunk ? c->n_records - start : kChunk;
+        rc = launch_metrics(c->stream, a, start, cnt, want_isize ? c->sample_a.p : nullptr, c->sample_b.p, state, ws,
+                            c->aux.cap - 64);
+        if (rc) return rc;
+        BESST_HIP_TRY(hipMemcpyAsync(host, state, 48, hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+        // the reference stops each scan once its 1,000,000-sample cut-off is reached (libmetrics.py:83,302)
+        if ((!want_isize || host[0] >= kCap) && host[1] >= kCap) break;
+    }
+    counts->n_isize = want_isize ? (host[0] < kCap ? host[0] : kCap) : 0;
+    counts->sample_counter = host[1] < kCap ? host[1] : kCap;
+    counts->counter_total = host[3];
+    counts->n_contam = host[4];
+    counts->records_scanned = host[5];
+    if (counts->n_isize)
+        BESST_HIP_TRY(hipMemcpyAsync(isize_out, c->sample_a.p, (size_t)counts->n_isize * 4, hipMemcpyDeviceToHost, c->stream));
+    if (counts->n_contam)
+        BESST_HIP_TRY(hipMemcpyAsync(contam_out, c->sample_b.p, (size_t)counts->n_contam * 4, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
 }
-int besst_ctx_value_histogram(besst_ctx*, const int32_t*, int64_t, int64_t, int64_t*, int64_t*) {
-    set_error("value_histogram: not built yet");
-    return BESST_ERR_STATE;
+
+int besst_ctx_value_histogram(besst_ctx* c, const int32_t* values, int64_t n, int64_t n_bins, int64_t* hist_out,
+                              int64_t* overflow) {
+    BESST_REQUIRE(c && hist_out && overflow, "value_histogram: null pointer");
+    BESST_REQUIRE(n >= 0 && n_bins > 0 && n_bins < ((int64_t)1 << 31), "value_histogram: size out of range");
+    BESST_REQUIRE(n == 0 || values, "value_histogram: null values");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = c->sample_a.ensure((size_t)(n > 0 ? n : 1)))) return rc;
+    if ((rc = c->aux.ensure((size_t)(n_bins + 1) * 8))) return rc;
+    auto* hist = reinterpret_cast<unsigned long long*>(c->aux.p);
+    BESST_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(n_bins + 1) * 8, c->stream));
+    if (n) BESST_HIP_TRY(hipMemcpyAsync(c->sample_a.p, values, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_value_histogram(c->stream, c->sample_a.p, n, n_bins, hist, hist + n_bins))) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(hist_out, hist, (size_t)n_bins * 8, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(overflow, hist + n_bins, 8, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
 }
-int besst_ctx_score_edges(besst_ctx*, int64_t, const uint32_t*, const uint8_t*, const int32_t*, const int32_t*, double,
-                          double, double, double*, double*, int32_t*, uint8_t*) {
-    set_error("score_edges: not built yet");
-    return BESST_ERR_STATE;
+
+int besst_ctx_score_edges(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
+                          const int32_t* len2, double mean, double sigma, double read_len, double* gap, double* sd0,
+                          int32_t* ks_h, uint8_t* flags) {
+    BESST_NEED_BUILT(c);
+    BESST_REQUIRE(n_edges >= 0, "score_edges: negative edge count");
+    if (n_edges == 0) return BESST_OK;
+    BESST_REQUIRE(row && swap && len1 && len2 && gap && sd0 && ks_h && flags, "score_edges: null pointer");
+    BESST_REQUIRE(sigma > 0.0, "score_edges: sigma must be positive");
+    int rc = use_device(c);
+    if (rc) return rc;
+    // scratch offsets for edges too large for the LDS sort
+    std::vector<uint32_t> h_n((size_t)c->n_rows);
+    BESST_HIP_TRY(hipMemcpyAsync(h_n.data(), c->row_n.p, (size_t)c->n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> big_off((size_t)n_edges, 0ull);
+    unsigned long long big_total = 0;
+    for (int64_t e = 0; e < n_edges; ++e) {
+        BESST_REQUIRE((int64_t)row[e] < c->n_rows, "score_edges: row index out of range");
+        const uint32_t n = h_n[row[e]];
+        BESST_REQUIRE(n >= 1, "score_edges: empty row");
+        unsigned long long np = 1;
+        while (np < n) np <<= 1;
+        if (np > 8192) { big_off[(size_t)e] = big_total; big_total += 2 * np; }
+    }
+    const size_t m = (size_t)n_edges;
+    const size_t in_bytes = align_up(m * 4, 256) + align_up(m, 256) + 2 * align_up(m * 4, 256);
+    const size_t out_bytes = 2 * align_up(m * 8, 256) + align_up(m * 4, 256) + align_up(m, 256);
+    const size_t ws_bytes = align_up(m * 8, 256) + align_up((size_t)big_total * 4 + 4, 256);
+    if ((rc = c->aux.ensure(in_bytes + out_bytes + ws_bytes))) return rc;
+    char* p = c->aux.p;
+    auto take = [&p](size_t bytes) { char* q = p; p += align_up(bytes, 256); return q; };
+    auto* d_row = reinterpret_cast<uint32_t*>(take(m * 4));
+    auto* d_swap = reinterpret_cast<uint8_t*>(take(m));
+    auto* d_len1 = reinterpret_cast<int32_t*>(take(m * 4));
+    auto* d_len2 = reinterpret_cast<int32_t*>(take(m * 4));
+    auto* d_gap = reinterpret_cast<double*>(take(m * 8));
+    auto* d_sd0 = reinterpret_cast<double*>(take(m * 8));
+    auto* d_ks = reinterpret_cast<int32_t*>(take(m * 4));
+    auto* d_flags = reinterpret_cast<uint8_t*>(take(m));
+    char* d_ws = p;
+    BESST_HIP_TRY(hipMemcpyAsync(d_row, row, m * 4, hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(d_swap, swap, m, hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(d_len1, len1, m * 4, hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(d_len2, len2, m * 4, hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(d_ws, big_off.data(), m * 8, hipMemcpyHostToDevice, c->stream));
+    ScoreArgs a;
+    a.row = d_row; a.swap = d_swap; a.len1 = d_len1; a.len2 = d_len2;
+    a.row_n = c->row_n.p; a.row_sum = c->row_sum.p; a.row_offset = c->row_offset.p;
+    a.obs_lo = c->obs_lo.p; a.obs_hi = c->obs_hi.p;
+    a.mean = mean; a.sigma = sigma; a.read_len = read_len;
+    a.n_edges = n_edges;
+    if ((rc = launch_score(c->stream, a, d_gap, d_sd0, d_ks, d_flags, d_ws, ws_bytes))) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(gap, d_gap, m * 8, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(sd0, d_sd0, m * 8, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(ks_h, d_ks, m * 4, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(flags, d_flags, m, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
 }
-}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""Library statistics: drop-in for ``BESST/libmetrics.py`` with the record scans on the MI355X.
+
+``get_metrics(bam_file, param, Information)`` keeps the reference signature and mutates ``param``
+exactly like libmetrics.py:226-432 does (read_len, mean/std of the insert size, -T/-k thresholds,
+skewness, GetDistr-adjusted distribution, log-normal switch, PE-contamination metrics).
+
+Split of work:
+  * device (csrc/metrics.hip, one ordered pass): the three ``for read in bam_file`` scans - predicate
+    evaluation, membership in the 1000 longest references, the "first 1,000,000 in stream order"
+    cut-offs, and order-preserving compaction of the |tlen| samples;
+  * host (this file): the float finishing on the <= 1,000,000 sampled values.  The reference's results
+    depend on the exact order of its float additions (naive left-to-right ``sum``, expanded-square
+    variance, repeated ``+= 1/w`` in GetDistr), so these loops replay that order literally; explicit
+    accumulation is used instead of ``sum()`` because CPython >= 3.12 sums floats with compensation.
+
+There is no CPU path for the scans: without libbesst_amd.so and a GPU the call raises.
+"""
+from __future__ import print_function
+
+import math
+import sys
+
+import numpy as np
+
+from . import session
+from .mathstats_compat import MaxObsDistr
+
+
+def _acc(values):
+    total = 0
+    for v in values:
+        total = total + v
+    return total
+
+
+def _mean_and_std(xs):
+    n = float(len(xs))
+    mean = _acc(xs) / n
+    sq = 0
+    for x in xs:
+        sq = sq + (x ** 2 - 2 * x * mean + mean ** 2)
+    return mean, (sq / (n - 1)) ** 0.5
+
+
+def AdjustInsertsizeDist(param, mean_insert, std_dev_insert, insert_list):
+    """One trimming round: keep observations within 1.5 * MaxObsDistr(n, 0.95) sigmas (libmetrics.py:22-28)."""
+    k = 1.5 * MaxObsDistr(len(insert_list), 0.95)
+    lo, hi = mean_insert - k * std_dev_insert, mean_insert + k * std_dev_insert
+    kept = [x for x in insert_list if (x < hi and x > lo)]
+    return len(insert_list) > len(kept), kept
+
+
+def largest_reference_indexes(lengths, k=1000):
+    """Indexes of the k longest references; ties go to the smaller index (heapq.nlargest, libmetrics.py:233)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    order = np.lexsort((np.arange(lengths.shape[0]), -lengths))
+    return order[:k]
+
+
+def getdistr(ins_size_reads, cont_lengths_list, param, Information):
+    """GetDistr observation-bias correction (libmetrics.py:141-223), quirks included."""
+    largest = sorted(int(x) for x in sorted(cont_lengths_list, reverse=True)[:1000])
+    max_isize = int(max(ins_size_reads))
+    adjusted = [0] * int(max_isize + 1)
+    cur_sum = _acc(largest)
+    cur_nr = len(largest)
+    at_least = [(cur_nr, cur_sum)]           # index obs -> (#contigs, their total length) for isize obs-1
+    smallest, smallest_index = largest[0], 0
+    upper_isize = min(max_isize + 1, largest[-1])
+    for isize in range(upper_isize):
+        if isize > smallest:
+            while isize > largest[smallest_index]:
+                smallest_index += 1
+                cur_nr -= 1
+                cur_sum -= smallest          # the reference subtracts the not-yet-updated value (:164-170)
+            at_least.append((cur_nr, cur_sum))
+            smallest = largest[smallest_index]
+        else:
+            at_least.append((cur_nr, cur_sum))
+    for o in ins_size_reads:
+        obs = int(o)
+        if obs > upper_isize:
+            continue
+        nr_ctgs, sum_ctgs = at_least[obs]
+        adjusted[obs] += 1 / float(max(sum_ctgs - (obs - 1) * nr_ctgs, 10000))
+
+    tot_density = float(_acc(adjusted))
+    cum, curr = 0, 0
+    while cum <= tot_density / 2.0:
+        cum += adjusted[curr]
+        curr += 1
+    median_adj = curr
+
+    modes = []
+    for chunk_size in range(1, 102, 5):
+        best_i, best_v = 0, None
+        for ci, start in enumerate(range(0, len(adjusted), chunk_size)):
+            v = _acc(adjusted[start:start + chunk_size])
+            if best_v is None or v > best_v:
+                best_i, best_v = ci, v
+        mode = (best_i + 0.5) * chunk_size
+        modes.append(int(mode))
+        print('mode for chunk size ', chunk_size, ' : ', mode, file=Information)
+    mode_adj = sorted(modes)[int(len(modes) / 2)]
+
+    mu_adj = _acc([i * f for i, f in enumerate(adjusted)]) / tot_density
+    sigma_adj = math.sqrt(_acc([(i - mu_adj) ** 2 * f for i, f in enumerate(adjusted)]) / tot_density)
+    m_3 = _acc([(i - mu_adj) ** 3 * f for i, f in enumerate(adjusted)]) / tot_density
+    skew_adj = m_3 / sigma_adj ** 3
+    return adjusted, mu_adj, sigma_adj, skew_adj, median_adj, mode_adj
+
+
+def _finish_contamination(contamination_reads, counter_total, param, Information):
+    """Trimming and acceptance rule of get_contamination_metrics (libmetrics.py:86-128)."""
+    n_contamine = float(len(contamination_reads))
+    mean_isize, std_dev_isize = 0, 0
+    if n_contamine > 2:
+        mean_isize, std_dev_isize = _mean_and_std(contamination_reads)
+        print('Contamine mean before filtering :', mean_isize, file=Information)
+        print('Contamine stddev before filtering: ', std_dev_isize, file=Information)
+        extreme_obs_occur = True
+        while extreme_obs_occur:
+            extreme_obs_occur, filtered = AdjustInsertsizeDist(param, mean_isize, std_dev_isize, contamination_reads)
+            n_contamine = float(len(filtered))
+            if n_contamine > 2:
+                mean_isize, std_dev_isize = _mean_and_std(filtered)
+                contamination_reads = filtered
+            else:
+                break
+        print('Contamine mean converged:', mean_isize, file=Information)
+        print('Contamine std_est converged: ', std_dev_isize, file=Information)
+    ratio = 2 * n_contamine / float(counter_total) if counter_total > 0 else 0
+    if mean_isize >= param.mean_ins_size or std_dev_isize >= param.std_dev_ins_size or ratio <= 0.05:
+        param.contamination_ratio = False
+        param.contamination_mean = 0
+        param.contamination_stddev = 0
+    else:
+        param.contamination_mean = mean_isize
+        param.contamination_stddev = std_dev_isize
+        param.contamination_ratio = ratio
+    return n_contamine
+
+
+def _set_thresholds(param):
+    param.ins_size_threshold = param.mean_ins_size + 6 * param.std_dev_ins_size
+    if param.extend_paths:
+        param.contig_threshold = param.mean_ins_size + 4 * param.std_dev_ins_size
+    else:
+        param.contig_threshold = param.mean_ins_size + \
+            (param.std_dev_ins_size / float(param.mean_ins_size)) * param.std_dev_ins_size
+
+
+def get_metrics(bam_file, param, Information):
+    sess = session.open_session(bam_file)
+    batch = sess.batch
+    cont_lengths_list = list(batch.lengths)
+    top = largest_reference_indexes(cont_lengths_list)
+    param.lognormal = False
+
+    if not param.read_len:                                        # libmetrics.py:246-273
+        if len(batch) < 1000:
+            sys.stderr.write('Did not get sufficient readmappings to calculate read_length from mappings. '
+                             'Got {0} mappings. Please provide this parameter or more importantly check why '
+                             'almost no reads are mapping to the contigs.\nterminating..\n'.format(len(batch)))
+            sys.exit(0)
+        rlen = (batch.rlen if batch.rlen is not None else batch.qlen)[:1000].astype(np.int64)
+        alen = (batch.alen if batch.alen is not None else batch.qlen)[:1000].astype(np.int64)
+        param.read_len = int(np.where(rlen != 0, rlen, alen).sum()) / float(1000)
+
+    if param.mean_ins_size and param.std_dev_ins_size and not param.ins_size_threshold:   # :275-281
+        _set_thresholds(param)
+        print('-T', param.ins_size_threshold, '-t', param.contig_threshold, file=Information)
+
+    want_isize = not param.mean_ins_size
+    top_mask = np.zeros(len(cont_lengths_list), dtype=np.uint8)
+    top_mask[top] = 1
+    abs_isize, abs_contam, counts = sess.metrics_sample(top_mask, param.orientation, param.min_mapq,
+                                                        param.read_len, want_isize)
+
+    if want_isize:                                                # :283-390
+        if param.orientation == 'fr':
+            ins_size_reads = abs_isize.tolist()
+        else:
+            two_r = 2 * param.read_len
+            ins_size_reads = [x + two_r for x in abs_isize.tolist()]
+        print('Estimating insert size from {0} mappings with quality over --min_mapq {1}.'.format(
+            len(ins_size_reads) + 1, param.min_mapq), file=Information)
+        if len(ins_size_reads) <= 1000:
+            sys.stderr.write('To few valid read alignments exists to compute mean and variance of library (need at '
+                             'least 1000 observations). Got only ' + str(len(ins_size_reads)) +
+                             ' valid alignments. Please specify -m and -s to the program. \nPrinting out '
+                             'scaffolds produced in earlier steps...\nterminating...\n')
+            sys.exit(0)
+        mean_isize, std_dev_isize = _mean_and_std(ins_size_reads)
+        print('Mean before filtering :', mean_isize, file=Information)
+        print('Std_est  before filtering: ', std_dev_isize, file=Information)
+        extreme_obs_occur = True
+        while extreme_obs_occur:
+            extreme_obs_occur, filtered = AdjustInsertsizeDist(param, mean_isize, std_dev_isize, ins_size_reads)
+            mean_isize, std_dev_isize = _mean_and_std(filtered)
+            ins_size_reads = filtered
+        mean_isize, std_dev_isize = _mean_and_std(ins_size_reads)
+        print('Mean converged:', mean_isize, file=Information)
+        print('Std_est converged: ', std_dev_isize, file=Information)
+        param.mean_ins_size = mean_isize
+        param.std_dev_ins_size = std_dev_isize
+        n = float(len(ins_size_reads))
+        param.skewness = (_acc([(x - mean_isize) ** 3 for x in ins_size_reads]) / n) / std_dev_isize ** 3
+        print('Skewness of distribution: ', param.skewness, file=Information)
+
+        adj_distr, mu_adj, sigma_adj, skew_adj, median_adj, mode_adj = getdistr(
+            ins_size_reads, cont_lengths_list, param, Information)
+        param.skew_adj = skew_adj
+        param.empirical_distribution = dict(zip(range(len(adj_distr)), adj_distr))
+        print('Mean of getdistr adjusted distribution: ', mu_adj, file=Information)
+        print('Sigma of getdistr adjusted distribution: ', sigma_adj, file=Information)
+        print('Skewness of getdistr adjusted distribution: ', skew_adj, file=Information)
+        print('Median of getdistr adjusted distribution: ', median_adj, file=Information)
+        print('Mode of getdistr adjusted distribution: ', mode_adj, file=Information)
+        print('Using mean and stddev of getdistr adjusted distribution from here: ', mu_adj, sigma_adj,
+              file=Information)
+        param.mean_ins_size = mu_adj
+        param.std_dev_ins_size = sigma_adj
+        if param.skew_adj > 0.5 and math.log(median_adj) > math.log(mode_adj):
+            param.lognormal_mean = math.log(median_adj)
+            param.lognormal_sigma = math.sqrt(param.lognormal_mean - math.log(mode_adj))
+            print('Lognormal mean getdistr adjusted: ', param.lognormal_mean, file=Information)
+            print('Lognormal stddev getdistr adjusted', param.lognormal_sigma, file=Information)
+            param.lognormal = True
+
+    if not param.ins_size_threshold:                              # :404-409
+        _set_thresholds(param)
+
+    # contamination: opposite-orientation pairs on the 1000 longest references (:49-131,412)
+    if param.orientation == 'fr':
+        two_r = 2 * param.read_len
+        contamination_reads = [x + two_r for x in abs_contam.tolist()]
+    else:
+        contamination_reads = abs_contam.tolist()
+    n_contamine = _finish_contamination(contamination_reads, counts.counter_total, param, Information)
+
+    print('', file=Information)
+    print('LIBRARY STATISTICS', file=Information)
+    print('Mean of library set to:', param.mean_ins_size, file=Information)
+    print('Standard deviation of library set to: ', param.std_dev_ins_size, file=Information)
+    print('MP library PE contamination:', file=Information)
+    print('Contamine rate (rev comp oriented) estimated to: ', param.contamination_ratio, file=Information)
+    print('lib contamine mean (avg fragmentation size): ', param.contamination_mean, file=Information)
+    print('lib contamine stddev: ', param.contamination_stddev, file=Information)
+    print('Number of contamined reads used for this calculation: ', n_contamine, file=Information)
+    print('-T (library insert size threshold) set to: ', param.ins_size_threshold, file=Information)
+    print('-k set to (Scaffolding with contigs larger than): ', param.contig_threshold, file=Information)
+    print('Number of links required to create an edge: ', param.edgesupport, file=Information)
+    print('Maximum identical contig-end overlap-length to merge of contigs that are adjacent in a scaffold: ',
+          param.max_contig_overlap, file=Information)
+    print('Read length set to: ', param.read_len, file=Information)
+    print('', file=Information)
+    return ()

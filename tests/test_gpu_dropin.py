@@ -1,0 +1,121 @@
+"""GPU parity of the drop-in entry points (get_metrics + PE) against the golden vectors of the real reference."""
+import io
+import tempfile
+
+import pytest
+
+from besst_amd import Contig, CreateGraph, Parameter, Scaffold, libmetrics, session
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+
+def make_param(overrides):
+    p = Parameter.parameter()
+    p.scaffold_indexer = 1
+    p.min_mapq = 11
+    p.lower_cov_cutoff = 0.001
+    p.cov_cutoff = None
+    p.first_lib = True
+    p.orientation = 'fr'
+    p.detect_duplicate = True
+    p.extend_paths = True
+    p.no_score = False
+    p.detect_haplotype = False
+    p.print_scores = False
+    p.max_contig_overlap = 200
+    p.pass_number = 1
+    p.information_file = io.StringIO()
+    p.output_directory = tempfile.mkdtemp(prefix='besst_amd_')
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def state_from_layout(doc, batch, threshold):
+    lay = doc['layout']
+    Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+    by_scaf = {}
+    for tid in range(len(batch.references)):
+        by_scaf.setdefault(lay['scaf_id'][tid], []).append(tid)
+    for sid, tids in by_scaf.items():
+        objs = []
+        for t in tids:
+            c = Contig.contig(batch.references[t], contig_scaffold=sid, contig_direction=bool(lay['direction'][t]),
+                              contig_position=lay['position'][t], contig_length=batch.lengths[t], contig_sequence='')
+            objs.append(c)
+        s = Scaffold.scaffold(sid, objs, lay['scaf_len'][tids[0]])
+        big = s.s_length >= threshold
+        (Scaffolds if big else small_scaffolds)[sid] = s
+        for c in objs:
+            (Contigs if big else small_contigs)[c.name] = c
+    return Contigs, Scaffolds, small_contigs, small_scaffolds
+
+
+def edge_rows(G, with_score):
+    rows = []
+    for u, v in G.edges():
+        d = G[u][v]
+        if d['nr_links'] is None:
+            continue
+        row = dict(u=list(u), v=list(v), nr_links=d['nr_links'], obs=d['obs'], obs_sq=d['obs_sq'])
+        if with_score:
+            for k in ('gap', 'score'):
+                if k in d:
+                    row[k] = d[k]
+        rows.append(row)
+    return rows
+
+
+@pytest.mark.parametrize('name', GU.scenario_names())
+def test_dropin_matches_reference_golden(name):
+    doc, batch = GU.load(name)
+    param = make_param(doc['overrides'])
+    info = param.information_file
+    libmetrics.get_metrics(batch, param, info)
+    for k, want in doc['metrics'].items():
+        if k == 'empirical_distribution':
+            ed = getattr(param, 'empirical_distribution', None)
+            got = None if ed is None else [ed[i] for i in range(len(ed))]
+        else:
+            got = getattr(param, k, None)
+        assert got == want, (name, k, got, want)     # library metrics: bit exact
+    if doc['layout'] is not None:
+        Contigs, Scaffolds, small_contigs, small_scaffolds = state_from_layout(doc, batch, doc['layout_threshold'])
+        param.scaffold_indexer = doc['layout']['next_scaffold_id']
+        param.tot_assembly_length = sum(batch.lengths)
+    else:
+        Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+    lens = dict(zip(batch.references, batch.lengths))
+    C_dict = {n: 'A' * int(lens.get(n, 10)) for n in doc['fasta_names']}
+    G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, batch)
+    session.close_session(batch)
+    fin = doc['final']
+    # structure, counts and integer sums: bit exact, same iteration order as the reference's graphs
+    assert edge_rows(G, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G']]
+    assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
+    assert [list(n) for n in G.nodes()] == fin['G_nodes']
+    assert [list(n) for n in G_prime.nodes()] == fin['G_prime_nodes']
+    assert [[c.name, c.scaffold, c.coverage] for c in Contigs.values()] == fin['contigs']
+    assert [[c.name, c.scaffold, c.coverage] for c in small_contigs.values()] == fin['small_contigs']
+    assert list(Scaffolds) == fin['scaffolds'] and list(small_scaffolds) == fin['small_scaffolds']
+    for k in ('mean_coverage', 'std_dev_coverage', 'edgesupport', 'expected_links_over_mean_plus_stddev',
+              'scaffold_indexer', 'tot_assembly_length', 'current_N50', 'current_L50'):
+        assert getattr(param, k) == fin['param'][k], (name, k)
+    # gap within +-1 bp, score within 1e-9 (device erf/exp are not bit-identical to libm)
+    got = {(tuple(e['u']), tuple(e['v'])): e for e in edge_rows(G, True)}
+    n_exact = 0
+    for e in fin['G']:
+        g = got[(tuple(e['u']), tuple(e['v']))]
+        assert abs(g['gap'] - e['gap']) <= 1, (name, e, g)
+        if g['gap'] == e['gap']:
+            n_exact += 1
+            assert abs(g['score'] - e['score']) <= 1e-9, (name, e, g)
+    assert n_exact >= 0.9 * len(fin['G'])
+    # observation lists keep BAM order
+    snap = doc['after_loop']
+    want_obs = {frozenset((tuple(e['u']), tuple(e['v']))): e['observations'] for e in snap['G_prime']}
+    for u, v in G_prime.edges():
+        d = G_prime[u][v]
+        if d['nr_links'] is not None:
+            assert d['observations'] == want_obs[frozenset((u, v))]
