@@ -327,7 +327,25 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                        const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
                        int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
                        int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
-                       besst_counters* counters, void* workspace, size_t workspace_bytes) {
+                       besst_counters* counters, void* workspace, size_t workspace_bytes);
+
+int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
+                     const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
+                     int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map) {
+    BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
+    BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
+                                    row_first && row_offset && obs_lo && obs_hi),
+                  "reduce: null buffer");
+    return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
+                              row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
+                              workspace, workspace_bytes, first_map);
+}
+
+static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                              const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                              int64_t n_contigs, const void* contig_table, const besst_lib_params* p,
+                              int32_t node_bits) {
     BESST_REQUIRE(p, "classify: null params");
     BESST_REQUIRE(n >= 0, "classify: negative record count");
     BESST_REQUIRE(n == 0 || (tid && mtid && pos && mpos && flag && mapq && qlen), "classify: null column");
@@ -335,12 +353,10 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                       aligned16(mapq) && aligned16(qlen),
                   "classify: record columns must be 16-byte aligned");
     BESST_REQUIRE(contig_table && aligned16(contig_table), "classify: contig table null or misaligned");
-    BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
     BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "classify: n_contigs out of range");
     BESST_REQUIRE(node_bits >= 1 && node_bits <= 29, "classify: node_bits must be in [1, 29]");
     BESST_REQUIRE(p->orientation == 0 || p->orientation == 1, "classify: orientation must be 0 or 1");
     BESST_REQUIRE(p->ins_size_threshold < 1073741824.0, "classify: ins_size_threshold must be below 2^30");
-    ClassifyArgs a;
     a.tid = tid; a.mtid = mtid; a.pos = pos; a.mpos = mpos; a.flag = flag; a.mapq = mapq; a.qlen = qlen;
     a.table = static_cast<const ContigRow*>(contig_table);
     a.n = n;
@@ -353,21 +369,68 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
     a.detect_dup = p->detect_duplicate;
     a.extend_paths = p->extend_paths;
     a.no_score = p->no_score;
+    return BESST_OK;
+}
+
+int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                       const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                       int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
+                       int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
+                       besst_counters* counters, void* workspace, size_t workspace_bytes) {
+    ClassifyArgs a;
+    int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
+    if (rc) return rc;
+    BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
     return launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
                            workspace, workspace_bytes);
 }
 
-int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
-                     const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
-                     int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                     uint32_t* n_rows, void* workspace, size_t workspace_bytes) {
-    BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
-    BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
-                                    row_first && row_offset && obs_lo && obs_hi),
-                  "reduce: null buffer");
-    return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
-                              row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
-                              workspace, workspace_bytes);
+int besst_dev_classify_scan(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                            const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                            int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
+                            int64_t* aligned, besst_counters* counters, void* workspace, size_t workspace_bytes) {
+    ClassifyArgs a;
+    int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
+    if (rc) return rc;
+    BESST_REQUIRE(aligned && counters, "classify_scan: null output");
+    return launch_classify_scan(static_cast<hipStream_t>(stream), a, aligned, counters, workspace, workspace_bytes);
+}
+
+int besst_dev_classify_tail(void* stream, int64_t n, int32_t* tail, void* workspace, size_t workspace_bytes) {
+    BESST_REQUIRE(tail, "classify_tail: null output");
+    return launch_classify_tail(static_cast<hipStream_t>(stream), n, tail, workspace, workspace_bytes);
+}
+
+int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, int32_t* carry) {
+    BESST_REQUIRE(tails && carry && rank >= 0, "resolve_carry: bad argument");
+    return launch_resolve_carry(static_cast<hipStream_t>(stream), tails, rank, carry);
+}
+
+int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
+                            uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
+                            size_t workspace_bytes) {
+    BESST_REQUIRE(carry && keys && payload && n_out && counters, "classify_emit: null pointer");
+    return launch_classify_emit(static_cast<hipStream_t>(stream), n, detect_duplicate, carry, keys, payload, n_out,
+                                counters, workspace, workspace_bytes);
+}
+
+size_t besst_dev_exchange_region_bytes(int64_t pair_capacity) { return exchange_region_bytes(pair_capacity); }
+
+uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world) { return owner_of_scaffold(scaffold_id, world ? world : 1); }
+
+int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits, int32_t world,
+                        const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity, void* send_buffer,
+                        void* workspace, size_t workspace_bytes) {
+    BESST_REQUIRE(n_tuples && keys && payload && send_buffer, "partition: null pointer");
+    return launch_partition(static_cast<hipStream_t>(stream), capacity, n_tuples, node_bits, world, keys, payload,
+                            pair_capacity, send_buffer, workspace, workspace_bytes);
+}
+
+int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
+                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow) {
+    BESST_REQUIRE(recv_buffer && keys && payload && gidx && n_out && overflow, "unpack: null pointer");
+    return launch_unpack(static_cast<hipStream_t>(stream), world, pair_capacity, recv_buffer, keys, payload, gidx,
+                         n_out, overflow);
 }
 
 int besst_ctx_build_graph(besst_ctx* c) {
@@ -413,7 +476,7 @@ int besst_ctx_build_graph(besst_ctx* c) {
     if ((rc = c->ws.ensure(reduce_workspace_bytes(L)))) return rc;
     rc = besst_dev_reduce(c->stream, L, &sb->n_out, 2 * c->node_bits + 1, c->keys.p, c->payload.p, c->row_key.p,
                           c->row_mask.p, c->row_n.p, c->row_sum.p, c->row_sum_sq.p, c->row_first.p, c->row_offset.p,
-                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap);
+                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap, nullptr);
     if (rc) return rc;
     BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
     BESST_HIP_TRY(hipStreamSynchronize(c->stream));

@@ -531,36 +531,107 @@ size_t classify_workspace_bytes(int64_t n) {
     return carve(nullptr, n).total;
 }
 
-int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned,
-                    uint64_t* keys, uint64_t* payload, uint32_t* n_out, besst_counters* counters,
-                    void* ws, size_t ws_bytes) {
-    if (a.n <= 0) {
-        BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
-        return BESST_OK;
+namespace {
+
+// last record of the slice that reached CreateEdge: {has, obs1, obs2, 0}
+__global__ __launch_bounds__(256) void tail_kernel(const BlockSummary* __restrict__ summ, uint32_t nblocks,
+                                                   int32_t* __restrict__ tail) {
+    __shared__ int s_best[4];
+    int best = -1;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x)
+        if (summ[b].has_reach) best = (int)b > best ? (int)b : best;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = __shfl_xor(best, d, 64);
+        best = o > best ? o : best;
     }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
+        tail[0] = best >= 0 ? 1 : 0;
+        tail[1] = best >= 0 ? summ[best].last_o1 : 0;
+        tail[2] = best >= 0 ? summ[best].last_o2 : 0;
+        tail[3] = 0;
+    }
+}
+
+__global__ void zero_tail_kernel(int32_t* tail) {
+    if (threadIdx.x < 4) tail[threadIdx.x] = 0;
+}
+
+// prev_obs entering rank `rank`: the tail of the nearest earlier rank that has one, else what is in carry
+__global__ void resolve_carry_kernel(const int32_t* __restrict__ tails, int rank, int32_t* __restrict__ carry) {
+    if (threadIdx.x != 0) return;
+    for (int j = 0; j < rank; ++j)
+        if (tails[j * 4]) { carry[0] = tails[j * 4 + 1]; carry[1] = tails[j * 4 + 2]; }
+}
+
+}  // namespace
+
+int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
+                         void* ws, size_t ws_bytes) {
+    if (a.n <= 0) return BESST_OK;
     BESST_REQUIRE(a.n < (int64_t)1 << 32, "classify: more than 2^32-1 records in one call");
     const ClsWorkspace w = carve(ws, a.n);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
-    auto* ctr = reinterpret_cast<unsigned long long*>(counters);
-    {
-        ProfScope ps(s, kProfClassify);
-        hipLaunchKernelGGL(classify_kernel, dim3(nblocks), dim3(kClsThreads), 0, s, a,
-                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload,
-                           w.summ, ctr);
-    }
-    {
-        ProfScope ps(s, kProfStitch);
-        hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry,
-                           a.detect_dup, w.offsets, w.skip, n_out, ctr);
-    }
-    {
-        ProfScope ps(s, kProfCompact);
-        hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip,
-                           w.seg_keys, w.seg_payload, keys, payload);
+    ProfScope ps(s, kProfClassify);
+    hipLaunchKernelGGL(classify_kernel, dim3(nblocks), dim3(kClsThreads), 0, s, a,
+                       reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ,
+                       reinterpret_cast<unsigned long long*>(counters));
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes) {
+    if (n <= 0) {
+        hipLaunchKernelGGL(zero_tail_kernel, dim3(1), dim3(64), 0, s, tail);
+    } else {
+        const ClsWorkspace w = carve(ws, n);
+        BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
+        hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(256), 0, s, w.summ, (uint32_t)((n + kClsTile - 1) / kClsTile), tail);
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
+}
+
+int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry) {
+    hipLaunchKernelGGL(resolve_carry_kernel, dim3(1), dim3(64), 0, s, tails, rank, carry);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
+                         uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
+                         size_t ws_bytes) {
+    if (n <= 0) {
+        BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
+        return BESST_OK;
+    }
+    const ClsWorkspace w = carve(ws, n);
+    BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
+    const uint32_t nblocks = (uint32_t)((n + kClsTile - 1) / kClsTile);
+    auto* ctr = reinterpret_cast<unsigned long long*>(counters);
+    {
+        ProfScope ps(s, kProfStitch);
+        hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                           w.skip, n_out, ctr);
+    }
+    {
+        ProfScope ps(s, kProfCompact);
+        hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
+                           w.seg_payload, keys, payload);
+    }
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned, uint64_t* keys,
+                    uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws, size_t ws_bytes) {
+    int rc = launch_classify_scan(s, a, aligned, counters, ws, ws_bytes);
+    if (rc) return rc;
+    return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes);
 }
 
 }  // namespace besst

@@ -108,18 +108,45 @@ constexpr int kRedTile = kRedThreads * kRedItems;      // 2048 tuples per block
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// digit selector of the radix kernels: mode 0 = 8-bit digit at `shift`, mode 1 = owner rank of the key
+struct DigitSel {
+    int mode;
+    int shift;
+    int node_bits;
+    uint32_t world;
+};
+
+// Owner rank of a scaffold's edges (multi-GPU key partition): multiplicative hash, then mod world.
+__host__ __device__ inline uint32_t owner_of_scaffold(uint32_t scaffold_id, uint32_t world) {
+    return ((scaffold_id * 2654435761u) >> 15) % world;
+}
+
 // ---- stage launchers (defined in the .hip files) -----------------------------------------------------
 size_t classify_workspace_bytes(int64_t n);
 int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned,
                     uint64_t* keys, uint64_t* payload, uint32_t* n_out, besst_counters* counters,
                     void* ws, size_t ws_bytes);
+// the same split in three phases for the multi-GPU path (the duplicate chain crosses rank boundaries)
+int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
+                         void* ws, size_t ws_bytes);
+int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes);
+int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry);
+int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
+                         uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
+                         size_t ws_bytes);
 
 size_t reduce_workspace_bytes(int64_t cap);
 int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
                        const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                       uint32_t* n_rows, void* ws, size_t ws_bytes);
+                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr);
+size_t exchange_region_bytes(int64_t pair_cap);
+int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
+                     const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
+                     size_t ws_bytes);
+int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow);
 
 struct MetricsArgs {
     const int32_t* tid;

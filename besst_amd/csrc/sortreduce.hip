@@ -23,12 +23,19 @@ namespace {
 
 __device__ __forceinline__ uint32_t nblocks_of(uint32_t n, uint32_t tile) { return (n + tile - 1) / tile; }
 
+// digit of a key: a radix digit (mode 0) or the owning rank of the key's min scaffold (mode 1)
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
+    if (ds.mode == 0) return (uint32_t)(key >> ds.shift) & (kRadix - 1);
+    const uint32_t scaf = (uint32_t)(key >> (2 + ds.node_bits));   // key = ((min_node << nb) | max_node) << 1 | f
+    return owner_of_scaffold(scaf, ds.world);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // radix sort
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys,
                                                                   const uint32_t* __restrict__ n_ptr,
-                                                                  int shift, uint32_t* __restrict__ table,
+                                                                  DigitSel ds, uint32_t* __restrict__ table,
                                                                   uint32_t stride) {
     const uint32_t n = *n_ptr;
     const uint32_t b = blockIdx.x;
@@ -41,7 +48,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t i = base + r * kSortThreads + t;
-        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (kRadix - 1)], 1u);
+        if (i < n) atomicAdd(&s_hist[digit_of(keys[i], ds)], 1u);
     }
     __syncthreads();
     table[(uint32_t)t * stride + b] = s_hist[t];
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
 template <bool kFirst>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-    const uint32_t* __restrict__ n_ptr, int shift, const uint32_t* __restrict__ table, uint32_t stride,
+    const uint32_t* __restrict__ n_ptr, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
     const uint32_t* __restrict__ row_total, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ idx_out) {
     const uint32_t n = *n_ptr;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const bool valid = i < n;
         key[r] = valid ? keys_in[i] : ~0ull;
         idx[r] = kFirst ? i : (valid ? idx_in[i] : 0u);
-        const uint32_t d = (uint32_t)(key[r] >> shift) & (kRadix - 1);
+        const uint32_t d = valid ? digit_of(key[r], ds) : (kRadix - 1);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int bit = 0; bit < kRadixBits; ++bit) {
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
     uint32_t* __restrict__ row_mask, uint32_t* __restrict__ row_n,
     unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
     uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo,
-    int32_t* __restrict__ obs_hi) {
+    int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map) {
     const uint32_t n = *n_ptr;
     const uint32_t b = blockIdx.x;
     if (b >= nblocks_of(n, kRedTile)) return;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
         if (head[k]) {
             row_key[row] = key[k];
             row_mask[row] = hi >> 30;
-            row_first[row] = src;
+            row_first[row] = first_map ? first_map[src] : src;
             row_offset[row] = i;
         }
         const unsigned long long o = (unsigned long long)((long long)o_lo + o_hi);
@@ -352,7 +359,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                       uint32_t* n_rows, void* ws, size_t ws_bytes) {
+                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map) {
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
     BESST_REQUIRE(key_bits >= 1 && key_bits <= 64, "reduce: key_bits out of range");
     if (cap == 0) {
@@ -367,7 +374,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRadixBits;
+        const DigitSel shift{0, p * kRadixBits, 0, 1u};
         uint64_t* kout = w.keys[p & 1];
         uint32_t* iout = w.idx[p & 1];
         {
@@ -408,9 +415,127 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     hipLaunchKernelGGL(row_reduce_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, iin, payload, n_tuples,
                        w.blk_base, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                        reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset, obs_lo,
-                       obs_hi);
+                       obs_hi, first_map);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU exchange: stable partition of the tuple stream by owner rank, packed into fixed-capacity
+// regions (one per destination) for a single equal-split all-to-all, and the matching unpack.
+//   region d = [ header 64 B | keys pair_cap x 8 | payload pair_cap x 8 | idx pair_cap x 4 ]
+//   header   = { count sent (<= pair_cap), tuples the source wanted to send, source's total n_out, 0.. }
+// Stable partitioning keeps each source's tuples in BAM order; regions arrive ordered by source rank and
+// ranks own contiguous slices of the stream, so the concatenation on the receiver is again in global BAM
+// order.  idx carries the tuple's position in its source's stream; the receiver turns it into a global
+// emit index (first-occurrence order across ranks).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint64_t* __restrict__ keys_sorted,
+                                                   const uint32_t* __restrict__ idx_sorted,
+                                                   const uint64_t* __restrict__ payload,
+                                                   const uint32_t* __restrict__ n_ptr,
+                                                   const uint32_t* __restrict__ owner_count, uint32_t world,
+                                                   uint32_t pair_cap, char* __restrict__ send, size_t region_bytes) {
+    __shared__ uint32_t s_pre[257];
+    const uint32_t n = *n_ptr;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t d = 0; d < world; ++d) { s_pre[d] = run; run += owner_count[d]; }
+        s_pre[world] = run;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < world) {
+        uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)threadIdx.x * region_bytes);
+        const uint32_t want = owner_count[threadIdx.x];
+        hdr[0] = want < pair_cap ? want : pair_cap;
+        hdr[1] = want;
+        hdr[2] = n;
+        hdr[3] = 0;
+    }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d = 0;
+    while (d + 1 < world && i >= s_pre[d + 1]) ++d;
+    const uint32_t p = i - s_pre[d];
+    if (p >= pair_cap) return;    // overflow: reported through hdr[1] > hdr[0]
+    char* region = send + (size_t)d * region_bytes + 64;
+    const uint32_t src = idx_sorted[i];
+    reinterpret_cast<uint64_t*>(region)[p] = keys_sorted[i];
+    reinterpret_cast<uint64_t*>(region + (size_t)pair_cap * 8)[p] = payload[src];
+    reinterpret_cast<uint32_t*>(region + (size_t)pair_cap * 16)[p] = src;
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ recv, uint32_t world, uint32_t pair_cap,
+                                                     size_t region_bytes, uint64_t* __restrict__ keys,
+                                                     uint64_t* __restrict__ payload, uint32_t* __restrict__ gidx,
+                                                     uint32_t* __restrict__ n_out, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t s_off[257], s_base[257];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, gb = 0, over = 0;
+        for (uint32_t sidx = 0; sidx < world; ++sidx) {
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(recv + (size_t)sidx * region_bytes);
+            s_off[sidx] = run;
+            s_base[sidx] = gb;
+            run += hdr[0];
+            gb += hdr[2];
+            over |= hdr[1] > hdr[0] ? 1u : 0u;
+        }
+        s_off[world] = run;
+        if (blockIdx.x == 0 && blockIdx.y == 0) { *n_out = run; if (over) *overflow = 1u; }
+    }
+    __syncthreads();
+    const uint32_t sidx = blockIdx.y;
+    const uint32_t cnt = s_off[sidx + 1] - s_off[sidx];
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= cnt) return;
+    const char* region = recv + (size_t)sidx * region_bytes + 64;
+    const uint32_t dst = s_off[sidx] + p;
+    keys[dst] = reinterpret_cast<const uint64_t*>(region)[p];
+    payload[dst] = reinterpret_cast<const uint64_t*>(region + (size_t)pair_cap * 8)[p];
+    gidx[dst] = s_base[sidx] + reinterpret_cast<const uint32_t*>(region + (size_t)pair_cap * 16)[p];
+}
+
+}  // namespace
+
+size_t exchange_region_bytes(int64_t pair_cap) { return 64 + (size_t)pair_cap * 20; }
+
+int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
+                     const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
+                     size_t ws_bytes) {
+    BESST_REQUIRE(world >= 1 && world <= 256, "partition: world size must be in [1, 256]");
+    BESST_REQUIRE(pair_cap > 0 && (pair_cap & 1) == 0, "partition: pair capacity must be a positive even number");
+    BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "partition: capacity out of range");
+    const RedWorkspace w = carve(ws, cap > 0 ? cap : 1);
+    BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "partition: workspace too small");
+    const size_t region = exchange_region_bytes(pair_cap);
+    const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
+    const DigitSel ds{1, 0, node_bits, (uint32_t)world};
+    if (cap > 0) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples, ds, w.table,
+                           w.stride);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table, w.stride,
+                           w.row_total);
+        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb_sort), dim3(kSortThreads), 0, s, keys, nullptr,
+                           n_tuples, ds, w.table, w.stride, w.row_total, w.keys[0], w.idx[0]);
+    }
+    const uint32_t nb_pack = (uint32_t)((cap + 255) / 256) + 1;
+    hipLaunchKernelGGL(pack_kernel, dim3(nb_pack), dim3(256), 0, s, w.keys[0], w.idx[0], payload, n_tuples,
+                       w.row_total, (uint32_t)world, (uint32_t)pair_cap, static_cast<char*>(send), region);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow) {
+    BESST_REQUIRE(world >= 1 && world <= 256, "unpack: world size must be in [1, 256]");
+    BESST_REQUIRE(pair_cap > 0, "unpack: pair capacity must be positive");
+    const size_t region = exchange_region_bytes(pair_cap);
+    hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)((pair_cap + 255) / 256), (uint32_t)world), dim3(256), 0, s,
+                       static_cast<const char*>(recv), (uint32_t)world, (uint32_t)pair_cap, region, keys, payload,
+                       gidx, n_out, overflow);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
 }  // namespace besst

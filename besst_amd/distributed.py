@@ -1,0 +1,198 @@
+"""Multi-GPU scaffold-graph build: one process per GPU, RCCL over xGMI.
+
+Partitioning
+  phase 1 (stream order)  rank r owns the r-th contiguous slice of the (tid,pos)-sorted record stream and
+                          runs the per-record kernel on it.  CreateEdge's duplicate rule compares a record
+                          with the previous record that reached CreateEdge *anywhere earlier in the stream*
+                          (CreateGraph.py:835-838,869-870), so every rank publishes the last such observation
+                          of its slice (16 bytes) and picks its incoming prev_obs from the gathered tails.
+  phase 2 (key owners)    every link/fishy tuple is routed to owner = hash(min scaffold of the key) mod W with
+                          ONE equal-split all-to-all of fixed-capacity regions (count in the region header, so
+                          no size exchange and no host round trip).  A stable partition on the sender plus
+                          source-rank-ordered regions on the receiver keep the global BAM order, hence per-edge
+                          observation order and first-occurrence order survive the exchange.
+  phase 3                 each rank sorts and reduces the keys it owns; coverage numerators and counters are
+                          all-reduced (sum).  Edge scoring is embarrassingly parallel per owner.
+
+xGMI is point-to-point, so the all-to-all puts each (src,dst) region on its own link; the only ring-style
+collectives are the tiny tail all-gather and the coverage/counter all-reduces.
+
+The kernel stages sit behind a small backend interface: ``HipBackend`` (the product: hand-written HIP through
+the besst_dev_* C ABI on torch-owned HBM).  CPU tests inject an oracle-backed stand-in over gloo to exercise
+exactly this file's orchestration with world_size 2.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class HipBackend(object):
+    """Kernel stages of one rank on its GPU."""
+
+    def __init__(self, device, wl, rank, world, pair_capacity, tuple_capacity=None):
+        from . import pipeline
+        self.pipeline = pipeline
+        self.lib = _lib.load()
+        self.device = device
+        self.rank, self.world = rank, world
+        self.rec = pipeline.DeviceRecords(wl['batch'], device)
+        self.pair_cap = int(pair_capacity + (pair_capacity & 1))
+        self.recv_cap = self.pair_cap * world
+        self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n,
+                                              self.recv_cap)
+        self.gb.set_contigs(**wl['table'])
+        self.region = self.lib.besst_dev_exchange_region_bytes(self.pair_cap)
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.send = torch.zeros(world * self.region, **u8)
+        self.part_cap = int(tuple_capacity) if tuple_capacity else self.rec.n
+        self.ws_part = torch.empty(self.lib.besst_dev_reduce_workspace_bytes(self.part_cap), **u8)
+        self.tail = torch.zeros(4, dtype=torch.int32, device=device)
+        self.rkeys = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
+        self.rpayload = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
+        self.gidx = torch.empty(self.recv_cap, dtype=torch.int32, device=device)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=device)     # n_recv, overflow
+
+    # -- tensors the orchestration reduces across ranks --
+    @property
+    def aligned(self):
+        return self.gb.aligned
+
+    @property
+    def counter_words(self):
+        return self.gb.small[:64].view(torch.int64)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        self.gb.reset()
+        self.flags.zero_()
+
+    def classify_scan(self):
+        g, r, p = self.gb, self.rec, self.pipeline._p
+        _lib.check(self.lib.besst_dev_classify_scan(
+            self._stream(), r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
+            g.n_contigs, p(g.table), C.byref(g.params), g.node_bits, p(g.aligned), g._small(0), p(g.ws1),
+            g.ws1.numel()), 'classify_scan')
+
+    def classify_tail(self):
+        g = self.gb
+        _lib.check(self.lib.besst_dev_classify_tail(self._stream(), self.rec.n, self.pipeline._p(self.tail),
+                                                    self.pipeline._p(g.ws1), g.ws1.numel()), 'classify_tail')
+        return self.tail
+
+    def classify_emit(self, tails):
+        g, p = self.gb, self.pipeline._p
+        _lib.check(self.lib.besst_dev_resolve_carry(self._stream(), p(tails), self.rank, g._carry), 'resolve_carry')
+        _lib.check(self.lib.besst_dev_classify_emit(
+            self._stream(), self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
+            g._small(0), p(g.ws1), g.ws1.numel()), 'classify_emit')
+
+    def partition(self):
+        g, p = self.gb, self.pipeline._p
+        _lib.check(self.lib.besst_dev_partition(
+            self._stream(), self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
+            p(self.send), p(self.ws_part), self.ws_part.numel()), 'partition')
+        return self.send
+
+    def unpack(self, recv):
+        p = self.pipeline._p
+        n_recv = C.c_void_p(self.flags.data_ptr())
+        overflow = C.c_void_p(self.flags.data_ptr() + 4)
+        _lib.check(self.lib.besst_dev_unpack(self._stream(), self.world, self.pair_cap, p(recv), p(self.rkeys),
+                                             p(self.rpayload), p(self.gidx), n_recv, overflow), 'unpack')
+
+    def reduce(self):
+        self.gb.reduce(keys=self.rkeys, payload=self.rpayload, n_tuples_ptr=C.c_void_p(self.flags.data_ptr()),
+                       capacity=self.recv_cap, first_map=self.gidx)
+
+    def overflowed(self):
+        return bool(self.flags.cpu()[1].item())
+
+    def sizes(self):
+        """(tuples received, edge rows owned) - synchronises."""
+        _, rows = self.gb.read_sizes()
+        return int(self.flags.cpu()[0].item()), rows
+
+    def local_table(self):
+        """This rank's owned edge rows as a host EdgeTable (first_idx = global emit index)."""
+        from .device import EdgeTable
+        L, r = self.sizes()
+        g = self.gb
+
+        def h(t, n, dt):
+            return t[:n].cpu().numpy().view(dt)
+        return EdgeTable(h(g.row_key, r, np.uint64), h(g.row_mask, r, np.uint32), h(g.row_n, r, np.uint32),
+                         h(g.row_sum, r, np.int64), h(g.row_sum_sq, r, np.int64), h(g.row_first, r, np.uint32),
+                         h(g.row_offset, r, np.uint32), g.node_bits, h(g.obs_lo, L, np.int32),
+                         h(g.obs_hi, L, np.int32))
+
+
+class ShardedGraphBuild(object):
+    """Orchestrates one sharded graph-build step; ``backend`` supplies the per-rank kernel stages."""
+
+    def __init__(self, device, wl, rank, world, backend=None, group=None, pair_capacity=None):
+        self.rank, self.world, self.group = rank, world, group
+        if backend is None:
+            tuple_capacity = None
+            if pair_capacity is None:
+                pair_capacity, tuple_capacity = self._probe_pair_capacity(device, wl, world)
+            backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
+        self.backend = backend
+        self._tails = None
+
+    @staticmethod
+    def _probe_pair_capacity(device, wl, world):
+        """One untimed local pass to size the exchange regions (tuples per (src,dst) pair, 1.5x slack)."""
+        from . import pipeline
+        rec = pipeline.DeviceRecords(wl['batch'], device)
+        probe = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, 1)
+        probe.set_contigs(**wl['table'])
+        probe.reset()
+        probe.classify(rec)
+        n_out, _ = probe.read_sizes()
+        cap = torch.tensor([int(n_out * 1.5 / world) + 4096], dtype=torch.int64, device=device)
+        if dist.is_initialized():
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        return int(cap.item()), int(n_out * 1.25) + 4096
+
+    def step(self):
+        b = self.backend
+        b.reset()
+        b.classify_scan()
+        tail = b.classify_tail()
+        if self._tails is None:
+            self._tails = [torch.empty_like(tail) for _ in range(self.world)]
+        dist.all_gather(self._tails, tail, group=self.group)
+        b.classify_emit(torch.cat(self._tails))
+        send = b.partition()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        b.unpack(recv)
+        b.reduce()
+        dist.all_reduce(b.aligned, group=self.group)
+        dist.all_reduce(b.counter_words, group=self.group)
+
+    def check_capacity(self):
+        if self.backend.overflowed():
+            raise _lib.BesstDeviceError('exchange region overflow: raise pair_capacity')
+
+    def sizes(self):
+        """Global (tuples, edge rows) summed over ranks - synchronises."""
+        n, r = self.backend.sizes()
+        t = torch.tensor([n, r], dtype=torch.int64, device=self.backend.aligned.device)
+        dist.all_reduce(t, group=self.group)
+        return int(t[0].item()), int(t[1].item())
+
+    def final_prev_obs(self):
+        """counter.prev_obs1/2 after the last record of the global stream."""
+        tails = torch.cat(self._tails).cpu().numpy().reshape(self.world, 4)
+        prev = (-1, -1)
+        for j in range(self.world):
+            if tails[j, 0]:
+                prev = (int(tails[j, 1]), int(tails[j, 2]))
+        return prev

@@ -119,7 +119,7 @@ class DeviceGraphBuilder(object):
             self._carry, _p(self.aligned), _p(self.keys), _p(self.payload), self._n_out, self._small(0),
             _p(self.ws1), self.ws1.numel()), 'dev_classify')
 
-    def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None):
+    def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None, first_map=None):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
@@ -128,7 +128,7 @@ class DeviceGraphBuilder(object):
             C.c_void_p(stream), cap, n_tuples_ptr or self._n_out, 2 * self.node_bits + 1, _p(keys), _p(payload),
             _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
             _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
-            _p(self.ws2), self.ws2.numel()), 'dev_reduce')
+            _p(self.ws2), self.ws2.numel(), _p(first_map)), 'dev_reduce')
 
     def step(self, rec):
         self.reset()

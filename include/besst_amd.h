@@ -224,7 +224,39 @@ int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, i
                      const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                      uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                      uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                     uint32_t* n_rows, void* workspace, size_t workspace_bytes);
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map);
+
+/* ---- multi-GPU path ----------------------------------------------------
+ * Ranks own contiguous slices of the (tid,pos)-sorted stream.  The duplicate chain of CreateEdge
+ * (CreateGraph.py:835-838,869-870) crosses slice boundaries, so stage 1 is split in three phases:
+ *   scan  - the per-record kernel on the local slice (independent of the incoming prev_obs)
+ *   tail  - {has, obs1, obs2, 0} of the slice's last record that reached CreateEdge  -> all_gather
+ *   emit  - resolve block/slice heads against the true incoming prev_obs and write the ordered tuples
+ * besst_dev_resolve_carry picks the incoming prev_obs of `rank` from the gathered tails (world x 4
+ * int32); `carry` must already hold the prev_obs entering rank 0.
+ * Then tuples are stably partitioned by owner rank (besst_owner_of_scaffold of the key's min scaffold)
+ * into `world` fixed-capacity regions for ONE equal-split all-to-all; besst_dev_unpack rebuilds an
+ * ordered stream on the receiver with a global emit index per tuple (first_map of besst_dev_reduce)
+ * and raises *overflow if any region was truncated (retry with a larger pair_capacity). */
+int besst_dev_classify_scan(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                            const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
+                            const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
+                            const void* contig_table, const besst_lib_params* h_params, int32_t node_bits,
+                            int64_t* aligned, besst_counters* counters, void* workspace,
+                            size_t workspace_bytes);
+int besst_dev_classify_tail(void* stream, int64_t n, int32_t* tail, void* workspace, size_t workspace_bytes);
+int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, int32_t* carry);
+int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
+                            uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
+                            size_t workspace_bytes);
+size_t besst_dev_exchange_region_bytes(int64_t pair_capacity);
+uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world);
+/* workspace: besst_dev_reduce_workspace_bytes(capacity) */
+int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits,
+                        int32_t world, const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity,
+                        void* send_buffer, void* workspace, size_t workspace_bytes);
+int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
+                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,73 @@
+"""world_size-2 gloo run of the multi-GPU orchestration (besst_amd.distributed) on CPU.
+
+The per-rank kernel stages are replaced by the oracle-backed stand-in of tests/dist_util.py; everything else
+- tail all-gather, carry resolution across the rank boundary, owner partition, the equal-split all-to-all of
+fixed-capacity regions, source-ordered unpack, coverage/counter all-reduce - is the product's code path.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from besst_amd import distributed, workload
+from tests import dist_util as DU
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        wl = workload.make('C2', 0, pairs=60000, nc=400)
+        # many duplicates so that the chain really crosses the rank boundary
+        parts = DU.split_batch(wl['batch'], WORLD)
+        backend = DU.OracleBackend(parts[rank], wl['table'], wl['lib'], wl['node_bits'], rank, WORLD, 4096)
+        job = distributed.ShardedGraphBuild(torch.device('cpu'), wl, rank, WORLD, backend=backend)
+        for _ in range(2):
+            job.step()
+        job.check_capacity()
+        want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+        # every rank ends with the global coverage and counters
+        assert backend.aligned.tolist() == want.aligned
+        assert backend.counter_words.tolist() == [want.count, want.non_unique, want.non_unique_for_scaf,
+                                                  want.nr_of_duplicates, want.too_long, want.fishy_reads,
+                                                  len(want.tuples), want.n_reach]
+        assert job.final_prev_obs() == want.prev
+        n_tuples, n_rows = job.sizes()
+        assert (n_tuples, n_rows) == (len(want.tuples), len(want_rows))
+        # this rank's rows are exactly the keys it owns, with identical sums, order and global first index
+        lib = backend.lib
+        mine = {k: r for k, r in want_rows.items()
+                if lib.besst_owner_of_scaffold(k >> (2 + wl['node_bits']), WORLD) == rank}
+        assert backend.rows == mine
+        out.put((rank, len(mine), want.nr_of_duplicates))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process_oracle():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, out)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(WORLD))
+    assert [g[0] for g in got] == [0, 1]
+    assert got[0][1] > 0 and got[1][1] > 0 and got[0][2] > 0
