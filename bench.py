@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument('--cpu-sample-records', type=int, default=6_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown-steps', type=int, default=3)
+    ap.add_argument('--no-verify', action='store_true', help='skip the full-size check against the C oracle')
+    ap.add_argument('--no-stages', action='store_true', help='skip the separate metrics / scoring stage timings')
     return ap.parse_args()
 
 
@@ -59,6 +61,69 @@ def cpu_baseline(batch, table, lib, n_sample):
     return dict(value=(n / 2.0) / dt, unit='read-pairs/s', cores=1, kind='port',
                 sample='first %d records (%d pairs) of the same stream, oracle/py_oracle.record_loop, %.1f s'
                        % (n, n // 2, dt)), res
+
+
+def verify_full(runner, wl):
+    """Full-size parity: device edge table == C oracle on the whole workload (rank 0, N=1)."""
+    import numpy as np
+    from oracle import c_oracle as CO
+    table = runner.gb.fetch_table()
+    ctr = runner.gb.read_counters()
+    keys, payload, aligned, c_ctr = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+    rows = CO.edge_rows(keys, payload)
+    link = ~table.is_fishy
+    ok = (np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
+          and np.array_equal(table.sum_obs[link], rows['sum_obs'][link])
+          and np.array_equal(table.sum_obs_sq[link], rows['sum_obs_sq'][link])
+          and np.array_equal(table.first_idx.astype(np.int64), rows['first_idx'])
+          and np.array_equal(table.obs_lo.astype(np.int64), rows['obs_lo'])
+          and np.array_equal(table.obs_hi.astype(np.int64), rows['obs_hi'])
+          and runner.gb.aligned.cpu().numpy().tolist() == aligned.tolist()
+          and [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates,
+               ctr.reads_with_too_long_insert, ctr.fishy_reads, ctr.n_tuples, ctr.n_reach, ctr.prev_obs1,
+               ctr.prev_obs2] == c_ctr.tolist())
+    return bool(ok)
+
+
+def stage_timings(wl):
+    """Wall time of the other stages through the host-buffer C ABI (reported separately)."""
+    import numpy as np
+    from besst_amd import device
+    batch, lib, asm = wl['batch'], wl['lib'], wl['asm']
+    out = {}
+    with device.GraphContext(0) as ctx:
+        ctx.set_contigs(**wl['table'])
+        ctx.set_library(lib['read_len'], lib['ins_size_threshold'], lib['min_mapq'], lib['orientation'],
+                        lib['detect_duplicate'], lib['extend_paths'], lib['no_score'])
+        t0 = time.perf_counter()
+        ctx.push_records(batch)
+        out['h2d_push_ms'] = (time.perf_counter() - t0) * 1e3
+        top = np.zeros(asm.nc, np.uint8)
+        top[np.lexsort((np.arange(asm.nc), -asm.lengths))[:1000]] = 1
+        ctx.metrics_sample(top, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+        t0 = time.perf_counter()
+        _, _, counts = ctx.metrics_sample(top, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+        out['metrics_scan_ms'] = (time.perf_counter() - t0) * 1e3
+        out['metrics_records_scanned'] = int(counts.records_scanned)
+        ctx.build_graph()
+        t0 = time.perf_counter()
+        table, _, _ = ctx.build_graph()
+        out['ctx_build_graph_ms'] = (time.perf_counter() - t0) * 1e3
+        rows = np.nonzero((~table.is_fishy) & ((table.mask & 1) != 0) & (table.n >= 5))[0].astype(np.uint32)
+        if rows.shape[0]:
+            len1 = (asm.lengths[(table.u[rows] >> 1) - 1]).astype(np.int32)
+            len2 = (asm.lengths[(table.v[rows] >> 1) - 1]).astype(np.int32)
+            swap = np.zeros(rows.shape[0], np.uint8)
+            ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
+            t0 = time.perf_counter()
+            ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
+            dt = time.perf_counter() - t0
+            out['score_ms'] = dt * 1e3
+            out['scored_edges'] = int(rows.shape[0])
+            out['score_edges_per_s'] = rows.shape[0] / dt
+        pairs = len(batch) // 2
+        out['pcie_inclusive_pairs_per_s'] = pairs / ((out['h2d_push_ms'] + out['ctx_build_graph_ms']) * 1e-3)
+    return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}
 
 
 def main():
@@ -124,6 +189,9 @@ def main():
     lib_h.besst_prof_enable(0)
 
     n_tuples, n_rows = runner.sizes()
+    verified = None
+    if world == 1 and not args.no_verify:
+        verified = verify_full(runner, wl)
     f = n_tuples / float(pairs)
     cls_ms, cls_launches = prof.get('classify_kernel', (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
@@ -155,7 +223,12 @@ def main():
                          'traffic': None, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
                          'algorithmic_bytes_per_launch': alg_bytes},
             'kernel_ms': breakdown,
+            'verified_vs_c_oracle': verified,
         }
+        if world == 1 and not args.no_stages:
+            del runner
+            torch.cuda.empty_cache()
+            out['stages'] = stage_timings(wl)
         if not args.no_cpu_baseline:
             base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
             out['cpu_baseline'] = base

@@ -1,0 +1,67 @@
+"""GPU parity at larger sizes against the C oracle, plus size-independent properties of the edge table."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from besst_amd import workload
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_table_equals_c_oracle(table, aligned, ctr, batch, wl):
+    keys, payload, c_aligned, c_ctr = CO.record_loop(batch, wl['table'], wl['lib'], wl['node_bits'])
+    rows = CO.edge_rows(keys, payload)
+    assert aligned.tolist() == c_aligned.tolist()
+    assert [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates, ctr.reads_with_too_long_insert,
+            ctr.fishy_reads, ctr.n_tuples, ctr.n_reach, ctr.prev_obs1, ctr.prev_obs2] == c_ctr.tolist()
+    assert np.array_equal(table.key, rows['key'])
+    assert np.array_equal(table.n.astype(np.int64), rows['n'])
+    assert np.array_equal(table.first_idx.astype(np.int64), rows['first_idx'])
+    assert np.array_equal(table.offset.astype(np.int64), rows['offset'])
+    link = ~table.is_fishy
+    assert np.array_equal(table.sum_obs[link], rows['sum_obs'][link])
+    assert np.array_equal(table.sum_obs_sq[link], rows['sum_obs_sq'][link])
+    assert np.array_equal(table.mask[link].astype(np.int64), rows['mask'][link])
+    assert np.array_equal(table.obs_lo.astype(np.int64), rows['obs_lo'])
+    assert np.array_equal(table.obs_hi.astype(np.int64), rows['obs_hi'])
+    # properties that hold at any size
+    assert np.all(np.diff(table.key.astype(np.uint64)) > 0)                      # strictly sorted, unique keys
+    assert int(table.n.sum()) == ctr.n_tuples                                     # every tuple lands in one row
+    assert np.array_equal(np.cumsum(np.r_[0, table.n[:-1]]), table.offset)        # slices tile the arrays
+    o = table.obs_lo.astype(np.int64) + table.obs_hi
+    assert int(table.sum_obs[link].sum()) == int(o.sum())
+    assert int(table.sum_obs_sq[link].sum()) == int((o * o).sum())
+
+
+@pytest.mark.parametrize('config,pairs,nc', [('C2', 1_000_000, 3000), ('C3', 600_000, 2000)])
+def test_device_equals_c_oracle(config, pairs, nc):
+    from besst_amd import device
+    if os.environ.get('BESST_FULL_SIZE') == '1' and config == 'C2':
+        pairs, nc = None, None                       # BASELINE.json configs[1]: 10k contigs / 10M pairs
+    wl = workload.make(config, 0, pairs=pairs, nc=nc)
+    batch = wl['batch']
+    with device.GraphContext(0) as ctx:
+        ctx.set_contigs(**wl['table'])
+        lib = wl['lib']
+        ctx.set_library(lib['read_len'], lib['ins_size_threshold'], lib['min_mapq'], lib['orientation'],
+                        lib['detect_duplicate'], lib['extend_paths'], lib['no_score'])
+        ctx.push_records(batch)
+        table, aligned, ctr = ctx.build_graph()
+        assert_table_equals_c_oracle(table, aligned, ctr, batch, wl)
+        # library-statistics sampler against the C oracle (ordered samples, cut-offs)
+        top = np.zeros(wl['asm'].nc, np.uint8)
+        top[np.lexsort((np.arange(wl['asm'].nc), -wl['asm'].lengths))[:1000]] = 1
+        for want_isize in (True, False):
+            isize, contam, counts = ctx.metrics_sample(top, lib['orientation'], lib['min_mapq'], lib['read_len'],
+                                                       want_isize)
+            c_isize, c_contam, c_counts = CO.metrics_sample(batch, top, lib['orientation'], lib['min_mapq'],
+                                                            lib['read_len'], want_isize)
+            assert isize.tolist() == c_isize.tolist()
+            assert contam.tolist() == c_contam.tolist()
+            assert [counts.n_isize, counts.n_contam, counts.counter_total, counts.sample_counter] == c_counts.tolist()
+        # count-per-value histogram (input of the bimodality splitter)
+        hist, overflow = ctx.value_histogram(c_isize, 2048)
+        want = np.bincount(np.minimum(c_isize, 2048), minlength=2049)
+        assert hist.tolist() == want[:2048].tolist() and overflow == int(want[2048])
