@@ -155,7 +155,7 @@ void besst_prof_enable(uint32_t slot_mask) { g_prof_mask = slot_mask; }
 int besst_prof_slots(void) { return kProfSlots; }
 
 const char* besst_prof_slot_name(int slot) {
-    static const char* names[kProfSlots] = {"classify_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
+    static const char* names[kProfSlots] = {"stream_kernel", "candidate_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
                                             "radix_rowscan_kernel", "radix_scatter_kernel", "row_heads_kernel",
                                             "row_scan_kernel", "row_zero_kernel", "row_reduce_kernel",
                                             "metrics_kernels", "score_kernels"};
@@ -253,6 +253,9 @@ int besst_dev_pack_contigs(void* stream, int64_t n, const int32_t* scaf_id, cons
     if (n) {
         BESST_HIP_TRY(hipMemcpyAsync(d_table, rows.data(), (size_t)n * sizeof(ContigRow), hipMemcpyHostToDevice,
                                      static_cast<hipStream_t>(stream)));
+        // class bytes follow the rows (the streaming kernel needs only the class of a contig)
+        BESST_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_table) + (size_t)n * sizeof(ContigRow), cls, (size_t)n,
+                                     hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
         BESST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // rows is a local
     }
     return BESST_OK;
@@ -264,7 +267,7 @@ int besst_ctx_set_contigs(besst_ctx* c, int64_t n, const int32_t* scaf_id, const
     BESST_REQUIRE(c, "null context");
     int rc = use_device(c);
     if (rc) return rc;
-    if ((rc = c->table.ensure((size_t)n + 1))) return rc;
+    if ((rc = c->table.ensure((size_t)n + (size_t)n / 16 + 2))) return rc;
     if ((rc = c->aligned.ensure((size_t)n + 1))) return rc;
     if ((rc = besst_dev_pack_contigs(c->stream, n, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls, c->table.p)))
         return rc;
@@ -321,6 +324,7 @@ int besst_ctx_push_records(besst_ctx* c, int64_t n, const int32_t* tid, const in
 }
 
 size_t besst_dev_classify_workspace_bytes(int64_t n_records) { return classify_workspace_bytes(n_records); }
+size_t besst_dev_contig_table_bytes(int64_t n_contigs) { return (size_t)(n_contigs > 0 ? n_contigs : 0) * 17 + 16; }
 size_t besst_dev_reduce_workspace_bytes(int64_t n_tuples) { return reduce_workspace_bytes(n_tuples); }
 
 int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
@@ -359,6 +363,7 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     BESST_REQUIRE(p->ins_size_threshold < 1073741824.0, "classify: ins_size_threshold must be below 2^30");
     a.tid = tid; a.mtid = mtid; a.pos = pos; a.mpos = mpos; a.flag = flag; a.mapq = mapq; a.qlen = qlen;
     a.table = static_cast<const ContigRow*>(contig_table);
+    a.cls8 = static_cast<const uint8_t*>(contig_table) + (size_t)n_contigs * sizeof(ContigRow);
     a.n = n;
     a.n_contigs = (int32_t)n_contigs;
     a.node_bits = node_bits;

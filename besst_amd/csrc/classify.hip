@@ -102,16 +102,17 @@ __device__ __forceinline__ void posdir(bool rf, bool cdir, bool rdir, int32_t cp
     }
 }
 
-__device__ __forceinline__ Eval eval_record(const ClassifyArgs& a, int32_t tid, int32_t mtid,
-                                            int32_t pos, int32_t mpos, uint32_t flag, uint32_t mapq) {
+// Evaluate one record given its two contig rows (gathered by the caller so that several records' gathers
+// can be in flight together); in_range = both tids are valid header indexes.
+__device__ __forceinline__ Eval eval_record(const ClassifyArgs& a, bool in_range, const ContigRow& c1,
+                                            const ContigRow& c2, int32_t tid, int32_t mtid, int32_t pos,
+                                            int32_t mpos, uint32_t flag, uint32_t mapq) {
     Eval e;
     e.bits = 0;
     e.o1 = e.o2 = 0;
     e.key = 0;
     e.lo = e.hi = 0;
-    if ((uint32_t)tid >= (uint32_t)a.n_contigs || (uint32_t)mtid >= (uint32_t)a.n_contigs) return e;
-    const ContigRow c1 = a.table[tid];
-    const ContigRow c2 = (mtid == tid) ? c1 : a.table[mtid];
+    if (!in_range) return e;
     const uint32_t cls1 = c1.w0 >> 29, cls2 = c2.w0 >> 29;
     if (cls1 == BESST_CLS_ABSENT || cls2 == BESST_CLS_ABSENT) return e;
     const uint32_t scaf1 = c1.w0 & kScafIdMask, scaf2 = c2.w0 & kScafIdMask;
@@ -185,201 +186,333 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(kClsThreads) void classify_kernel(
-    ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
+// ---------------------------------------------------------------------------------------------------------
+// stream_kernel: the bandwidth-bound pass.  Per record it needs only tid, mtid, mapq, qlen (11 B):
+//   * tid == mtid (98 % of a real stream): the record can only contribute coverage            [:138-139]
+//   * tid != mtid: "candidate" - everything else in the loop body requires contig1 != contig2 or
+//     different scaffolds (:141-169); its bit is published and candidate_kernel does the rest,
+//     including the candidate's own coverage contribution.
+// The stream is (tid,pos)-sorted, so the 256 records of a wave normally share one tid: coverage is a wave
+// reduction accumulated across the workgroup's sub-tiles and flushed with one 64-bit atomic per run.
+// ---------------------------------------------------------------------------------------------------------
+// Add `val` to dst[key] for every active lane with ONE atomic per distinct key of the wave.  The stream is
+// (tid,pos)-sorted, so a wave sees one or two distinct contigs; per-lane atomics on the same two addresses
+// were measured at ~0.1 ns each chip-wide and dominated the pass.  After 8 distinct keys the remaining lanes
+// fall back to their own atomics (unsorted input stays correct, only slower).
+__device__ __forceinline__ void wave_add_by_key(unsigned long long* dst, int32_t key, int val, bool active,
+                                                int lane) {
+    unsigned long long mask = __ballot(active);
+    int iter = 0;
+    while (mask) {
+        if (iter++ == 8) {
+            if (active) atomicAdd(&dst[key], (unsigned long long)val);
+            break;
+        }
+        const int leader = __ffsll((long long)mask) - 1;
+        const int32_t k = __shfl(key, leader, 64);
+        const bool match = active && key == k;
+        const int tot = wave_sum(match ? val : 0);
+        if (lane == leader && tot) atomicAdd(&dst[k], (unsigned long long)tot);
+        active = active && !match;
+        mask = __ballot(active);
+    }
+}
+
+__device__ __forceinline__ void flush_cov(const ClassifyArgs& a, unsigned long long* aligned, int lane,
+                                          int32_t ref, int sum) {
+    if (lane == 0 && sum && (uint32_t)ref < (uint32_t)a.n_contigs && a.cls8[ref])
+        atomicAdd(&aligned[ref], (unsigned long long)sum);
+}
+
+__global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
+                                                                unsigned long long* __restrict__ aligned,
+                                                                unsigned long long* __restrict__ bitmask) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t block_base = (int64_t)blockIdx.x * kStreamTile;
+    int4 v_tid[kStreamSubTiles], v_mtid[kStreamSubTiles];
+    uchar4 v_mapq[kStreamSubTiles];
+    ushort4 v_qlen[kStreamSubTiles];
+    if (block_base + kStreamTile <= a.n) {
+        // full tile: issue every load of the workgroup's 4096 records before touching any of them
+#pragma unroll
+        for (int st = 0; st < kStreamSubTiles; ++st) {
+            const int64_t i0 = block_base + (int64_t)st * kStreamSubTile + (int64_t)t * kStreamVec;
+            v_tid[st] = *reinterpret_cast<const int4*>(a.tid + i0);
+            v_mtid[st] = *reinterpret_cast<const int4*>(a.mtid + i0);
+            v_mapq[st] = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            v_qlen[st] = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < kStreamSubTiles; ++st) {
+            const int64_t i0 = block_base + (int64_t)st * kStreamSubTile + (int64_t)t * kStreamVec;
+            int32_t x[4], y[4];
+            uint32_t m[4], q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                x[k] = in ? a.tid[i] : -1;
+                y[k] = in ? a.mtid[i] : -1;
+                m[k] = in ? a.mapq[i] : 0;
+                q[k] = in ? a.qlen[i] : 0;
+            }
+            v_tid[st] = make_int4(x[0], x[1], x[2], x[3]);
+            v_mtid[st] = make_int4(y[0], y[1], y[2], y[3]);
+            v_mapq[st] = make_uchar4((unsigned char)m[0], (unsigned char)m[1], (unsigned char)m[2], (unsigned char)m[3]);
+            v_qlen[st] = make_ushort4((unsigned short)q[0], (unsigned short)q[1], (unsigned short)q[2], (unsigned short)q[3]);
+        }
+    }
+    int32_t acc_ref = -1;
+    int acc_sum = 0;
+#pragma unroll
+    for (int st = 0; st < kStreamSubTiles; ++st) {
+        const int32_t r_tid[4] = {v_tid[st].x, v_tid[st].y, v_tid[st].z, v_tid[st].w};
+        const int32_t r_mtid[4] = {v_mtid[st].x, v_mtid[st].y, v_mtid[st].z, v_mtid[st].w};
+        const uint32_t r_mapq[4] = {v_mapq[st].x, v_mapq[st].y, v_mapq[st].z, v_mapq[st].w};
+        const uint32_t r_qlen[4] = {v_qlen[st].x, v_qlen[st].y, v_qlen[st].z, v_qlen[st].w};
+        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
+        bool uni = true;
+        int mine = 0;
+        bool cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cand[k] = r_tid[k] != r_mtid[k];
+            uni = uni && (r_tid[k] == ref);
+            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+            if (!cand[k] && cov) mine += (int)r_qlen[k];
+        }
+        if (__all(uni)) {
+            const int tot = wave_sum(mine);
+            if (ref != acc_ref) {
+                flush_cov(a, aligned, lane, acc_ref, acc_sum);
+                acc_ref = ref;
+                acc_sum = 0;
+            }
+            acc_sum += tot;
+        } else {
+            // a contig boundary (or unsorted input) inside the wave: one atomic per distinct contig and slot
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && a.cls8[r_tid[k]];
+                wave_add_by_key(aligned, r_tid[k], (int)r_qlen[k], act, lane);
+            }
+        }
+        // candidate bits of this wave's group: word k, bit l  <->  record group_base + 4*l + k
+        const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
+        const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
+        if (lane < 4) {
+            const int64_t g = ((int64_t)blockIdx.x * kStreamSubTiles + st) * 4 + wave;
+            bitmask[g * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        }
+    }
+    flush_cov(a, aligned, lane, acc_ref, acc_sum);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// candidate_kernel: the order-dependent part, on the sparse candidates only.  Single-wave workgroups; lane l
+// owns the 256-record group l of the workgroup's 16384 consecutive records.
+//   1. ordered index of every candidate (popcounts + wave scan)
+//   2. candidates' record offsets are listed in LDS in stream order, then evaluated in full by ALL lanes
+//      round-robin (record fields re-read by index, contig rows gathered) - candidates cluster at contig
+//      ends, so evaluation by the owning lane would serialise dozens of dependent loads on one lane
+//   3. the staged list is processed 64 entries at a time: previous reaching observation via ballot,
+//      CreateEdge semantics, ordered slots for the emitted tuples; the chain is carried in registers
+// ---------------------------------------------------------------------------------------------------------
+struct CandEntry {
+    uint64_t key;
+    int32_t o1, o2;
+    uint32_t bits;     // EV_* | mask << 8 | first_min << 10
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(kCandThreads) void candidate_kernel(
+    ClassifyArgs a, const unsigned long long* __restrict__ bitmask, int64_t n_groups,
+    unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
     uint64_t* __restrict__ seg_payload, BlockSummary* __restrict__ summ,
     unsigned long long* __restrict__ counters) {
-    __shared__ int32_t s_has[4], s_o1[4], s_o2[4];
-    __shared__ int32_t s_cnt[4];
-    __shared__ int32_t s_head[5];       // o1, o2, info, slot, present
-    __shared__ int32_t s_red[4][8];
+    __shared__ CandEntry s_ent[kCandCap];
+    __shared__ uint16_t s_rec[kCandCap];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lane = threadIdx.x;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
-    if (t == 0) { s_head[4] = 0; s_head[3] = (int32_t)kNoSlot; }
+    const int64_t g = (int64_t)blockIdx.x * kCandThreads + lane;
+    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
 
-    // block-carried state, identical in every thread
+    unsigned long long b[4] = {0ull, 0ull, 0ull, 0ull};
+    if (g < n_groups) {
+        const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
+        const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
+        b[0] = w0.x; b[1] = w0.y; b[2] = w1.x; b[3] = w1.y;
+    }
+    const int cnt = __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
+    const int incl = wave_incl_scan(cnt, lane);
+    const int my_base = incl - cnt;
+    const int total = __shfl(incl, 63, 64);
+    __syncthreads();
+
+    // chain state, identical in every lane
     bool prev_known = false;
     int32_t prev1 = 0, prev2 = 0;
     bool blk_has = false;
-    int32_t last1 = 0, last2 = 0;
     int emit_base = 0;
-    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
+    bool head_present = false;
+    int32_t head1 = 0, head2 = 0;
+    uint32_t head_info = 0, head_slot = kNoSlot;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    for (int st = 0; st < kClsSubTiles; ++st) {
-        const int64_t i0 = block_base + (int64_t)st * kClsSubTile + (int64_t)t * kClsVec;
-        int32_t r_tid[kClsVec], r_mtid[kClsVec], r_pos[kClsVec], r_mpos[kClsVec];
-        uint32_t r_flag[kClsVec], r_mapq[kClsVec], r_qlen[kClsVec];
-        if (i0 + kClsVec <= a.n) {
-            const int4 v0 = *reinterpret_cast<const int4*>(a.tid + i0);
-            const int4 v1 = *reinterpret_cast<const int4*>(a.mtid + i0);
-            const int4 v2 = *reinterpret_cast<const int4*>(a.pos + i0);
-            const int4 v3 = *reinterpret_cast<const int4*>(a.mpos + i0);
-            const ushort4 f = *reinterpret_cast<const ushort4*>(a.flag + i0);
-            const uchar4 m = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            const ushort4 q = *reinterpret_cast<const ushort4*>(a.qlen + i0);
-            r_tid[0] = v0.x; r_tid[1] = v0.y; r_tid[2] = v0.z; r_tid[3] = v0.w;
-            r_mtid[0] = v1.x; r_mtid[1] = v1.y; r_mtid[2] = v1.z; r_mtid[3] = v1.w;
-            r_pos[0] = v2.x; r_pos[1] = v2.y; r_pos[2] = v2.z; r_pos[3] = v2.w;
-            r_mpos[0] = v3.x; r_mpos[1] = v3.y; r_mpos[2] = v3.z; r_mpos[3] = v3.w;
-            r_flag[0] = f.x; r_flag[1] = f.y; r_flag[2] = f.z; r_flag[3] = f.w;
-            r_mapq[0] = m.x; r_mapq[1] = m.y; r_mapq[2] = m.z; r_mapq[3] = m.w;
-            r_qlen[0] = q.x; r_qlen[1] = q.y; r_qlen[2] = q.z; r_qlen[3] = q.w;
-        } else {
+    for (int win = 0; win < total; win += kCandCap) {
+        // ---- list this lane's candidates (record offset inside the workgroup's range) ------------------------
+        if (cnt && my_base < win + kCandCap && my_base + cnt > win) {
+            int idx = my_base;
+            unsigned long long any = b[0] | b[1] | b[2] | b[3];
+            while (any) {
+                const int l = __ffsll((long long)any) - 1;
+                any &= any - 1;
 #pragma unroll
-            for (int k = 0; k < kClsVec; ++k) {
-                const int64_t i = i0 + k;
-                const bool in = i < a.n;
-                r_tid[k] = in ? a.tid[i] : -1;
-                r_mtid[k] = in ? a.mtid[i] : -1;
-                r_pos[k] = in ? a.pos[i] : 0;
-                r_mpos[k] = in ? a.mpos[i] : 0;
-                r_flag[k] = in ? a.flag[i] : 0;
-                r_mapq[k] = in ? a.mapq[i] : 0;
-                r_qlen[k] = in ? a.qlen[i] : 0;
-            }
-        }
-
-        // ---- phase 1: evaluate, coverage, per-thread chain summary --------------------------------
-        Eval e[kClsVec];
-        bool th_has = false;
-        int32_t tl1 = 0, tl2 = 0;
-#pragma unroll
-        for (int k = 0; k < kClsVec; ++k) {
-            e[k] = eval_record(a, r_tid[k], r_mtid[k], r_pos[k], r_mpos[k], r_flag[k], r_mapq[k]);
-            if (e[k].bits & EV_REACH) { th_has = true; tl1 = e[k].o1; tl2 = e[k].o2; }
-        }
-        {   // coverage: the stream is (tid,pos)-sorted, so a wave's records usually share one tid
-            const int32_t ref_tid = __shfl(r_tid[0], 0, 64);
-            bool uni = true;
-            int mine = 0;
-#pragma unroll
-            for (int k = 0; k < kClsVec; ++k) {
-                uni = uni && (r_tid[k] == ref_tid);
-                if (e[k].bits & EV_COV) mine += (int)r_qlen[k];
-            }
-            if (__all(uni)) {
-                const int tot = wave_sum(mine);
-                if (lane == 0 && tot) atomicAdd(&aligned[ref_tid], (unsigned long long)tot);
-            } else {
-                int run_tid = -1, run_sum = 0;
-#pragma unroll
-                for (int k = 0; k < kClsVec; ++k) {
-                    if (!(e[k].bits & EV_COV)) continue;
-                    if (r_tid[k] != run_tid) {
-                        if (run_sum) atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
-                        run_tid = r_tid[k];
-                        run_sum = 0;
-                    }
-                    run_sum += (int)r_qlen[k];
+                for (int k = 0; k < 4; ++k) {
+                    if (!((b[k] >> l) & 1ull)) continue;
+                    if (idx >= win && idx < win + kCandCap) s_rec[idx - win] = (uint16_t)(lane * kGroup + 4 * l + k);
+                    idx++;
                 }
-                if (run_sum) atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
             }
         }
-        const unsigned long long has_mask = __ballot(th_has);
-        if (lane == 0) s_has[wave] = has_mask != 0ull;
-        if (has_mask != 0ull && lane == 63 - __clzll((long long)has_mask)) { s_o1[wave] = tl1; s_o2[wave] = tl2; }
         __syncthreads();
-
-        // ---- phase 2: incoming prev_obs for this thread ---------------------------------------------
-        bool pk = prev_known;
-        int32_t p1 = prev1, p2 = prev2;
-        for (int w = 0; w < wave; ++w)
-            if (s_has[w]) { pk = true; p1 = s_o1[w]; p2 = s_o2[w]; }
-        {
-            const unsigned long long below = has_mask & ((1ull << lane) - 1ull);
-            const int src = below ? 63 - __clzll((long long)below) : 0;
-            const int32_t q1 = __shfl(tl1, src, 64), q2 = __shfl(tl2, src, 64);
-            if (below) { pk = true; p1 = q1; p2 = q2; }
-        }
-        // sequential CreateEdge semantics over this thread's records
-        int n_emit = 0;
-        uint32_t emit_bits = 0;
-        int head_k = -1;
-        int32_t h1 = 0, h2 = 0;
-        uint32_t hbits = 0;
+        const int len = (total - win) < kCandCap ? (total - win) : kCandCap;
+        // ---- evaluate, all lanes round-robin ------------------------------------------------------------------
+        for (int j0 = 0; j0 < len; j0 += kCandThreads * kCandBatch) {
+            // batch: every lane keeps kCandBatch candidates' loads in flight (record fields, then contig rows)
+            int32_t r_tid[kCandBatch], r_mtid[kCandBatch], r_pos[kCandBatch], r_mpos[kCandBatch];
+            uint32_t r_flag[kCandBatch], r_mapq[kCandBatch];
+            int r_qlen[kCandBatch];
+            bool r_valid[kCandBatch];
 #pragma unroll
-        for (int k = 0; k < kClsVec; ++k) {
-            const uint32_t b = e[k].bits;
-            if (b & EV_NONUNIQ) c_nonuniq++;
-            if (b & EV_FISHY) { c_fishy++; emit_bits |= 1u << k; n_emit++; }
-            if (!(b & EV_REACH)) continue;
-            c_reach++;
-            const bool accept = b & EV_ACCEPT;
-            if (!pk) {
-                // head of the block: predecessor unknown, resolved by the stitch kernel
-                head_k = k;
-                h1 = e[k].o1; h2 = e[k].o2; hbits = b;
-                if (accept) { emit_bits |= 1u << k; n_emit++; }
-            } else {
-                const CEDelta d = create_edge(e[k].o1, e[k].o2, p1, p2, accept, b & EV_DOUBLE,
-                                              b & EV_MAPQ0, a.detect_dup != 0);
-                c_count += d.count; c_long += d.too_long; c_dup += d.dup; c_nus += d.nus;
-                if (d.keep) { emit_bits |= 1u << k; n_emit++; }
+            for (int u = 0; u < kCandBatch; ++u) {
+                const int j = j0 + u * kCandThreads + lane;
+                r_valid[u] = j < len;
+                const int64_t i = block_base + (r_valid[u] ? s_rec[j] : 0);
+                r_tid[u] = r_valid[u] ? a.tid[i] : -1;
+                r_mtid[u] = r_valid[u] ? a.mtid[i] : -1;
+                r_pos[u] = r_valid[u] ? a.pos[i] : 0;
+                r_mpos[u] = r_valid[u] ? a.mpos[i] : 0;
+                r_flag[u] = r_valid[u] ? a.flag[i] : 0;
+                r_mapq[u] = r_valid[u] ? a.mapq[i] : 0;
+                r_qlen[u] = r_valid[u] ? (int)a.qlen[i] : 0;
             }
-            pk = true; p1 = e[k].o1; p2 = e[k].o2;
+            ContigRow c1[kCandBatch], c2[kCandBatch];
+            bool in_range[kCandBatch];
+#pragma unroll
+            for (int u = 0; u < kCandBatch; ++u) {
+                in_range[u] = (uint32_t)r_tid[u] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[u] < (uint32_t)a.n_contigs;
+                c1[u] = a.table[in_range[u] ? r_tid[u] : 0];
+                c2[u] = a.table[in_range[u] ? r_mtid[u] : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kCandBatch; ++u) {
+                const Eval e = eval_record(a, in_range[u], c1[u], c2[u], r_tid[u], r_mtid[u], r_pos[u], r_mpos[u],
+                                           r_flag[u], r_mapq[u]);
+                wave_add_by_key(aligned, r_tid[u], r_qlen[u], (e.bits & EV_COV) != 0, lane);
+                c_nonuniq += (e.bits & EV_NONUNIQ) ? 1 : 0;
+                c_fishy += (e.bits & EV_FISHY) ? 1 : 0;
+                c_reach += (e.bits & EV_REACH) ? 1 : 0;
+                if (r_valid[u]) {
+                    CandEntry ce;
+                    ce.key = e.key;
+                    ce.o1 = e.o1;
+                    ce.o2 = e.o2;
+                    const bool first_min = (e.lo == (uint32_t)e.o1);   // lo is the observation of the key's min node
+                    ce.bits = e.bits | ((e.hi >> 30) << 8) | ((first_min ? 1u : 0u) << 10);
+                    ce.pad = 0;
+                    s_ent[j0 + u * kCandThreads + lane] = ce;
+                }
+            }
         }
-        // ordered slots inside the block-local segment
-        const int incl = wave_incl_scan(n_emit, lane);
-        if (lane == 63) s_cnt[wave] = incl;
         __syncthreads();
-        int slot = emit_base + incl - n_emit;
-        int sub_total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) slot += s_cnt[w];
-            sub_total += s_cnt[w];
-        }
-#pragma unroll
-        for (int k = 0; k < kClsVec; ++k) {
-            if (!(emit_bits & (1u << k))) continue;
-            if (k == head_k) s_head[3] = slot;
-            seg_keys[block_base + slot] = e[k].key;
-            seg_payload[block_base + slot] = (uint64_t)e[k].lo | ((uint64_t)e[k].hi << 32);
-            slot++;
-        }
-        if (head_k >= 0) {
-            s_head[0] = h1; s_head[1] = h2;
-            s_head[2] = (int32_t)(((hbits & EV_ACCEPT) ? 9u : 0u) | ((hbits & EV_DOUBLE) ? 2u : 0u) |
-                                  ((hbits & EV_MAPQ0) ? 4u : 0u));
-            s_head[4] = 1;
-        }
-        // advance the block carry (every thread computes the same values)
-        for (int w = 0; w < 4; ++w)
-            if (s_has[w]) {
-                if (!blk_has) blk_has = true;
-                prev_known = true; prev1 = s_o1[w]; prev2 = s_o2[w];
-                last1 = prev1; last2 = prev2;
+        // ---- ordered pass over the staged entries -------------------------------------------------------------
+        for (int c0 = 0; c0 < len; c0 += kCandThreads) {
+            const int j = c0 + lane;
+            CandEntry e;
+            e.key = 0; e.o1 = 0; e.o2 = 0; e.bits = 0; e.pad = 0;
+            if (j < len) e = s_ent[j];
+            const bool reach = e.bits & EV_REACH;
+            const unsigned long long has_mask = __ballot(reach);
+            bool pk = prev_known;
+            int32_t p1 = prev1, p2 = prev2;
+            {
+                const unsigned long long below = has_mask & lt_mask;
+                const int src = below ? 63 - __clzll((long long)below) : 0;
+                const int32_t q1 = __shfl(e.o1, src, 64), q2 = __shfl(e.o2, src, 64);
+                if (below) { pk = true; p1 = q1; p2 = q2; }
             }
-        emit_base += sub_total;
-        __syncthreads();   // s_has / s_o* / s_cnt are rewritten by the next sub-tile
+            bool emit = (e.bits & EV_FISHY) != 0;
+            bool is_head = false;
+            if (reach) {
+                const bool accept = e.bits & EV_ACCEPT;
+                if (!pk) {
+                    is_head = true;                      // first reaching record of the workgroup
+                    emit = accept;
+                } else {
+                    const CEDelta d = create_edge(e.o1, e.o2, p1, p2, accept, e.bits & EV_DOUBLE, e.bits & EV_MAPQ0,
+                                                  a.detect_dup != 0);
+                    c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                    emit = d.keep;
+                }
+            }
+            const unsigned long long emit_mask = __ballot(emit);
+            const int slot = emit_base + __popcll(emit_mask & lt_mask);
+            if (emit) {
+                const uint32_t mask = (e.bits >> 8) & 3u;
+                const bool first_min = (e.bits >> 10) & 1u;
+                const bool fishy = e.bits & EV_FISHY;
+                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? e.o1 : e.o2);
+                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? e.o2 : e.o1) | (mask << 30));
+                seg_keys[block_base + slot] = e.key;
+                seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+            }
+            // the head is unique per workgroup; broadcast it to every lane
+            const unsigned long long head_mask = __ballot(is_head);
+            if (head_mask) {
+                const int hl = __ffsll((long long)head_mask) - 1;
+                head_present = true;
+                head1 = __shfl(e.o1, hl, 64);
+                head2 = __shfl(e.o2, hl, 64);
+                const uint32_t hb = (uint32_t)__shfl((int)e.bits, hl, 64);
+                head_info = ((hb & EV_ACCEPT) ? 9u : 0u) | ((hb & EV_DOUBLE) ? 2u : 0u) | ((hb & EV_MAPQ0) ? 4u : 0u);
+                const int hs = __shfl(slot, hl, 64);
+                head_slot = (hb & EV_ACCEPT) ? (uint32_t)hs : kNoSlot;
+            }
+            if (has_mask) {
+                const int src = 63 - __clzll((long long)has_mask);
+                blk_has = true;
+                prev_known = true;
+                prev1 = __shfl(e.o1, src, 64);
+                prev2 = __shfl(e.o2, src, 64);
+            }
+            emit_base += __popcll(emit_mask);
+        }
+        __syncthreads();   // s_rec / s_ent are rewritten by the next window
     }
 
-    // ---- block epilogue: counters and summary ---------------------------------------------------------
-    int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
+    int tot[7];
+    {
+        const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int v = wave_sum(vals[j]);
-        if (lane == 0) s_red[wave][j] = v;
+        for (int f = 0; f < 7; ++f) tot[f] = wave_sum(vals[f]);
     }
-    __syncthreads();
-    if (t < 7) {
-        const long long v = (long long)s_red[0][t] + s_red[1][t] + s_red[2][t] + s_red[3][t];
-        // besst_counters field order: count, non_unique, non_unique_for_scaf, nr_of_duplicates,
-        // reads_with_too_long_insert, fishy_reads, n_tuples, n_reach
-        const int field = t < 6 ? t : 7;
-        if (v) atomicAdd(&counters[field], (unsigned long long)v);
-    }
-    if (t == 0) {
+    if (lane == 0) {
         BlockSummary s;
+#pragma unroll
+        for (int f = 0; f < 7; ++f) s.ctr[f] = (uint32_t)tot[f];
+        s.ctr[7] = 0;
         s.n_emit = (uint32_t)emit_base;
         s.has_reach = blk_has ? 1u : 0u;
-        s.first_o1 = s_head[4] ? s_head[0] : 0;
-        s.first_o2 = s_head[4] ? s_head[1] : 0;
-        s.last_o1 = last1;
-        s.last_o2 = last2;
-        s.head_info = s_head[4] ? (uint32_t)s_head[2] : 0u;
-        s.head_slot = (uint32_t)s_head[3];
+        s.first_o1 = head_present ? head1 : 0;
+        s.first_o2 = head_present ? head2 : 0;
+        s.last_o1 = prev1;
+        s.last_o2 = prev2;
+        s.head_info = head_present ? head_info : 0u;
+        s.head_slot = head_slot;
         summ[blockIdx.x] = s;
     }
 }
@@ -411,17 +544,21 @@ __global__ __launch_bounds__(1024) void stitch_kernel(const BlockSummary* __rest
     __shared__ int32_t s_l1[1024], s_l2[1024];
     __shared__ int32_t s_carry[2];
     __shared__ int s_base;
-    __shared__ int s_redc[16][4];
+    __shared__ int s_redc[16][7];
     const int t = threadIdx.x;
     if (t == 0) { s_carry[0] = carry[0]; s_carry[1] = carry[1]; s_base = 0; }
     __syncthreads();
-    int c_count = 0, c_long = 0, c_dup = 0, c_nus = 0;
+    int c_count = 0, c_long = 0, c_dup = 0, c_nus = 0, c_nonuniq = 0, c_fishy = 0, c_reach = 0;
     for (uint32_t c0 = 0; c0 < nblocks; c0 += 1024) {
         const uint32_t b = c0 + t;
         BlockSummary s;
         s.n_emit = 0; s.has_reach = 0; s.first_o1 = s.first_o2 = s.last_o1 = s.last_o2 = 0;
         s.head_info = 0; s.head_slot = kNoSlot;
-        if (b < nblocks) s = summ[b];
+        if (b < nblocks) {
+            s = summ[b];
+            c_count += (int)s.ctr[0]; c_nonuniq += (int)s.ctr[1]; c_nus += (int)s.ctr[2]; c_dup += (int)s.ctr[3];
+            c_long += (int)s.ctr[4]; c_fishy += (int)s.ctr[5]; c_reach += (int)s.ctr[6];
+        }
         s_l1[t] = s.last_o1;
         s_l2[t] = s.last_o2;
         const int incl = block_incl_scan_1024<true>(s.has_reach ? t : -1, s_w, t);
@@ -457,20 +594,20 @@ __global__ __launch_bounds__(1024) void stitch_kernel(const BlockSummary* __rest
         __syncthreads();
     }
     // counters fixed up by the heads
-    int vals[4] = {c_count, c_nus, c_dup, c_long};
+    // besst_counters fields: count 0, non_unique 1, non_unique_for_scaf 2, nr_of_duplicates 3,
+    // reads_with_too_long_insert 4, fishy_reads 5, n_reach 7 (n_tuples, 6, below)
+    int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
     const int lane = t & 63, wave = t >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 7; ++j) {
         const int v = wave_sum(vals[j]);
         if (lane == 0) s_redc[wave][j] = v;
     }
     __syncthreads();
-    if (t < 4) {
+    if (t < 7) {
         long long v = 0;
         for (int w = 0; w < 16; ++w) v += s_redc[w][t];
-        // fields: count(0), non_unique_for_scaf(2), nr_of_duplicates(3), reads_with_too_long_insert(4)
-        const int field = t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 3 : 4;
-        if (v) atomicAdd(&counters[field], (unsigned long long)v);
+        if (v) atomicAdd(&counters[t < 6 ? t : 7], (unsigned long long)v);
     }
     if (t == 0) {
         carry[0] = s_carry[0];
@@ -506,6 +643,8 @@ struct ClsWorkspace {
     BlockSummary* summ;
     uint32_t* offsets;
     uint32_t* skip;
+    unsigned long long* bitmask;
+    int64_t n_groups;
     size_t total;
 };
 
@@ -520,6 +659,10 @@ ClsWorkspace carve(void* ws, int64_t n) {
     w.summ = reinterpret_cast<BlockSummary*>(p + off); off += align_up((size_t)nblocks * sizeof(BlockSummary), 256);
     w.offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.skip = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
+    // candidate bits: stream_kernel writes whole workgroups, so round the group count up to its tile
+    const int64_t stream_blocks = (n + kStreamTile - 1) / kStreamTile;
+    w.n_groups = stream_blocks * (kStreamTile / kGroup);
+    w.bitmask = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)w.n_groups * 32, 256);
     w.total = off;
     return w;
 }
@@ -576,10 +719,18 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     const ClsWorkspace w = carve(ws, a.n);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
-    ProfScope ps(s, kProfClassify);
-    hipLaunchKernelGGL(classify_kernel, dim3(nblocks), dim3(kClsThreads), 0, s, a,
-                       reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ,
-                       reinterpret_cast<unsigned long long*>(counters));
+    const uint32_t stream_blocks = (uint32_t)((a.n + kStreamTile - 1) / kStreamTile);
+    {
+        ProfScope ps(s, kProfClassify);
+        hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                           reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
+    }
+    {
+        ProfScope ps(s, kProfCandidate);
+        hipLaunchKernelGGL(candidate_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups,
+                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ,
+                           reinterpret_cast<unsigned long long*>(counters));
+    }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

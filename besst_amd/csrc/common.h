@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
-    kProfClassify = 0, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter,
+    kProfClassify = 0, kProfCandidate, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter,
     kProfRowHeads, kProfRowScan, kProfRowZero, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
 };
 struct ProfScope {
@@ -56,12 +56,20 @@ struct __attribute__((aligned(16))) ContigRow {
 };
 constexpr uint32_t kScafIdMask = (1u << 28) - 1;
 
-// ---- classify kernel geometry ----------------------------------------------------------------------
-constexpr int kClsThreads = 256;
-constexpr int kClsVec = 4;                                   // records per thread per sub-tile
-constexpr int kClsSubTile = kClsThreads * kClsVec;           // 1024 records
-constexpr int kClsSubTiles = 4;
-constexpr int kClsTile = kClsSubTile * kClsSubTiles;         // 4096 records per block
+// ---- classify stage geometry ------------------------------------------------------------------------
+// stream_kernel: 256 threads x 4 records per sub-tile, kStreamSubTiles sub-tiles per workgroup.  A wave covers
+// a GROUP of 256 consecutive records per sub-tile and publishes their candidate bits as 4 x u64 (32 bytes).
+constexpr int kStreamThreads = 256;
+constexpr int kStreamVec = 4;
+constexpr int kStreamSubTile = kStreamThreads * kStreamVec;      // 1024 records
+constexpr int kStreamSubTiles = 4;
+constexpr int kStreamTile = kStreamSubTile * kStreamSubTiles;    // 4096 records per workgroup
+constexpr int kGroup = 64 * kStreamVec;                          // 256 records per candidate-bit group
+// candidate_kernel: single-wave workgroups, one lane per group -> one BlockSummary per 16384 records
+constexpr int kCandThreads = 64;
+constexpr int kClsTile = kCandThreads * kGroup;                  // 16384 records per summary block
+constexpr int kCandCap = 1024;                                   // candidate entries staged in LDS per round
+constexpr int kCandBatch = 4;                                    // candidates per lane evaluated with their loads overlapped
 
 // Per-block summary of the classify kernel, resolved by the single-block "stitch" kernel.
 struct __attribute__((aligned(16))) BlockSummary {
@@ -71,6 +79,9 @@ struct __attribute__((aligned(16))) BlockSummary {
     int32_t last_o1, last_o2;     // last reaching record of the block
     uint32_t head_info;   // bit0 accept, bit1 double call, bit2 mapq == 0, bit3 has slot
     uint32_t head_slot;   // local slot of the head's tuple
+    // the block's share of besst_counters fields 0..5 and 7 (summed by the stitch kernel: thousands of
+    // workgroups hitting the same seven device-scope atomics were the slowest part of the kernel)
+    uint32_t ctr[8];
 };
 
 // Launch-time constants of the record loop.
@@ -83,6 +94,7 @@ struct ClassifyArgs {
     const uint8_t* mapq;
     const uint16_t* qlen;
     const ContigRow* table;
+    const uint8_t* cls8;    // class per tid (follows the rows in the packed table)
     int64_t n;
     int32_t n_contigs;
     int32_t node_bits;

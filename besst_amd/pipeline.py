@@ -62,7 +62,7 @@ class DeviceGraphBuilder(object):
         u8 = dict(dtype=torch.uint8, device=device)
         i64 = dict(dtype=torch.int64, device=device)
         i32 = dict(dtype=torch.int32, device=device)
-        self.table = torch.zeros(self.n_contigs * 16, **u8)
+        self.table = torch.zeros(self.lib.besst_dev_contig_table_bytes(self.n_contigs), **u8)
         self.aligned = torch.zeros(self.n_contigs, **i64)
         self.small = torch.zeros(COUNTER_BYTES + 32, **u8)        # counters | carry[2] | n_out | n_rows
         self.keys = torch.empty(self.rec_cap, **i64)

@@ -193,8 +193,9 @@ int besst_ctx_score_edges(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, 
 size_t besst_dev_classify_workspace_bytes(int64_t n_records);
 size_t besst_dev_reduce_workspace_bytes(int64_t n_tuples);
 
-/* Pack the contig table into the 16-byte rows the kernels gather from (host pointers in,
- * device pointer out; table must hold n_contigs * 16 bytes). */
+/* Pack the contig table into the 16-byte rows the kernels gather from, followed by one class byte per
+ * contig (host pointers in, device pointer out; table must hold besst_dev_contig_table_bytes(n) bytes). */
+size_t besst_dev_contig_table_bytes(int64_t n_contigs);
 int besst_dev_pack_contigs(void* stream, int64_t n_contigs, const int32_t* h_scaf_id,
                            const int32_t* h_scaf_len, const int32_t* h_ctg_pos,
                            const int32_t* h_ctg_len, const uint8_t* h_direction,
