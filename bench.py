@@ -218,9 +218,9 @@ def main():
             'vs_baseline': None,
             'dtype': 'int32/int64 (fp64 for read_len truncation)',
             'data': 'synthetic',
-            'config': {'workload': '%s: %d contigs / %d PE read-pairs per GPU, one fr library, records resident in HBM '
+            'config': {'workload': '%s: %d contigs / %d read-pairs per GPU, one %s library, records resident in HBM '
                                    '(%d copies cycled to defeat the Infinity Cache)'
-                                   % (args.config, wl['asm'].nc, pairs, args.copies if world == 1 else 1),
+                                   % (args.config, wl['asm'].nc, pairs, lib['orientation'], args.copies if world == 1 else 1),
                        'records_per_gpu': n_rec, 'link_tuples_per_pair': round(f, 5), 'edge_rows': n_rows,
                        'parallelism': 'stream-slice x%d + key-owner all-to-all' % world if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': 'stream_kernel', 'achieved': round(achieved, 1),

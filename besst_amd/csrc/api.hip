@@ -157,7 +157,7 @@ int besst_prof_slots(void) { return kProfSlots; }
 const char* besst_prof_slot_name(int slot) {
     static const char* names[kProfSlots] = {"stream_kernel", "candidate_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
                                             "radix_rowscan_kernel", "radix_scatter_kernel", "row_heads_kernel",
-                                            "row_scan_kernel", "row_zero_kernel", "row_reduce_kernel",
+                                            "row_scan_kernel", "row_reduce_kernel",
                                             "metrics_kernels", "score_kernels"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
 }
@@ -413,10 +413,13 @@ int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, in
 
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
-                            size_t workspace_bytes) {
-    BESST_REQUIRE(carry && keys && payload && n_out && counters, "classify_emit: null pointer");
+                            size_t workspace_bytes, int64_t n_contigs, const void* contig_table, int64_t* aligned) {
+    BESST_REQUIRE(carry && keys && payload && n_out && counters && contig_table && aligned,
+                  "classify_emit: null pointer");
+    BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "classify_emit: n_contigs out of range");
+    const uint8_t* cls8 = static_cast<const uint8_t*>(contig_table) + (size_t)n_contigs * sizeof(ContigRow);
     return launch_classify_emit(static_cast<hipStream_t>(stream), n, detect_duplicate, carry, keys, payload, n_out,
-                                counters, workspace, workspace_bytes);
+                                counters, workspace, workspace_bytes, cls8, (int32_t)n_contigs, aligned);
 }
 
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity) { return exchange_region_bytes(pair_capacity); }

@@ -220,7 +220,9 @@ __device__ __forceinline__ void wave_add_by_key(unsigned long long* dst, int32_t
 
 __device__ __forceinline__ void flush_cov(const ClassifyArgs& a, unsigned long long* aligned, int lane,
                                           int32_t ref, int sum) {
-    if (lane == 0 && sum && (uint32_t)ref < (uint32_t)a.n_contigs && a.cls8[ref])
+    // No class lookup here (it would be a dependent memory round trip at the end of every wave): any in-range
+    // tid is credited and compact_kernel clears the entries of contigs that are not in the table.
+    if (lane == 0 && sum && (uint32_t)ref < (uint32_t)a.n_contigs)
         atomicAdd(&aligned[ref], (unsigned long long)sum);
 }
 
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && a.cls8[r_tid[k]];
+                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
                 wave_add_by_key(aligned, r_tid[k], (int)r_qlen[k], act, lane);
             }
         }
@@ -623,7 +625,12 @@ __global__ __launch_bounds__(256) void compact_kernel(const BlockSummary* __rest
                                                       const uint64_t* __restrict__ seg_keys,
                                                       const uint64_t* __restrict__ seg_payload,
                                                       uint64_t* __restrict__ keys,
-                                                      uint64_t* __restrict__ payload) {
+                                                      uint64_t* __restrict__ payload,
+                                                      const uint8_t* __restrict__ cls8, int32_t n_contigs,
+                                                      unsigned long long* __restrict__ aligned) {
+    // coverage of contigs that are not in the table is not part of cont_aligned_len (CreateGraph.py:89-95)
+    for (int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); c < n_contigs; c += (int32_t)(gridDim.x * blockDim.x))
+        if (!cls8[c]) aligned[c] = 0;
     const uint32_t b = blockIdx.x;
     const uint32_t n = summ[b].n_emit;
     if (n == 0) return;
@@ -755,7 +762,7 @@ int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t*
 
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
-                         size_t ws_bytes) {
+                         size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned) {
     if (n <= 0) {
         BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
         return BESST_OK;
@@ -772,7 +779,7 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     {
         ProfScope ps(s, kProfCompact);
         hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
-                           w.seg_payload, keys, payload);
+                           w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned));
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
@@ -782,7 +789,8 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
                     uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws, size_t ws_bytes) {
     int rc = launch_classify_scan(s, a, aligned, counters, ws, ws_bytes);
     if (rc) return rc;
-    return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes);
+    return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
+                                a.n_contigs, aligned);
 }
 
 }  // namespace besst

@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
     kProfClassify = 0, kProfCandidate, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter,
-    kProfRowHeads, kProfRowScan, kProfRowZero, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
+    kProfRowHeads, kProfRowScan, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
 };
 struct ProfScope {
     hipStream_t s;
@@ -126,6 +126,7 @@ struct DigitSel {
     int shift;
     int node_bits;
     uint32_t world;
+    int bits;      // digit width in mode 0
 };
 
 // Owner rank of a scaffold's edges (multi-GPU key partition): multiplicative hash, then mod world.
@@ -145,7 +146,7 @@ int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size
 int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry);
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
-                         size_t ws_bytes);
+                         size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned);
 
 size_t reduce_workspace_bytes(int64_t cap);
 int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,

@@ -4,7 +4,9 @@
 //                the edge by the unordered node pair; fishy_edges :161-162 likewise)
 //   payload[i] = obs_of_min_node | (obs_of_max_node | mask << 30) << 32
 //
-// 1. Stable LSD radix sort (8-bit digits, only the significant key bits) of (key, stream index).
+// 1. Stable LSD radix sort (only the significant key bits; 11-bit digits while the tuple count is small and
+//    the stage is launch-latency bound, 8-bit digits for large streams where scatter locality matters) of
+//    (key, stream index).
 //    Stability keeps every edge's observations in BAM order, which is the order the reference appends
 //    them in (CreateGraph.py:845,856,862), and makes the first tuple of a row its first occurrence.
 //    Ranking is wave-native: a 64-lane match-any built from 8 ballots gives each key its rank among
@@ -25,7 +27,7 @@ __device__ __forceinline__ uint32_t nblocks_of(uint32_t n, uint32_t tile) { retu
 
 // digit of a key: a radix digit (mode 0) or the owning rank of the key's min scaffold (mode 1)
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
-    if (ds.mode == 0) return (uint32_t)(key >> ds.shift) & (kRadix - 1);
+    if (ds.mode == 0) return (uint32_t)(key >> ds.shift) & ((1u << ds.bits) - 1u);
     const uint32_t scaf = (uint32_t)(key >> (2 + ds.node_bits));   // key = ((min_node << nb) | max_node) << 1 | f
     return owner_of_scaffold(scaf, ds.world);
 }
@@ -33,32 +35,61 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
 // ---------------------------------------------------------------------------------------------------
 // radix sort
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys,
-                                                                  const uint32_t* __restrict__ n_ptr,
-                                                                  DigitSel ds, uint32_t* __restrict__ table,
-                                                                  uint32_t stride) {
-    const uint32_t n = *n_ptr;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks_of(n, kSortTile)) return;
-    __shared__ uint32_t s_hist[kRadix];
+// Per-block digit counts live in `table`.  Two layouts:
+//   scan-free (few blocks): table[block][digit]; every scatter workgroup sums the columns of the blocks
+//                           before it and the digit totals itself - no scan kernel, coalesced reads
+//   scanned   (many blocks): table[digit][block], exclusive-scanned along blocks by radix_rowscan_kernel
+// Every kernel loads its keys speculatively (guarded by the caller's capacity, not by the device-side count)
+// so that the count, the table and the keys arrive after ONE memory latency instead of three.
+constexpr int kScanFreeMaxBlocks = 64;
+
+template <int BITS>
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
+    const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds,
+    uint32_t* __restrict__ table, uint32_t stride, int scanned, uint32_t* __restrict__ zero_n,
+    unsigned long long* __restrict__ zero_sum, unsigned long long* __restrict__ zero_sum_sq) {
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint32_t s_hist[RADIX];
     const int t = threadIdx.x;
-    s_hist[t] = 0;
-    __syncthreads();
+    const uint32_t b = blockIdx.x;
     const uint32_t base = b * kSortTile;
+    uint64_t k[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t i = base + r * kSortThreads + t;
-        if (i < n) atomicAdd(&s_hist[digit_of(keys[i], ds)], 1u);
+        k[r] = i < cap ? keys[i] : 0ull;
+    }
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    if (b >= nblocks_of(n, kSortTile)) return;
+    for (int d = t; d < RADIX; d += kSortThreads) s_hist[d] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = base + r * kSortThreads + t;
+        if (i < n) atomicAdd(&s_hist[digit_of(k[r], ds)], 1u);
     }
     __syncthreads();
-    table[(uint32_t)t * stride + b] = s_hist[t];
+    for (int d = t; d < RADIX; d += kSortThreads) {
+        if (scanned) table[(uint32_t)d * stride + b] = s_hist[d];
+        else table[b * RADIX + d] = s_hist[d];
+    }
+    if (zero_n) {   // last pass: clear the edge-row accumulators this tile can reach (rows <= tuples)
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t i = base + r * kSortThreads + t;
+            if (i < n) { zero_n[i] = 0; zero_sum[i] = 0; zero_sum_sq[i] = 0; }
+        }
+    }
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total to row_total[d]
-__global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                             uint32_t* __restrict__ table, uint32_t stride,
                                                             uint32_t* __restrict__ row_total) {
-    const uint32_t nb = nblocks_of(*n_ptr, kSortTile);
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, kSortTile);
     uint32_t* row = table + (size_t)blockIdx.x * stride;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry;
@@ -86,25 +117,74 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
     if (t == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <bool kFirst>
+template <int BITS, bool kFirst>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-    const uint32_t* __restrict__ n_ptr, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
-    const uint32_t* __restrict__ row_total, uint64_t* __restrict__ keys_out,
+    const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table,
+    uint32_t stride, const uint32_t* __restrict__ row_total, int scanned, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ idx_out) {
-    const uint32_t n = *n_ptr;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks_of(n, kSortTile)) return;
-    __shared__ uint32_t s_whist[4][kRadix];
-    __shared__ uint32_t s_base[kRadix];
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / kSortThreads;     // digits per thread (contiguous)
+    __shared__ uint32_t s_whist[4][RADIX];
+    __shared__ uint32_t s_base[RADIX];
     __shared__ uint32_t s_w[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
+    uint64_t key[kSortItems];
+    uint32_t idx[kSortItems];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_whist[w][t] = 0;
-    // exclusive scan of the 256 digit totals -> global start of each digit
-    {
-        const uint32_t v = row_total[t];
-        uint32_t x = v;
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        key[r] = i < cap ? keys_in[i] : ~0ull;
+        idx[r] = kFirst ? i : (i < cap ? idx_in[i] : 0u);
+    }
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, kSortTile);
+    if (b >= nb) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        for (int d = t; d < RADIX; d += kSortThreads) s_whist[w][d] = 0;
+    {   // global start of this block's share of every digit
+        uint32_t pre[DPT], tot[DPT];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) { pre[q] = 0; tot[q] = 0; }
+        if (scanned) {
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) {
+                const uint32_t d = (uint32_t)t * DPT + q;
+                tot[q] = row_total[d];
+                pre[q] = table[d * stride + b];
+            }
+        } else {
+            // 8 blocks' rows in flight per round trip (the loads of one group are issued before any is used)
+            constexpr int kGroupBlocks = 8;
+            for (uint32_t bb0 = 0; bb0 < nb; bb0 += kGroupBlocks) {
+                uint32_t v[kGroupBlocks][DPT];
+#pragma unroll
+                for (int u = 0; u < kGroupBlocks; ++u) {
+                    const uint32_t bb = bb0 + u;
+                    const uint32_t* row = table + (size_t)(bb < nb ? bb : 0) * RADIX + (size_t)t * DPT;
+#pragma unroll
+                    for (int q = 0; q < DPT; ++q) v[u][q] = row[q];
+                }
+#pragma unroll
+                for (int u = 0; u < kGroupBlocks; ++u) {
+                    const uint32_t bb = bb0 + u;
+#pragma unroll
+                    for (int q = 0; q < DPT; ++q) {
+                        const uint32_t x = bb < nb ? v[u][q] : 0u;
+                        tot[q] += x;
+                        if (bb < b) pre[q] += x;
+                    }
+                }
+            }
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) run += tot[q];
+        uint32_t x = run;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(x, d, 64);
@@ -112,27 +192,26 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         }
         if (lane == 63) s_w[wave] = x;
         __syncthreads();
-        uint32_t pre = 0;
-        for (int w = 0; w < wave; ++w) pre += s_w[w];
-        s_base[t] = pre + x - v + table[(uint32_t)t * stride + b];
+        uint32_t start = x - run;
+        for (int w = 0; w < wave; ++w) start += s_w[w];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            s_base[t * DPT + q] = start + pre[q];
+            start += tot[q];
+        }
     }
     __syncthreads();
 
-    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint64_t key[kSortItems];
-    uint32_t idx[kSortItems];
-    uint32_t dig_rank[kSortItems];   // digit | rank << 8
+    uint32_t dig_rank[kSortItems];   // digit | rank << BITS
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : ~0ull;
-        idx[r] = kFirst ? i : (valid ? idx_in[i] : 0u);
-        const uint32_t d = valid ? digit_of(key[r], ds) : (kRadix - 1);
+        const uint32_t d = valid ? digit_of(key[r], ds) : (uint32_t)(RADIX - 1);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int bit = 0; bit < kRadixBits; ++bit) {
+        for (int bit = 0; bit < BITS; ++bit) {
             const bool one = (d >> bit) & 1u;
             const unsigned long long bal = __ballot(one);
             peers &= one ? bal : ~bal;
@@ -146,15 +225,15 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             *slot = pre + (uint32_t)__popcll(peers);
         }
         pre = __shfl(pre, leader < 0 ? 0 : leader, 64);
-        dig_rank[r] = d | ((pre + (uint32_t)__popcll(peers & lt_mask)) << 8);
+        dig_rank[r] = d | ((pre + (uint32_t)__popcll(peers & lt_mask)) << BITS);
     }
     __syncthreads();
-    {   // per-digit start of each wave inside this block's range of the digit
-        uint32_t run = s_base[t];
+    for (int d = t; d < RADIX; d += kSortThreads) {   // per-digit start of each wave inside the block's range
+        uint32_t run = s_base[d];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const uint32_t c = s_whist[w][t];
-            s_whist[w][t] = run;
+            const uint32_t c = s_whist[w][d];
+            s_whist[w][d] = run;
             run += c;
         }
     }
@@ -163,7 +242,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
-            const uint32_t dst = s_whist[wave][dig_rank[r] & 0xffu] + (dig_rank[r] >> 8);
+            const uint32_t dst = s_whist[wave][dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
             keys_out[dst] = key[r];
             idx_out[dst] = idx[r];
         }
@@ -173,25 +252,27 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 // ---------------------------------------------------------------------------------------------------
 // segmented reduction into edge rows
 // ---------------------------------------------------------------------------------------------------
+constexpr int kRowScanFreeMaxBlocks = 2048;
+
 __global__ __launch_bounds__(kRedThreads) void row_heads_kernel(const uint64_t* __restrict__ keys,
-                                                                const uint32_t* __restrict__ n_ptr,
+                                                                const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                                 uint32_t* __restrict__ blk_heads) {
-    const uint32_t n = *n_ptr;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks_of(n, kRedTile)) return;
     __shared__ int s_w[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
     const uint32_t i0 = b * kRedTile + t * kRedItems;
-    int cnt = 0;
-    uint64_t prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : 0;
+    uint64_t k[kRedItems + 1];
+    k[0] = (i0 > 0 && i0 - 1 < cap) ? keys[i0 - 1] : 0ull;
 #pragma unroll
-    for (int k = 0; k < kRedItems; ++k) {
-        const uint32_t i = i0 + k;
-        if (i < n) {
-            const uint64_t key = keys[i];
-            cnt += (i == 0 || key != prev) ? 1 : 0;
-            prev = key;
-        }
+    for (int j = 0; j < kRedItems; ++j) k[j + 1] = (i0 + j) < cap ? keys[i0 + j] : 0ull;
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    if (b >= nblocks_of(n, kRedTile)) return;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kRedItems; ++j) {
+        const uint32_t i = i0 + j;
+        if (i < n) cnt += (i == 0 || k[j + 1] != k[j]) ? 1 : 0;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
@@ -200,11 +281,13 @@ __global__ __launch_bounds__(kRedThreads) void row_heads_kernel(const uint64_t* 
     if (t == 0) blk_heads[b] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
 }
 
-__global__ __launch_bounds__(1024) void row_scan_kernel(const uint32_t* __restrict__ n_ptr,
+__global__ __launch_bounds__(1024) void row_scan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                         const uint32_t* __restrict__ blk_heads,
                                                         uint32_t* __restrict__ blk_base,
                                                         uint32_t* __restrict__ n_rows) {
-    const uint32_t nb = nblocks_of(*n_ptr, kRedTile);
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, kRedTile);
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -231,40 +314,55 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const uint32_t* __restri
     if (t == 0) *n_rows = s_carry;
 }
 
-__global__ __launch_bounds__(256) void row_zero_kernel(const uint32_t* __restrict__ n_rows,
-                                                       uint32_t* __restrict__ row_n,
-                                                       unsigned long long* __restrict__ row_sum,
-                                                       unsigned long long* __restrict__ row_sum_sq) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < *n_rows) {
-        row_n[i] = 0;
-        row_sum[i] = 0;
-        row_sum_sq[i] = 0;
-    }
-}
-
 __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-    const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
-    const uint32_t* __restrict__ blk_base, uint64_t* __restrict__ row_key,
-    uint32_t* __restrict__ row_mask, uint32_t* __restrict__ row_n,
-    unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
-    uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo,
-    int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map) {
-    const uint32_t n = *n_ptr;
-    const uint32_t b = blockIdx.x;
-    if (b >= nblocks_of(n, kRedTile)) return;
+    const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+    const uint32_t* __restrict__ blk_heads, const uint32_t* __restrict__ blk_base, int scanned,
+    uint32_t* __restrict__ n_rows, uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
+    uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
+    unsigned long long* __restrict__ row_sum_sq, uint32_t* __restrict__ row_first,
+    uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi,
+    const uint32_t* __restrict__ first_map) {
     __shared__ int s_w[4];
+    __shared__ uint32_t s_pre[4], s_tot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
     const uint32_t i0 = b * kRedTile + t * kRedItems;
     uint64_t key[kRedItems];
-    bool head[kRedItems];
-    int cnt = 0;
-    uint64_t prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : 0;
+    uint32_t src[kRedItems];
+    uint64_t prev = (i0 > 0 && i0 - 1 < cap) ? keys[i0 - 1] : 0ull;
 #pragma unroll
     for (int k = 0; k < kRedItems; ++k) {
         const uint32_t i = i0 + k;
-        key[k] = i < n ? keys[i] : 0;
+        key[k] = i < cap ? keys[i] : 0ull;
+        src[k] = i < cap ? idx[i] : 0u;
+    }
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, kRedTile);
+    if (b >= nb) return;
+    uint32_t base;
+    if (scanned) {
+        base = blk_base[b];
+    } else {   // few blocks: every workgroup adds up the head counts before it (block 0 also publishes the total)
+        uint32_t pre = 0, tot = 0;
+        for (uint32_t bb = t; bb < nb; bb += kRedThreads) {
+            const uint32_t v = blk_heads[bb];
+            tot += v;
+            if (bb < b) pre += v;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { pre += __shfl_xor(pre, d, 64); tot += __shfl_xor(tot, d, 64); }
+        if (lane == 0) { s_pre[wave] = pre; s_tot[wave] = tot; }
+        __syncthreads();
+        base = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+        if (b == 0 && t == 0) *n_rows = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    }
+    bool head[kRedItems];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kRedItems; ++k) {
+        const uint32_t i = i0 + k;
         head[k] = i < n && (i == 0 || key[k] != prev);
         cnt += head[k] ? 1 : 0;
         prev = key[k];
@@ -280,7 +378,10 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
     int pre = 0;
     for (int w = 0; w < wave; ++w) pre += s_w[w];
     // index of the row the thread's first item belongs to (rows are numbered by their heads)
-    int64_t row = (int64_t)blk_base[b] + pre + x - cnt - 1;
+    int64_t row = (int64_t)base + pre + x - cnt - 1;
+    uint64_t pl[kRedItems];
+#pragma unroll
+    for (int k = 0; k < kRedItems; ++k) pl[k] = (i0 + k) < n ? payload[src[k]] : 0ull;
     uint32_t run_n = 0;
     unsigned long long run_s = 0, run_s2 = 0;
 #pragma unroll
@@ -296,16 +397,14 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
             }
             row++;
         }
-        const uint32_t src = idx[i];
-        const uint64_t p = payload[src];
-        const uint32_t lo = (uint32_t)p, hi = (uint32_t)(p >> 32);
+        const uint32_t lo = (uint32_t)pl[k], hi = (uint32_t)(pl[k] >> 32);
         const int32_t o_lo = (int32_t)lo, o_hi = (int32_t)(hi & 0x3fffffffu);
         obs_lo[i] = o_lo;
         obs_hi[i] = o_hi;
         if (head[k]) {
             row_key[row] = key[k];
             row_mask[row] = hi >> 30;
-            row_first[row] = first_map ? first_map[src] : src;
+            row_first[row] = first_map ? first_map[src[k]] : src[k];
             row_offset[row] = i;
         }
         const unsigned long long o = (unsigned long long)((long long)o_lo + o_hi);
@@ -331,6 +430,8 @@ struct RedWorkspace {
     size_t total;
 };
 
+constexpr int kMaxRadix = 1 << 11;
+
 RedWorkspace carve(void* ws, int64_t cap) {
     RedWorkspace w;
     char* p = static_cast<char*>(ws);
@@ -340,12 +441,40 @@ RedWorkspace carve(void* ws, int64_t cap) {
     for (int j = 0; j < 2; ++j) { w.keys[j] = reinterpret_cast<uint64_t*>(p + off); off += align_up((size_t)cap * 8, 256); }
     for (int j = 0; j < 2; ++j) { w.idx[j] = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)cap * 4, 256); }
     w.stride = (uint32_t)nb_sort;
-    w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_sort * kRadix * 4, 256);
-    w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kRadix * 4, 256);
+    // the wide-digit path is only taken for small streams, the 8-bit path for any size
+    const size_t table_entries = nb_sort * kRadix > (size_t)kScanFreeMaxBlocks * kMaxRadix ? nb_sort * kRadix
+                                                                                         : (size_t)kScanFreeMaxBlocks * kMaxRadix;
+    w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
+    w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.total = off;
     return w;
+}
+
+// one LSD pass over `bits`-bit digits selected by ds; zero_* != nullptr on the last pass
+template <int BITS>
+void launch_pass(hipStream_t s, const RedWorkspace& w, uint32_t nb_sort, uint32_t cap, const uint32_t* n_tuples,
+                 DigitSel ds, bool first, const uint64_t* kin, const uint32_t* iin, uint64_t* kout, uint32_t* iout,
+                 uint32_t* zero_n, unsigned long long* zero_sum, unsigned long long* zero_sum_sq) {
+    const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
+    {
+        ProfScope ps(s, kProfSortHist);
+        hipLaunchKernelGGL((radix_hist_kernel<BITS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples, cap, ds,
+                           w.table, w.stride, scanned, zero_n, zero_sum, zero_sum_sq);
+    }
+    if (scanned) {
+        ProfScope ps(s, kProfSortScan);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << BITS), dim3(256), 0, s, n_tuples, cap, w.table, w.stride,
+                           w.row_total);
+    }
+    ProfScope ps(s, kProfSortScatter);
+    if (first)
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
+                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout);
+    else
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, false>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
+                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout);
 }
 
 }  // namespace
@@ -370,52 +499,42 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: workspace too small");
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
-    const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
+    // wide digits (fewer dependent launches) while the stage is latency bound, 8-bit digits for large streams
+    const int bits = nb_sort <= (uint32_t)kScanFreeMaxBlocks ? 11 : kRadixBits;
+    const int passes = (key_bits + bits - 1) / bits;
+    auto* zsum = reinterpret_cast<unsigned long long*>(row_sum);
+    auto* zsq = reinterpret_cast<unsigned long long*>(row_sum_sq);
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;
     for (int p = 0; p < passes; ++p) {
-        const DigitSel shift{0, p * kRadixBits, 0, 1u};
+        const DigitSel ds{0, p * bits, 0, 1u, bits};
         uint64_t* kout = w.keys[p & 1];
         uint32_t* iout = w.idx[p & 1];
-        {
-            ProfScope ps(s, kProfSortHist);
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples,
-                               shift, w.table, w.stride);
-        }
-        {
-            ProfScope ps(s, kProfSortScan);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table,
-                               w.stride, w.row_total);
-        }
-        ProfScope ps(s, kProfSortScatter);
-        if (p == 0)
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb_sort), dim3(kSortThreads), 0, s, kin,
-                               iin, n_tuples, shift, w.table, w.stride, w.row_total, kout, iout);
+        const bool last = p == passes - 1;
+        if (bits == 11)
+            launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
+                            last ? row_n : nullptr, zsum, zsq);
         else
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb_sort), dim3(kSortThreads), 0, s, kin,
-                               iin, n_tuples, shift, w.table, w.stride, w.row_total, kout, iout);
+            launch_pass<kRadixBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
+                                    last ? row_n : nullptr, zsum, zsq);
         kin = kout;
         iin = iout;
     }
+    const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {
         ProfScope ps(s, kProfRowHeads);
-        hipLaunchKernelGGL(row_heads_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, n_tuples, w.blk_heads);
+        hipLaunchKernelGGL(row_heads_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, n_tuples, (uint32_t)cap,
+                           w.blk_heads);
     }
-    {
+    if (rscanned) {
         ProfScope ps(s, kProfRowScan);
-        hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_tuples, w.blk_heads, w.blk_base, n_rows);
-    }
-    {
-    ProfScope ps(s, kProfRowZero);
-    hipLaunchKernelGGL(row_zero_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, s, n_rows, row_n,
-                       reinterpret_cast<unsigned long long*>(row_sum),
-                       reinterpret_cast<unsigned long long*>(row_sum_sq));
+        hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, s, n_tuples, (uint32_t)cap, w.blk_heads, w.blk_base,
+                           n_rows);
     }
     ProfScope ps(s, kProfRowReduce);
     hipLaunchKernelGGL(row_reduce_kernel, dim3(nb_red), dim3(kRedThreads), 0, s, kin, iin, payload, n_tuples,
-                       w.blk_base, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
-                       reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset, obs_lo,
-                       obs_hi, first_map);
+                       (uint32_t)cap, w.blk_heads, w.blk_base, rscanned, n_rows, row_key, row_mask, row_n, zsum, zsq,
+                       row_first, row_offset, obs_lo, obs_hi, first_map);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }
@@ -511,14 +630,16 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "partition: workspace too small");
     const size_t region = exchange_region_bytes(pair_cap);
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
-    const DigitSel ds{1, 0, node_bits, (uint32_t)world};
+    const DigitSel ds{1, 0, node_bits, (uint32_t)world, kRadixBits};
     if (cap > 0) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples, ds, w.table,
-                           w.stride);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, w.table, w.stride,
-                           w.row_total);
-        hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb_sort), dim3(kSortThreads), 0, s, keys, nullptr,
-                           n_tuples, ds, w.table, w.stride, w.row_total, w.keys[0], w.idx[0]);
+        // rowscan path: pack_kernel reads the per-owner totals from row_total
+        hipLaunchKernelGGL((radix_hist_kernel<kRadixBits>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples,
+                           (uint32_t)cap, ds, w.table, w.stride, 1, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.table,
+                           w.stride, w.row_total);
+        hipLaunchKernelGGL((radix_scatter_kernel<kRadixBits, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys,
+                           nullptr, n_tuples, (uint32_t)cap, ds, w.table, w.stride, w.row_total, 1, w.keys[0],
+                           w.idx[0]);
     }
     const uint32_t nb_pack = (uint32_t)((cap + 255) / 256) + 1;
     hipLaunchKernelGGL(pack_kernel, dim3(nb_pack), dim3(256), 0, s, w.keys[0], w.idx[0], payload, n_tuples,

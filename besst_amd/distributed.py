@@ -90,7 +90,7 @@ class HipBackend(object):
         _lib.check(self.lib.besst_dev_resolve_carry(self._stream(), p(tails), self.rank, g._carry), 'resolve_carry')
         _lib.check(self.lib.besst_dev_classify_emit(
             self._stream(), self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
-            g._small(0), p(g.ws1), g.ws1.numel()), 'classify_emit')
+            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned)), 'classify_emit')
 
     def partition(self):
         g, p = self.gb, self.pipeline._p

@@ -249,7 +249,8 @@ int besst_dev_classify_tail(void* stream, int64_t n, int32_t* tail, void* worksp
 int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, int32_t* carry);
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
-                            size_t workspace_bytes);
+                            size_t workspace_bytes, int64_t n_contigs, const void* contig_table,
+                            int64_t* aligned);
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity);
 uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world);
 /* workspace: besst_dev_reduce_workspace_bytes(capacity) */

@@ -35,7 +35,8 @@ def assert_table_equals_c_oracle(table, aligned, ctr, batch, wl):
     assert int(table.sum_obs_sq[link].sum()) == int((o * o).sum())
 
 
-@pytest.mark.parametrize('config,pairs,nc', [('C2', 1_000_000, 3000), ('C3', 600_000, 2000)])
+@pytest.mark.parametrize('config,pairs,nc', [('C2', 1_000_000, 3000), ('C3', 600_000, 2000),
+                                             ('C3', 5_000_000, 4000)])   # > 262144 tuples: 8-bit scanned sort path
 def test_device_equals_c_oracle(config, pairs, nc):
     from besst_amd import device
     if os.environ.get('BESST_FULL_SIZE') == '1' and config == 'C2':
