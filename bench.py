@@ -27,6 +27,21 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 CLASSIFY_SLOT = 0
+PMC_SUMMARY = os.path.join(REPO, 'profiles', 'r01_c2_pmc_traffic.json')
+
+
+def pmc_traffic(config, n_rec):
+    """HBM bytes per stream_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    separately, gfx950 x2 correction on FETCH_SIZE; see profiles/README.md).  Only valid for the workload it was
+    collected on, otherwise None."""
+    try:
+        with open(PMC_SUMMARY) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if config != 'C2' or n_rec * 11 != doc.get('stream_kernel_algorithmic_bytes_per_launch'):
+        return None
+    return doc.get('stream_kernel_traffic_bytes_per_launch')
 
 
 def parse_args():
@@ -225,7 +240,8 @@ def main():
                        'parallelism': 'stream-slice x%d + key-owner all-to-all' % world if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': 'stream_kernel', 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
+                         'traffic': pmc_traffic(args.config, n_rec) if world == 1 else None,
+                         'avg_launch_ms': round(cls_avg_s * 1e3, 4),
                          'algorithmic_bytes_per_launch': alg_bytes},
             # whole graph-build pass = 38 B/pair of records + each tuple written and read once
             'graph_pass': {'algorithmic_bytes_per_step': pairs * (38.0 + 32.0 * f),

@@ -239,10 +239,17 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
 #pragma unroll
         for (int st = 0; st < kStreamSubTiles; ++st) {
             const int64_t i0 = block_base + (int64_t)st * kStreamSubTile + (int64_t)t * kStreamVec;
+#ifdef BESST_NT
+            v_tid[st] = __builtin_nontemporal_load(reinterpret_cast<const int4*>(a.tid + i0));
+            v_mtid[st] = __builtin_nontemporal_load(reinterpret_cast<const int4*>(a.mtid + i0));
+            v_mapq[st] = __builtin_nontemporal_load(reinterpret_cast<const uchar4*>(a.mapq + i0));
+            v_qlen[st] = __builtin_nontemporal_load(reinterpret_cast<const ushort4*>(a.qlen + i0));
+#else
             v_tid[st] = *reinterpret_cast<const int4*>(a.tid + i0);
             v_mtid[st] = *reinterpret_cast<const int4*>(a.mtid + i0);
             v_mapq[st] = *reinterpret_cast<const uchar4*>(a.mapq + i0);
             v_qlen[st] = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+#endif
         }
     } else {
 #pragma unroll
@@ -339,11 +346,11 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
 
     const int lane = threadIdx.x;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
-    const int64_t g = (int64_t)blockIdx.x * kCandThreads + lane;
+    const int64_t g = (int64_t)blockIdx.x * kCandGroups + lane;
     int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
 
     unsigned long long b[4] = {0ull, 0ull, 0ull, 0ull};
-    if (g < n_groups) {
+    if (lane < kCandGroups && g < n_groups) {
         const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
         const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
         b[0] = w0.x; b[1] = w0.y; b[2] = w1.x; b[3] = w1.y;
@@ -351,7 +358,11 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
     const int cnt = __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
     const int incl = wave_incl_scan(cnt, lane);
     const int my_base = incl - cnt;
+#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 0
+    const int total = 0 * __shfl(incl, 63, 64);
+#else
     const int total = __shfl(incl, 63, 64);
+#endif
     __syncthreads();
 
     // chain state, identical in every lane
@@ -381,6 +392,9 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
             }
         }
         __syncthreads();
+#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 1
+        continue;
+#endif
         const int len = (total - win) < kCandCap ? (total - win) : kCandCap;
         // ---- evaluate, all lanes round-robin ------------------------------------------------------------------
         for (int j0 = 0; j0 < len; j0 += kCandThreads * kCandBatch) {
@@ -431,6 +445,9 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
             }
         }
         __syncthreads();
+#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 2
+        continue;
+#endif
         // ---- ordered pass over the staged entries -------------------------------------------------------------
         for (int c0 = 0; c0 < len; c0 += kCandThreads) {
             const int j = c0 + lane;
