@@ -146,6 +146,11 @@ def stage_timings(wl):
 
 def main():
     args = parse_args()
+    # Only the final JSON line may reach stdout: RCCL prints a version banner to fd 1 when the process group is
+    # created, so everything before the result is routed to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from besst_amd import _lib, pipeline, workload
@@ -157,8 +162,12 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no GPU visible; besst_amd has no CPU path)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+    force_dist = os.environ.get('BESST_FORCE_DISTRIBUTED') == '1'   # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ['MASTER_ADDR'] = '127.0.0.1'
+            os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
@@ -168,7 +177,7 @@ def main():
     n_rec = len(batch)
     pairs = n_rec // 2
 
-    if world > 1:
+    if world > 1 or force_dist:
         from besst_amd import distributed
         runner = distributed.ShardedGraphBuild(device, wl, rank, world)
     else:
@@ -208,7 +217,7 @@ def main():
 
     n_tuples, n_rows = runner.sizes()
     verified = None
-    if world == 1 and not args.no_verify:
+    if world == 1 and not args.no_verify and not force_dist:
         verified = verify_full(runner, wl)
     f = n_tuples / float(pairs)
     cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
@@ -251,7 +260,7 @@ def main():
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': verified,
         }
-        if world == 1 and not args.no_stages:
+        if world == 1 and not args.no_stages and not force_dist:
             del runner
             torch.cuda.empty_cache()
             out['stages'] = stage_timings(wl)
@@ -260,8 +269,9 @@ def main():
             out['cpu_baseline'] = base
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

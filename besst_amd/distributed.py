@@ -45,6 +45,9 @@ class HipBackend(object):
         self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n,
                                               self.recv_cap)
         self.gb.set_contigs(**wl['table'])
+        # coverage numerators and the 8 counter words share one buffer so that ONE all-reduce sums both
+        self._sum_buf = torch.zeros(self.gb.n_contigs + 8, dtype=torch.int64, device=device)
+        self.gb.aligned = self._sum_buf[:self.gb.n_contigs]
         self.region = self.lib.besst_dev_exchange_region_bytes(self.pair_cap)
         u8 = dict(dtype=torch.uint8, device=device)
         self.send = torch.zeros(world * self.region, **u8)
@@ -110,6 +113,13 @@ class HipBackend(object):
         self.gb.reduce(keys=self.rkeys, payload=self.rpayload, n_tuples_ptr=C.c_void_p(self.flags.data_ptr()),
                        capacity=self.recv_cap, first_map=self.gidx)
 
+    def pack_for_allreduce(self):
+        self._sum_buf[self.gb.n_contigs:].copy_(self.counter_words)
+        return self._sum_buf
+
+    def unpack_after_allreduce(self):
+        self.counter_words.copy_(self._sum_buf[self.gb.n_contigs:])
+
     def overflowed(self):
         return bool(self.flags.cpu()[1].item())
 
@@ -174,8 +184,8 @@ class ShardedGraphBuild(object):
         dist.all_to_all_single(recv, send, group=self.group)
         b.unpack(recv)
         b.reduce()
-        dist.all_reduce(b.aligned, group=self.group)
-        dist.all_reduce(b.counter_words, group=self.group)
+        dist.all_reduce(b.pack_for_allreduce(), group=self.group)
+        b.unpack_after_allreduce()
 
     def check_capacity(self):
         if self.backend.overflowed():

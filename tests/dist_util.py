@@ -127,6 +127,14 @@ class OracleBackend(object):
             r['hi'].append(o_hi)
         self.rows = rows
 
+    def pack_for_allreduce(self):
+        self._sum_buf = torch.cat([self.aligned, self.counter_words])
+        return self._sum_buf
+
+    def unpack_after_allreduce(self):
+        self.aligned.copy_(self._sum_buf[:self.n_contigs])
+        self.counter_words.copy_(self._sum_buf[self.n_contigs:])
+
     def overflowed(self):
         return self.overflow
 

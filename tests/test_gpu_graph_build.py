@@ -76,3 +76,23 @@ def test_empty_and_tiny_inputs():
         loop = O.record_loop(GU.rec_lists(sub), tab, p)
         table, aligned, ctr = DU.device_build(sub, tab, p)
         DU.assert_matches_oracle(table, aligned, ctr, loop, 5)
+
+
+def test_unsorted_stream_is_still_exact():
+    """A name-sorted / shuffled BAM breaks every sortedness assumption the kernels exploit for speed
+    (wave-uniform tids, clustered candidates); results must not change."""
+    asm = synth.make_assembly(900, 1500, 21)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 600.0, 80.0), 120000, 22)
+    rng = np.random.default_rng(23)
+    perm = rng.permutation(len(batch))
+    cols = {c: getattr(batch, c)[perm] for c in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen')}
+    from besst_amd.records import RecordBatch
+    shuffled = RecordBatch(batch.references, batch.lengths, rlen=batch.rlen[perm], alen=batch.alen[perm], **cols)
+    lens = asm.lengths.tolist()
+    tab = dict(cls=[1 if l >= 900 else 2 for l in lens], scaf=list(range(1, asm.nc + 1)), slen=lens,
+               cpos=[0] * asm.nc, clen=lens, cdir=[True] * asm.nc)
+    p = O.LibParams(read_len=100, ins_size_threshold=1080.0)
+    loop = O.record_loop(GU.rec_lists(shuffled), tab, p)
+    assert loop.count > 1000
+    table, aligned, ctr = DU.device_build(shuffled, tab, p)
+    DU.assert_matches_oracle(table, aligned, ctr, loop, asm.nc)
