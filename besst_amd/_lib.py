@@ -62,6 +62,12 @@ _SIGNATURES = {
     'besst_ctx_fetch_counters': (C.c_int, [_P, C.POINTER(Counters)]),
     'besst_ctx_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
                                         _P, _P, _P, _P]),
+    'besst_bam_open': (_P, [C.c_char_p, C.c_int]),
+    'besst_bam_close': (None, [_P]),
+    'besst_bam_n_references': (C.c_int64, [_P]),
+    'besst_bam_reference_name': (C.c_char_p, [_P, C.c_int64]),
+    'besst_bam_reference_lengths': (C.c_int, [_P, _P]),
+    'besst_bam_read_records': (C.c_int64, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_classify_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_reduce_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_contig_table_bytes': (C.c_size_t, [C.c_int64]),

@@ -154,6 +154,10 @@ class ShardedGraphBuild(object):
             backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
         self.backend = backend
         self._tails = None
+        self._recv = None
+        # the coverage/counter all-reduce overlaps the tuple exchange and the sort; it gets its own communicator so
+        # that it is not serialised behind the all-to-all on the default one
+        self.side_group = dist.new_group() if dist.is_initialized() and group is None else group
 
     @staticmethod
     def _probe_pair_capacity(device, wl, world):
@@ -179,12 +183,15 @@ class ShardedGraphBuild(object):
             self._tails = [torch.empty_like(tail) for _ in range(self.world)]
         dist.all_gather(self._tails, tail, group=self.group)
         b.classify_emit(torch.cat(self._tails))
+        # coverage numerators and counters are final here; sum them across ranks while tuples are exchanged
+        summed = dist.all_reduce(b.pack_for_allreduce(), group=self.side_group, async_op=True)
         send = b.partition()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        b.unpack(recv)
+        if self._recv is None:
+            self._recv = torch.empty_like(send)
+        dist.all_to_all_single(self._recv, send, group=self.group)
+        b.unpack(self._recv)
         b.reduce()
-        dist.all_reduce(b.pack_for_allreduce(), group=self.group)
+        summed.wait()
         b.unpack_after_allreduce()
 
     def check_capacity(self):

@@ -186,6 +186,23 @@ int besst_ctx_score_edges(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, 
                           double read_len, double* gap, double* sd0, int32_t* ks_h, uint8_t* flags);
 
 /* ------------------------------------------------------------------------------------------------
+ * BAM front-end (host): BGZF inflate + record decode into the SoA columns, replacing the
+ * `pysam.Samfile(param.bamfile, 'rb')` iteration of runBESST:162 / CreateGraph.py:111 /
+ * libmetrics.py:63,257,293.  qlen = query_alignment_length, rlen = query_length, alen = reference_length
+ * (pysam 0.8 attribute names).  n_threads inflate workers (libdeflate if present, else zlib).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct besst_bam besst_bam;
+besst_bam* besst_bam_open(const char* path, int n_threads);
+void besst_bam_close(besst_bam* bam);
+int64_t besst_bam_n_references(const besst_bam* bam);
+const char* besst_bam_reference_name(const besst_bam* bam, int64_t index);
+int besst_bam_reference_lengths(const besst_bam* bam, int32_t* out);
+/* Returns the number of records decoded (0 at end of file) or a negative status. */
+int64_t besst_bam_read_records(besst_bam* bam, int64_t max_records, int32_t* tid, int32_t* mtid, int32_t* pos,
+                               int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen,
+                               int32_t* rlen, int32_t* alen);
+
+/* ------------------------------------------------------------------------------------------------
  * device-pointer API (caller owns HBM; all pointers are device pointers unless noted)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -119,3 +119,28 @@ def test_dropin_matches_reference_golden(name):
         d = G_prime[u][v]
         if d['nr_links'] is not None:
             assert d['observations'] == want_obs[frozenset((u, v))]
+
+
+@pytest.mark.parametrize('name', ['fr_infer', 'rf_contam'])
+def test_dropin_from_bam_file(name, tmp_path):
+    """BAM bytes -> library's own BGZF/BAM reader -> get_metrics + PE: same metrics and graphs as from columns."""
+    from besst_amd import bamio
+    from tests import bam_writer
+    doc, batch = GU.load(name)
+    path = str(tmp_path / 'mapped.bam')
+    bam_writer.write_bam(path, batch)
+    records = bamio.read_bam(path, threads=4)
+    param = make_param(doc['overrides'])
+    info = param.information_file
+    libmetrics.get_metrics(records, param, info)
+    for k, want in doc['metrics'].items():
+        if k != 'empirical_distribution':
+            assert getattr(param, k, None) == want, (name, k)
+    lens = dict(zip(batch.references, batch.lengths))
+    C_dict = {n: 'A' * int(lens.get(n, 10)) for n in doc['fasta_names']}
+    Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+    G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, records)
+    session.close_session(records)
+    fin = doc['final']
+    assert edge_rows(G, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G']]
+    assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
