@@ -1,0 +1,90 @@
+"""Oracle-backed stand-in for ``besst_amd.device.GraphContext`` (test infrastructure only).
+
+Lets the CPU suite run the product's HOST code (besst_amd.libmetrics / besst_amd.CreateGraph: graph assembly in
+first-occurrence order, coverage statistics, order-dependent filters, score assembly) without a GPU, with the
+device stages answered by the oracle.  It is injected by monkeypatching ``besst_amd.session.device.GraphContext``
+inside tests; nothing in besst_amd/ refers to it.
+"""
+import numpy as np
+
+from besst_amd import device
+from besst_amd._lib import Counters, MetricsCounts
+from oracle import c_oracle as CO
+from oracle import py_oracle as O
+
+
+class FakeGraphContext(object):
+    def __init__(self, device_index=0):
+        self.batches = []
+        self.n_contigs = 0
+
+    def close(self):
+        pass
+
+    def set_contigs(self, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls):
+        self.table = dict(scaf_id=np.asarray(scaf_id), scaf_len=np.asarray(scaf_len), ctg_pos=np.asarray(ctg_pos),
+                          ctg_len=np.asarray(ctg_len), direction=np.asarray(direction), cls=np.asarray(cls))
+        self.n_contigs = len(self.table['cls'])
+
+    def set_library(self, read_len, ins_size_threshold, min_mapq, orientation, detect_duplicate, extend_paths, no_score):
+        self.lib = dict(read_len=read_len, ins_size_threshold=ins_size_threshold, min_mapq=min_mapq,
+                        orientation=orientation, detect_duplicate=detect_duplicate, extend_paths=extend_paths,
+                        no_score=no_score)
+
+    def clear_records(self):
+        self.batches = []
+
+    def push_records(self, batch):
+        self.batches.append(batch)
+
+    def _batch(self):
+        assert len(self.batches) == 1
+        return self.batches[0]
+
+    def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):
+        isize, contam, c = CO.metrics_sample(self._batch(), top_mask, orientation, min_mapq, read_len, want_isize)
+        counts = MetricsCounts(int(c[0]), int(c[1]), int(c[2]), int(c[3]), len(self._batch()))
+        return isize, contam, counts
+
+    def build_graph(self):
+        ids = self.table['scaf_id'][self.table['cls'] != 0]
+        nb = max(1, int((int(ids.max()) if len(ids) else 1) * 2 + 1).bit_length())
+        keys, payload, aligned, c = CO.record_loop(self._batch(), self.table, self.lib, nb)
+        rows = CO.edge_rows(keys, payload)
+        self.rows = rows
+        table = device.EdgeTable(rows['key'].astype(np.uint64), rows['mask'].astype(np.uint32),
+                                 rows['n'].astype(np.uint32), rows['sum_obs'].astype(np.int64),
+                                 rows['sum_obs_sq'].astype(np.int64), rows['first_idx'].astype(np.uint32),
+                                 rows['offset'].astype(np.uint32), nb, rows['obs_lo'].astype(np.int32),
+                                 rows['obs_hi'].astype(np.int32))
+        ctr = Counters(*[int(x) for x in c[:8]], int(c[8]), int(c[9]))
+        return table, aligned, ctr
+
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+        r = self.rows
+        m = len(rows)
+        gap = np.zeros(m)
+        sd0 = np.zeros(m)
+        ks = np.zeros(m, np.int32)
+        flags = np.zeros(m, np.uint8)
+        for j in range(m):
+            i = int(rows[j])
+            n = int(r['n'][i])
+            lo, hi = int(r['offset'][i]), int(r['offset'][i]) + n
+            a = r['obs_hi'][lo:hi] if swap[j] else r['obs_lo'][lo:hi]
+            b = r['obs_lo'][lo:hi] if swap[j] else r['obs_hi'][lo:hi]
+            obs = int(r['sum_obs'][i])
+            mean_ = obs / float(n)
+            l1, l2 = int(len1[j]), int(len2[j])
+            long_enough = 2 * sigma < l1 and 2 * sigma < l2
+            g = O.gap_estimator(mean, sigma, read_len, mean_, l1, l2) if long_enough else (n * mean - obs) / float(n)
+            gap[j] = g
+            flags[j] = (1 if long_enough else 0) | (2 if (-g > l1 or -g > l2) else 0)
+            sd0[j] = O.tr_sk_std_dev(mean, sigma, read_len, l1, l2, g) if long_enough else 2.0 ** 32
+            s1 = sorted(int(x) for x in a)
+            m1 = sum(s1) / float(n)
+            mx = int(max(b))
+            s2 = sorted(mx - int(x) for x in b)
+            m2 = sum(s2) / float(n)
+            ks[j] = O.ks_h([x - m1 for x in s1], [x - m2 for x in s2])
+        return gap, sd0, ks, flags
