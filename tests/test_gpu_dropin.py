@@ -144,3 +144,23 @@ def test_dropin_from_bam_file(name, tmp_path):
     fin = doc['final']
     assert edge_rows(G, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G']]
     assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
+
+
+def test_cli_end_to_end(tmp_path):
+    """FASTA + BAM on disk -> besst_amd.cli -> scored edge table, equal to the reference golden."""
+    from besst_amd import cli
+    from tests import bam_writer
+    doc, batch = GU.load('fr_infer')
+    bam = str(tmp_path / 'lib.bam')
+    bam_writer.write_bam(bam, batch)
+    fasta = str(tmp_path / 'contigs.fa')
+    lens = dict(zip(batch.references, batch.lengths))
+    with open(fasta, 'w') as fh:
+        for n in doc['fasta_names']:
+            fh.write('>%s\n%s\n' % (n, 'A' * lens[n]))
+    assert cli.main(['-c', fasta, '-f', bam, '-orientation', 'fr', '-o', str(tmp_path)]) == 0
+    rows = [l.rstrip('\n').split('\t') for l in open(str(tmp_path / 'BESST_output' / 'pass1' / 'edges_G.tsv'))][1:]
+    got = [(int(r[0]), r[1], int(r[2]), r[3], int(r[4]), int(r[5]), int(r[6])) for r in rows]
+    want = [(e['u'][0], e['u'][1], e['v'][0], e['v'][1], e['nr_links'], e['obs'], e['obs_sq']) for e in doc['final']['G']]
+    assert got == want
+    assert (tmp_path / 'BESST_output' / 'Statistics.txt').exists()
