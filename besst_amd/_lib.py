@@ -62,6 +62,9 @@ _SIGNATURES = {
     'besst_ctx_fetch_counters': (C.c_int, [_P, C.POINTER(Counters)]),
     'besst_ctx_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
                                         _P, _P, _P, _P]),
+    'besst_host_isize_stats': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_double, _P, _P, _P]),
+    'besst_host_contam_stats': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_double, _P, _P]),
+    'besst_host_getdistr': (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_double, _P, C.c_int64, _P, C.c_int64, _P, _P]),
     'besst_bam_open': (_P, [C.c_char_p, C.c_int]),
     'besst_bam_close': (None, [_P]),
     'besst_bam_n_references': (C.c_int64, [_P]),

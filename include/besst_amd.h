@@ -203,6 +203,21 @@ int64_t besst_bam_read_records(besst_bam* bam, int64_t max_records, int32_t* tid
                                int32_t* rlen, int32_t* alen);
 
 /* ------------------------------------------------------------------------------------------------
+ * Host float finishing of libmetrics (no GPU): the statistics on the <= 1,000,000 sampled insert sizes,
+ * replayed in the reference's exact operation order (libmetrics.py:22-28,88-110,141-223,316-343) so the
+ * doubles are bit-identical to CPython's.  values = abs(tlen) in BAM order; is_float/offset select the
+ * float form abs(tlen) + offset (offset = 2*read_len).
+ * ---------------------------------------------------------------------------------------------- */
+int besst_host_isize_stats(const int32_t* values, int64_t n, int32_t is_float, double offset,
+                           int64_t* kept_out, int64_t* n_kept, double* stats_out /* [5] */);
+int besst_host_contam_stats(const int32_t* values, int64_t n, int32_t is_float, double offset,
+                            int64_t* n_final, double* stats_out /* [4] */);
+int besst_host_getdistr(const int32_t* values, const int64_t* kept, int64_t n_kept, int32_t is_float,
+                        double offset, const int32_t* contig_lengths, int64_t n_contigs,
+                        double* adjusted_out, int64_t adjusted_cap, int64_t* n_adjusted,
+                        double* out /* [26] */);
+
+/* ------------------------------------------------------------------------------------------------
  * device-pointer API (caller owns HBM; all pointers are device pointers unless noted)
  * ---------------------------------------------------------------------------------------------- */
 
