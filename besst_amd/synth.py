@@ -20,6 +20,8 @@ from .records import (FLAG_MATE_REVERSE, FLAG_MATE_UNMAPPED, FLAG_PAIRED, FLAG_P
                       FLAG_READ2, FLAG_REVERSE, FLAG_UNMAPPED, RecordBatch)
 
 BASE_SEED = 20240929
+_DTYPES = dict(tid=np.int32, mtid=np.int32, pos=np.int32, mpos=np.int32, tlen=np.int32, flag=np.uint16,
+               mapq=np.uint8, qlen=np.uint16)
 
 
 class Assembly(object):
@@ -120,10 +122,13 @@ def simulate_library(asm, spec, n_pairs, seed, chunk=4_000_000):
         for name, left, right in (('tid', lt, rt), ('mtid', rt, lt), ('pos', lp, rp), ('mpos', rp, lp),
                                   ('tlen', tl, -tl), ('flag', fl, fr_), ('mapq', mapq, mapq),
                                   ('qlen', ql, qr)):
-            cols[name].append(np.concatenate((left[sel], right[sel])))
+            # final column dtypes right away: the 200 M-pair configs would not fit as int64 intermediates
+            cols[name].append(np.concatenate((left[sel], right[sel])).astype(_DTYPES[name]))
     cat = {name: np.concatenate(parts) for name, parts in cols.items()}
+    cols.clear()
     order = np.argsort((cat['tid'].astype(np.int64) << 32) | cat['pos'].astype(np.int64), kind='stable')
-    cat = {name: v[order] for name, v in cat.items()}
+    for name in list(cat):
+        cat[name] = cat[name][order]
     n = cat['tid'].shape[0]
     return RecordBatch(asm.names, asm.lengths.tolist(), rlen=np.full(n, r, dtype=np.int32),
                        alen=cat['qlen'].astype(np.int32), **cat)
