@@ -20,6 +20,7 @@
 // No inter-workgroup communication happens inside a launch.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -30,14 +31,13 @@ namespace {
 constexpr uint32_t kNoSlot = 0xffffffffu;
 
 // evaluation bits of one record
-constexpr uint32_t EV_COV = 1u, EV_FISHY = 2u, EV_NONUNIQ = 4u, EV_REACH = 8u, EV_ACCEPT = 16u,
-                   EV_DOUBLE = 32u, EV_MAPQ0 = 64u;
+constexpr uint32_t EV_COV = 1u, EV_FISHY = 2u, EV_NONUNIQ = 4u, EV_REACH = 8u,
+                   EV_DOUBLE = 32u, EV_MAPQ0 = 64u, EV_CASEA = 128u, EV_FIRSTMIN = 256u;
 
 struct Eval {
     uint32_t bits;
     int32_t o1, o2;
-    uint64_t key;     // sort key of the tuple this record may emit
-    uint32_t lo, hi;  // payload words
+    uint32_t n_min, n_max;   // node codes (scaffold * 2 + side) of the edge this record may support
 };
 
 struct CEDelta {
@@ -110,8 +110,7 @@ __device__ __forceinline__ Eval eval_record(const ClassifyArgs& a, bool in_range
     Eval e;
     e.bits = 0;
     e.o1 = e.o2 = 0;
-    e.key = 0;
-    e.lo = e.hi = 0;
+    e.n_min = e.n_max = 0;
     if (!in_range) return e;
     const uint32_t cls1 = c1.w0 >> 29, cls2 = c2.w0 >> 29;
     if (cls1 == BESST_CLS_ABSENT || cls2 == BESST_CLS_ABSENT) return e;
@@ -129,45 +128,33 @@ __device__ __forceinline__ Eval eval_record(const ClassifyArgs& a, bool in_range
         // CheckDir: PosDir with zeroed coordinates, only the sides matter
         const uint32_t s1 = (dir1 == (rf ? !rdir : rdir)) ? 1u : 0u;
         const uint32_t s2 = (dir2 == (rf ? !mdir : mdir)) ? 1u : 0u;
-        const uint64_t n1 = (uint64_t)scaf1 * 2 + s1, n2 = (uint64_t)scaf2 * 2 + s2;
-        const uint64_t lo = n1 < n2 ? n1 : n2, hi = n1 < n2 ? n2 : n1;
-        e.key = (((lo << a.node_bits) | hi) << 1) | 1u;
+        const uint32_t n1 = scaf1 * 2 + s1, n2 = scaf2 * 2 + s2;
+        e.n_min = n1 < n2 ? n1 : n2;
+        e.n_max = n1 < n2 ? n2 : n1;
         e.bits |= EV_FISHY;
         return e;   // an unmapped record cannot also be a link candidate (:169)
     }
 
     if (!(other && (flag & kFlagRead2) && !(flag & kFlagUnmapped) && (int32_t)mapq >= a.min_mapq))
         return e;
-    uint32_t mask;
-    bool dbl = false;
+    bool case_a = false;
     if (cls1 == BESST_CLS_LARGE && cls2 == BESST_CLS_LARGE && scaf1 != scaf2) {
-        if (a.no_score) {
-            mask = BESST_MASK_GPRIME;
-        } else {
-            mask = BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u);
-            dbl = a.extend_paths != 0;
-        }
-    } else if (a.extend_paths) {
+        case_a = true;                                           // case A (:170-183)
+    } else if (a.extend_paths) {                                 // case B (:184-206)
         const bool sm1 = cls1 == BESST_CLS_SMALL, sm2 = cls2 == BESST_CLS_SMALL;
-        if ((sm1 && sm2 && scaf1 != scaf2) || (sm1 != sm2)) mask = BESST_MASK_GPRIME;
-        else return e;
+        if (!((sm1 && sm2 && scaf1 != scaf2) || (sm1 != sm2))) return e;
     } else {
         return e;
     }
     uint32_t s1, s2;
     posdir(rf, dir1, rdir, c1.ctg_pos, pos, c1.scaf_len, c1.ctg_len, a.read_len, e.o1, s1);
     posdir(rf, dir2, mdir, c2.ctg_pos, mpos, c2.scaf_len, c2.ctg_len, a.read_len, e.o2, s2);
-    e.bits |= EV_REACH | (dbl ? EV_DOUBLE : 0u);
-    const bool accept = ((double)((int64_t)e.o1 + e.o2) < a.ins_size_threshold) && e.o1 > 25 && e.o2 > 25;
-    if (accept) {
-        e.bits |= EV_ACCEPT;
-        const uint64_t n1 = (uint64_t)scaf1 * 2 + s1, n2 = (uint64_t)scaf2 * 2 + s2;
-        const bool first_min = n1 < n2;
-        const uint64_t lo = first_min ? n1 : n2, hi = first_min ? n2 : n1;
-        e.key = ((lo << a.node_bits) | hi) << 1;
-        e.lo = (uint32_t)(first_min ? e.o1 : e.o2);
-        e.hi = (uint32_t)(first_min ? e.o2 : e.o1) | (mask << 30);
-    }
+    const bool dbl = case_a && a.extend_paths && !a.no_score;    // second CreateEdge call for G_prime
+    e.bits |= EV_REACH | (case_a ? EV_CASEA : 0u) | (dbl ? EV_DOUBLE : 0u);
+    const uint32_t n1 = scaf1 * 2 + s1, n2 = scaf2 * 2 + s2;
+    e.n_min = n1 < n2 ? n1 : n2;
+    e.n_max = n1 < n2 ? n2 : n1;
+    if (n1 < n2) e.bits |= EV_FIRSTMIN;
     return e;
 }
 
@@ -226,9 +213,16 @@ __device__ __forceinline__ void flush_cov(const ClassifyArgs& a, unsigned long l
         atomicAdd(&aligned[ref], (unsigned long long)sum);
 }
 
+__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
+                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
+                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
+                                           int lane);
+
+template <bool kFuseEval>
 __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
                                                                 unsigned long long* __restrict__ aligned,
-                                                                unsigned long long* __restrict__ bitmask) {
+                                                                unsigned long long* __restrict__ bitmask,
+                                                                uint4* __restrict__ staging) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kStreamTile;
     int4 v_tid[kStreamSubTiles], v_mtid[kStreamSubTiles];
@@ -311,58 +305,155 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
         // candidate bits of this wave's group: word k, bit l  <->  record group_base + 4*l + k
         const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
         const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
-        if (lane < 4) {
-            const int64_t g = ((int64_t)blockIdx.x * kStreamSubTiles + st) * 4 + wave;
-            bitmask[g * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-        }
+        const int64_t g = ((int64_t)blockIdx.x * kStreamSubTiles + st) * 4 + wave;
+        if (lane < 4) bitmask[g * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        if (kFuseEval && (b0 | b1 | b2 | b3) != 0ull)      // dense libraries: evaluate while the lines are hot
+            eval_group(a, g, b0, b1, b2, b3, aligned, staging, lane);
     }
     flush_cov(a, aligned, lane, acc_ref, acc_sum);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// candidate_kernel: the order-dependent part, on the sparse candidates only.  Single-wave workgroups; lane l
-// owns the 256-record group l of the workgroup's 16384 consecutive records.
-//   1. ordered index of every candidate (popcounts + wave scan)
-//   2. candidates' record offsets are listed in LDS in stream order, then evaluated in full by ALL lanes
-//      round-robin (record fields re-read by index, contig rows gathered) - candidates cluster at contig
-//      ends, so evaluation by the owning lane would serialise dozens of dependent loads on one lane
-//   3. the staged list is processed 64 entries at a time: previous reaching observation via ballot,
-//      CreateEdge semantics, ordered slots for the emitted tuples; the chain is carried in registers
+// eval_kernel: evaluate every candidate, balanced and order-free.  One wave per 256-record group, in the same
+// record <-> lane layout as stream_kernel (lane l owns records 4l..4l+3), so the record fields are fetched
+// with the same coalesced vector loads (only by lanes that own a candidate) and a lane evaluates at most four
+// records.  Waves whose group has no candidate exit after one broadcast load of their 32 bytes of bits.  The
+// evaluated candidates are written as 16-byte entries, compacted in record order inside the group's staging
+// slice (group g -> staging[g*256 ...]); candidates' coverage is added with one atomic per distinct contig.
+//   entry = { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31,
+//                         node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
 // ---------------------------------------------------------------------------------------------------------
-struct CandEntry {
-    uint64_t key;
-    int32_t o1, o2;
-    uint32_t bits;     // EV_* | mask << 8 | first_min << 10
-    uint32_t pad;
-};
+constexpr int kEvalGroupsPerWave = 1;
 
-__global__ __launch_bounds__(kCandThreads) void candidate_kernel(
+__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
+                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
+                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
+                                           int lane);
+
+// One wave per group; waves whose group has no candidate exit after one broadcast load of their 32 bytes of bits.
+// (Letting a wave walk several groups was measured slower: the two dependent memory round trips of every active
+// group then serialise inside the wave, while the launch of ~N/256 mostly empty waves costs ~20 us on C2.)
+__global__ __launch_bounds__(256) void eval_kernel(ClassifyArgs a, const unsigned long long* __restrict__ bitmask,
+                                                   int64_t n_groups, unsigned long long* __restrict__ aligned,
+                                                   uint4* __restrict__ staging) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    if (g >= n_groups) return;
+    const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
+    const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
+    if ((w0.x | w0.y | w1.x | w1.y) == 0ull) return;
+    eval_group(a, g, w0.x, w0.y, w1.x, w1.y, aligned, staging, lane);
+}
+
+__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
+                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
+                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
+                                           int lane) {
+    const ulonglong2 w0 = make_ulonglong2(b0, b1), w1 = make_ulonglong2(b2, b3);
+    const bool c[4] = {(bool)((w0.x >> lane) & 1ull), (bool)((w0.y >> lane) & 1ull), (bool)((w1.x >> lane) & 1ull),
+                       (bool)((w1.y >> lane) & 1ull)};
+    const int cnt = (int)c[0] + (int)c[1] + (int)c[2] + (int)c[3];
+    const int excl = wave_incl_scan(cnt, lane) - cnt;
+    const int64_t i0 = g * kGroup + (int64_t)lane * 4;
+    int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
+    uint32_t r_flag[4], r_mapq[4], r_qlen[4];
+    if (cnt) {
+        if (i0 + 4 <= a.n) {
+            const int4 v0 = *reinterpret_cast<const int4*>(a.tid + i0);
+            const int4 v1 = *reinterpret_cast<const int4*>(a.mtid + i0);
+            const int4 v2 = *reinterpret_cast<const int4*>(a.pos + i0);
+            const int4 v3 = *reinterpret_cast<const int4*>(a.mpos + i0);
+            const ushort4 f = *reinterpret_cast<const ushort4*>(a.flag + i0);
+            const uchar4 m = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            const ushort4 q = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            r_tid[0] = v0.x; r_tid[1] = v0.y; r_tid[2] = v0.z; r_tid[3] = v0.w;
+            r_mtid[0] = v1.x; r_mtid[1] = v1.y; r_mtid[2] = v1.z; r_mtid[3] = v1.w;
+            r_pos[0] = v2.x; r_pos[1] = v2.y; r_pos[2] = v2.z; r_pos[3] = v2.w;
+            r_mpos[0] = v3.x; r_mpos[1] = v3.y; r_mpos[2] = v3.z; r_mpos[3] = v3.w;
+            r_flag[0] = f.x; r_flag[1] = f.y; r_flag[2] = f.z; r_flag[3] = f.w;
+            r_mapq[0] = m.x; r_mapq[1] = m.y; r_mapq[2] = m.z; r_mapq[3] = m.w;
+            r_qlen[0] = q.x; r_qlen[1] = q.y; r_qlen[2] = q.z; r_qlen[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                r_tid[k] = in ? a.tid[i] : -1;
+                r_mtid[k] = in ? a.mtid[i] : -1;
+                r_pos[k] = in ? a.pos[i] : 0;
+                r_mpos[k] = in ? a.mpos[i] : 0;
+                r_flag[k] = in ? a.flag[i] : 0;
+                r_mapq[k] = in ? a.mapq[i] : 0;
+                r_qlen[k] = in ? a.qlen[i] : 0;
+            }
+        }
+    }
+    // contig rows of all this lane's candidates first (their gathers overlap), then the arithmetic
+    ContigRow c1[4], c2[4];
+    bool in_range[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        in_range[k] = c[k] && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs;
+        if (in_range[k]) {
+            c1[k] = a.table[r_tid[k]];
+            c2[k] = a.table[r_mtid[k]];
+        }
+    }
+    int32_t cov_tid = -1;
+    int cov_sum = 0;
+    int slot = excl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!c[k]) continue;
+        const Eval e = eval_record(a, in_range[k], c1[k], c2[k], r_tid[k], r_mtid[k], r_pos[k], r_mpos[k], r_flag[k],
+                                   r_mapq[k]);
+        if (e.bits & EV_COV) {
+            if (r_tid[k] != cov_tid && cov_sum) {          // a second contig inside one lane: rare, flush directly
+                atomicAdd(&aligned[cov_tid], (unsigned long long)cov_sum);
+                cov_sum = 0;
+            }
+            cov_tid = r_tid[k];
+            cov_sum += (int)r_qlen[k];
+        }
+        uint4 ent;
+        ent.x = (uint32_t)e.o1;
+        ent.y = (uint32_t)e.o2;
+        ent.z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
+                ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
+        ent.w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
+                ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+        staging[g * kGroup + slot] = ent;
+        slot++;
+    }
+    wave_add_by_key(aligned, cov_tid, cov_sum, cov_sum != 0, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ordered_kernel: the order-dependent part, over the evaluated candidates only.  Single-wave workgroups; the
+// workgroup covers kCandGroups consecutive groups and walks their staged entries 64 at a time in stream order:
+// previous reaching observation via ballot, CreateEdge semantics (acceptance rule :840 re-evaluated from the
+// stored observations), ordered slots for the emitted tuples.  The chain is carried in registers, nothing but a
+// 64-entry prefix table lives in LDS.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCandThreads) void ordered_kernel(
     ClassifyArgs a, const unsigned long long* __restrict__ bitmask, int64_t n_groups,
-    unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
-    uint64_t* __restrict__ seg_payload, BlockSummary* __restrict__ summ,
-    unsigned long long* __restrict__ counters) {
-    __shared__ CandEntry s_ent[kCandCap];
-    __shared__ uint16_t s_rec[kCandCap];
-
+    const uint4* __restrict__ staging, uint64_t* __restrict__ seg_keys, uint64_t* __restrict__ seg_payload,
+    BlockSummary* __restrict__ summ) {
+    __shared__ int s_pre[kCandThreads + 1];
     const int lane = threadIdx.x;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
-    const int64_t g = (int64_t)blockIdx.x * kCandGroups + lane;
-    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
-
-    unsigned long long b[4] = {0ull, 0ull, 0ull, 0ull};
+    const int64_t g0 = (int64_t)blockIdx.x * kCandGroups;
+    const int64_t g = g0 + lane;
+    int cnt = 0;
     if (lane < kCandGroups && g < n_groups) {
         const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
         const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
-        b[0] = w0.x; b[1] = w0.y; b[2] = w1.x; b[3] = w1.y;
+        cnt = __popcll(w0.x) + __popcll(w0.y) + __popcll(w1.x) + __popcll(w1.y);
     }
-    const int cnt = __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
     const int incl = wave_incl_scan(cnt, lane);
-    const int my_base = incl - cnt;
-#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 0
-    const int total = 0 * __shfl(incl, 63, 64);
-#else
     const int total = __shfl(incl, 63, 64);
-#endif
+    s_pre[lane] = incl - cnt;
+    if (lane == 0) s_pre[kCandThreads] = total;
     __syncthreads();
 
     // chain state, identical in every lane
@@ -373,107 +464,56 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
     bool head_present = false;
     int32_t head1 = 0, head2 = 0;
     uint32_t head_info = 0, head_slot = kNoSlot;
+    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
 
-    for (int win = 0; win < total; win += kCandCap) {
-        // ---- list this lane's candidates (record offset inside the workgroup's range) ------------------------
-        if (cnt && my_base < win + kCandCap && my_base + cnt > win) {
-            int idx = my_base;
-            unsigned long long any = b[0] | b[1] | b[2] | b[3];
-            while (any) {
-                const int l = __ffsll((long long)any) - 1;
-                any &= any - 1;
+    constexpr int kAhead = 4;    // chunks whose entries are fetched before the chain consumes them
+    for (int c0 = 0; c0 < total; c0 += kCandThreads * kAhead) {
+        uint4 ents[kAhead];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (!((b[k] >> l) & 1ull)) continue;
-                    if (idx >= win && idx < win + kCandCap) s_rec[idx - win] = (uint16_t)(lane * kGroup + 4 * l + k);
-                    idx++;
+        for (int u = 0; u < kAhead; ++u) {
+            const int j = c0 + u * kCandThreads + lane;
+            ents[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < total) {
+                int lo = 0, hi = kCandThreads;          // last group whose exclusive prefix is <= j
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= j) lo = mid; else hi = mid;
                 }
+                ents[u] = staging[(g0 + lo) * kGroup + (j - s_pre[lo])];
             }
         }
-        __syncthreads();
-#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 1
-        continue;
-#endif
-        const int len = (total - win) < kCandCap ? (total - win) : kCandCap;
-        // ---- evaluate, all lanes round-robin ------------------------------------------------------------------
-        for (int j0 = 0; j0 < len; j0 += kCandThreads * kCandBatch) {
-            // batch: every lane keeps kCandBatch candidates' loads in flight (record fields, then contig rows)
-            int32_t r_tid[kCandBatch], r_mtid[kCandBatch], r_pos[kCandBatch], r_mpos[kCandBatch];
-            uint32_t r_flag[kCandBatch], r_mapq[kCandBatch];
-            int r_qlen[kCandBatch];
-            bool r_valid[kCandBatch];
 #pragma unroll
-            for (int u = 0; u < kCandBatch; ++u) {
-                const int j = j0 + u * kCandThreads + lane;
-                r_valid[u] = j < len;
-                const int64_t i = block_base + (r_valid[u] ? s_rec[j] : 0);
-                r_tid[u] = r_valid[u] ? a.tid[i] : -1;
-                r_mtid[u] = r_valid[u] ? a.mtid[i] : -1;
-                r_pos[u] = r_valid[u] ? a.pos[i] : 0;
-                r_mpos[u] = r_valid[u] ? a.mpos[i] : 0;
-                r_flag[u] = r_valid[u] ? a.flag[i] : 0;
-                r_mapq[u] = r_valid[u] ? a.mapq[i] : 0;
-                r_qlen[u] = r_valid[u] ? (int)a.qlen[i] : 0;
-            }
-            ContigRow c1[kCandBatch], c2[kCandBatch];
-            bool in_range[kCandBatch];
-#pragma unroll
-            for (int u = 0; u < kCandBatch; ++u) {
-                in_range[u] = (uint32_t)r_tid[u] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[u] < (uint32_t)a.n_contigs;
-                c1[u] = a.table[in_range[u] ? r_tid[u] : 0];
-                c2[u] = a.table[in_range[u] ? r_mtid[u] : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < kCandBatch; ++u) {
-                const Eval e = eval_record(a, in_range[u], c1[u], c2[u], r_tid[u], r_mtid[u], r_pos[u], r_mpos[u],
-                                           r_flag[u], r_mapq[u]);
-                wave_add_by_key(aligned, r_tid[u], r_qlen[u], (e.bits & EV_COV) != 0, lane);
-                c_nonuniq += (e.bits & EV_NONUNIQ) ? 1 : 0;
-                c_fishy += (e.bits & EV_FISHY) ? 1 : 0;
-                c_reach += (e.bits & EV_REACH) ? 1 : 0;
-                if (r_valid[u]) {
-                    CandEntry ce;
-                    ce.key = e.key;
-                    ce.o1 = e.o1;
-                    ce.o2 = e.o2;
-                    const bool first_min = (e.lo == (uint32_t)e.o1);   // lo is the observation of the key's min node
-                    ce.bits = e.bits | ((e.hi >> 30) << 8) | ((first_min ? 1u : 0u) << 10);
-                    ce.pad = 0;
-                    s_ent[j0 + u * kCandThreads + lane] = ce;
-                }
-            }
-        }
-        __syncthreads();
-#if defined(BESST_DBG_PHASE) && BESST_DBG_PHASE == 2
-        continue;
-#endif
-        // ---- ordered pass over the staged entries -------------------------------------------------------------
-        for (int c0 = 0; c0 < len; c0 += kCandThreads) {
-            const int j = c0 + lane;
-            CandEntry e;
-            e.key = 0; e.o1 = 0; e.o2 = 0; e.bits = 0; e.pad = 0;
-            if (j < len) e = s_ent[j];
-            const bool reach = e.bits & EV_REACH;
+        for (int u = 0; u < kAhead; ++u) {
+            if (c0 + u * kCandThreads >= total) break;       // uniform
+            const uint4 ent = ents[u];
+            const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
+            const bool reach = (ent.z >> 29) & 1u, fishy = (ent.z >> 30) & 1u, nonuniq = (ent.z >> 31) & 1u;
+            const bool mapq0 = (ent.w >> 29) & 1u, case_a = (ent.w >> 30) & 1u, first_min = (ent.w >> 31) & 1u;
+            const uint32_t n_min = ent.z & 0x1fffffffu, n_max = ent.w & 0x1fffffffu;
+            const bool dbl = case_a && a.extend_paths && !a.no_score;
+            c_nonuniq += nonuniq ? 1 : 0;
+            c_fishy += fishy ? 1 : 0;
+            c_reach += reach ? 1 : 0;
             const unsigned long long has_mask = __ballot(reach);
             bool pk = prev_known;
             int32_t p1 = prev1, p2 = prev2;
             {
                 const unsigned long long below = has_mask & lt_mask;
                 const int src = below ? 63 - __clzll((long long)below) : 0;
-                const int32_t q1 = __shfl(e.o1, src, 64), q2 = __shfl(e.o2, src, 64);
+                const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
                 if (below) { pk = true; p1 = q1; p2 = q2; }
             }
-            bool emit = (e.bits & EV_FISHY) != 0;
+            const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+            bool emit = fishy;
             bool is_head = false;
             if (reach) {
-                const bool accept = e.bits & EV_ACCEPT;
                 if (!pk) {
                     is_head = true;                      // first reaching record of the workgroup
                     emit = accept;
                 } else {
-                    const CEDelta d = create_edge(e.o1, e.o2, p1, p2, accept, e.bits & EV_DOUBLE, e.bits & EV_MAPQ0,
-                                                  a.detect_dup != 0);
+                    const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
                     c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
                     emit = d.keep;
                 }
@@ -481,12 +521,10 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
             const unsigned long long emit_mask = __ballot(emit);
             const int slot = emit_base + __popcll(emit_mask & lt_mask);
             if (emit) {
-                const uint32_t mask = (e.bits >> 8) & 3u;
-                const bool first_min = (e.bits >> 10) & 1u;
-                const bool fishy = e.bits & EV_FISHY;
-                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? e.o1 : e.o2);
-                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? e.o2 : e.o1) | (mask << 30));
-                seg_keys[block_base + slot] = e.key;
+                const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+                seg_keys[block_base + slot] = ((((uint64_t)n_min << a.node_bits) | n_max) << 1) | (fishy ? 1u : 0u);
                 seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
             }
             // the head is unique per workgroup; broadcast it to every lane
@@ -494,23 +532,23 @@ __global__ __launch_bounds__(kCandThreads) void candidate_kernel(
             if (head_mask) {
                 const int hl = __ffsll((long long)head_mask) - 1;
                 head_present = true;
-                head1 = __shfl(e.o1, hl, 64);
-                head2 = __shfl(e.o2, hl, 64);
-                const uint32_t hb = (uint32_t)__shfl((int)e.bits, hl, 64);
-                head_info = ((hb & EV_ACCEPT) ? 9u : 0u) | ((hb & EV_DOUBLE) ? 2u : 0u) | ((hb & EV_MAPQ0) ? 4u : 0u);
+                head1 = __shfl(o1, hl, 64);
+                head2 = __shfl(o2, hl, 64);
+                const bool h_acc = __shfl((int)accept, hl, 64), h_dbl = __shfl((int)dbl, hl, 64);
+                const bool h_mq0 = __shfl((int)mapq0, hl, 64);
+                head_info = (h_acc ? 9u : 0u) | (h_dbl ? 2u : 0u) | (h_mq0 ? 4u : 0u);
                 const int hs = __shfl(slot, hl, 64);
-                head_slot = (hb & EV_ACCEPT) ? (uint32_t)hs : kNoSlot;
+                head_slot = h_acc ? (uint32_t)hs : kNoSlot;
             }
             if (has_mask) {
                 const int src = 63 - __clzll((long long)has_mask);
                 blk_has = true;
                 prev_known = true;
-                prev1 = __shfl(e.o1, src, 64);
-                prev2 = __shfl(e.o2, src, 64);
+                prev1 = __shfl(o1, src, 64);
+                prev2 = __shfl(o2, src, 64);
             }
             emit_base += __popcll(emit_mask);
         }
-        __syncthreads();   // s_rec / s_ent are rewritten by the next window
     }
 
     int tot[7];
@@ -668,6 +706,7 @@ struct ClsWorkspace {
     uint32_t* offsets;
     uint32_t* skip;
     unsigned long long* bitmask;
+    uint4* staging;
     int64_t n_groups;
     size_t total;
 };
@@ -687,6 +726,8 @@ ClsWorkspace carve(void* ws, int64_t n) {
     const int64_t stream_blocks = (n + kStreamTile - 1) / kStreamTile;
     w.n_groups = stream_blocks * (kStreamTile / kGroup);
     w.bitmask = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)w.n_groups * 32, 256);
+    // evaluated candidates, 16 B each, group g at [g*256, ...): every record may be a candidate
+    w.staging = reinterpret_cast<uint4*>(p + off); off += align_up((size_t)w.n_groups * kGroup * sizeof(uint4), 256);
     w.total = off;
     return w;
 }
@@ -744,17 +785,32 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
     const uint32_t stream_blocks = (uint32_t)((a.n + kStreamTile - 1) / kStreamTile);
+    // Mate-pair ('rf') libraries have inserts comparable to the contig lengths, so a large share of the records
+    // are candidates and evaluating them inside the streaming pass (lines still hot, no second sweep) wins a few
+    // percent; for paired-end libraries the separate, mostly-empty eval launch is as fast.  BESST_FUSE_EVAL=0/1
+    // overrides the choice (development knob).
+    static const int fuse_env = getenv("BESST_FUSE_EVAL") ? atoi(getenv("BESST_FUSE_EVAL")) : -1;
+    const bool fuse = fuse_env >= 0 ? fuse_env != 0 : a.rf != 0;
     {
         ProfScope ps(s, kProfClassify);
-        hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
-                           reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
+        if (fuse)
+            hipLaunchKernelGGL(stream_kernel<true>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask, w.staging);
+        else
+            hipLaunchKernelGGL(stream_kernel<false>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask, w.staging);
+    }
+    if (!fuse) {
+        ProfScope ps(s, kProfCandidate);
+        hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)((w.n_groups + 4 * kEvalGroupsPerWave - 1) / (4 * kEvalGroupsPerWave))), dim3(256), 0, s, a, w.bitmask, w.n_groups,
+                           reinterpret_cast<unsigned long long*>(aligned), w.staging);
     }
     {
-        ProfScope ps(s, kProfCandidate);
-        hipLaunchKernelGGL(candidate_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups,
-                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ,
-                           reinterpret_cast<unsigned long long*>(counters));
+        ProfScope ps(s, kProfOrdered);
+        hipLaunchKernelGGL(ordered_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups, w.staging,
+                           w.seg_keys, w.seg_payload, w.summ);
     }
+    (void)counters;
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -42,6 +42,7 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
 // Every kernel loads its keys speculatively (guarded by the caller's capacity, not by the device-side count)
 // so that the count, the table and the keys arrive after ONE memory latency instead of three.
 constexpr int kScanFreeMaxBlocks = 64;
+constexpr int kWideDigitMaxBlocks = 4096;   // up to 16.7 M tuples: 3 passes of 11 bits instead of up to 8 of 8
 
 template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
@@ -64,10 +65,24 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     if (b >= nblocks_of(n, kSortTile)) return;
     for (int d = t; d < RADIX; d += kSortThreads) s_hist[d] = 0;
     __syncthreads();
+    // Later passes see nearly sorted keys: whole waves share one digit and per-lane LDS atomics on one bin
+    // serialise.  Lanes are consecutive keys, so count RUNS: only the first lane of a run of equal digits adds,
+    // with the run length.
+    const int lane = t & 63;
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const uint32_t i = base + r * kSortThreads + t;
-        if (i < n) atomicAdd(&s_hist[digit_of(k[r], ds)], 1u);
+        const bool valid = i < n;
+        const uint32_t d = valid ? digit_of(k[r], ds) : 0xffffffffu;
+        const uint32_t up = (uint32_t)__shfl_up((int)d, 1, 64);
+        const bool head = valid && (lane == 0 || d != up);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long vmask = __ballot(valid);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int next = later ? lane + 1 + (__ffsll((long long)later) - 1) : (int)__popcll(vmask);
+            atomicAdd(&s_hist[d], (uint32_t)(next - lane));
+        }
     }
     __syncthreads();
     for (int d = t; d < RADIX; d += kSortThreads) {
@@ -382,6 +397,10 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
     uint64_t pl[kRedItems];
 #pragma unroll
     for (int k = 0; k < kRedItems; ++k) pl[k] = (i0 + k) < n ? payload[src[k]] : 0ull;
+    // Per-thread runs: only a thread's LAST run can continue into the next thread, and only its FIRST run can
+    // continue from the previous one.  Runs that start and end inside the thread are flushed directly; the open
+    // run of every lane is then combined across the wave by row id (one atomic triple per distinct row of the
+    // wave instead of one per lane: the per-lane version spent most of its time in device-scope atomics).
     uint32_t run_n = 0;
     unsigned long long run_s = 0, run_s2 = 0;
 #pragma unroll
@@ -412,10 +431,47 @@ __global__ __launch_bounds__(kRedThreads) void row_reduce_kernel(
         run_s += o;
         run_s2 += o * o;
     }
-    if (run_n) {
-        atomicAdd(&row_n[row], run_n);
-        atomicAdd(&row_sum[row], run_s);
-        atomicAdd(&row_sum_sq[row], run_s2);
+    {
+        bool active = run_n != 0;
+        unsigned long long mask = __ballot(active);
+        // rows are numbered in key order, so the open rows of a wave span [row of first active lane, row of last]:
+        // with many short rows (PE libraries: ~15 links per edge) the combine loop would cost more than it saves
+        int iter = 0;
+        if (mask) {
+            const int first_l = __ffsll((long long)mask) - 1, last_l = 63 - __clzll((long long)mask);
+            const int span = __shfl((int)(row & 0xffffffff), last_l, 64) - __shfl((int)(row & 0xffffffff), first_l, 64);
+            if (span >= 8) iter = 48;
+        }
+        while (mask) {
+            if (iter++ >= 48) {              // many rows per wave: per-lane atomics
+                if (active) {
+                    atomicAdd(&row_n[row], run_n);
+                    atomicAdd(&row_sum[row], run_s);
+                    atomicAdd(&row_sum_sq[row], run_s2);
+                }
+                break;
+            }
+            const int leader = __ffsll((long long)mask) - 1;
+            const long long r0 = __shfl((int)(row & 0xffffffff), leader, 64);
+            const bool match = active && (int)(row & 0xffffffff) == (int)r0;
+            uint32_t tn = match ? run_n : 0u;
+            unsigned long long ts = match ? run_s : 0ull, ts2 = match ? run_s2 : 0ull;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                tn += (uint32_t)__shfl_xor((int)tn, d, 64);
+                ts += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(ts >> 32), d, 64) << 32) |
+                      (uint32_t)__shfl_xor((int)(uint32_t)ts, d, 64);
+                ts2 += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(ts2 >> 32), d, 64) << 32) |
+                       (uint32_t)__shfl_xor((int)(uint32_t)ts2, d, 64);
+            }
+            if (lane == leader) {
+                atomicAdd(&row_n[row], tn);
+                atomicAdd(&row_sum[row], ts);
+                atomicAdd(&row_sum_sq[row], ts2);
+            }
+            active = active && !match;
+            mask = __ballot(active);
+        }
     }
 }
 
@@ -442,8 +498,9 @@ RedWorkspace carve(void* ws, int64_t cap) {
     for (int j = 0; j < 2; ++j) { w.idx[j] = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)cap * 4, 256); }
     w.stride = (uint32_t)nb_sort;
     // the wide-digit path is only taken for small streams, the 8-bit path for any size
-    const size_t table_entries = nb_sort * kRadix > (size_t)kScanFreeMaxBlocks * kMaxRadix ? nb_sort * kRadix
-                                                                                         : (size_t)kScanFreeMaxBlocks * kMaxRadix;
+    const size_t table_entries = nb_sort <= (size_t)kWideDigitMaxBlocks
+                                     ? (nb_sort > (size_t)kScanFreeMaxBlocks ? nb_sort : (size_t)kScanFreeMaxBlocks) * kMaxRadix
+                                     : nb_sort * kRadix;
     w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
     w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
@@ -500,7 +557,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
     // wide digits (fewer dependent launches) while the stage is latency bound, 8-bit digits for large streams
-    const int bits = nb_sort <= (uint32_t)kScanFreeMaxBlocks ? 11 : kRadixBits;
+    const int bits = nb_sort <= (uint32_t)kWideDigitMaxBlocks ? 11 : kRadixBits;
     const int passes = (key_bits + bits - 1) / bits;
     auto* zsum = reinterpret_cast<unsigned long long*>(row_sum);
     auto* zsq = reinterpret_cast<unsigned long long*>(row_sum_sq);
