@@ -68,18 +68,14 @@ constexpr int kStreamSubTile = kStreamThreads * kStreamVec;      // 1024 records
 constexpr int kStreamSubTiles = BESST_STREAM_SUBTILES;
 constexpr int kStreamTile = kStreamSubTile * kStreamSubTiles;    // 4096 records per workgroup
 constexpr int kGroup = 64 * kStreamVec;                          // 256 records per candidate-bit group
-// candidate_kernel: single-wave workgroups, one lane per group -> one BlockSummary per 16384 records
+// eval_kernel: one wave per group.  ordered_kernel: single-wave workgroups, one lane per group -> one BlockSummary
+// per kCandGroups * 256 records
 constexpr int kCandThreads = 64;
 #ifndef BESST_CAND_GROUPS
 #define BESST_CAND_GROUPS 64
 #endif
 constexpr int kCandGroups = BESST_CAND_GROUPS;                   // groups (lanes that own one) per workgroup
 constexpr int kClsTile = kCandGroups * kGroup;                   // records per summary block
-#ifndef BESST_CAND_CAP
-#define BESST_CAND_CAP 1024
-#endif
-constexpr int kCandCap = BESST_CAND_CAP;                                   // candidate entries staged in LDS per round
-constexpr int kCandBatch = 4;                                    // candidates per lane evaluated with their loads overlapped
 
 // Per-block summary of the classify kernel, resolved by the single-block "stitch" kernel.
 struct __attribute__((aligned(16))) BlockSummary {
