@@ -106,9 +106,10 @@ def verify_full(runner, wl):
 def stage_timings(wl):
     """Wall time of the other stages through the host-buffer C ABI (reported separately)."""
     import numpy as np
-    from besst_amd import device
+    from besst_amd import _lib, device, pipeline
     batch, lib, asm = wl['batch'], wl['lib'], wl['asm']
     out = {}
+    lib_h = _lib.load()
     with device.GraphContext(0) as ctx:
         ctx.set_contigs(**wl['table'])
         ctx.set_library(lib['read_len'], lib['ins_size_threshold'], lib['min_mapq'], lib['orientation'],
@@ -119,9 +120,11 @@ def stage_timings(wl):
         top = np.zeros(asm.nc, np.uint8)
         top[np.lexsort((np.arange(asm.nc), -asm.lengths))[:1000]] = 1
         ctx.metrics_sample(top, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+        lib_h.besst_prof_enable(0xffffffff)
         t0 = time.perf_counter()
         _, _, counts = ctx.metrics_sample(top, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
         out['metrics_scan_ms'] = (time.perf_counter() - t0) * 1e3
+        out['metrics_kernels_ms'] = pipeline.prof_collect().get('metrics_kernels', (0.0, 0))[0]
         out['metrics_records_scanned'] = int(counts.records_scanned)
         ctx.build_graph()
         t0 = time.perf_counter()
@@ -133,12 +136,15 @@ def stage_timings(wl):
             len2 = (asm.lengths[(table.v[rows] >> 1) - 1]).astype(np.int32)
             swap = np.zeros(rows.shape[0], np.uint8)
             ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
+            pipeline.prof_collect()
             t0 = time.perf_counter()
             ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
             dt = time.perf_counter() - t0
+            out['score_kernel_ms'] = pipeline.prof_collect().get('score_kernels', (0.0, 0))[0]
             out['score_ms'] = dt * 1e3
             out['scored_edges'] = int(rows.shape[0])
             out['score_edges_per_s'] = rows.shape[0] / dt
+        lib_h.besst_prof_enable(0)
         pairs = len(batch) // 2
         out['pcie_inclusive_pairs_per_s'] = pairs / ((out['h2d_push_ms'] + out['ctx_build_graph_ms']) * 1e-3)
     return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}

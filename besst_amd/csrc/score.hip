@@ -56,18 +56,48 @@ __device__ Moments gap_moments(double d, double mean, double sigma, double c_min
     return M;
 }
 
-__device__ double gap_estimator(double mean, double sigma, double r, double mean_obs, double c1, double c2) {
+// ML gap: the reference restatement bisects d + sigma^2 g'(d)/g(d) = mean - mean_obs from
+// [trunc(-4 sigma), trunc(mean + 4 sigma - 2r)] down to unit width (10-14 dependent steps, ~16 erf/exp each).  The
+// workgroup replays EXACTLY that bisection, eight levels per round: every midpoint the bisection can reach within
+// the next eight steps is a node of a 255-node dyadic tree over the current bracket; one thread evaluates one node
+// (the interval ends are integers and the tree spacing a power-of-two fraction, so the fp64 midpoints are the very
+// values (upper + lower) / 2.0 produces), then a single thread walks the eight comparisons.  Same result as the
+// sequential loop whether or not the function is numerically monotone.
+__device__ double gap_estimator_parallel(double mean, double sigma, double r, double mean_obs, double c1, double c2,
+                                         unsigned char* s_cmp, double* s_bracket) {
     const double c_min = c1 < c2 ? c1 : c2, c_max = c1 < c2 ? c2 : c1;
     const double naive = mean - mean_obs;
-    double upper = trunc(mean + 4 * sigma - 2 * r);
-    double lower = trunc(-4 * sigma);
-    while (upper - lower > 1) {
-        const double mid = (upper + lower) / 2.0;
-        const Moments M = gap_moments(mid, mean, sigma, c_min, c_max, r);
-        const double f = M.m0 > 0.0 ? mid + sigma * sigma * M.gprime / M.m0 : mid;
-        if (f > naive) upper = mid; else lower = mid;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        s_bracket[0] = trunc(-4 * sigma);                    // lower
+        s_bracket[1] = trunc(mean + 4 * sigma - 2 * r);      // upper
     }
-    return floor((upper + lower) / 2.0 + 0.5);
+    __syncthreads();
+    while (true) {
+        const double lower = s_bracket[0], upper = s_bracket[1];
+        if (!(upper - lower > 1)) break;                     // uniform: every thread reads the same bracket
+        // node i (1..255) of the tree = lower + i * (upper - lower) / 256
+        if (t >= 1 && t < 256) {
+            const double mid = lower + (double)t * ((upper - lower) / 256.0);
+            const Moments M = gap_moments(mid, mean, sigma, c_min, c_max, r);
+            const double f = M.m0 > 0.0 ? mid + sigma * sigma * M.gprime / M.m0 : mid;
+            s_cmp[t] = f > naive ? 1 : 0;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double lo = lower, hi = upper;
+            int ilo = 0, ihi = 256;
+            for (int step = 0; step < 8 && hi - lo > 1; ++step) {
+                const int imid = (ilo + ihi) >> 1;
+                const double mid = (hi + lo) / 2.0;
+                if (s_cmp[imid]) { hi = mid; ihi = imid; } else { lo = mid; ilo = imid; }
+            }
+            s_bracket[0] = lo;
+            s_bracket[1] = hi;
+        }
+        __syncthreads();
+    }
+    return floor((s_bracket[1] + s_bracket[0]) / 2.0 + 0.5);
 }
 
 __device__ double tr_sk_std_dev(double mean, double sigma, double r, double c1, double c2, double d) {
@@ -106,45 +136,56 @@ __device__ __forceinline__ int upper_bound_centred(const int32_t* a, int n, doub
     return lo;
 }
 
+template <int CAP, bool kSmall>
 __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, double* __restrict__ gap_out,
                                                               double* __restrict__ sd0_out,
                                                               int32_t* __restrict__ ks_out,
                                                               uint8_t* __restrict__ flags_out,
                                                               int32_t* __restrict__ big_scratch,
                                                               const unsigned long long* __restrict__ big_off) {
-    __shared__ int32_t s_buf[2 * kLdsCap];
+    __shared__ int32_t s_buf[2 * CAP];
     __shared__ long long s_red[4];
     __shared__ int s_max[4];
+    __shared__ unsigned char s_cmp[256];
+    __shared__ double s_bracket[2];
     const int e = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t row = a.row[e];
     const int n = (int)a.row_n[row];
+    {   // two launches share the edge list: small edges sort in a 2 x 1024-entry LDS buffer (many workgroups per
+        // CU), the rest in 2 x 8192 entries or, beyond that, in global scratch
+        int np_probe = 1;
+        while (np_probe < n) np_probe <<= 1;
+        if (kSmall != (np_probe <= 1024)) return;
+    }
     const uint32_t off = a.row_offset[row];
     const bool swap = a.swap[e] != 0;
     const int32_t* src1 = (swap ? a.obs_hi : a.obs_lo) + off;
     const int32_t* src2 = (swap ? a.obs_lo : a.obs_hi) + off;
 
-    if (t == 0) {
+    {
         const double len1 = (double)a.len1[e], len2 = (double)a.len2[e];
         const double obs = (double)a.row_sum[row];
         const double nf = (double)n;
         const double mean_ = obs / nf;
         const double data_observation = (nf * a.mean - obs) / nf;
-        const bool long_enough = 2 * a.sigma < len1 && 2 * a.sigma < len2;
-        const double gap = long_enough ? gap_estimator(a.mean, a.sigma, a.read_len, mean_, len1, len2)
-                                       : data_observation;
-        uint8_t fl = long_enough ? 1 : 0;
-        if (-gap > len1 || -gap > len2) fl |= 2;
-        gap_out[e] = gap;
-        sd0_out[e] = long_enough ? tr_sk_std_dev(a.mean, a.sigma, a.read_len, len1, len2, gap) : 4294967296.0;
-        flags_out[e] = fl;
+        const bool long_enough = 2 * a.sigma < len1 && 2 * a.sigma < len2;       // uniform per workgroup
+        double gap = data_observation;
+        if (long_enough) gap = gap_estimator_parallel(a.mean, a.sigma, a.read_len, mean_, len1, len2, s_cmp, s_bracket);
+        if (t == 0) {
+            uint8_t fl = long_enough ? 1 : 0;
+            if (-gap > len1 || -gap > len2) fl |= 2;
+            gap_out[e] = gap;
+            sd0_out[e] = long_enough ? tr_sk_std_dev(a.mean, a.sigma, a.read_len, len1, len2, gap) : 4294967296.0;
+            flags_out[e] = fl;
+        }
     }
 
     int np = 1;
     while (np < n) np <<= 1;
     int32_t* l1;
     int32_t* l2;
-    if (np <= kLdsCap) {
+    if (np <= CAP) {
         l1 = s_buf;
         l2 = s_buf + np;
     } else {
@@ -235,8 +276,10 @@ int launch_score(hipStream_t s, const ScoreArgs& a, double* gap, double* sd0, in
     auto* big_scratch = reinterpret_cast<int32_t*>(p + align_up((size_t)a.n_edges * 8, 256));
     (void)ws_bytes;
     ProfScope ps(s, kProfScore);
-    hipLaunchKernelGGL(score_kernel, dim3((uint32_t)a.n_edges), dim3(kScoreThreads), 0, s, a, gap, sd0, ks_h, flags,
-                       big_scratch, big_off);
+    hipLaunchKernelGGL((score_kernel<1024, true>), dim3((uint32_t)a.n_edges), dim3(kScoreThreads), 0, s, a, gap, sd0,
+                       ks_h, flags, big_scratch, big_off);
+    hipLaunchKernelGGL((score_kernel<kLdsCap, false>), dim3((uint32_t)a.n_edges), dim3(kScoreThreads), 0, s, a, gap, sd0,
+                       ks_h, flags, big_scratch, big_off);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }
