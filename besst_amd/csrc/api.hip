@@ -156,7 +156,7 @@ int besst_prof_slots(void) { return kProfSlots; }
 
 const char* besst_prof_slot_name(int slot) {
     static const char* names[kProfSlots] = {"stream_kernel", "eval_kernel", "ordered_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
-                                            "radix_rowscan_kernel", "radix_scatter_kernel", "row_heads_kernel",
+                                            "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "row_heads_kernel",
                                             "row_scan_kernel", "row_reduce_kernel",
                                             "metrics_kernels", "score_kernels"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";

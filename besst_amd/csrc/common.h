@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
-    kProfClassify = 0, kProfCandidate, kProfOrdered, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter,
+    kProfClassify = 0, kProfCandidate, kProfOrdered, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter, kProfBucketSort,
     kProfRowHeads, kProfRowScan, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
 };
 struct ProfScope {

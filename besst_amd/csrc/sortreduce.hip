@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
     const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table,
     uint32_t stride, const uint32_t* __restrict__ row_total, int scanned, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ idx_out) {
+    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ bucket_start) {
     constexpr int RADIX = 1 << BITS;
     constexpr int DPT = RADIX / kSortThreads;     // digits per thread (contiguous)
     __shared__ uint32_t s_whist[4][RADIX];
@@ -212,8 +212,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             s_base[t * DPT + q] = start + pre[q];
+            if (bucket_start && b == 0) bucket_start[t * DPT + q] = start;     // where digit d begins (MSD buckets)
             start += tot[q];
         }
+        if (bucket_start && b == 0 && t == kSortThreads - 1) bucket_start[RADIX] = start;
     }
     __syncthreads();
 
@@ -260,6 +262,90 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             const uint32_t dst = s_whist[wave][dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
             keys_out[dst] = key[r];
             idx_out[dst] = idx[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small streams (<= 262 144 tuples): ONE most-significant-digit pass + a per-bucket sort
+// ---------------------------------------------------------------------------------------------------
+// The LSD sort needs one dependent hist+scatter pair per 11 key bits; at this size every launch costs more than
+// its work.  Instead the stream is partitioned once by the TOP 11 significant key bits (2048 buckets of a few
+// dozen tuples; the stable scatter keeps stream order inside a bucket) and every bucket is finished by its own
+// workgroup with a bitonic sort on (key, stream index) - equivalent to a stable sort by key because the index is
+// unique.  Buckets up to 512 tuples sort in LDS (6 KB, so every bucket of the launch is resident at once); larger
+// ones (a hub scaffold) sort in place in global scratch.
+constexpr int kBucketLds = 512;
+#ifndef BESST_BUCKET_THREADS
+#define BESST_BUCKET_THREADS 256
+#endif
+constexpr int kBucketThreads = BESST_BUCKET_THREADS;
+
+__device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+template <typename KP, typename IP>
+__device__ __forceinline__ void bitonic_pairs(KP k, IP x, int np) {
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint64_t ka = k[i], kb = k[p];
+                    const uint32_t ia = x[i], ib = x[p];
+                    const bool up = (i & size) == 0;
+                    if (pair_less(kb, ib, ka, ia) == up) { k[i] = kb; k[p] = ka; x[i] = ib; x[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                          const uint32_t* __restrict__ bucket_start,
+                                                          const uint32_t* __restrict__ n_ptr,
+                                                          uint64_t* __restrict__ big_keys,
+                                                          uint32_t* __restrict__ big_idx) {
+    __shared__ uint64_t s_k[kBucketLds];
+    __shared__ uint32_t s_x[kBucketLds];
+    if (*n_ptr == 0) return;          // nothing was partitioned, bucket_start is stale
+    const uint32_t s0 = bucket_start[blockIdx.x], e0 = bucket_start[blockIdx.x + 1];
+    const int n = (int)(e0 - s0);
+    if (n <= 1) return;
+    int np = 2;
+    while (np < n) np <<= 1;
+    if (n <= kBucketLds) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            s_k[i] = keys[s0 + i];
+            s_x[i] = idx[s0 + i];
+        }
+        __syncthreads();
+        // rank sort: element i goes to position #{j : (key_j, idx_j) < (key_i, idx_i)}.  O(n^2) LDS broadcast reads
+        // (every lane reads the same j: conflict free) but a single barrier - for the ~100-tuple buckets of this path
+        // that beats a bitonic network's 28-45 barrier-separated stages.
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t ki = s_k[i];
+            const uint32_t xi = s_x[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += pair_less(s_k[j], s_x[j], ki, xi) ? 1 : 0;
+            keys[s0 + rank] = ki;
+            idx[s0 + rank] = xi;
+        }
+    } else {
+        // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
+        uint64_t* gk = big_keys + 2 * (size_t)s0;
+        uint32_t* gx = big_idx + 2 * (size_t)s0;
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            gk[i] = i < n ? keys[s0 + i] : ~0ull;
+            gx[i] = i < n ? idx[s0 + i] : ~0u;
+        }
+        __syncthreads();
+        bitonic_pairs(gk, gx, np);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            keys[s0 + i] = gk[i];
+            idx[s0 + i] = gx[i];
         }
     }
 }
@@ -482,6 +568,9 @@ struct RedWorkspace {
     uint32_t* row_total;
     uint32_t* blk_heads;
     uint32_t* blk_base;
+    uint32_t* bucket_start;
+    uint64_t* big_keys;
+    uint32_t* big_idx;
     uint32_t stride;
     size_t total;
 };
@@ -505,6 +594,11 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
+    w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up((kMaxRadix + 1) * 4, 256);
+    // in-place scratch of the bucket sort (only streams that take the MSD path can use it)
+    const size_t big = nb_sort <= (size_t)kScanFreeMaxBlocks ? 2 * (size_t)cap + 8 : 8;
+    w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
+    w.big_idx = reinterpret_cast<uint32_t*>(p + off); off += align_up(big * 4, 256);
     w.total = off;
     return w;
 }
@@ -513,7 +607,8 @@ RedWorkspace carve(void* ws, int64_t cap) {
 template <int BITS>
 void launch_pass(hipStream_t s, const RedWorkspace& w, uint32_t nb_sort, uint32_t cap, const uint32_t* n_tuples,
                  DigitSel ds, bool first, const uint64_t* kin, const uint32_t* iin, uint64_t* kout, uint32_t* iout,
-                 uint32_t* zero_n, unsigned long long* zero_sum, unsigned long long* zero_sum_sq) {
+                 uint32_t* zero_n, unsigned long long* zero_sum, unsigned long long* zero_sum_sq,
+                 uint32_t* bucket_start = nullptr) {
     const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
     {
         ProfScope ps(s, kProfSortHist);
@@ -528,10 +623,10 @@ void launch_pass(hipStream_t s, const RedWorkspace& w, uint32_t nb_sort, uint32_
     ProfScope ps(s, kProfSortScatter);
     if (first)
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
-                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout);
+                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout, bucket_start);
     else
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, false>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
-                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout);
+                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout, bucket_start);
 }
 
 }  // namespace
@@ -563,19 +658,34 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     auto* zsq = reinterpret_cast<unsigned long long*>(row_sum_sq);
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;
-    for (int p = 0; p < passes; ++p) {
-        const DigitSel ds{0, p * bits, 0, 1u, bits};
-        uint64_t* kout = w.keys[p & 1];
-        uint32_t* iout = w.idx[p & 1];
-        const bool last = p == passes - 1;
-        if (bits == 11)
-            launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
-                            last ? row_n : nullptr, zsum, zsq);
-        else
-            launch_pass<kRadixBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
-                                    last ? row_n : nullptr, zsum, zsq);
-        kin = kout;
-        iin = iout;
+    if (nb_sort <= (uint32_t)kScanFreeMaxBlocks) {
+        // small stream: one MSD pass on the top 11 significant bits, then every bucket sorts itself
+        const int shift = key_bits > 11 ? key_bits - 11 : 0;
+        const DigitSel ds{0, shift, 0, 1u, 11};
+        launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0], row_n,
+                        zsum, zsq, w.bucket_start);
+        if (shift > 0) {
+            ProfScope ps(s, kProfBucketSort);
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(kMaxRadix), dim3(kBucketThreads), 0, s, w.keys[0], w.idx[0], w.bucket_start,
+                               n_tuples, w.big_keys, w.big_idx);
+        }
+        kin = w.keys[0];
+        iin = w.idx[0];
+    } else {
+        for (int p = 0; p < passes; ++p) {
+            const DigitSel ds{0, p * bits, 0, 1u, bits};
+            uint64_t* kout = w.keys[p & 1];
+            uint32_t* iout = w.idx[p & 1];
+            const bool last = p == passes - 1;
+            if (bits == 11)
+                launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
+                                last ? row_n : nullptr, zsum, zsq);
+            else
+                launch_pass<kRadixBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
+                                        last ? row_n : nullptr, zsum, zsq);
+            kin = kout;
+            iin = iout;
+        }
     }
     const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {
@@ -696,7 +806,7 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
                            w.stride, w.row_total);
         hipLaunchKernelGGL((radix_scatter_kernel<kRadixBits, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys,
                            nullptr, n_tuples, (uint32_t)cap, ds, w.table, w.stride, w.row_total, 1, w.keys[0],
-                           w.idx[0]);
+                           w.idx[0], nullptr);
     }
     const uint32_t nb_pack = (uint32_t)((cap + 255) / 256) + 1;
     hipLaunchKernelGGL(pack_kernel, dim3(nb_pack), dim3(256), 0, s, w.keys[0], w.idx[0], payload, n_tuples,

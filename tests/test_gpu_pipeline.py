@@ -27,3 +27,50 @@ def test_dev_layer_matches_oracle():
     torch.cuda.synchronize()
     edges = gb.fetch_table()
     DU.assert_matches_oracle(edges, gb.aligned.cpu().numpy(), gb.read_counters(), loop, wl['asm'].nc)
+
+
+@pytest.mark.parametrize('n,key_bits,hub', [(50_000, 31, 20_000), (3_000, 9, 0), (200_000, 41, 700), (1, 31, 0),
+                                            (600_000, 33, 100_000)])
+def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
+    """The sort/reduce stage alone, on skewed keys: a hub bucket larger than the LDS sort capacity, fewer key bits
+    than one digit, both small-stream (MSD + bucket sort) and large-stream (LSD passes) paths."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from besst_amd import pipeline
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(n + key_bits)
+    node_bits = (key_bits - 1) // 2
+    pair = rng.integers(0, 1 << (2 * node_bits), n, dtype=np.int64)
+    if hub:
+        pair[rng.choice(n, hub, replace=False)] = (5 << node_bits) | rng.integers(0, 40, hub)   # one crowded top-bits bucket
+    fishy = (rng.random(n) < 0.01).astype(np.int64)
+    keys = ((pair << 1) | fishy).astype(np.uint64)
+    lo = rng.integers(26, 5000, n).astype(np.uint64)
+    hi = rng.integers(26, 5000, n).astype(np.uint64) | (np.uint64(3) << np.uint64(30))
+    lo[fishy == 1] = 0
+    hi[fishy == 1] = 0
+    payload = lo | (hi << np.uint64(32))
+    dev = torch.device('cuda', 0)
+    lib = dict(read_len=100.0, ins_size_threshold=800.0, min_mapq=11, orientation='fr', detect_duplicate=True,
+               extend_paths=True, no_score=False)
+    gb = pipeline.DeviceGraphBuilder(dev, 4, node_bits, lib, n, n)
+    dk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    dp = torch.from_numpy(payload.view(np.int64)).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    for _ in range(2):
+        gb.reduce(keys=dk, payload=dp, n_tuples_ptr=C.c_void_p(cnt.data_ptr()), capacity=n)
+    torch.cuda.synchronize()
+    want = CO.edge_rows(keys, payload)
+    r = len(want['key'])
+    raw = gb.small.cpu().numpy()
+    n_rows = int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0])
+    assert n_rows == r
+    get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
+    assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
+    assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
+    assert np.array_equal(get(gb.row_sum, r, np.int64), want['sum_obs'])
+    assert np.array_equal(get(gb.row_sum_sq, r, np.int64), want['sum_obs_sq'])
+    assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
+    assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
+    assert np.array_equal(get(gb.obs_hi, n, np.int32).astype(np.int64), want['obs_hi'])
