@@ -155,7 +155,7 @@ void besst_prof_enable(uint32_t slot_mask) { g_prof_mask = slot_mask; }
 int besst_prof_slots(void) { return kProfSlots; }
 
 const char* besst_prof_slot_name(int slot) {
-    static const char* names[kProfSlots] = {"stream_kernel", "eval_kernel", "ordered_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
+    static const char* names[kProfSlots] = {"stream_kernel", "(unused)", "ordered_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
                                             "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "row_heads_kernel",
                                             "row_scan_kernel", "row_reduce_kernel",
                                             "metrics_kernels", "score_kernels"};

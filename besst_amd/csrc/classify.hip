@@ -213,16 +213,9 @@ __device__ __forceinline__ void flush_cov(const ClassifyArgs& a, unsigned long l
         atomicAdd(&aligned[ref], (unsigned long long)sum);
 }
 
-__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
-                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
-                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
-                                           int lane);
-
-template <bool kFuseEval>
 __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
                                                                 unsigned long long* __restrict__ aligned,
-                                                                unsigned long long* __restrict__ bitmask,
-                                                                uint4* __restrict__ staging) {
+                                                                unsigned long long* __restrict__ bitmask) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kStreamTile;
     int4 v_tid[kStreamSubTiles], v_mtid[kStreamSubTiles];
@@ -307,154 +300,85 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
         const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
         const int64_t g = ((int64_t)blockIdx.x * kStreamSubTiles + st) * 4 + wave;
         if (lane < 4) bitmask[g * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-        if (kFuseEval && (b0 | b1 | b2 | b3) != 0ull)      // dense libraries: evaluate while the lines are hot
-            eval_group(a, g, b0, b1, b2, b3, aligned, staging, lane);
     }
     flush_cov(a, aligned, lane, acc_ref, acc_sum);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// eval_kernel: evaluate every candidate, balanced and order-free.  One wave per 256-record group, in the same
-// record <-> lane layout as stream_kernel (lane l owns records 4l..4l+3), so the record fields are fetched
-// with the same coalesced vector loads (only by lanes that own a candidate) and a lane evaluates at most four
-// records.  Waves whose group has no candidate exit after one broadcast load of their 32 bytes of bits.  The
-// evaluated candidates are written as 16-byte entries, compacted in record order inside the group's staging
-// slice (group g -> staging[g*256 ...]); candidates' coverage is added with one atomic per distinct contig.
-//   entry = { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31,
-//                         node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
+// ordered_kernel: everything a candidate needs, evaluation included.  Single-wave workgroups; the workgroup
+// covers kCandGroups consecutive groups and walks their candidates 64 at a time in stream order, kAhead chunks
+// in flight: r-th set bit of the group's mask -> record gather (7 columns) -> two contig rows -> observations
+// (PosDirCalculator), then the order-dependent part - previous reaching observation via ballot, CreateEdge
+// semantics (acceptance rule :840), ordered slots for the emitted tuples.  The evaluated candidates and the
+// chain live in registers; LDS holds a 64-entry prefix table and the groups' masks.  (A separate evaluation
+// launch, one wave per group, cost ~N/256 mostly idle waves and a staging round trip: 31 + 18 us on C2 against
+// 30 us for this kernel.  Handing tid/mtid/mapq/qlen over from stream_kernel instead of re-gathering them did
+// not make this kernel faster and cost the streaming pass 2-3 us.)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kEvalGroupsPerWave = 1;
-
-__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
-                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
-                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
-                                           int lane);
-
-// One wave per group; waves whose group has no candidate exit after one broadcast load of their 32 bytes of bits.
-// (Letting a wave walk several groups was measured slower: the two dependent memory round trips of every active
-// group then serialise inside the wave, while the launch of ~N/256 mostly empty waves costs ~20 us on C2.)
-__global__ __launch_bounds__(256) void eval_kernel(ClassifyArgs a, const unsigned long long* __restrict__ bitmask,
-                                                   int64_t n_groups, unsigned long long* __restrict__ aligned,
-                                                   uint4* __restrict__ staging) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t g = (int64_t)blockIdx.x * 4 + wave;
-    if (g >= n_groups) return;
-    const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
-    const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
-    if ((w0.x | w0.y | w1.x | w1.y) == 0ull) return;
-    eval_group(a, g, w0.x, w0.y, w1.x, w1.y, aligned, staging, lane);
+// r-th candidate (record order) of a group: word k, bit l <-> record 4*l + k.  Returns the record's offset in
+// the group.
+__device__ __forceinline__ int select_candidate(unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                                                unsigned long long w3, int r) {
+    int lo = 0;                                         // largest l with (#candidates in lanes < l) <= r
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int mid = lo + step;
+        const unsigned long long m = (1ull << mid) - 1ull;
+        const int below = __popcll(w0 & m) + __popcll(w1 & m) + __popcll(w2 & m) + __popcll(w3 & m);
+        if (below <= r) lo = mid;
+    }
+    const unsigned long long m = (1ull << lo) - 1ull;
+    int rest = r - (__popcll(w0 & m) + __popcll(w1 & m) + __popcll(w2 & m) + __popcll(w3 & m));
+    const int b[4] = {(int)((w0 >> lo) & 1ull), (int)((w1 >> lo) & 1ull), (int)((w2 >> lo) & 1ull),
+                      (int)((w3 >> lo) & 1ull)};
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (b[q]) {
+            if (rest == 0) { k = q; rest = -1; }
+            else if (rest > 0) --rest;
+        }
+    }
+    return lo * 4 + k;
 }
 
-__device__ __forceinline__ void eval_group(const ClassifyArgs& a, int64_t g, unsigned long long b0,
-                                           unsigned long long b1, unsigned long long b2, unsigned long long b3,
-                                           unsigned long long* __restrict__ aligned, uint4* __restrict__ staging,
-                                           int lane) {
-    const ulonglong2 w0 = make_ulonglong2(b0, b1), w1 = make_ulonglong2(b2, b3);
-    const bool c[4] = {(bool)((w0.x >> lane) & 1ull), (bool)((w0.y >> lane) & 1ull), (bool)((w1.x >> lane) & 1ull),
-                       (bool)((w1.y >> lane) & 1ull)};
-    const int cnt = (int)c[0] + (int)c[1] + (int)c[2] + (int)c[3];
-    const int excl = wave_incl_scan(cnt, lane) - cnt;
-    const int64_t i0 = g * kGroup + (int64_t)lane * 4;
-    int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
-    uint32_t r_flag[4], r_mapq[4], r_qlen[4];
-    if (cnt) {
-        if (i0 + 4 <= a.n) {
-            const int4 v0 = *reinterpret_cast<const int4*>(a.tid + i0);
-            const int4 v1 = *reinterpret_cast<const int4*>(a.mtid + i0);
-            const int4 v2 = *reinterpret_cast<const int4*>(a.pos + i0);
-            const int4 v3 = *reinterpret_cast<const int4*>(a.mpos + i0);
-            const ushort4 f = *reinterpret_cast<const ushort4*>(a.flag + i0);
-            const uchar4 m = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            const ushort4 q = *reinterpret_cast<const ushort4*>(a.qlen + i0);
-            r_tid[0] = v0.x; r_tid[1] = v0.y; r_tid[2] = v0.z; r_tid[3] = v0.w;
-            r_mtid[0] = v1.x; r_mtid[1] = v1.y; r_mtid[2] = v1.z; r_mtid[3] = v1.w;
-            r_pos[0] = v2.x; r_pos[1] = v2.y; r_pos[2] = v2.z; r_pos[3] = v2.w;
-            r_mpos[0] = v3.x; r_mpos[1] = v3.y; r_mpos[2] = v3.z; r_mpos[3] = v3.w;
-            r_flag[0] = f.x; r_flag[1] = f.y; r_flag[2] = f.z; r_flag[3] = f.w;
-            r_mapq[0] = m.x; r_mapq[1] = m.y; r_mapq[2] = m.z; r_mapq[3] = m.w;
-            r_qlen[0] = q.x; r_qlen[1] = q.y; r_qlen[2] = q.z; r_qlen[3] = q.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t i = i0 + k;
-                const bool in = i < a.n;
-                r_tid[k] = in ? a.tid[i] : -1;
-                r_mtid[k] = in ? a.mtid[i] : -1;
-                r_pos[k] = in ? a.pos[i] : 0;
-                r_mpos[k] = in ? a.mpos[i] : 0;
-                r_flag[k] = in ? a.flag[i] : 0;
-                r_mapq[k] = in ? a.mapq[i] : 0;
-                r_qlen[k] = in ? a.qlen[i] : 0;
-            }
-        }
-    }
-    // contig rows of all this lane's candidates first (their gathers overlap), then the arithmetic
-    ContigRow c1[4], c2[4];
-    bool in_range[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        in_range[k] = c[k] && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs;
-        if (in_range[k]) {
-            c1[k] = a.table[r_tid[k]];
-            c2[k] = a.table[r_mtid[k]];
-        }
-    }
-    int32_t cov_tid = -1;
-    int cov_sum = 0;
-    int slot = excl;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!c[k]) continue;
-        const Eval e = eval_record(a, in_range[k], c1[k], c2[k], r_tid[k], r_mtid[k], r_pos[k], r_mpos[k], r_flag[k],
-                                   r_mapq[k]);
-        if (e.bits & EV_COV) {
-            if (r_tid[k] != cov_tid && cov_sum) {          // a second contig inside one lane: rare, flush directly
-                atomicAdd(&aligned[cov_tid], (unsigned long long)cov_sum);
-                cov_sum = 0;
-            }
-            cov_tid = r_tid[k];
-            cov_sum += (int)r_qlen[k];
-        }
-        uint4 ent;
-        ent.x = (uint32_t)e.o1;
-        ent.y = (uint32_t)e.o2;
-        ent.z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
-                ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
-        ent.w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
-                ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
-        staging[g * kGroup + slot] = ent;
-        slot++;
-    }
-    wave_add_by_key(aligned, cov_tid, cov_sum, cov_sum != 0, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// ordered_kernel: the order-dependent part, over the evaluated candidates only.  Single-wave workgroups; the
-// workgroup covers kCandGroups consecutive groups and walks their staged entries 64 at a time in stream order:
-// previous reaching observation via ballot, CreateEdge semantics (acceptance rule :840 re-evaluated from the
-// stored observations), ordered slots for the emitted tuples.  The chain is carried in registers, nothing but a
-// 64-entry prefix table lives in LDS.
-// ---------------------------------------------------------------------------------------------------------
+#ifdef BESST_PHASE_TIMER   // development probe: per-phase 100 MHz ticks summed into the counters (results are garbage)
+#define PT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
+                   pt[k] += (uint32_t)(now_ - pt_last); pt_last = now_; } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
     ClassifyArgs a, const unsigned long long* __restrict__ bitmask, int64_t n_groups,
-    const uint4* __restrict__ staging, uint64_t* __restrict__ seg_keys, uint64_t* __restrict__ seg_payload,
-    BlockSummary* __restrict__ summ) {
+    unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
+    uint64_t* __restrict__ seg_payload, SummView summ) {
     __shared__ int s_pre[kCandThreads + 1];
+    __shared__ unsigned long long s_bits[kCandThreads * 4];
+#ifdef BESST_PHASE_TIMER
+    uint32_t pt[7] = {0, 0, 0, 0, 0, 0, 1};
+    unsigned long long pt_last = wall_clock64();
+#endif
     const int lane = threadIdx.x;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
     const int64_t g0 = (int64_t)blockIdx.x * kCandGroups;
     const int64_t g = g0 + lane;
     int cnt = 0;
-    if (lane < kCandGroups && g < n_groups) {
-        const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
-        const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
-        cnt = __popcll(w0.x) + __popcll(w0.y) + __popcll(w1.x) + __popcll(w1.y);
+    {
+        ulonglong2 w0 = make_ulonglong2(0ull, 0ull), w1 = w0;
+        if (lane < kCandGroups && g < n_groups) {
+            w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
+            w1 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4 + 2);
+            cnt = __popcll(w0.x) + __popcll(w0.y) + __popcll(w1.x) + __popcll(w1.y);
+        }
+        s_bits[lane * 4 + 0] = w0.x; s_bits[lane * 4 + 1] = w0.y;
+        s_bits[lane * 4 + 2] = w1.x; s_bits[lane * 4 + 3] = w1.y;
     }
     const int incl = wave_incl_scan(cnt, lane);
     const int total = __shfl(incl, 63, 64);
     s_pre[lane] = incl - cnt;
     if (lane == 0) s_pre[kCandThreads] = total;
     __syncthreads();
+    PT(0);
 
     // chain state, identical in every lane
     bool prev_known = false;
@@ -470,19 +394,66 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
 
     constexpr int kAhead = 4;    // chunks whose entries are fetched before the chain consumes them
     for (int c0 = 0; c0 < total; c0 += kCandThreads * kAhead) {
-        uint4 ents[kAhead];
+        uint4 ents[kAhead];     // { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31,
+                                //               node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
+        {
+            int32_t r_tid[kAhead], r_mtid[kAhead], r_pos[kAhead], r_mpos[kAhead];
+            uint32_t r_flag[kAhead], r_mapq[kAhead], r_qlen[kAhead];
+            bool valid[kAhead];
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const int j = c0 + u * kCandThreads + lane;
-            ents[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (j < total) {
-                int lo = 0, hi = kCandThreads;          // last group whose exclusive prefix is <= j
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_pre[mid] <= j) lo = mid; else hi = mid;
+            for (int u = 0; u < kAhead; ++u) {              // record gathers of every chunk first ...
+                const int j = c0 + u * kCandThreads + lane;
+                valid[u] = j < total;
+                r_tid[u] = r_mtid[u] = -1;
+                r_pos[u] = r_mpos[u] = 0;
+                r_flag[u] = r_mapq[u] = r_qlen[u] = 0;
+                if (valid[u]) {
+                    int lo = 0, hi = kCandThreads;          // last group whose exclusive prefix is <= j
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= j) lo = mid; else hi = mid;
+                    }
+                    const int off = select_candidate(s_bits[lo * 4], s_bits[lo * 4 + 1], s_bits[lo * 4 + 2],
+                                                     s_bits[lo * 4 + 3], j - s_pre[lo]);
+                    const int64_t i = (g0 + lo) * kGroup + off;
+                    r_tid[u] = a.tid[i];
+                    r_mtid[u] = a.mtid[i];
+                    r_pos[u] = a.pos[i];
+                    r_mpos[u] = a.mpos[i];
+                    r_flag[u] = a.flag[i];
+                    r_mapq[u] = a.mapq[i];
+                    r_qlen[u] = a.qlen[i];
                 }
-                ents[u] = staging[(g0 + lo) * kGroup + (j - s_pre[lo])];
             }
+            PT(1);
+            ContigRow c1[kAhead], c2[kAhead];
+            bool in_range[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {              // ... then their contig rows ...
+                in_range[u] = valid[u] && (uint32_t)r_tid[u] < (uint32_t)a.n_contigs &&
+                              (uint32_t)r_mtid[u] < (uint32_t)a.n_contigs;
+                if (in_range[u]) {
+                    c1[u] = a.table[r_tid[u]];
+                    c2[u] = a.table[r_mtid[u]];
+                }
+            }
+            PT(2);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {              // ... then the arithmetic
+                ents[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (c0 + u * kCandThreads >= total) break;   // uniform
+                const Eval e = eval_record(a, in_range[u], c1[u], c2[u], r_tid[u], r_mtid[u], r_pos[u], r_mpos[u],
+                                           r_flag[u], r_mapq[u]);
+                ents[u].x = (uint32_t)e.o1;
+                ents[u].y = (uint32_t)e.o2;
+                ents[u].z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
+                            ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
+                ents[u].w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
+                            ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+                // the candidates' own coverage (the streaming pass credits only tid == mtid records)
+                wave_add_by_key(aligned, r_tid[u], (int)r_qlen[u], (e.bits & EV_COV) != 0, lane);
+            }
+            PT(3);
         }
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
@@ -549,6 +520,7 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
             }
             emit_base += __popcll(emit_mask);
         }
+        PT(4);
     }
 
     int tot[7];
@@ -557,96 +529,158 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
 #pragma unroll
         for (int f = 0; f < 7; ++f) tot[f] = wave_sum(vals[f]);
     }
-    if (lane == 0) {
-        BlockSummary s;
+    {
+        uint32_t v = 0;                                      // lane f publishes plane f
+        if (lane == kSumEmit) v = (uint32_t)emit_base;
+        if (lane == kSumHas) v = blk_has ? 1u : 0u;
+        if (lane == kSumFirst1) v = head_present ? (uint32_t)head1 : 0u;
+        if (lane == kSumFirst2) v = head_present ? (uint32_t)head2 : 0u;
+        if (lane == kSumLast1) v = (uint32_t)prev1;
+        if (lane == kSumLast2) v = (uint32_t)prev2;
+        if (lane == kSumHeadInfo) v = head_present ? head_info : 0u;
+        if (lane == kSumHeadSlot) v = head_slot;
+#ifdef BESST_PHASE_TIMER
+        PT(5);
 #pragma unroll
-        for (int f = 0; f < 7; ++f) s.ctr[f] = (uint32_t)tot[f];
-        s.ctr[7] = 0;
-        s.n_emit = (uint32_t)emit_base;
-        s.has_reach = blk_has ? 1u : 0u;
-        s.first_o1 = head_present ? head1 : 0;
-        s.first_o2 = head_present ? head2 : 0;
-        s.last_o1 = prev1;
-        s.last_o2 = prev2;
-        s.head_info = head_present ? head_info : 0u;
-        s.head_slot = head_slot;
-        summ[blockIdx.x] = s;
+        for (int f = 0; f < 7; ++f) tot[f] = (int)pt[f];
+#endif
+#pragma unroll
+        for (int f = 0; f < 7; ++f)
+            if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
+        if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
     }
 }
 
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------
-template <bool kMax>
-__device__ __forceinline__ int block_incl_scan_1024(int v, int* s_w, int t) {
-    const int lane = t & 63, wave = t >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v = kMax ? (o > v ? o : v) : v + o;
-    }
-    __syncthreads();
-    if (lane == 63) s_w[wave] = v;
-    __syncthreads();
-    int acc = kMax ? -1 : 0;
-    for (int w = 0; w < wave; ++w) acc = kMax ? (s_w[w] > acc ? s_w[w] : acc) : acc + s_w[w];
-    return kMax ? (acc > v ? acc : v) : v + acc;
-}
+// One workgroup, one lane per block and round, kStitchRounds rounds (4096 blocks) per iteration.  The summaries of
+// all rounds are fetched up front (one memory round trip); both scans - "nearest earlier block that reached
+// CreateEdge" (a max-scan of block indexes) and the tuple offsets (a sum-scan) - run as wave scans of every
+// round at once plus ONE wave scan over the 64 (round, wave) totals, so an iteration costs six barriers whatever
+// the number of blocks.  (A barrier-heavy scan per 1024 blocks cost 4.3 us per round.)
+constexpr int kStitchRounds = 4;
+static_assert(kStitchRounds * 16 == 64, "the (round, wave) totals are scanned by one wave");
 
-__global__ __launch_bounds__(1024) void stitch_kernel(const BlockSummary* __restrict__ summ,
-                                                      uint32_t nblocks, int32_t* carry, int detect,
+__global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nblocks, int32_t* carry, int detect,
                                                       uint32_t* __restrict__ offsets,
                                                       uint32_t* __restrict__ skip_slot,
                                                       uint32_t* n_out,
                                                       unsigned long long* counters) {
-    __shared__ int s_w[16];
-    __shared__ int32_t s_l1[1024], s_l2[1024];
+    __shared__ int32_t s_l1[1024 * kStitchRounds], s_l2[1024 * kStitchRounds];
+    __shared__ int s_tab[64];
+    __shared__ int s_total;
     __shared__ int32_t s_carry[2];
     __shared__ int s_base;
     __shared__ int s_redc[16][7];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) { s_carry[0] = carry[0]; s_carry[1] = carry[1]; s_base = 0; }
     __syncthreads();
     int c_count = 0, c_long = 0, c_dup = 0, c_nus = 0, c_nonuniq = 0, c_fishy = 0, c_reach = 0;
-    for (uint32_t c0 = 0; c0 < nblocks; c0 += 1024) {
-        const uint32_t b = c0 + t;
-        BlockSummary s;
-        s.n_emit = 0; s.has_reach = 0; s.first_o1 = s.first_o2 = s.last_o1 = s.last_o2 = 0;
-        s.head_info = 0; s.head_slot = kNoSlot;
-        if (b < nblocks) {
-            s = summ[b];
-            c_count += (int)s.ctr[0]; c_nonuniq += (int)s.ctr[1]; c_nus += (int)s.ctr[2]; c_dup += (int)s.ctr[3];
-            c_long += (int)s.ctr[4]; c_fishy += (int)s.ctr[5]; c_reach += (int)s.ctr[6];
+    for (uint32_t c0 = 0; c0 < nblocks; c0 += 1024 * kStitchRounds) {
+        uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], head_slot[kStitchRounds], has[kStitchRounds];
+        int32_t f1[kStitchRounds], f2[kStitchRounds], l1[kStitchRounds], l2[kStitchRounds];
+#pragma unroll
+        for (int r = 0; r < kStitchRounds; ++r) {
+            const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
+            n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0; head_slot[r] = kNoSlot;
+            if (b < nblocks) {
+                n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
+                f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
+                l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
+                head_info[r] = summ.at(kSumHeadInfo, b); head_slot[r] = summ.at(kSumHeadSlot, b);
+                c_count += (int)summ.at(kSumCtr0 + 0, b); c_nonuniq += (int)summ.at(kSumCtr0 + 1, b);
+                c_nus += (int)summ.at(kSumCtr0 + 2, b); c_dup += (int)summ.at(kSumCtr0 + 3, b);
+                c_long += (int)summ.at(kSumCtr0 + 4, b); c_fishy += (int)summ.at(kSumCtr0 + 5, b);
+                c_reach += (int)summ.at(kSumCtr0 + 6, b);
+            }
         }
-        s_l1[t] = s.last_o1;
-        s_l2[t] = s.last_o2;
-        const int incl = block_incl_scan_1024<true>(s.has_reach ? t : -1, s_w, t);
+        // ---- nearest earlier block (of this iteration) with a reaching record
+        int incl[kStitchRounds];
+#pragma unroll
+        for (int r = 0; r < kStitchRounds; ++r) {
+            int v = has[r] ? r * 1024 + t : -1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d, 64);
+                if (lane >= d) v = o > v ? o : v;
+            }
+            incl[r] = v;
+            s_l1[r * 1024 + t] = l1[r];
+            s_l2[r * 1024 + t] = l2[r];
+            if (lane == 63) s_tab[r * 16 + wave] = v;
+        }
         __syncthreads();
-        const int excl = __shfl_up(incl, 1, 64);
-        int prev_idx;
-        if ((t & 63) == 0) {
-            prev_idx = -1;
-            for (int w = 0; w < (t >> 6); ++w) prev_idx = s_w[w] > prev_idx ? s_w[w] : prev_idx;
-        } else {
-            prev_idx = excl;
+        if (wave == 0) {
+            int v = s_tab[lane];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d, 64);
+                if (lane >= d) v = o > v ? o : v;
+            }
+            const int ex = __shfl_up(v, 1, 64);
+            s_tab[lane] = lane ? ex : -1;
+            if (lane == 63) s_total = v;
         }
-        int32_t p1 = prev_idx >= 0 ? s_l1[prev_idx] : s_carry[0];
-        int32_t p2 = prev_idx >= 0 ? s_l2[prev_idx] : s_carry[1];
-        uint32_t n_final = s.n_emit, skip = kNoSlot;
-        if (s.has_reach) {
-            const CEDelta d = create_edge(s.first_o1, s.first_o2, p1, p2, s.head_info & 1u,
-                                          s.head_info & 2u, s.head_info & 4u, detect != 0);
-            c_count += d.count; c_long += d.too_long; c_dup += d.dup; c_nus += d.nus;
-            if ((s.head_info & 8u) && !d.keep) { n_final -= 1; skip = s.head_slot; }
+        __syncthreads();
+        const int last_idx = s_total;
+        uint32_t n_final[kStitchRounds], skip[kStitchRounds];
+#pragma unroll
+        for (int r = 0; r < kStitchRounds; ++r) {
+            int ex = __shfl_up(incl[r], 1, 64);
+            if (lane == 0) ex = -1;
+            const int wpre = s_tab[r * 16 + wave];
+            const int pi = ex > wpre ? ex : wpre;
+            const int32_t p1 = pi >= 0 ? s_l1[pi] : s_carry[0];
+            const int32_t p2 = pi >= 0 ? s_l2[pi] : s_carry[1];
+            n_final[r] = n_emit[r];
+            skip[r] = kNoSlot;
+            if (has[r]) {
+                const CEDelta d = create_edge(f1[r], f2[r], p1, p2, head_info[r] & 1u, head_info[r] & 2u,
+                                              head_info[r] & 4u, detect != 0);
+                c_count += d.count; c_long += d.too_long; c_dup += d.dup; c_nus += d.nus;
+                if ((head_info[r] & 8u) && !d.keep) { n_final[r] -= 1; skip[r] = head_slot[r]; }
+            }
         }
-        const int sum_incl = block_incl_scan_1024<false>((int)n_final, s_w, t);
+        __syncthreads();                                     // s_tab is reused for the sums
+        // ---- tuple offsets
+        int sincl[kStitchRounds];
+#pragma unroll
+        for (int r = 0; r < kStitchRounds; ++r) {
+            int v = (int)n_final[r];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d, 64);
+                if (lane >= d) v += o;
+            }
+            sincl[r] = v;
+            if (lane == 63) s_tab[r * 16 + wave] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int own = s_tab[lane];
+            int v = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d, 64);
+                if (lane >= d) v += o;
+            }
+            s_tab[lane] = v - own;
+            if (lane == 63) s_total = v;
+        }
+        __syncthreads();
         const int base = s_base;
-        if (b < nblocks) {
-            offsets[b] = (uint32_t)(base + sum_incl - (int)n_final);
-            skip_slot[b] = skip;
+#pragma unroll
+        for (int r = 0; r < kStitchRounds; ++r) {
+            const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
+            if (b < nblocks) {
+                offsets[b] = (uint32_t)(base + s_tab[r * 16 + wave] + sincl[r] - (int)n_final[r]);
+                skip_slot[b] = skip[r];
+            }
         }
+        const int iter_total = s_total;
         __syncthreads();
-        if (t == 1023) {
-            s_base = base + sum_incl;
-            if (incl >= 0) { s_carry[0] = s_l1[incl]; s_carry[1] = s_l2[incl]; }
+        if (t == 0) {
+            s_base = base + iter_total;
+            if (last_idx >= 0) { s_carry[0] = s_l1[last_idx]; s_carry[1] = s_l2[last_idx]; }
         }
         __syncthreads();
     }
@@ -654,7 +688,6 @@ __global__ __launch_bounds__(1024) void stitch_kernel(const BlockSummary* __rest
     // besst_counters fields: count 0, non_unique 1, non_unique_for_scaf 2, nr_of_duplicates 3,
     // reads_with_too_long_insert 4, fishy_reads 5, n_reach 7 (n_tuples, 6, below)
     int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
-    const int lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         const int v = wave_sum(vals[j]);
@@ -674,7 +707,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(const BlockSummary* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void compact_kernel(const BlockSummary* __restrict__ summ,
+__global__ __launch_bounds__(256) void compact_kernel(SummView summ,
                                                       const uint32_t* __restrict__ offsets,
                                                       const uint32_t* __restrict__ skip_slot,
                                                       const uint64_t* __restrict__ seg_keys,
@@ -687,7 +720,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const BlockSummary* __rest
     for (int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); c < n_contigs; c += (int32_t)(gridDim.x * blockDim.x))
         if (!cls8[c]) aligned[c] = 0;
     const uint32_t b = blockIdx.x;
-    const uint32_t n = summ[b].n_emit;
+    const uint32_t n = summ.at(kSumEmit, b);
     if (n == 0) return;
     const uint32_t skip = skip_slot[b], off = offsets[b];
     const int64_t base = (int64_t)b * kClsTile;
@@ -702,11 +735,10 @@ __global__ __launch_bounds__(256) void compact_kernel(const BlockSummary* __rest
 struct ClsWorkspace {
     uint64_t* seg_keys;
     uint64_t* seg_payload;
-    BlockSummary* summ;
+    SummView summ;
     uint32_t* offsets;
     uint32_t* skip;
     unsigned long long* bitmask;
-    uint4* staging;
     int64_t n_groups;
     size_t total;
 };
@@ -719,15 +751,15 @@ ClsWorkspace carve(void* ws, int64_t n) {
     size_t off = 0;
     w.seg_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(seg, 256);
     w.seg_payload = reinterpret_cast<uint64_t*>(p + off); off += align_up(seg, 256);
-    w.summ = reinterpret_cast<BlockSummary*>(p + off); off += align_up((size_t)nblocks * sizeof(BlockSummary), 256);
+    w.summ.p = reinterpret_cast<uint32_t*>(p + off);
+    w.summ.stride = (uint32_t)align_up((size_t)nblocks, 64);
+    off += align_up((size_t)w.summ.stride * kSumPlanes * sizeof(uint32_t), 256);
     w.offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.skip = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     // candidate bits: stream_kernel writes whole workgroups, so round the group count up to its tile
     const int64_t stream_blocks = (n + kStreamTile - 1) / kStreamTile;
     w.n_groups = stream_blocks * (kStreamTile / kGroup);
     w.bitmask = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)w.n_groups * 32, 256);
-    // evaluated candidates, 16 B each, group g at [g*256, ...): every record may be a candidate
-    w.staging = reinterpret_cast<uint4*>(p + off); off += align_up((size_t)w.n_groups * kGroup * sizeof(uint4), 256);
     w.total = off;
     return w;
 }
@@ -742,12 +774,12 @@ size_t classify_workspace_bytes(int64_t n) {
 namespace {
 
 // last record of the slice that reached CreateEdge: {has, obs1, obs2, 0}
-__global__ __launch_bounds__(256) void tail_kernel(const BlockSummary* __restrict__ summ, uint32_t nblocks,
+__global__ __launch_bounds__(256) void tail_kernel(SummView summ, uint32_t nblocks,
                                                    int32_t* __restrict__ tail) {
     __shared__ int s_best[4];
     int best = -1;
     for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x)
-        if (summ[b].has_reach) best = (int)b > best ? (int)b : best;
+        if (summ.at(kSumHas, b)) best = (int)b > best ? (int)b : best;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const int o = __shfl_xor(best, d, 64);
@@ -758,8 +790,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const BlockSummary* __restric
     if (threadIdx.x == 0) {
         best = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
         tail[0] = best >= 0 ? 1 : 0;
-        tail[1] = best >= 0 ? summ[best].last_o1 : 0;
-        tail[2] = best >= 0 ? summ[best].last_o2 : 0;
+        tail[1] = best >= 0 ? (int32_t)summ.at(kSumLast1, (uint32_t)best) : 0;
+        tail[2] = best >= 0 ? (int32_t)summ.at(kSumLast2, (uint32_t)best) : 0;
         tail[3] = 0;
     }
 }
@@ -785,30 +817,15 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
     const uint32_t stream_blocks = (uint32_t)((a.n + kStreamTile - 1) / kStreamTile);
-    // Mate-pair ('rf') libraries have inserts comparable to the contig lengths, so a large share of the records
-    // are candidates and evaluating them inside the streaming pass (lines still hot, no second sweep) wins a few
-    // percent; for paired-end libraries the separate, mostly-empty eval launch is as fast.  BESST_FUSE_EVAL=0/1
-    // overrides the choice (development knob).
-    static const int fuse_env = getenv("BESST_FUSE_EVAL") ? atoi(getenv("BESST_FUSE_EVAL")) : -1;
-    const bool fuse = fuse_env >= 0 ? fuse_env != 0 : a.rf != 0;
     {
         ProfScope ps(s, kProfClassify);
-        if (fuse)
-            hipLaunchKernelGGL(stream_kernel<true>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
-                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask, w.staging);
-        else
-            hipLaunchKernelGGL(stream_kernel<false>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
-                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask, w.staging);
-    }
-    if (!fuse) {
-        ProfScope ps(s, kProfCandidate);
-        hipLaunchKernelGGL(eval_kernel, dim3((uint32_t)((w.n_groups + 4 * kEvalGroupsPerWave - 1) / (4 * kEvalGroupsPerWave))), dim3(256), 0, s, a, w.bitmask, w.n_groups,
-                           reinterpret_cast<unsigned long long*>(aligned), w.staging);
+        hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                           reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
     }
     {
         ProfScope ps(s, kProfOrdered);
-        hipLaunchKernelGGL(ordered_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups, w.staging,
-                           w.seg_keys, w.seg_payload, w.summ);
+        hipLaunchKernelGGL(ordered_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups,
+                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
     }
     (void)counters;
     BESST_HIP_TRY(hipGetLastError());

@@ -68,26 +68,35 @@ constexpr int kStreamSubTile = kStreamThreads * kStreamVec;      // 1024 records
 constexpr int kStreamSubTiles = BESST_STREAM_SUBTILES;
 constexpr int kStreamTile = kStreamSubTile * kStreamSubTiles;    // 4096 records per workgroup
 constexpr int kGroup = 64 * kStreamVec;                          // 256 records per candidate-bit group
-// eval_kernel: one wave per group.  ordered_kernel: single-wave workgroups, one lane per group -> one BlockSummary
-// per kCandGroups * 256 records
+// ordered_kernel: single-wave workgroups, one lane per group -> one block summary per kCandGroups * 256 records.
+// 32 groups (8192 records) balances the serial candidate rounds of the busiest workgroup (its candidates are
+// walked 256 at a time) against the number of summaries the single-workgroup stitch has to resolve: on C2
+// ordered + stitch took 55.7 / 45.2 / 47.5 / 63 us with 64 / 32 / 16 / 8 groups.
 constexpr int kCandThreads = 64;
 #ifndef BESST_CAND_GROUPS
-#define BESST_CAND_GROUPS 64
+#define BESST_CAND_GROUPS 32
 #endif
 constexpr int kCandGroups = BESST_CAND_GROUPS;                   // groups (lanes that own one) per workgroup
 constexpr int kClsTile = kCandGroups * kGroup;                   // records per summary block
 
-// Per-block summary of the classify kernel, resolved by the single-block "stitch" kernel.
-struct __attribute__((aligned(16))) BlockSummary {
-    uint32_t n_emit;      // tuples written to the block's local segment (head tuple included)
-    uint32_t has_reach;   // block holds >= 1 record that reached CreateEdge
-    int32_t first_o1, first_o2;   // head = first reaching record of the block
-    int32_t last_o1, last_o2;     // last reaching record of the block
-    uint32_t head_info;   // bit0 accept, bit1 double call, bit2 mapq == 0, bit3 has slot
-    uint32_t head_slot;   // local slot of the head's tuple
-    // the block's share of besst_counters fields 0..5 and 7 (summed by the stitch kernel: thousands of
-    // workgroups hitting the same seven device-scope atomics were the slowest part of the kernel)
-    uint32_t ctr[8];
+// Per-block summaries of ordered_kernel, resolved by the single-workgroup stitch kernel.  Stored as planes of
+// `stride` u32 (plane f of block b at p[f * stride + b]) so that stitch, one lane per block, reads them coalesced:
+// as 64-byte structs the single CU running stitch spent most of its time on one cache line per lane and load.
+enum SummPlane {
+    kSumEmit = 0,     // tuples written to the block's local segment (head tuple included)
+    kSumHas,          // block holds >= 1 record that reached CreateEdge
+    kSumFirst1, kSumFirst2,   // head = first reaching record of the block
+    kSumLast1, kSumLast2,     // last reaching record of the block
+    kSumHeadInfo,     // bit0 accept, bit1 double call, bit2 mapq == 0, bit3 has slot
+    kSumHeadSlot,     // local slot of the head's tuple
+    kSumCtr0,         // the block's share of besst_counters fields 0..5 and 7 (summed by stitch: thousands of
+                      // workgroups hitting the same seven device-scope atomics were the slowest part of the kernel)
+    kSumPlanes = kSumCtr0 + 7
+};
+struct SummView {
+    uint32_t* p;
+    uint32_t stride;
+    __device__ __forceinline__ uint32_t& at(int plane, uint32_t b) const { return p[(size_t)plane * stride + b]; }
 };
 
 // Launch-time constants of the record loop.

@@ -1,8 +1,10 @@
 #!/bin/bash
+# Development helper (runs on the GPU box): rebuild the library with each flag set and print the C2 step and kernel times.
+#   tools/variants.sh "-DBESST_CAND_GROUPS=32" "-DBESST_CAND_GROUPS=16"
 cd "$(dirname "$0")/.."
-for flags in "-DBESST_BUCKET_THREADS=64" "-DBESST_BUCKET_THREADS=128" "-DBESST_BUCKET_THREADS=256"; do
+for flags in "$@"; do
   BESST_EXTRA_FLAGS="$flags" besst_amd/csrc/build.sh > /dev/null 2>&1
   python bench.py --steps 21 --warmup 3 --no-stages --no-cpu-baseline --breakdown-steps 3 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print('$flags', round(d['ms_per_step']*1000,1), k['bucket_sort_kernel'], d['verified_vs_c_oracle'])"
+d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print('$flags', round(d['ms_per_step']*1000,1), k, d['verified_vs_c_oracle'])"
 done
