@@ -720,15 +720,18 @@ __global__ __launch_bounds__(256) void compact_kernel(SummView summ,
     for (int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); c < n_contigs; c += (int32_t)(gridDim.x * blockDim.x))
         if (!cls8[c]) aligned[c] = 0;
     const uint32_t b = blockIdx.x;
-    const uint32_t n = summ.at(kSumEmit, b);
-    if (n == 0) return;
-    const uint32_t skip = skip_slot[b], off = offsets[b];
     const int64_t base = (int64_t)b * kClsTile;
+    // the first 256 segment entries are fetched together with the block's bookkeeping (the segment is always
+    // kClsTile entries long, so the speculative read is in bounds): one memory round trip for nearly every block
+    const uint64_t k0 = seg_keys[base + threadIdx.x], p0 = seg_payload[base + threadIdx.x];
+    const uint32_t n = summ.at(kSumEmit, b);
+    const uint32_t skip = skip_slot[b], off = offsets[b];
+    if (n == 0) return;
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
         if (j == skip) continue;
         const uint32_t dst = off + j - (j > skip ? 1u : 0u);
-        keys[dst] = seg_keys[base + j];
-        payload[dst] = seg_payload[base + j];
+        keys[dst] = j < blockDim.x ? k0 : seg_keys[base + j];
+        payload[dst] = j < blockDim.x ? p0 : seg_payload[base + j];
     }
 }
 

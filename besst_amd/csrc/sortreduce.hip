@@ -310,8 +310,10 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
                                                           uint32_t* __restrict__ big_idx) {
     __shared__ uint64_t s_k[kBucketLds];
     __shared__ uint32_t s_x[kBucketLds];
-    if (*n_ptr == 0) return;          // nothing was partitioned, bucket_start is stale
+    // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
+    const uint32_t n_all = *n_ptr;
     const uint32_t s0 = bucket_start[blockIdx.x], e0 = bucket_start[blockIdx.x + 1];
+    if (n_all == 0) return;
     const int n = (int)(e0 - s0);
     if (n <= 1) return;
     int np = 2;
