@@ -305,15 +305,17 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ordered_kernel: everything a candidate needs, evaluation included.  Single-wave workgroups; the workgroup
-// covers kCandGroups consecutive groups and walks their candidates 64 at a time in stream order, kAhead chunks
-// in flight: r-th set bit of the group's mask -> record gather (7 columns) -> two contig rows -> observations
-// (PosDirCalculator), then the order-dependent part - previous reaching observation via ballot, CreateEdge
-// semantics (acceptance rule :840), ordered slots for the emitted tuples.  The evaluated candidates and the
-// chain live in registers; LDS holds a 64-entry prefix table and the groups' masks.  (A separate evaluation
-// launch, one wave per group, cost ~N/256 mostly idle waves and a staging round trip: 31 + 18 us on C2 against
-// 30 us for this kernel.  Handing tid/mtid/mapq/qlen over from stream_kernel instead of re-gathering them did
-// not make this kernel faster and cost the streaming pass 2-3 us.)
+// ordered_kernel: everything a candidate needs, evaluation included.  One 4-wave workgroup per kCandGroups
+// consecutive groups.  Evaluation is order free and spread over the waves, 64 candidates per wave and chunk,
+// kAhead chunks in flight: r-th set bit of the group's mask -> record gather (7 columns) -> two contig rows ->
+// observations (PosDirCalculator) -> 16-byte entry in LDS.  Wave 0 then walks the entries in stream order for
+// the order-dependent part: previous reaching observation via ballot, CreateEdge semantics (acceptance rule
+// :840), ordered slots for the emitted tuples; the chain state lives in its registers.
+// History on C2 (20 M records, 306 k candidates): a separate evaluation launch with one wave per group cost
+// ~N/256 mostly idle waves and a staging round trip (31 + 18 us); single-wave workgroups doing both were set
+// by their busiest block's serial rounds (31 us at 8192 records per block); this version takes 21 us.
+// Handing tid/mtid/mapq/qlen over from stream_kernel instead of re-gathering them did not help here and cost
+// the streaming pass 2-3 us.
 // ---------------------------------------------------------------------------------------------------------
 // r-th candidate (record order) of a group: word k, bit l <-> record 4*l + k.  Returns the record's offset in
 // the group.
@@ -342,28 +344,42 @@ __device__ __forceinline__ int select_candidate(unsigned long long w0, unsigned 
     return lo * 4 + k;
 }
 
-#ifdef BESST_PHASE_TIMER   // development probe: per-phase 100 MHz ticks summed into the counters (results are garbage)
-#define PT(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = wall_clock64(); \
-                   pt[k] += (uint32_t)(now_ - pt_last); pt_last = now_; } while (0)
-#else
-#define PT(k) do { } while (0)
-#endif
-__global__ __launch_bounds__(kCandThreads) void ordered_kernel(
+// Add val to dst[key] with ONE atomic per run of equal keys in the wave (segmented scan over the run heads; exact
+// for any key order, one atomic per contig for a sorted stream).  Lanes with val == 0 only carry their key.
+__device__ __forceinline__ void wave_add_runs(unsigned long long* dst, int32_t key, int val, int lane) {
+    const int32_t up = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != up;
+    const unsigned long long heads = __ballot(head);
+    const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+    int v = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane - d >= start) v += o;
+    }
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (tail && v) atomicAdd(&dst[key], (unsigned long long)v);
+}
+
+constexpr int kOrdWaves = 4;                              // waves of an ordered_kernel workgroup
+constexpr int kOrdThreads = kOrdWaves * 64;
+constexpr int kAhead = 4;                                 // chunks a wave evaluates per round, all gathers in flight
+constexpr int kOrdRound = kOrdWaves * kAhead * 64;        // candidates per round (1024): 16 KB of entries in LDS
+
+__global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
     ClassifyArgs a, const unsigned long long* __restrict__ bitmask, int64_t n_groups,
     unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
     uint64_t* __restrict__ seg_payload, SummView summ) {
     __shared__ int s_pre[kCandThreads + 1];
     __shared__ unsigned long long s_bits[kCandThreads * 4];
-#ifdef BESST_PHASE_TIMER
-    uint32_t pt[7] = {0, 0, 0, 0, 0, 0, 1};
-    unsigned long long pt_last = wall_clock64();
-#endif
-    const int lane = threadIdx.x;
+    // { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31, node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
+    __shared__ uint4 s_ent[kOrdRound];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
     const int64_t g0 = (int64_t)blockIdx.x * kCandGroups;
-    const int64_t g = g0 + lane;
-    int cnt = 0;
-    {
+    if (wave == 0) {
+        const int64_t g = g0 + lane;
+        int cnt = 0;
         ulonglong2 w0 = make_ulonglong2(0ull, 0ull), w1 = w0;
         if (lane < kCandGroups && g < n_groups) {
             w0 = *reinterpret_cast<const ulonglong2*>(bitmask + g * 4);
@@ -372,15 +388,14 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
         }
         s_bits[lane * 4 + 0] = w0.x; s_bits[lane * 4 + 1] = w0.y;
         s_bits[lane * 4 + 2] = w1.x; s_bits[lane * 4 + 3] = w1.y;
+        const int incl = wave_incl_scan(cnt, lane);
+        s_pre[lane] = incl - cnt;
+        if (lane == 63) s_pre[kCandThreads] = incl;
     }
-    const int incl = wave_incl_scan(cnt, lane);
-    const int total = __shfl(incl, 63, 64);
-    s_pre[lane] = incl - cnt;
-    if (lane == 0) s_pre[kCandThreads] = total;
     __syncthreads();
-    PT(0);
+    const int total = s_pre[kCandThreads];
 
-    // chain state, identical in every lane
+    // chain state (wave 0), identical in every lane
     bool prev_known = false;
     int32_t prev1 = 0, prev2 = 0;
     bool blk_has = false;
@@ -392,17 +407,16 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
 
-    constexpr int kAhead = 4;    // chunks whose entries are fetched before the chain consumes them
-    for (int c0 = 0; c0 < total; c0 += kCandThreads * kAhead) {
-        uint4 ents[kAhead];     // { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31,
-                                //               node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
+    for (int c0 = 0; c0 < total; c0 += kOrdRound) {
+        // ---- evaluation, order free: chunk q = u * kOrdWaves + wave of the round goes to this wave's slot u, so a
+        // round with few candidates still spreads over the waves
         {
             int32_t r_tid[kAhead], r_mtid[kAhead], r_pos[kAhead], r_mpos[kAhead];
             uint32_t r_flag[kAhead], r_mapq[kAhead], r_qlen[kAhead];
             bool valid[kAhead];
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {              // record gathers of every chunk first ...
-                const int j = c0 + u * kCandThreads + lane;
+                const int j = c0 + (u * kOrdWaves + wave) * 64 + lane;
                 valid[u] = j < total;
                 r_tid[u] = r_mtid[u] = -1;
                 r_pos[u] = r_mpos[u] = 0;
@@ -425,7 +439,6 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
                     r_qlen[u] = a.qlen[i];
                 }
             }
-            PT(1);
             ContigRow c1[kAhead], c2[kAhead];
             bool in_range[kAhead];
 #pragma unroll
@@ -437,91 +450,97 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
                     c2[u] = a.table[r_mtid[u]];
                 }
             }
-            PT(2);
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {              // ... then the arithmetic
-                ents[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (c0 + u * kCandThreads >= total) break;   // uniform
+                const int q = u * kOrdWaves + wave;
+                if (c0 + q * 64 >= total) break;             // uniform in the wave
                 const Eval e = eval_record(a, in_range[u], c1[u], c2[u], r_tid[u], r_mtid[u], r_pos[u], r_mpos[u],
                                            r_flag[u], r_mapq[u]);
-                ents[u].x = (uint32_t)e.o1;
-                ents[u].y = (uint32_t)e.o2;
-                ents[u].z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
-                            ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
-                ents[u].w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
-                            ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+                uint4 ent;
+                ent.x = (uint32_t)e.o1;
+                ent.y = (uint32_t)e.o2;
+                ent.z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
+                        ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
+                ent.w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
+                        ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+                s_ent[q * 64 + lane] = ent;
                 // the candidates' own coverage (the streaming pass credits only tid == mtid records)
-                wave_add_by_key(aligned, r_tid[u], (int)r_qlen[u], (e.bits & EV_COV) != 0, lane);
+                wave_add_runs(aligned, r_tid[u], (e.bits & EV_COV) ? (int)r_qlen[u] : 0, lane);
             }
-            PT(3);
         }
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            if (c0 + u * kCandThreads >= total) break;       // uniform
-            const uint4 ent = ents[u];
-            const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
-            const bool reach = (ent.z >> 29) & 1u, fishy = (ent.z >> 30) & 1u, nonuniq = (ent.z >> 31) & 1u;
-            const bool mapq0 = (ent.w >> 29) & 1u, case_a = (ent.w >> 30) & 1u, first_min = (ent.w >> 31) & 1u;
-            const uint32_t n_min = ent.z & 0x1fffffffu, n_max = ent.w & 0x1fffffffu;
-            const bool dbl = case_a && a.extend_paths && !a.no_score;
-            c_nonuniq += nonuniq ? 1 : 0;
-            c_fishy += fishy ? 1 : 0;
-            c_reach += reach ? 1 : 0;
-            const unsigned long long has_mask = __ballot(reach);
-            bool pk = prev_known;
-            int32_t p1 = prev1, p2 = prev2;
-            {
-                const unsigned long long below = has_mask & lt_mask;
-                const int src = below ? 63 - __clzll((long long)below) : 0;
-                const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
-                if (below) { pk = true; p1 = q1; p2 = q2; }
-            }
-            const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
-            bool emit = fishy;
-            bool is_head = false;
-            if (reach) {
-                if (!pk) {
-                    is_head = true;                      // first reaching record of the workgroup
-                    emit = accept;
-                } else {
-                    const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
-                    c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
-                    emit = d.keep;
+        __syncthreads();
+        // ---- the order-dependent part, wave 0 over the round's entries in stream order
+        if (wave == 0) {
+            const int round_n = total - c0 < kOrdRound ? total - c0 : kOrdRound;
+            for (int q0 = 0; q0 < round_n; q0 += 64) {
+                const uint4 ent = s_ent[q0 + lane];          // entries past `total` were not written: masked below
+                const bool live = q0 + lane < round_n;
+                const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
+                const bool reach = live && ((ent.z >> 29) & 1u), fishy = live && ((ent.z >> 30) & 1u);
+                const bool nonuniq = live && ((ent.z >> 31) & 1u);
+                const bool mapq0 = (ent.w >> 29) & 1u, case_a = (ent.w >> 30) & 1u, first_min = (ent.w >> 31) & 1u;
+                const uint32_t n_min = ent.z & 0x1fffffffu, n_max = ent.w & 0x1fffffffu;
+                const bool dbl = case_a && a.extend_paths && !a.no_score;
+                c_nonuniq += nonuniq ? 1 : 0;
+                c_fishy += fishy ? 1 : 0;
+                c_reach += reach ? 1 : 0;
+                const unsigned long long has_mask = __ballot(reach);
+                bool pk = prev_known;
+                int32_t p1 = prev1, p2 = prev2;
+                {
+                    const unsigned long long below = has_mask & lt_mask;
+                    const int src = below ? 63 - __clzll((long long)below) : 0;
+                    const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
+                    if (below) { pk = true; p1 = q1; p2 = q2; }
                 }
+                const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+                bool emit = fishy;
+                bool is_head = false;
+                if (reach) {
+                    if (!pk) {
+                        is_head = true;                      // first reaching record of the workgroup
+                        emit = accept;
+                    } else {
+                        const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
+                        c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                        emit = d.keep;
+                    }
+                }
+                const unsigned long long emit_mask = __ballot(emit);
+                const int slot = emit_base + __popcll(emit_mask & lt_mask);
+                if (emit) {
+                    const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+                    const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+                    const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+                    seg_keys[block_base + slot] = ((((uint64_t)n_min << a.node_bits) | n_max) << 1) | (fishy ? 1u : 0u);
+                    seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+                }
+                // the head is unique per workgroup; broadcast it to every lane
+                const unsigned long long head_mask = __ballot(is_head);
+                if (head_mask) {
+                    const int hl = __ffsll((long long)head_mask) - 1;
+                    head_present = true;
+                    head1 = __shfl(o1, hl, 64);
+                    head2 = __shfl(o2, hl, 64);
+                    const bool h_acc = __shfl((int)accept, hl, 64), h_dbl = __shfl((int)dbl, hl, 64);
+                    const bool h_mq0 = __shfl((int)mapq0, hl, 64);
+                    head_info = (h_acc ? 9u : 0u) | (h_dbl ? 2u : 0u) | (h_mq0 ? 4u : 0u);
+                    const int hs = __shfl(slot, hl, 64);
+                    head_slot = h_acc ? (uint32_t)hs : kNoSlot;
+                }
+                if (has_mask) {
+                    const int src = 63 - __clzll((long long)has_mask);
+                    blk_has = true;
+                    prev_known = true;
+                    prev1 = __shfl(o1, src, 64);
+                    prev2 = __shfl(o2, src, 64);
+                }
+                emit_base += __popcll(emit_mask);
             }
-            const unsigned long long emit_mask = __ballot(emit);
-            const int slot = emit_base + __popcll(emit_mask & lt_mask);
-            if (emit) {
-                const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
-                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
-                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
-                seg_keys[block_base + slot] = ((((uint64_t)n_min << a.node_bits) | n_max) << 1) | (fishy ? 1u : 0u);
-                seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
-            }
-            // the head is unique per workgroup; broadcast it to every lane
-            const unsigned long long head_mask = __ballot(is_head);
-            if (head_mask) {
-                const int hl = __ffsll((long long)head_mask) - 1;
-                head_present = true;
-                head1 = __shfl(o1, hl, 64);
-                head2 = __shfl(o2, hl, 64);
-                const bool h_acc = __shfl((int)accept, hl, 64), h_dbl = __shfl((int)dbl, hl, 64);
-                const bool h_mq0 = __shfl((int)mapq0, hl, 64);
-                head_info = (h_acc ? 9u : 0u) | (h_dbl ? 2u : 0u) | (h_mq0 ? 4u : 0u);
-                const int hs = __shfl(slot, hl, 64);
-                head_slot = h_acc ? (uint32_t)hs : kNoSlot;
-            }
-            if (has_mask) {
-                const int src = 63 - __clzll((long long)has_mask);
-                blk_has = true;
-                prev_known = true;
-                prev1 = __shfl(o1, src, 64);
-                prev2 = __shfl(o2, src, 64);
-            }
-            emit_base += __popcll(emit_mask);
         }
-        PT(4);
+        if (c0 + kOrdRound < total) __syncthreads();         // the next round overwrites the entries (uniform)
     }
+    if (wave != 0) return;
 
     int tot[7];
     {
@@ -539,11 +558,6 @@ __global__ __launch_bounds__(kCandThreads) void ordered_kernel(
         if (lane == kSumLast2) v = (uint32_t)prev2;
         if (lane == kSumHeadInfo) v = head_present ? head_info : 0u;
         if (lane == kSumHeadSlot) v = head_slot;
-#ifdef BESST_PHASE_TIMER
-        PT(5);
-#pragma unroll
-        for (int f = 0; f < 7; ++f) tot[f] = (int)pt[f];
-#endif
 #pragma unroll
         for (int f = 0; f < 7; ++f)
             if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
@@ -827,7 +841,7 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     }
     {
         ProfScope ps(s, kProfOrdered);
-        hipLaunchKernelGGL(ordered_kernel, dim3(nblocks), dim3(kCandThreads), 0, s, a, w.bitmask, w.n_groups,
+        hipLaunchKernelGGL(ordered_kernel, dim3(nblocks), dim3(kOrdThreads), 0, s, a, w.bitmask, w.n_groups,
                            reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
     }
     (void)counters;

@@ -68,13 +68,13 @@ constexpr int kStreamSubTile = kStreamThreads * kStreamVec;      // 1024 records
 constexpr int kStreamSubTiles = BESST_STREAM_SUBTILES;
 constexpr int kStreamTile = kStreamSubTile * kStreamSubTiles;    // 4096 records per workgroup
 constexpr int kGroup = 64 * kStreamVec;                          // 256 records per candidate-bit group
-// ordered_kernel: single-wave workgroups, one lane per group -> one block summary per kCandGroups * 256 records.
-// 32 groups (8192 records) balances the serial candidate rounds of the busiest workgroup (its candidates are
-// walked 256 at a time) against the number of summaries the single-workgroup stitch has to resolve: on C2
-// ordered + stitch took 55.7 / 45.2 / 47.5 / 63 us with 64 / 32 / 16 / 8 groups.
+// ordered_kernel: one workgroup per kCandGroups * 256 records (one lane of its first wave per group) -> one
+// block summary each.  With the evaluation spread over the workgroup's four waves the busiest block no longer
+// sets the kernel time, so the larger block wins (fewer summaries for the single-workgroup stitch): on C2
+// ordered + stitch took 33.4 us with 64 groups, 37.7 us with 32.
 constexpr int kCandThreads = 64;
 #ifndef BESST_CAND_GROUPS
-#define BESST_CAND_GROUPS 32
+#define BESST_CAND_GROUPS 64
 #endif
 constexpr int kCandGroups = BESST_CAND_GROUPS;                   // groups (lanes that own one) per workgroup
 constexpr int kClsTile = kCandGroups * kGroup;                   // records per summary block
