@@ -275,7 +275,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 // workgroup with a bitonic sort on (key, stream index) - equivalent to a stable sort by key because the index is
 // unique.  Buckets up to 512 tuples sort in LDS (6 KB, so every bucket of the launch is resident at once); larger
 // ones (a hub scaffold) sort in place in global scratch.
-constexpr int kBucketLds = 512;
+// Digit width of the partition: wider digits make the scatter's table walk longer, narrower ones make the
+// O(n^2) bucket sort explode (C2: scatter + bucket sort = 37.5 / 44 / 73 / 165 us with 11 / 10 / 9 / 8 bits).
+#ifndef BESST_MSD_BITS
+#define BESST_MSD_BITS 11
+#endif
+constexpr int kMsdBits = BESST_MSD_BITS;
+#ifndef BESST_BUCKET_LDS
+#define BESST_BUCKET_LDS 512
+#endif
+constexpr int kBucketLds = BESST_BUCKET_LDS;
 #ifndef BESST_BUCKET_THREADS
 #define BESST_BUCKET_THREADS 256
 #endif
@@ -662,14 +671,14 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint32_t* iin = nullptr;
     if (nb_sort <= (uint32_t)kScanFreeMaxBlocks) {
         // small stream: one MSD pass on the top 11 significant bits, then every bucket sorts itself
-        const int shift = key_bits > 11 ? key_bits - 11 : 0;
-        const DigitSel ds{0, shift, 0, 1u, 11};
-        launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0], row_n,
-                        zsum, zsq, w.bucket_start);
+        const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
+        const DigitSel ds{0, shift, 0, 1u, kMsdBits};
+        launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
+                              row_n, zsum, zsq, w.bucket_start);
         if (shift > 0) {
             ProfScope ps(s, kProfBucketSort);
-            hipLaunchKernelGGL(bucket_sort_kernel, dim3(kMaxRadix), dim3(kBucketThreads), 0, s, w.keys[0], w.idx[0], w.bucket_start,
-                               n_tuples, w.big_keys, w.big_idx);
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0], w.idx[0],
+                               w.bucket_start, n_tuples, w.big_keys, w.big_idx);
         }
         kin = w.keys[0];
         iin = w.idx[0];
