@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument('--config', default='C2')
     ap.add_argument('--pairs', type=int, default=None, help='override pairs per GPU (smoke runs)')
     ap.add_argument('--contigs', type=int, default=None)
-    ap.add_argument('--cpu-sample-records', type=int, default=6_000_000)
+    ap.add_argument('--cpu-sample-records', type=int, default=20_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown-steps', type=int, default=3)
     ap.add_argument('--copies', type=int, default=3,
