@@ -441,6 +441,31 @@ int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const v
                          n_out, overflow);
 }
 
+size_t besst_dev_metrics_workspace_bytes(int64_t n_records) { return metrics_workspace_bytes(n_records < 1 ? 1 : n_records); }
+
+int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* tlen,
+                             const uint16_t* flag, const uint8_t* mapq, int64_t n_contigs, const uint8_t* top_mask,
+                             int32_t orientation, int32_t min_mapq, double read_len, int32_t count_only,
+                             int32_t* isize_out, int32_t* contam_out, int64_t* state, void* workspace,
+                             size_t workspace_bytes) {
+    BESST_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "dev_metrics_sample: n out of range");
+    BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "dev_metrics_sample: n_contigs out of range");
+    BESST_REQUIRE(orientation == 0 || orientation == 1, "dev_metrics_sample: orientation must be 0 or 1");
+    BESST_REQUIRE(state && top_mask, "dev_metrics_sample: null pointer");
+    BESST_REQUIRE(count_only || contam_out, "dev_metrics_sample: contam_out is null");
+    BESST_REQUIRE(n == 0 || (tid && mtid && tlen && flag && mapq), "dev_metrics_sample: null column");
+    MetricsArgs a;
+    a.tid = tid; a.mtid = mtid; a.tlen = tlen; a.flag = flag; a.mapq = mapq;
+    a.top_mask = top_mask;
+    a.n = n;
+    a.n_contigs = (int32_t)n_contigs;
+    a.rf = orientation;
+    a.min_mapq = min_mapq;
+    a.read_len = read_len;
+    return launch_metrics(static_cast<hipStream_t>(stream), a, 0, n, isize_out, contam_out, state, workspace,
+                          workspace_bytes, count_only != 0);
+}
+
 int besst_ctx_build_graph(besst_ctx* c) {
     BESST_REQUIRE(c, "null context");
     if (!c->have_lib || c->n_contigs <= 0) {

@@ -191,7 +191,8 @@ struct MetricsArgs {
 };
 size_t metrics_workspace_bytes(int64_t n);
 int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t count,
-                   int32_t* isize_out, int32_t* contam_out, int64_t* state, void* ws, size_t ws_bytes);
+                   int32_t* isize_out, int32_t* contam_out, int64_t* state, void* ws, size_t ws_bytes,
+                   bool count_only = false);
 int launch_value_histogram(hipStream_t s, const int32_t* values, int64_t n, int64_t n_bins,
                            unsigned long long* hist, unsigned long long* overflow);
 

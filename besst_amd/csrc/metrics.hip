@@ -220,8 +220,10 @@ size_t metrics_workspace_bytes(int64_t n) {
 }
 
 // Scan records [start, start+count).  state: 6 x int64 on the device (see layout above).
+// count_only: only the three running counts (state[0..2]) advance - the first phase of a sharded scan, whose
+// slices need the counts of the slices before them to place their samples.
 int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t count, int32_t* isize_out,
-                   int32_t* contam_out, int64_t* state, void* ws, size_t ws_bytes) {
+                   int32_t* contam_out, int64_t* state, void* ws, size_t ws_bytes, bool count_only) {
     if (count <= 0) return BESST_OK;
     BESST_REQUIRE((start & 3) == 0, "metrics: chunk start must be a multiple of 4");
     BESST_REQUIRE(ws && ws_bytes >= metrics_workspace_bytes(count), "metrics: workspace too small");
@@ -236,11 +238,12 @@ int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t c
     hipLaunchKernelGGL(metrics_count_kernel, dim3(nb), dim3(kMetThreads), 0, s, a, start, end, blk);
     hipLaunchKernelGGL(metrics_scan_kernel, dim3(1), dim3(1024), 0, s, blk, nb,
                        reinterpret_cast<const long long*>(state), base, totals);
-    hipLaunchKernelGGL(metrics_emit_kernel, dim3(nb), dim3(kMetThreads), 0, s, a, start, end, base,
-                       isize_out != nullptr ? 1 : 0, isize_out, contam_out,
-                       reinterpret_cast<unsigned long long*>(state));
+    if (!count_only)
+        hipLaunchKernelGGL(metrics_emit_kernel, dim3(nb), dim3(kMetThreads), 0, s, a, start, end, base,
+                           isize_out != nullptr ? 1 : 0, isize_out, contam_out,
+                           reinterpret_cast<unsigned long long*>(state));
     hipLaunchKernelGGL(metrics_commit_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<long long*>(state), totals,
-                       (long long)count);
+                       (long long)(count_only ? 0 : count));
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -213,3 +213,40 @@ class ShardedGraphBuild(object):
             if tails[j, 0]:
                 prev = (int(tails[j, 1]), int(tails[j, 2]))
         return prev
+
+
+class ShardedMetricsSample(object):
+    """libmetrics' three BAM scans over a stream sharded in contiguous slices.
+
+    The reference takes the FIRST 1,000,000 qualifying observations in stream order (libmetrics.py:83,302), so a
+    slice has to know how many came before it: every rank counts its slice, the counts are all-gathered (3 int64
+    per rank), and each rank then writes its samples at their global positions in zeroed 1,000,000-entry buffers.
+    Positions are disjoint across ranks, hence ONE all-reduce(sum) of the buffers is the ordered sample of the
+    whole stream on every rank, and a second tiny one sums counter_total / n_contam.  ``backend`` supplies
+    ``count() -> int64[3]`` and ``emit(before) -> (samples int32[2e6], state int64[8])``
+    (pipeline.DeviceMetricsSampler on the GPU; an oracle-backed stand-in in the gloo tests)."""
+
+    def __init__(self, backend, rank, world, group=None):
+        self.backend, self.rank, self.world, self.group = backend, rank, world, group
+
+    def sample(self, orientation, min_mapq, read_len, want_isize=True):
+        from .pipeline import SAMPLE_CAP
+        b = self.backend
+        local = b.count(orientation, min_mapq, read_len).clone()
+        counts = [torch.empty_like(local) for _ in range(self.world)]
+        dist.all_gather(counts, local, group=self.group)
+        before = torch.zeros_like(local)
+        for r in range(self.rank):
+            before += counts[r]
+        samples, state = b.emit(before, orientation, min_mapq, read_len, want_isize)
+        dist.all_reduce(samples, group=self.group)
+        tot = state[3:6].clone()
+        dist.all_reduce(tot, group=self.group)
+        total = torch.stack(counts).sum(0).cpu().numpy()
+        tot = tot.cpu().numpy()
+        n_isize = int(min(total[0], SAMPLE_CAP)) if want_isize else 0
+        n_contam = int(tot[1])
+        host = samples.cpu().numpy()
+        return (host[:n_isize].copy(), host[SAMPLE_CAP:SAMPLE_CAP + n_contam].copy(),
+                dict(n_isize=n_isize, n_contam=n_contam, counter_total=int(tot[0]),
+                     sample_counter=int(min(total[1], SAMPLE_CAP)), records_scanned=int(tot[2])))

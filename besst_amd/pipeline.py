@@ -163,6 +163,53 @@ class DeviceGraphBuilder(object):
                          h(self.obs_lo, L, np.int32), h(self.obs_hi, L, np.int32))
 
 
+SAMPLE_CAP = 1000000     # libmetrics' "first 1,000,000" cut-offs (libmetrics.py:83,302)
+
+
+class DeviceMetricsSampler(object):
+    """libmetrics scans of one resident slice through besst_dev_metrics_sample (see include/besst_amd.h).
+
+    ``samples`` holds the insert-size sample in [0, 1e6) and the contamination sample in [1e6, 2e6); ``state`` is
+    the 6-word running state of the scan (counts of earlier slices in, counts including this slice out)."""
+
+    def __init__(self, device, rec, n_contigs):
+        self.lib = _lib.load()
+        self.device = device
+        self.rec = rec
+        self.n_contigs = int(n_contigs)
+        self.samples = torch.zeros(2 * SAMPLE_CAP, dtype=torch.int32, device=device)
+        self.state = torch.zeros(8, dtype=torch.int64, device=device)
+        self.top = torch.zeros(self.n_contigs, dtype=torch.uint8, device=device)
+        self.ws = torch.empty(self.lib.besst_dev_metrics_workspace_bytes(max(1, rec.n)), dtype=torch.uint8, device=device)
+
+    def set_top(self, top_mask):
+        self.top.copy_(torch.from_numpy(np.ascontiguousarray(top_mask, np.uint8)))
+
+    def _launch(self, orientation, min_mapq, read_len, count_only, want_isize):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rec = self.rec
+        isize = C.c_void_p(self.samples.data_ptr()) if want_isize else None
+        contam = C.c_void_p(self.samples.data_ptr() + 4 * SAMPLE_CAP)
+        _lib.check(self.lib.besst_dev_metrics_sample(
+            C.c_void_p(stream), rec.n, _p(rec.tid), _p(rec.mtid), _p(rec.tlen), _p(rec.flag), _p(rec.mapq),
+            self.n_contigs, _p(self.top), {'fr': 0, 'rf': 1}[orientation], int(min_mapq), float(read_len),
+            1 if count_only else 0, isize, contam, _p(self.state), _p(self.ws), self.ws.numel()), 'dev_metrics_sample')
+
+    def count(self, orientation, min_mapq, read_len):
+        """state[0:3] <- this slice's (isize-qualifying, top-contig, contamination) record counts."""
+        self.state.zero_()
+        self._launch(orientation, min_mapq, read_len, True, True)
+        return self.state[:3]
+
+    def emit(self, before, orientation, min_mapq, read_len, want_isize=True):
+        """Write this slice's share of the two samples, given the counts of the slices before it."""
+        self.samples.zero_()
+        self.state.zero_()
+        self.state[:3] = before
+        self._launch(orientation, min_mapq, read_len, False, want_isize)
+        return self.samples, self.state
+
+
 def prof_collect():
     lib = _lib.load()
     n = lib.besst_prof_slots()

@@ -283,6 +283,23 @@ int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, i
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table,
                             int64_t* aligned);
+/* libmetrics sampling on caller-owned device columns (the device-pointer form of besst_ctx_metrics_sample;
+ * libmetrics.py:63-84,293-303).  `state` is 6 x int64 on the device, in/out:
+ *   [0] records so far that qualify for the insert-size sample   (is_proper_aligned_unique_innie/outie on a top contig)
+ *   [1] records so far on a top contig                            (the contamination scan's sample_counter)
+ *   [2] contamination observations so far
+ *   [3] counter_total, [4] n_contam - both only over records inside the first-1,000,000 cut-off, [5] records scanned
+ * A record's sample slot is its running count, so a slice of the stream whose state[0..2] was preset to the
+ * counts of the slices before it writes exactly its share of the two 1,000,000-entry sample buffers (everything
+ * else stays untouched): with zeroed buffers, an all-reduce(sum) over the slices' buffers is the ordered sample
+ * of the whole stream.  count_only != 0 advances state[0..2] only (first phase of a sharded scan).
+ * n is limited to 2^31 records per call; workspace: besst_dev_metrics_workspace_bytes(n). */
+size_t besst_dev_metrics_workspace_bytes(int64_t n_records);
+int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                             const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq,
+                             int64_t n_contigs, const uint8_t* top_mask, int32_t orientation,
+                             int32_t min_mapq, double read_len, int32_t count_only, int32_t* isize_out,
+                             int32_t* contam_out, int64_t* state, void* workspace, size_t workspace_bytes);
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity);
 uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world);
 /* workspace: besst_dev_reduce_workspace_bytes(capacity) */

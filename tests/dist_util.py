@@ -168,3 +168,58 @@ def expected_rows(batch, table, lib, node_bits):
         r['lo'].append(ou)
         r['hi'].append(ov)
     return rows, res
+
+
+class OracleMetricsBackend(object):
+    """Stand-in for pipeline.DeviceMetricsSampler: the predicates of libmetrics' scans restated in numpy
+    (bam_parser.py:22-29, libmetrics.py:63-84,293-303), with running counts so that a slice can continue the scan
+    of the slices before it."""
+    CAP = 1000000
+
+    def __init__(self, batch_slice, top_mask):
+        b = batch_slice
+        self.b = b
+        tid = b.tid.astype(np.int64)
+        ok = (tid >= 0) & (tid < len(top_mask))
+        self.top = np.zeros(len(b), bool)
+        self.top[ok] = np.asarray(top_mask, bool)[tid[ok]]
+        self.at = np.abs(b.tlen.astype(np.int64))
+
+    def _flags(self, orientation, min_mapq, read_len):
+        b = self.b
+        f = b.flag.astype(np.int64)
+        rev, mrev = (f & 0x10) != 0, (f & 0x20) != 0
+        tl = b.tlen.astype(np.int64)
+        base = ((f & 0x80) != 0) & (b.tid == b.mtid) & ((f & 0x8) == 0) & (b.mapq.astype(np.int64) > min_mapq) & \
+               ((f & 0x100) == 0)
+        innie = base & ((rev & ~mrev & (tl < 0)) | (~rev & mrev & (tl > 0)))
+        outie = base & ((rev & ~mrev & (tl > 0)) | (~rev & mrev & (tl < 0)))
+        rf = orientation == 'rf'
+        a = self.top & (outie if rf else innie)
+        c = self.top & ((f & 0x4) == 0)
+        if rf:
+            d = self.top & innie & (read_len < self.at.astype(np.float64))
+        else:
+            d = self.top & outie & (read_len < self.at.astype(np.float64) + 2.0 * read_len)
+        return a, self.top, c, d
+
+    def count(self, orientation, min_mapq, read_len):
+        a, b, c, d = self._flags(orientation, min_mapq, read_len)
+        return torch.tensor([int(a.sum()), int(b.sum()), int(d.sum())], dtype=torch.int64)
+
+    def emit(self, before, orientation, min_mapq, read_len, want_isize=True):
+        a, b, c, d = self._flags(orientation, min_mapq, read_len)
+        pa0, pb0, pd0 = [int(x) for x in before.tolist()]
+        samples = np.zeros(2 * self.CAP, np.int32)
+        state = np.zeros(8, np.int64)
+        if want_isize:
+            pos = pa0 + np.cumsum(a) - 1
+            sel = a & (pos < self.CAP)
+            samples[pos[sel]] = self.at[sel]
+        inside = b & (pb0 + np.cumsum(b) - 1 < self.CAP)
+        posd = pd0 + np.cumsum(d) - 1
+        seld = d & inside
+        samples[self.CAP + posd[seld]] = self.at[seld]
+        state[0], state[1], state[2] = pa0 + int(a.sum()), pb0 + int(b.sum()), pd0 + int(d.sum())
+        state[3], state[4], state[5] = int((c & inside).sum()), int(seld.sum()), len(self.b)
+        return torch.from_numpy(samples), torch.from_numpy(state)

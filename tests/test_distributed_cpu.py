@@ -71,3 +71,43 @@ def test_two_rank_gloo_matches_single_process_oracle():
     got = sorted(out.get(timeout=5) for _ in range(WORLD))
     assert [g[0] for g in got] == [0, 1]
     assert got[0][1] > 0 and got[1][1] > 0 and got[0][2] > 0
+
+
+def _metrics_worker(rank, port, out):
+    import numpy as np
+    from oracle import c_oracle as CO
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        for cfg in ('C2', 'C3'):
+            wl = workload.make(cfg, 0, pairs=60000, nc=400)
+            lib, asm, batch = wl['lib'], wl['asm'], wl['batch']
+            top = np.zeros(asm.nc, np.uint8)
+            top[np.lexsort((np.arange(asm.nc), -asm.lengths))[:100]] = 1
+            parts = DU.split_batch(batch, WORLD)
+            job = distributed.ShardedMetricsSample(DU.OracleMetricsBackend(parts[rank], top), rank, WORLD)
+            isize, contam, counts = job.sample(lib['orientation'], lib['min_mapq'], lib['read_len'])
+            w_isize, w_contam, w_counts = CO.metrics_sample(batch, top, lib['orientation'], lib['min_mapq'], lib['read_len'])
+            assert np.array_equal(isize, w_isize) and np.array_equal(contam, w_contam)
+            assert [counts['n_isize'], counts['n_contam'], counts['counter_total'], counts['sample_counter']] == \
+                   w_counts.tolist()
+            assert len(isize) > 1000
+        out.put((rank, len(isize), len(contam)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_metrics_sample_matches_single_process_oracle():
+    """libmetrics' scans over two slices: counts all-gathered, samples placed at global positions, one all-reduce."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, port, out)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(WORLD))
+    assert got[0][1:] == got[1][1:] and got[0][2] > 0

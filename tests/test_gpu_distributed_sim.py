@@ -66,3 +66,45 @@ def test_simulated_ranks_match_oracle(world, orientation):
         if k & 1:
             r['s'] = r['s2'] = 0
     assert merged == want_rows
+
+
+@pytest.mark.parametrize('world,config,pairs', [(2, 'C2', 3_000_000), (3, 'C3', 1_500_000), (8, 'C2', 200_000)])
+def test_simulated_ranks_metrics_sample(world, config, pairs):
+    """Sharded libmetrics scans: per-slice counts, prefix, samples written at their global positions; the sum of the
+    ranks' buffers (what the all-reduce computes) equals the single-process scan.  The 3 M-pair case reaches the
+    first-1,000,000 cut-off inside a later slice."""
+    import numpy as np
+    import torch
+    from besst_amd import pipeline, workload
+    from oracle import c_oracle as CO
+    wl = workload.make(config, 0, pairs=pairs, nc=600)
+    lib, asm, batch = wl['lib'], wl['asm'], wl['batch']
+    top = np.zeros(asm.nc, np.uint8)
+    top[np.lexsort((np.arange(asm.nc), -asm.lengths))[:500]] = 1
+    dev = torch.device('cuda', 0)
+    samplers = []
+    for part in DU.split_batch(batch, world):
+        s = pipeline.DeviceMetricsSampler(dev, pipeline.DeviceRecords(part, dev), asm.nc)
+        s.set_top(top)
+        samplers.append(s)
+    args = (lib['orientation'], lib['min_mapq'], lib['read_len'])
+    counts = [s.count(*args).clone() for s in samplers]
+    total_samples = torch.zeros(2 * pipeline.SAMPLE_CAP, dtype=torch.int32, device=dev)
+    total_state = torch.zeros(3, dtype=torch.int64, device=dev)
+    before = torch.zeros(3, dtype=torch.int64, device=dev)
+    for r, s in enumerate(samplers):
+        samples, state = s.emit(before, *args)
+        total_samples += samples
+        total_state += state[3:6]
+        before = before + counts[r]
+    n_all = before.cpu().numpy()
+    tot = total_state.cpu().numpy()
+    w_isize, w_contam, w_counts = CO.metrics_sample(batch, top, *args)
+    n_isize = int(min(n_all[0], pipeline.SAMPLE_CAP))
+    host = total_samples.cpu().numpy()
+    assert [n_isize, int(tot[1]), int(tot[0]), int(min(n_all[1], pipeline.SAMPLE_CAP))] == w_counts.tolist()
+    assert np.array_equal(host[:n_isize], w_isize)
+    assert np.array_equal(host[pipeline.SAMPLE_CAP:pipeline.SAMPLE_CAP + int(tot[1])], w_contam)
+    assert not host[n_isize:pipeline.SAMPLE_CAP].any()
+    if pairs >= 3_000_000:
+        assert n_all[0] > pipeline.SAMPLE_CAP                  # the cut-off really was crossed
