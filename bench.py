@@ -84,13 +84,39 @@ def cpu_baseline(batch, table, lib, n_sample):
                        % (n, n // 2, dt)), res
 
 
+def measured_copy_bandwidth(device):
+    """Device-to-device copy of 1 GiB (report the fraction of a MEASURED ceiling too): GB/s moved,
+    read + write."""
+    import torch
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * (1 << 30) / dt / 1e9
+
+
+C_PORT_TIMING = {}
+
+
 def verify_full(runner, wl):
     """Full-size parity: device edge table == C oracle on the whole workload (rank 0, N=1)."""
     import numpy as np
     from oracle import c_oracle as CO
     table = runner.gb.fetch_table()
     ctr = runner.gb.read_counters()
+    t0 = time.perf_counter()
     keys, payload, aligned, c_ctr = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+    C_PORT_TIMING['seconds'] = time.perf_counter() - t0
+    C_PORT_TIMING['records'] = len(wl['batch'])
     rows = CO.edge_rows(keys, payload)
     link = ~table.is_fishy
     ok = (np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
@@ -236,6 +262,7 @@ def main():
     alg_bytes = n_rec * 11.0
     achieved = alg_bytes / cls_avg_s / 1e9 if cls_avg_s > 0 else 0.0
 
+    copy_gbs = measured_copy_bandwidth(device) if rank == 0 else None
     if rank == 0:
         total_pairs = pairs * world
         out = {
@@ -260,6 +287,8 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': pmc_traffic(args.config, n_rec) if world == 1 else None,
                          'avg_launch_ms': round(cls_avg_s * 1e3, 4),
+                         'measured_d2d_copy_GBps': round(copy_gbs, 1),
+                         'frac_of_measured_copy': round(achieved / copy_gbs, 4),
                          'algorithmic_bytes_per_launch': alg_bytes},
             # whole graph-build pass = 38 B/pair of records + each tuple written and read once
             'graph_pass': {'algorithmic_bytes_per_step': pairs * (38.0 + 32.0 * f),
@@ -277,6 +306,11 @@ def main():
             out['stages'] = stage_timings(wl)
         if not args.no_cpu_baseline:
             base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
+            if C_PORT_TIMING:      # the C restatement (oracle/besst_oracle.c), one thread, whole stream: record loop only
+                base['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'],
+                                  'unit': 'read-pairs/s', 'cores': 1,
+                                  'sample': 'whole stream (%d records), oracle/besst_oracle.c record loop, %.2f s'
+                                            % (C_PORT_TIMING['records'], C_PORT_TIMING['seconds'])}
             out['cpu_baseline'] = base
         else:
             out['cpu_baseline'] = None

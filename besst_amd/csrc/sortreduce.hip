@@ -42,7 +42,15 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
 // Every kernel loads its keys speculatively (guarded by the caller's capacity, not by the device-side count)
 // so that the count, the table and the keys arrive after ONE memory latency instead of three.
 constexpr int kScanFreeMaxBlocks = 64;
-constexpr int kWideDigitMaxBlocks = 4096;   // up to 16.7 M tuples: 3 passes of 11 bits instead of up to 8 of 8
+// Largest stream (in sort tiles) that still gets 11-bit LSD digits.  Measured on C3 slices of 0.5 - 8.5 M tuples:
+// the per-tile table of 2048 counters then holds as many entries as a quarter to a half of the keys, written
+// and read as scattered 4-byte words, and 8-bit digits win at every size (8.5 M tuples: 0.45 vs 0.63 ms for the
+// sort) although they need one more pass.  Streams of <= 64 tiles take the MSD + bucket path below, so the
+// wide LSD variant is effectively retired; the knob stays for experiments.
+#ifndef BESST_WIDE_DIGIT_MAX_BLOCKS
+#define BESST_WIDE_DIGIT_MAX_BLOCKS 64
+#endif
+constexpr int kWideDigitMaxBlocks = BESST_WIDE_DIGIT_MAX_BLOCKS;
 
 template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
