@@ -117,6 +117,12 @@ def verify_full(runner, wl):
     keys, payload, aligned, c_ctr = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
     C_PORT_TIMING['seconds'] = time.perf_counter() - t0
     C_PORT_TIMING['records'] = len(wl['batch'])
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    mt = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'], threads=cores)
+    C_PORT_TIMING['mt_seconds'] = time.perf_counter() - t0
+    C_PORT_TIMING['mt_cores'] = cores
+    C_PORT_TIMING['mt_equal'] = bool(np.array_equal(mt[0], keys) and np.array_equal(mt[3], c_ctr))
     rows = CO.edge_rows(keys, payload)
     link = ~table.is_fishy
     ok = (np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
@@ -311,6 +317,11 @@ def main():
                                   'unit': 'read-pairs/s', 'cores': 1,
                                   'sample': 'whole stream (%d records), oracle/besst_oracle.c record loop, %.2f s'
                                             % (C_PORT_TIMING['records'], C_PORT_TIMING['seconds'])}
+                base['c_port_all_cores'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['mt_seconds'],
+                                            'unit': 'read-pairs/s', 'cores': C_PORT_TIMING['mt_cores'],
+                                            'equals_sequential': C_PORT_TIMING['mt_equal'],
+                                            'sample': 'whole stream, contiguous slices, %.3f s (includes numpy column '
+                                                      'setup and thread start)' % C_PORT_TIMING['mt_seconds']}
             out['cpu_baseline'] = base
         else:
             out['cpu_baseline'] = None

@@ -10,13 +10,17 @@
  *   oracle_record_loop     CreateGraph.PE record loop            BESST/CreateGraph.py:111-211
  *                          CreateEdge                            :812-871
  *                          PosDirCalculatorPE / MP, CheckDir     :1024-1076, :678-688
+ *   oracle_record_loop_mt  the same loop on T host threads (contiguous slices; only used as the "all host cores"
+ *                          CPU baseline of bench.py and checked against the sequential loop in tests/)
  *   oracle_metrics_sample  libmetrics scans                      BESST/libmetrics.py:63-84, :293-303
  *                          is_proper_aligned_unique_innie/outie  BESST/bam_parser.py:22-29
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -shared -fPIC)
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define F_UNMAPPED 0x4
 #define F_MATE_UNMAPPED 0x8
@@ -136,6 +140,104 @@ int64_t oracle_record_loop(int64_t n, const int32_t* tid, const int32_t* mtid, c
     counters[6] += n_tuples;
     counters[8] = prev1;
     counters[9] = prev2;
+    return n_tuples;
+}
+
+/* ---- multi-threaded baseline ------------------------------------------------------------------------------
+ * The only coupling between records is CreateEdge's prev_obs = observation of the previous record that reached
+ * CreateEdge (it is updated whether or not that record was accepted or a duplicate).  A slice therefore finds
+ * its incoming prev_obs by walking BACKWARDS from its first record to the nearest reaching record (a few
+ * hundred records on a real stream) and then runs the sequential loop on private outputs, merged at the end. */
+static int reaches(int64_t i, const int32_t* tid, const int32_t* mtid, const int32_t* pos, const int32_t* mpos,
+                   const uint16_t* flag, const uint8_t* mapq, int64_t n_contigs, const uint8_t* cls,
+                   const int32_t* scaf, const int32_t* slen, const int32_t* cpos, const int32_t* clen,
+                   const uint8_t* cdir, const oracle_params* p, int32_t* o1, int32_t* o2) {
+    const int32_t t = tid[i], m = mtid[i];
+    if (t < 0 || t >= n_contigs || m < 0 || m >= n_contigs) return 0;
+    if (cls[t] == 0 || cls[m] == 0) return 0;
+    const uint32_t f = flag[i];
+    const int32_t q = mapq[i];
+    if (!(t != m && (f & F_READ2) && !(f & F_UNMAPPED) && q >= p->min_mapq)) return 0;
+    if (!(cls[t] == 1 && cls[m] == 1 && scaf[t] != scaf[m])) {
+        if (!p->extend_paths) return 0;
+        const int st = cls[t] == 2, sm = cls[m] == 2;
+        if (!((st && sm && scaf[t] != scaf[m]) || (st != sm))) return 0;
+    }
+    uint32_t s1, s2;
+    posdir(p->rf, cdir[t], !(f & F_REVERSE), cpos[t], pos[i], slen[t], clen[t], p->read_len, o1, &s1);
+    posdir(p->rf, cdir[m], !(f & F_MATE_REVERSE), cpos[m], mpos[i], slen[m], clen[m], p->read_len, o2, &s2);
+    return 1;
+}
+
+typedef struct {
+    int64_t start, end, n_contigs, n_tuples;
+    const int32_t *tid, *mtid, *pos, *mpos;
+    const uint16_t *flag, *qlen;
+    const uint8_t* mapq;
+    const uint8_t *cls, *cdir;
+    const int32_t *scaf, *slen, *cpos, *clen;
+    const oracle_params* p;
+    int64_t* aligned;      /* private, n_contigs */
+    int64_t counters[10];
+    uint64_t *keys, *payload;   /* shared arrays; this slice writes at [start, ...) */
+} slice_job;
+
+static void* slice_main(void* arg) {
+    slice_job* j = (slice_job*)arg;
+    for (int64_t i = j->start - 1; i >= 0; --i) {       /* incoming prev_obs (counters[8..9] preset to the caller's) */
+        int32_t o1, o2;
+        if (reaches(i, j->tid, j->mtid, j->pos, j->mpos, j->flag, j->mapq, j->n_contigs, j->cls, j->scaf, j->slen,
+                    j->cpos, j->clen, j->cdir, j->p, &o1, &o2)) {
+            j->counters[8] = o1;
+            j->counters[9] = o2;
+            break;
+        }
+    }
+    const int64_t s = j->start;
+    j->n_tuples = oracle_record_loop(j->end - s, j->tid + s, j->mtid + s, j->pos + s, j->mpos + s, j->flag + s,
+                                     j->mapq + s, j->qlen + s, j->n_contigs, j->cls, j->scaf, j->slen, j->cpos,
+                                     j->clen, j->cdir, j->p, j->aligned, j->counters, j->keys + s, j->payload + s);
+    return NULL;
+}
+
+int64_t oracle_record_loop_mt(int n_threads, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                              const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                              int64_t n_contigs, const uint8_t* cls, const int32_t* scaf, const int32_t* slen,
+                              const int32_t* cpos, const int32_t* clen, const uint8_t* cdir, const oracle_params* p,
+                              int64_t* aligned, int64_t* counters, uint64_t* keys, uint64_t* payload) {
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n) n_threads = n > 0 ? (int)n : 1;
+    slice_job* jobs = (slice_job*)calloc((size_t)n_threads, sizeof(slice_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; ++t) {
+        slice_job* j = &jobs[t];
+        j->start = n * t / n_threads;
+        j->end = n * (t + 1) / n_threads;
+        j->n_contigs = n_contigs;
+        j->tid = tid; j->mtid = mtid; j->pos = pos; j->mpos = mpos; j->flag = flag; j->mapq = mapq; j->qlen = qlen;
+        j->cls = cls; j->scaf = scaf; j->slen = slen; j->cpos = cpos; j->clen = clen; j->cdir = cdir;
+        j->p = p;
+        j->aligned = (int64_t*)calloc((size_t)n_contigs, sizeof(int64_t));
+        j->counters[8] = counters[8];
+        j->counters[9] = counters[9];
+        j->keys = keys;
+        j->payload = payload;
+        pthread_create(&th[t], NULL, slice_main, j);
+    }
+    int64_t n_tuples = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        pthread_join(th[t], NULL);
+        slice_job* j = &jobs[t];
+        memmove(keys + n_tuples, keys + j->start, (size_t)j->n_tuples * sizeof(uint64_t));
+        memmove(payload + n_tuples, payload + j->start, (size_t)j->n_tuples * sizeof(uint64_t));
+        n_tuples += j->n_tuples;
+        for (int64_t c = 0; c < n_contigs; ++c) aligned[c] += j->aligned[c];
+        for (int f = 0; f < 8; ++f) counters[f] += j->counters[f];
+        if (j->counters[7]) { counters[8] = j->counters[8]; counters[9] = j->counters[9]; }
+        free(j->aligned);
+    }
+    free(jobs);
+    free(th);
     return n_tuples;
 }
 

@@ -23,6 +23,7 @@ def load():
             subprocess.check_call(['make', '-s', '-C', _HERE])
         _lib = C.CDLL(_SO)
         _lib.oracle_record_loop.restype = C.c_int64
+        _lib.oracle_record_loop_mt.restype = C.c_int64
     return _lib
 
 
@@ -30,8 +31,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def record_loop(batch, table, lib, node_bits, prev=(-1, -1)):
-    """Ordered tuple stream + coverage + counters for a RecordBatch.  table: dict of numpy columns."""
+def record_loop(batch, table, lib, node_bits, prev=(-1, -1), threads=1):
+    """Ordered tuple stream + coverage + counters for a RecordBatch.  table: dict of numpy columns.
+    threads > 1 runs the slice-parallel variant (same results; bench.py's "all host cores" baseline)."""
     L = load()
     n = len(batch)
     cols = [np.ascontiguousarray(batch.tid, np.int32), np.ascontiguousarray(batch.mtid, np.int32),
@@ -50,8 +52,12 @@ def record_loop(batch, table, lib, node_bits, prev=(-1, -1)):
     counters[8], counters[9] = prev
     keys = np.empty(max(n, 1), np.uint64)
     payload = np.empty(max(n, 1), np.uint64)
-    nt = L.oracle_record_loop(C.c_int64(n), *[_p(c) for c in cols], C.c_int64(nc), *[_p(t) for t in tab],
-                              C.byref(p), _p(aligned), _p(counters), _p(keys), _p(payload))
+    if threads > 1:
+        nt = L.oracle_record_loop_mt(C.c_int(int(threads)), C.c_int64(n), *[_p(c) for c in cols], C.c_int64(nc),
+                                     *[_p(t) for t in tab], C.byref(p), _p(aligned), _p(counters), _p(keys), _p(payload))
+    else:
+        nt = L.oracle_record_loop(C.c_int64(n), *[_p(c) for c in cols], C.c_int64(nc), *[_p(t) for t in tab],
+                                  C.byref(p), _p(aligned), _p(counters), _p(keys), _p(payload))
     return keys[:nt].copy(), payload[:nt].copy(), aligned, counters
 
 

@@ -56,3 +56,18 @@ def test_c_metrics_sample_matches_reference_metrics(name):
                 want_contam.append(abs(tl))
     assert isize.tolist() == want_isize[:1000000]
     assert contam.tolist() == want_contam
+
+
+@pytest.mark.parametrize('config,threads', [('C2', 2), ('C2', 7), ('C3', 16)])
+def test_threaded_record_loop_equals_sequential(config, threads):
+    """The slice-parallel variant (bench.py's all-cores CPU baseline) walks back to the previous reaching record
+    for its incoming prev_obs; tuples, coverage and counters must equal the sequential loop."""
+    import numpy as np
+    from besst_amd import workload
+    from oracle import c_oracle as CO
+    wl = workload.make(config, 0, pairs=120000, nc=500)
+    want = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+    got = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'], threads=threads)
+    assert want[3][3] > 0          # duplicates exist, so the chain matters
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
