@@ -411,15 +411,30 @@ int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, in
     return launch_resolve_carry(static_cast<hipStream_t>(stream), tails, rank, carry);
 }
 
+int besst_dev_classify_tail_search(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                                   const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
+                                   const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
+                                   const void* contig_table, const besst_lib_params* p, int32_t node_bits,
+                                   int32_t* tail, void* scratch16) {
+    ClassifyArgs a;
+    int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
+    if (rc) return rc;
+    BESST_REQUIRE(tail && scratch16, "classify_tail_search: null output");
+    return launch_classify_tail_search(static_cast<hipStream_t>(stream), a, tail,
+                                       static_cast<unsigned long long*>(scratch16));
+}
+
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
-                            size_t workspace_bytes, int64_t n_contigs, const void* contig_table, int64_t* aligned) {
+                            size_t workspace_bytes, int64_t n_contigs, const void* contig_table, int64_t* aligned,
+                            const int32_t* tails, int32_t rank) {
     BESST_REQUIRE(carry && keys && payload && n_out && counters && contig_table && aligned,
                   "classify_emit: null pointer");
     BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "classify_emit: n_contigs out of range");
+    BESST_REQUIRE(rank >= 0 && rank <= 65536, "classify_emit: rank out of range");
     const uint8_t* cls8 = static_cast<const uint8_t*>(contig_table) + (size_t)n_contigs * sizeof(ContigRow);
     return launch_classify_emit(static_cast<hipStream_t>(stream), n, detect_duplicate, carry, keys, payload, n_out,
-                                counters, workspace, workspace_bytes, cls8, (int32_t)n_contigs, aligned);
+                                counters, workspace, workspace_bytes, cls8, (int32_t)n_contigs, aligned, tails, rank);
 }
 
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity) { return exchange_region_bytes(pair_capacity); }

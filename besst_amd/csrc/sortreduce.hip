@@ -737,39 +737,110 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ __launch_bounds__(256) void pack_kernel(const uint64_t* __restrict__ keys_sorted,
-                                                   const uint32_t* __restrict__ idx_sorted,
-                                                   const uint64_t* __restrict__ payload,
-                                                   const uint32_t* __restrict__ n_ptr,
-                                                   const uint32_t* __restrict__ owner_count, uint32_t world,
-                                                   uint32_t pair_cap, char* __restrict__ send, size_t region_bytes) {
-    __shared__ uint32_t s_pre[257];
-    const uint32_t n = *n_ptr;
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t d = 0; d < world; ++d) { s_pre[d] = run; run += owner_count[d]; }
-        s_pre[world] = run;
+// Stable partition of the ordered tuple stream by owner rank, written straight into the all-to-all regions
+// (keys, payload and stream index of every tuple; the header by tile 0).  Same ranking as radix_scatter_kernel
+// (wave match-any on the owner byte, per-wave counters in LDS, per-tile counts from radix_hist_kernel in owner
+// mode), but a tuple's destination is its rank INSIDE its owner's region, and the payload travels with the key:
+// the thread that ranks tuple i copies payload[i] (coalesced), so no sorted copy and no gather are needed.
+__global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
+    uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
+    const uint32_t* __restrict__ row_total, int scanned, uint32_t world, uint32_t pair_cap,
+    char* __restrict__ send, size_t region_bytes) {
+    constexpr int RADIX = kRadix;                 // one counter per thread (world <= 256)
+    __shared__ uint32_t s_whist[4][RADIX];
+    __shared__ uint32_t s_base[RADIX];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
+    uint64_t key[kSortItems], pl[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        key[r] = i < cap ? keys_in[i] : ~0ull;
+        pl[r] = i < cap ? payload[i] : 0ull;
+    }
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, kSortTile);
+    if (nb == 0 && b == 0 && (uint32_t)t < world) {          // empty stream: headers only
+        uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)t * region_bytes);
+        hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0;
+    }
+    if (b >= nb) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_whist[w][t] = 0;
+    {
+        uint32_t pre = 0, tot = 0;
+        if (scanned) {
+            tot = row_total[t];
+            pre = table[(uint32_t)t * stride + b];
+        } else {
+            for (uint32_t bb = 0; bb < nb; ++bb) {           // <= 64 rows, all loads independent
+                const uint32_t x = table[bb * RADIX + t];
+                tot += x;
+                if (bb < b) pre += x;
+            }
+        }
+        s_base[t] = pre;
+        if (b == 0 && (uint32_t)t < world) {
+            uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)t * region_bytes);
+            hdr[0] = tot < pair_cap ? tot : pair_cap;        // tuples sent
+            hdr[1] = tot;                                    // tuples the source wanted to send (overflow check)
+            hdr[2] = n;                                      // the source's total: base of the next source's indexes
+            hdr[3] = 0;
+        }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < world) {
-        uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)threadIdx.x * region_bytes);
-        const uint32_t want = owner_count[threadIdx.x];
-        hdr[0] = want < pair_cap ? want : pair_cap;
-        hdr[1] = want;
-        hdr[2] = n;
-        hdr[3] = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t dig_rank[kSortItems];   // owner | rank << 8
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t d = valid ? digit_of(key[r], ds) : (uint32_t)(RADIX - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < kRadixBits; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const unsigned long long bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        uint32_t pre = 0;
+        const int leader = __ffsll((long long)peers) - 1;
+        if (valid && lane == leader) {
+            volatile uint32_t* slot = &s_whist[wave][d];
+            pre = *slot;
+            *slot = pre + (uint32_t)__popcll(peers);
+        }
+        pre = __shfl(pre, leader < 0 ? 0 : leader, 64);
+        dig_rank[r] = d | ((pre + (uint32_t)__popcll(peers & lt_mask)) << kRadixBits);
     }
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t d = 0;
-    while (d + 1 < world && i >= s_pre[d + 1]) ++d;
-    const uint32_t p = i - s_pre[d];
-    if (p >= pair_cap) return;    // overflow: reported through hdr[1] > hdr[0]
-    char* region = send + (size_t)d * region_bytes + 64;
-    const uint32_t src = idx_sorted[i];
-    reinterpret_cast<uint64_t*>(region)[p] = keys_sorted[i];
-    reinterpret_cast<uint64_t*>(region + (size_t)pair_cap * 8)[p] = payload[src];
-    reinterpret_cast<uint32_t*>(region + (size_t)pair_cap * 16)[p] = src;
+    __syncthreads();
+    {
+        uint32_t run = s_base[t];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_whist[w][t];
+            s_whist[w][t] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) {
+            const uint32_t d = dig_rank[r] & (RADIX - 1);
+            const uint32_t p = s_whist[wave][d] + (dig_rank[r] >> kRadixBits);
+            if (p < pair_cap) {                              // overflow is reported through hdr[1] > hdr[0]
+                char* region = send + (size_t)d * region_bytes + 64;
+                reinterpret_cast<uint64_t*>(region)[p] = key[r];
+                reinterpret_cast<uint64_t*>(region + (size_t)pair_cap * 8)[p] = pl[r];
+                reinterpret_cast<uint32_t*>(region + (size_t)pair_cap * 16)[p] = i;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ recv, uint32_t world, uint32_t pair_cap,
@@ -817,19 +888,16 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
     const size_t region = exchange_region_bytes(pair_cap);
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const DigitSel ds{1, 0, node_bits, (uint32_t)world, kRadixBits};
-    if (cap > 0) {
-        // rowscan path: pack_kernel reads the per-owner totals from row_total
-        hipLaunchKernelGGL((radix_hist_kernel<kRadixBits>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples,
-                           (uint32_t)cap, ds, w.table, w.stride, 1, nullptr, nullptr, nullptr);
+    const uint32_t nb_launch = nb_sort ? nb_sort : 1;
+    const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
+    hipLaunchKernelGGL((radix_hist_kernel<kRadixBits>), dim3(nb_launch), dim3(kSortThreads), 0, s, keys, n_tuples,
+                       (uint32_t)cap, ds, w.table, w.stride, scanned, nullptr, nullptr, nullptr);
+    if (scanned)
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.table,
                            w.stride, w.row_total);
-        hipLaunchKernelGGL((radix_scatter_kernel<kRadixBits, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys,
-                           nullptr, n_tuples, (uint32_t)cap, ds, w.table, w.stride, w.row_total, 1, w.keys[0],
-                           w.idx[0], nullptr);
-    }
-    const uint32_t nb_pack = (uint32_t)((cap + 255) / 256) + 1;
-    hipLaunchKernelGGL(pack_kernel, dim3(nb_pack), dim3(256), 0, s, w.keys[0], w.idx[0], payload, n_tuples,
-                       w.row_total, (uint32_t)world, (uint32_t)pair_cap, static_cast<char*>(send), region);
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(nb_launch), dim3(kSortThreads), 0, s, keys, payload, n_tuples,
+                       (uint32_t)cap, ds, w.table, w.stride, w.row_total, scanned, (uint32_t)world, (uint32_t)pair_cap,
+                       static_cast<char*>(send), region);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -22,6 +22,7 @@ the besst_dev_* C ABI on torch-owned HBM).  CPU tests inject an oracle-backed st
 exactly this file's orchestration with world_size 2.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -45,19 +46,21 @@ class HipBackend(object):
         self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n,
                                               self.recv_cap)
         self.gb.set_contigs(**wl['table'])
-        # coverage numerators and the 8 counter words share one buffer so that ONE all-reduce sums both
-        self._sum_buf = torch.zeros(self.gb.n_contigs + 8, dtype=torch.int64, device=device)
-        self.gb.aligned = self._sum_buf[:self.gb.n_contigs]
+        # coverage numerators and the 8 summable counter words are adjacent in the builder's state block, so ONE
+        # in-place all-reduce sums both
+        self._sum_buf = self.gb.state[:self.gb.n_contigs + 8]
         self.region = self.lib.besst_dev_exchange_region_bytes(self.pair_cap)
         u8 = dict(dtype=torch.uint8, device=device)
         self.send = torch.zeros(world * self.region, **u8)
         self.part_cap = int(tuple_capacity) if tuple_capacity else self.rec.n
         self.ws_part = torch.empty(self.lib.besst_dev_reduce_workspace_bytes(self.part_cap), **u8)
         self.tail = torch.zeros(4, dtype=torch.int32, device=device)
+        self.tail_scratch = torch.zeros(2, dtype=torch.int64, device=device)
+        self._args = {}
         self.rkeys = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
         self.rpayload = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
         self.gidx = torch.empty(self.recv_cap, dtype=torch.int32, device=device)
-        self.flags = torch.zeros(2, dtype=torch.int32, device=device)     # n_recv, overflow
+        self.flags = self.gb.spare[:2]                                    # n_recv, overflow (zeroed by gb.reset)
 
     # -- tensors the orchestration reduces across ranks --
     @property
@@ -73,52 +76,75 @@ class HipBackend(object):
 
     def reset(self):
         self.gb.reset()
-        self.flags.zero_()
+
+    # The argument lists of the stage calls never change (all buffers are allocated once), so they are marshalled
+    # once: at ~230 us per step the Python side of a ctypes call with 20 pointer arguments is not free.
+    def _call(self, name, fn, build, stream=None):
+        args = self._args.get(name)
+        if args is None:
+            args = self._args[name] = build()
+        _lib.check(fn(self._stream() if stream is None else C.c_void_p(stream.cuda_stream), *args), name)
 
     def classify_scan(self):
         g, r, p = self.gb, self.rec, self.pipeline._p
-        _lib.check(self.lib.besst_dev_classify_scan(
-            self._stream(), r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
+        self._call('classify_scan', self.lib.besst_dev_classify_scan, lambda: (
+            r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
             g.n_contigs, p(g.table), C.byref(g.params), g.node_bits, p(g.aligned), g._small(0), p(g.ws1),
-            g.ws1.numel()), 'classify_scan')
+            g.ws1.numel()))
 
     def classify_tail(self):
         g = self.gb
-        _lib.check(self.lib.besst_dev_classify_tail(self._stream(), self.rec.n, self.pipeline._p(self.tail),
-                                                    self.pipeline._p(g.ws1), g.ws1.numel()), 'classify_tail')
+        self._call('classify_tail', self.lib.besst_dev_classify_tail, lambda: (
+            self.rec.n, self.pipeline._p(self.tail), self.pipeline._p(g.ws1), g.ws1.numel()))
+        return self.tail
+
+    def classify_tail_early(self, stream=None):
+        """The same tail from the record columns alone (backward search for the last reaching record): independent
+        of classify_scan, so the orchestration runs it - and the tail all-gather - on a side stream meanwhile."""
+        g, r, p = self.gb, self.rec, self.pipeline._p
+        self._call('classify_tail_search', self.lib.besst_dev_classify_tail_search, lambda: (
+            r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
+            g.n_contigs, p(g.table), C.byref(g.params), g.node_bits, p(self.tail), p(self.tail_scratch)), stream)
         return self.tail
 
     def classify_emit(self, tails):
+        """tails: the gathered world x 4 int32 (contiguous); the stitch kernel picks this rank's incoming prev_obs."""
         g, p = self.gb, self.pipeline._p
-        _lib.check(self.lib.besst_dev_resolve_carry(self._stream(), p(tails), self.rank, g._carry), 'resolve_carry')
-        _lib.check(self.lib.besst_dev_classify_emit(
-            self._stream(), self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
-            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned)), 'classify_emit')
+        if self._args.get('tails_ptr') != tails.data_ptr():
+            self._args.pop('classify_emit', None)
+            self._args['tails_ptr'] = tails.data_ptr()
+        self._call('classify_emit', self.lib.besst_dev_classify_emit, lambda: (
+            self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
+            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned), p(tails), self.rank))
 
     def partition(self):
         g, p = self.gb, self.pipeline._p
-        _lib.check(self.lib.besst_dev_partition(
-            self._stream(), self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
-            p(self.send), p(self.ws_part), self.ws_part.numel()), 'partition')
+        self._call('partition', self.lib.besst_dev_partition, lambda: (
+            self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
+            p(self.send), p(self.ws_part), self.ws_part.numel()))
         return self.send
 
     def unpack(self, recv):
         p = self.pipeline._p
-        n_recv = C.c_void_p(self.flags.data_ptr())
-        overflow = C.c_void_p(self.flags.data_ptr() + 4)
-        _lib.check(self.lib.besst_dev_unpack(self._stream(), self.world, self.pair_cap, p(recv), p(self.rkeys),
-                                             p(self.rpayload), p(self.gidx), n_recv, overflow), 'unpack')
+        if self._args.get('recv_ptr') != recv.data_ptr():
+            self._args.pop('unpack', None)
+            self._args['recv_ptr'] = recv.data_ptr()
+        self._call('unpack', self.lib.besst_dev_unpack, lambda: (
+            self.world, self.pair_cap, p(recv), p(self.rkeys), p(self.rpayload), p(self.gidx),
+            C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4)))
 
     def reduce(self):
-        self.gb.reduce(keys=self.rkeys, payload=self.rpayload, n_tuples_ptr=C.c_void_p(self.flags.data_ptr()),
-                       capacity=self.recv_cap, first_map=self.gidx)
+        g, p = self.gb, self.pipeline._p
+        self._call('dev_reduce', self.lib.besst_dev_reduce, lambda: (
+            self.recv_cap, C.c_void_p(self.flags.data_ptr()), 2 * g.node_bits + 1, p(self.rkeys), p(self.rpayload),
+            p(g.row_key), p(g.row_mask), p(g.row_n), p(g.row_sum), p(g.row_sum_sq), p(g.row_first), p(g.row_offset),
+            p(g.obs_lo), p(g.obs_hi), g._n_rows, p(g.ws2), g.ws2.numel(), p(self.gidx)))
 
     def pack_for_allreduce(self):
-        self._sum_buf[self.gb.n_contigs:].copy_(self.counter_words)
         return self._sum_buf
 
     def unpack_after_allreduce(self):
-        self.counter_words.copy_(self._sum_buf[self.gb.n_contigs:])
+        pass
 
     def overflowed(self):
         return bool(self.flags.cpu()[1].item())
@@ -154,6 +180,12 @@ class ShardedGraphBuild(object):
             backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
         self.backend = backend
         self._tails = None
+        self._side_stream = None
+        # How the 16-byte tails travel (see step()).  'late' is the default: on one GPU (RCCL, world = 1) the three
+        # variants are within 4 % of each other because the step is bound by the host's launch rate there; 'side'
+        # hides the gather behind the per-record pass and should win once the gather crosses xGMI, but that could
+        # not be measured on the single-GPU development box.
+        self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'late')      # 'late' | 'side' | 'inline'
         self._recv = None
         # the coverage/counter all-reduce overlaps the tuple exchange and the sort; it gets its own communicator so
         # that it is not serialised behind the all-to-all on the default one
@@ -177,12 +209,47 @@ class ShardedGraphBuild(object):
     def step(self):
         b = self.backend
         b.reset()
-        b.classify_scan()
-        tail = b.classify_tail()
-        if self._tails is None:
-            self._tails = [torch.empty_like(tail) for _ in range(self.world)]
-        dist.all_gather(self._tails, tail, group=self.group)
-        b.classify_emit(torch.cat(self._tails))
+        mode = self.tail_mode if hasattr(b, 'classify_tail_early') else 'late'
+        if mode == 'side':
+            # The tail of a slice is its last record that reaches CreateEdge - found by a backward search that is
+            # independent of the per-record pass - so the search and the tail all-gather run on a side stream while
+            # stream_kernel / ordered_kernel occupy the main one: the gather's latency is hidden.
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(b.device)
+                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
+                self._ev_main = torch.cuda.Event()
+                self._ev_side = torch.cuda.Event()
+            main, side = torch.cuda.current_stream(b.device), self._side_stream
+            self._ev_main.record(main)                   # the previous step's stitch has read the old tails
+            side.wait_event(self._ev_main)
+            tail = b.classify_tail_early(stream=side)
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(self._tails, tail, group=self.side_group)
+            self._ev_side.record(side)
+            b.classify_scan()
+            main.wait_event(self._ev_side)
+            tails = self._tails
+        elif mode == 'inline':
+            if self._tails is None:
+                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
+            tail = b.classify_tail_early()
+            dist.all_gather_into_tensor(self._tails, tail, group=self.group)
+            b.classify_scan()
+            tails = self._tails
+        elif hasattr(b, 'classify_tail_early'):
+            # 'late': the tail comes from the per-record pass's block summaries, the gather sits on the critical path
+            if self._tails is None:
+                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
+            b.classify_scan()
+            dist.all_gather_into_tensor(self._tails, b.classify_tail(), group=self.group)
+            tails = self._tails
+        else:                                            # CPU stand-in backends (gloo has no all_gather_into_tensor)
+            b.classify_scan()
+            tail = b.classify_tail()
+            gathered = [torch.empty_like(tail) for _ in range(self.world)]
+            dist.all_gather(gathered, tail, group=self.group)
+            self._tails = tails = torch.cat(gathered)
+        b.classify_emit(tails)
         # coverage numerators and counters are final here; sum them across ranks while tuples are exchanged
         summed = dist.all_reduce(b.pack_for_allreduce(), group=self.side_group, async_op=True)
         send = b.partition()
@@ -207,7 +274,7 @@ class ShardedGraphBuild(object):
 
     def final_prev_obs(self):
         """counter.prev_obs1/2 after the last record of the global stream."""
-        tails = torch.cat(self._tails).cpu().numpy().reshape(self.world, 4)
+        tails = self._tails.cpu().numpy().reshape(self.world, 4)
         prev = (-1, -1)
         for j in range(self.world):
             if tails[j, 0]:

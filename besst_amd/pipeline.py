@@ -63,8 +63,14 @@ class DeviceGraphBuilder(object):
         i64 = dict(dtype=torch.int64, device=device)
         i32 = dict(dtype=torch.int32, device=device)
         self.table = torch.zeros(self.lib.besst_dev_contig_table_bytes(self.n_contigs), **u8)
-        self.aligned = torch.zeros(self.n_contigs, **i64)
-        self.small = torch.zeros(COUNTER_BYTES + 32, **u8)        # counters | carry[2] | n_out | n_rows
+        # ONE int64 block holds everything a pass starts from zero: coverage numerators | 8 summable counter words |
+        # prev_obs words, carry[2], n_out, n_rows | 2 spare words.  reset() is a single device copy from a template,
+        # and the multi-GPU path all-reduces state[:n_contigs + 8] in place (coverage and counters in one call).
+        self.small_words = (COUNTER_BYTES + 32) // 8
+        self.state = torch.zeros(self.n_contigs + self.small_words + 2, **i64)
+        self.aligned = self.state[:self.n_contigs]
+        self.small = self.state[self.n_contigs:self.n_contigs + self.small_words].view(torch.uint8)
+        self.spare = self.state[self.n_contigs + self.small_words:].view(torch.int32)     # 4 x int32 for callers
         self.keys = torch.empty(self.rec_cap, **i64)
         self.payload = torch.empty(self.rec_cap, **i64)
         self.ws1 = torch.empty(self.lib.besst_dev_classify_workspace_bytes(self.rec_cap), **u8)
@@ -79,9 +85,11 @@ class DeviceGraphBuilder(object):
         self.row_offset = torch.empty(c, **i32)
         self.obs_lo = torch.empty(c, **i32)
         self.obs_hi = torch.empty(c, **i32)
-        self._init = torch.zeros(COUNTER_BYTES + 32, dtype=torch.uint8)
-        self._init[COUNTER_BYTES:COUNTER_BYTES + 8] = torch.from_numpy(np.array([-1, -1], dtype=np.int32).view(np.uint8))
-        self._init = self._init.to(device)
+        init = torch.zeros(self.state.numel(), dtype=torch.int64)
+        init_small = init[self.n_contigs:self.n_contigs + self.small_words].view(torch.uint8)
+        init_small[COUNTER_BYTES:COUNTER_BYTES + 8] = torch.from_numpy(np.array([-1, -1], dtype=np.int32).view(np.uint8))
+        self._init = init.to(device)
+        self._args = {}
 
     # device addresses inside the small block
     def _small(self, off):
@@ -108,19 +116,31 @@ class DeviceGraphBuilder(object):
 
     def reset(self):
         """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
-        self.aligned.zero_()
-        self.small.copy_(self._init)
+        self.state.copy_(self._init)
 
     def classify(self, rec):
+        # argument lists are marshalled once per record set (every buffer is allocated once)
+        args = self._args.get(id(rec))
+        if args is None:
+            args = self._args[id(rec)] = (
+                rec.n, _p(rec.tid), _p(rec.mtid), _p(rec.pos), _p(rec.mpos), _p(rec.flag), _p(rec.mapq), _p(rec.qlen),
+                self.n_contigs, _p(self.table), C.byref(self.params), self.node_bits, self._carry, _p(self.aligned),
+                _p(self.keys), _p(self.payload), self._n_out, self._small(0), _p(self.ws1), self.ws1.numel())
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.besst_dev_classify(
-            C.c_void_p(stream), rec.n, _p(rec.tid), _p(rec.mtid), _p(rec.pos), _p(rec.mpos), _p(rec.flag),
-            _p(rec.mapq), _p(rec.qlen), self.n_contigs, _p(self.table), C.byref(self.params), self.node_bits,
-            self._carry, _p(self.aligned), _p(self.keys), _p(self.payload), self._n_out, self._small(0),
-            _p(self.ws1), self.ws1.numel()), 'dev_classify')
+        _lib.check(self.lib.besst_dev_classify(C.c_void_p(stream), *args), 'dev_classify')
 
     def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None, first_map=None):
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if keys is None and payload is None and n_tuples_ptr is None and capacity is None and first_map is None:
+            args = self._args.get('reduce')
+            if args is None:
+                args = self._args['reduce'] = (
+                    self.tup_cap, self._n_out, 2 * self.node_bits + 1, _p(self.keys), _p(self.payload),
+                    _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
+                    _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
+                    _p(self.ws2), self.ws2.numel(), None)
+            _lib.check(self.lib.besst_dev_reduce(C.c_void_p(stream), *args), 'dev_reduce')
+            return
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
         cap = self.tup_cap if capacity is None else int(capacity)

@@ -127,6 +127,13 @@ class RecordBatch(object):
         alen = None if self.alen is None else self.alen[start:stop]
         return RecordBatch(self.references, self.lengths, rlen=rlen, alen=alen, **kw)
 
+    def take(self, index):
+        """Rows `index` (any numpy index expression) as a new batch."""
+        kw = {name: np.ascontiguousarray(getattr(self, name)[index]) for name, _ in _COLUMNS}
+        rlen = None if self.rlen is None else np.ascontiguousarray(self.rlen[index])
+        alen = None if self.alen is None else np.ascontiguousarray(self.alen[index])
+        return RecordBatch(self.references, self.lengths, rlen=rlen, alen=alen, **kw)
+
     @classmethod
     def from_pysam_like(cls, bam_file):
         """Materialise any pysam-like iterable (slow host loop; compatibility path only)."""

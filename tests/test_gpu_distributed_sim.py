@@ -32,6 +32,8 @@ def test_simulated_ranks_match_oracle(world, orientation):
             b.reset()
             b.classify_scan()
             tails.append(b.classify_tail().clone())
+            # the backward search over the record columns finds the same tail as the per-record pass
+            assert torch.equal(b.classify_tail_early(), tails[-1])
         tails = torch.cat(tails)
         sends = []
         for b in backends:
@@ -108,3 +110,35 @@ def test_simulated_ranks_metrics_sample(world, config, pairs):
     assert not host[n_isize:pipeline.SAMPLE_CAP].any()
     if pairs >= 3_000_000:
         assert n_all[0] > pipeline.SAMPLE_CAP                  # the cut-off really was crossed
+
+
+@pytest.mark.parametrize('n_records', [0, 1, 63, 64, 1000, 1024, 1025, 5000])
+def test_tail_search_on_short_and_linkless_slices(n_records):
+    """Backward tail search: slices shorter than a chunk, exactly a chunk, and slices without any reaching record
+    (records of one contig only) must agree with the summary-based tail."""
+    import torch
+    from besst_amd import distributed, workload
+    wl = workload.make('C2', 0, pairs=40000, nc=60)
+    dev = torch.device('cuda', 0)
+    batch = wl['batch']
+    for start in (0, len(batch) // 3, len(batch) - n_records):
+        sub = dict(wl)
+        sub['batch'] = batch.slice(start, start + n_records)
+        b = distributed.HipBackend(dev, sub, 0, 1, 4096)
+        b.reset()
+        b.classify_scan()
+        want = b.classify_tail().clone()
+        assert torch.equal(b.classify_tail_early(), want)
+    # a slice holding a single contig's interior has no link at all
+    import numpy as np
+    same = np.nonzero((batch.tid == batch.mtid))[0][:n_records]
+    if len(same):
+        sub = dict(wl)
+        sub['batch'] = batch.take(same)
+        if True:
+            b = distributed.HipBackend(dev, sub, 0, 1, 4096)
+            b.reset()
+            b.classify_scan()
+            want = b.classify_tail().clone()
+            assert int(want[0]) == 0
+            assert torch.equal(b.classify_tail_early(), want)
