@@ -12,9 +12,11 @@ from . import _lib
 from .records import RecordBatch
 
 
-def read_bam(path, threads=None, chunk_records=4_000_000):
+def read_bam(path, threads=None, chunk_records=8_000_000):
     lib = _lib.load()
-    threads = threads or min(16, os.cpu_count() or 1)
+    # inflate, the record walk and the column fill are block/record parallel; beyond ~32-64 threads waking the pool
+    # costs more than it buys (76 M records/s at 64 threads, 18 M at 256 on the 256-core bench host)
+    threads = threads or min(32, os.cpu_count() or 1)
     handle = lib.besst_bam_open(os.fsencode(path), int(threads))
     if not handle:
         raise IOError('cannot read BAM %s: %s' % (path, _lib.last_error()))

@@ -13,10 +13,13 @@ def _bgzf_block(data):
     return head + payload + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data))
 
 
-def write_bam(path, batch, soft_clip=None, block_bytes=60000):
+def write_bam(path, batch, soft_clip=None, block_bytes=60000, align_records=False):
     """Write ``batch`` as BAM.  CIGAR per record: [soft clip S] qlen M, so that qlen/rlen/alen round-trip:
-    rlen = qlen + clip (or 0 when batch.rlen is 0), alen = qlen."""
+    rlen = qlen + clip (or 0 when batch.rlen is 0), alen = qlen.
+    align_records=False cuts BGZF blocks at arbitrary bytes (records straddle blocks); True flushes the block
+    before a record that would not fit, like htslib's bam_write1, so that every block starts with a record."""
     out = bytearray()
+    cuts = []                        # block boundaries when align_records
     text = b'@HD\tVN:1.0\tSO:coordinate\n'
     hdr = b'BAM\x01' + struct.pack('<I', len(text)) + text + struct.pack('<I', len(batch.references))
     for name, length in zip(batch.references, batch.lengths):
@@ -39,8 +42,16 @@ def write_bam(path, batch, soft_clip=None, block_bytes=60000):
                            int(batch.tlen[i]))
         body += name + b''.join(struct.pack('<I', c) for c in cigar)
         body += b'\x11' * ((seq_len + 1) // 2) + b'\xff' * seq_len
+        if align_records and (not cuts or len(out) + 4 + len(body) - cuts[-1] > block_bytes):
+            cuts.append(len(out))    # the header gets blocks of its own, then a new block whenever one is full
         out += struct.pack('<I', len(body)) + body
     with open(path, 'wb') as fh:
-        for off in range(0, len(out), block_bytes):
-            fh.write(_bgzf_block(bytes(out[off:off + block_bytes])))
+        if align_records:
+            bounds = [0] + [c for c in cuts if c > 0] + [len(out)]
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                for off in range(lo, hi, 65000):         # only the header can exceed one block
+                    fh.write(_bgzf_block(bytes(out[off:min(off + 65000, hi)])))
+        else:
+            for off in range(0, len(out), block_bytes):
+                fh.write(_bgzf_block(bytes(out[off:off + block_bytes])))
         fh.write(_bgzf_block(b''))      # BGZF EOF marker
