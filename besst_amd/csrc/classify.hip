@@ -182,27 +182,21 @@ __device__ __forceinline__ int wave_sum(int v) {
 // The stream is (tid,pos)-sorted, so the 256 records of a wave normally share one tid: coverage is a wave
 // reduction accumulated across the workgroup's sub-tiles and flushed with one 64-bit atomic per run.
 // ---------------------------------------------------------------------------------------------------------
-// Add `val` to dst[key] for every active lane with ONE atomic per distinct key of the wave.  The stream is
-// (tid,pos)-sorted, so a wave sees one or two distinct contigs; per-lane atomics on the same two addresses
-// were measured at ~0.1 ns each chip-wide and dominated the pass.  After 8 distinct keys the remaining lanes
-// fall back to their own atomics (unsorted input stays correct, only slower).
-__device__ __forceinline__ void wave_add_by_key(unsigned long long* dst, int32_t key, int val, bool active,
-                                                int lane) {
-    unsigned long long mask = __ballot(active);
-    int iter = 0;
-    while (mask) {
-        if (iter++ == 8) {
-            if (active) atomicAdd(&dst[key], (unsigned long long)val);
-            break;
-        }
-        const int leader = __ffsll((long long)mask) - 1;
-        const int32_t k = __shfl(key, leader, 64);
-        const bool match = active && key == k;
-        const int tot = wave_sum(match ? val : 0);
-        if (lane == leader && tot) atomicAdd(&dst[k], (unsigned long long)tot);
-        active = active && !match;
-        mask = __ballot(active);
+// Add val to dst[key] with ONE atomic per run of equal keys in the wave (segmented scan over the run heads; exact
+// for any key order, one atomic per contig for a sorted stream).  Lanes with val == 0 only carry their key.
+__device__ __forceinline__ void wave_add_runs(unsigned long long* dst, int32_t key, int val, int lane) {
+    const int32_t up = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != up;
+    const unsigned long long heads = __ballot(head);
+    const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+    int v = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane - d >= start) v += o;
     }
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (tail && v) atomicAdd(&dst[key], (unsigned long long)v);
 }
 
 __device__ __forceinline__ void flush_cov(const ClassifyArgs& a, unsigned long long* aligned, int lane,
@@ -287,13 +281,24 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
             }
             acc_sum += tot;
         } else {
-            // a contig boundary (or unsorted input) inside the wave: one atomic per distinct contig and slot
+            // a contig boundary (or unsorted input) inside the wave.  Lanes own 4 consecutive records: a lane whose
+            // records share one contig contributes (contig, sum) to a run-segmented wave reduction - one atomic per
+            // run of lanes, i.e. per contig of a sorted stream; a lane that itself straddles a boundary adds its
+            // records directly and breaks the run.  (Fragmented assemblies put a dozen contigs in every wave: the
+            // previous per-slot keyed reduction with its per-lane fallback ran this pass at 0.6 TB/s there.)
+            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
+            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);       // unique: never equal to a neighbour's key
+            int val = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
                 const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
-                wave_add_by_key(aligned, r_tid[k], (int)r_qlen[k], act, lane);
+                if (!act) continue;
+                if (lane_uni) val += (int)r_qlen[k];
+                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
             }
+            if (lane_uni) key = r_tid[0];
+            wave_add_runs(aligned, key, val, lane);
         }
         // candidate bits of this wave's group: word k, bit l  <->  record group_base + 4*l + k
         const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
@@ -342,23 +347,6 @@ __device__ __forceinline__ int select_candidate(unsigned long long w0, unsigned 
         }
     }
     return lo * 4 + k;
-}
-
-// Add val to dst[key] with ONE atomic per run of equal keys in the wave (segmented scan over the run heads; exact
-// for any key order, one atomic per contig for a sorted stream).  Lanes with val == 0 only carry their key.
-__device__ __forceinline__ void wave_add_runs(unsigned long long* dst, int32_t key, int val, int lane) {
-    const int32_t up = __shfl_up(key, 1, 64);
-    const bool head = lane == 0 || key != up;
-    const unsigned long long heads = __ballot(head);
-    const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
-    int v = val;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane - d >= start) v += o;
-    }
-    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    if (tail && v) atomicAdd(&dst[key], (unsigned long long)v);
 }
 
 constexpr int kOrdWaves = 4;                              // waves of an ordered_kernel workgroup

@@ -96,3 +96,21 @@ def test_unsorted_stream_is_still_exact():
     assert loop.count > 1000
     table, aligned, ctr = DU.device_build(shuffled, tab, p)
     DU.assert_matches_oracle(table, aligned, ctr, loop, asm.nc)
+
+
+def test_fragmented_assembly_many_contigs_per_wave():
+    """20 records per contig: every wave of the streaming pass spans a dozen contigs and takes the run-segmented
+    coverage path (lanes straddling a boundary add their records directly); coverage must stay exact, also with
+    unmapped (-1) and absent contigs in the mix."""
+    asm = synth.make_assembly(6000, 600, 41)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 450.0, 40.0), 60000, 42)
+    lens = asm.lengths.tolist()
+    tab = dict(cls=[1 if l >= 500 else 2 for l in lens], scaf=list(range(1, asm.nc + 1)), slen=lens,
+               cpos=[0] * asm.nc, clen=lens, cdir=[True] * asm.nc)
+    for t in range(3, asm.nc, 17):
+        tab['cls'][t] = 0
+    p = O.LibParams(read_len=100, ins_size_threshold=690.0)
+    loop = O.record_loop(GU.rec_lists(batch), tab, p)
+    assert loop.count > 500 and sum(1 for x in loop.aligned if x) > 4000
+    table, aligned, ctr = DU.device_build(batch, tab, p)
+    DU.assert_matches_oracle(table, aligned, ctr, loop, asm.nc)
