@@ -349,6 +349,121 @@ __device__ __forceinline__ int select_candidate(unsigned long long w0, unsigned 
     return lo * 4 + k;
 }
 
+// The order-dependent part of the record loop, run by ONE wave over evaluated entries in stream order, 64 at a time:
+// previous reaching observation via ballot, CreateEdge semantics (acceptance rule :840), ordered slots for the
+// emitted tuples in the block's segment.  The state is identical in every lane.  Entry layout:
+//   { obs1, obs2, node_min | REACH<<29 | FISHY<<30 | NONUNIQ<<31, node_max | MAPQ0<<29 | CASEA<<30 | FIRSTMIN<<31 }
+struct Chain {
+    bool prev_known = false;
+    int32_t prev1 = 0, prev2 = 0;
+    bool blk_has = false;
+    int emit_base = 0;
+    bool head_present = false;
+    int32_t head1 = 0, head2 = 0;
+    uint32_t head_info = 0, head_slot = kNoSlot;
+    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
+
+    __device__ __forceinline__ void step(const ClassifyArgs& a, const uint4 ent, const bool live, const int lane,
+                                         uint64_t* __restrict__ seg_keys, uint64_t* __restrict__ seg_payload,
+                                         const int64_t block_base) {
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
+        const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
+        const bool reach = live && ((ent.z >> 29) & 1u), fishy = live && ((ent.z >> 30) & 1u);
+        const bool nonuniq = live && ((ent.z >> 31) & 1u);
+        const bool mapq0 = (ent.w >> 29) & 1u, case_a = (ent.w >> 30) & 1u, first_min = (ent.w >> 31) & 1u;
+        const uint32_t n_min = ent.z & 0x1fffffffu, n_max = ent.w & 0x1fffffffu;
+        const bool dbl = case_a && a.extend_paths && !a.no_score;
+        c_nonuniq += nonuniq ? 1 : 0;
+        c_fishy += fishy ? 1 : 0;
+        c_reach += reach ? 1 : 0;
+        const unsigned long long has_mask = __ballot(reach);
+        bool pk = prev_known;
+        int32_t p1 = prev1, p2 = prev2;
+        {
+            const unsigned long long below = has_mask & lt_mask;
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
+            if (below) { pk = true; p1 = q1; p2 = q2; }
+        }
+        const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+        bool emit = fishy;
+        bool is_head = false;
+        if (reach) {
+            if (!pk) {
+                is_head = true;                      // first reaching record of the workgroup
+                emit = accept;
+            } else {
+                const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
+                c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                emit = d.keep;
+            }
+        }
+        const unsigned long long emit_mask = __ballot(emit);
+        const int slot = emit_base + __popcll(emit_mask & lt_mask);
+        if (emit) {
+            const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+            const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+            const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+            seg_keys[block_base + slot] = ((((uint64_t)n_min << a.node_bits) | n_max) << 1) | (fishy ? 1u : 0u);
+            seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+        // the head is unique per workgroup; broadcast it to every lane
+        const unsigned long long head_mask = __ballot(is_head);
+        if (head_mask) {
+            const int hl = __ffsll((long long)head_mask) - 1;
+            head_present = true;
+            head1 = __shfl(o1, hl, 64);
+            head2 = __shfl(o2, hl, 64);
+            const bool h_acc = __shfl((int)accept, hl, 64), h_dbl = __shfl((int)dbl, hl, 64);
+            const bool h_mq0 = __shfl((int)mapq0, hl, 64);
+            head_info = (h_acc ? 9u : 0u) | (h_dbl ? 2u : 0u) | (h_mq0 ? 4u : 0u);
+            const int hs = __shfl(slot, hl, 64);
+            head_slot = h_acc ? (uint32_t)hs : kNoSlot;
+        }
+        if (has_mask) {
+            const int src = 63 - __clzll((long long)has_mask);
+            blk_has = true;
+            prev_known = true;
+            prev1 = __shfl(o1, src, 64);
+            prev2 = __shfl(o2, src, 64);
+        }
+        emit_base += __popcll(emit_mask);
+    }
+
+    // lane f publishes plane f of the block's summary
+    __device__ __forceinline__ void publish(SummView summ, const uint32_t block, const int lane) {
+        int tot[7];
+        const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
+#pragma unroll
+        for (int f = 0; f < 7; ++f) tot[f] = wave_sum(vals[f]);
+        uint32_t v = 0;
+        if (lane == kSumEmit) v = (uint32_t)emit_base;
+        if (lane == kSumHas) v = blk_has ? 1u : 0u;
+        if (lane == kSumFirst1) v = head_present ? (uint32_t)head1 : 0u;
+        if (lane == kSumFirst2) v = head_present ? (uint32_t)head2 : 0u;
+        if (lane == kSumLast1) v = (uint32_t)prev1;
+        if (lane == kSumLast2) v = (uint32_t)prev2;
+        if (lane == kSumHeadInfo) v = head_present ? head_info : 0u;
+        if (lane == kSumHeadSlot) v = head_slot;
+#pragma unroll
+        for (int f = 0; f < 7; ++f)
+            if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
+        if (lane < kSumPlanes) summ.at(lane, block) = v;
+    }
+};
+
+__device__ __forceinline__ uint4 pack_entry(const Eval& e) {
+    uint4 ent;
+    ent.x = (uint32_t)e.o1;
+    ent.y = (uint32_t)e.o2;
+    ent.z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
+            ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
+    ent.w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
+            ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+    return ent;
+}
+
 constexpr int kOrdWaves = 4;                              // waves of an ordered_kernel workgroup
 constexpr int kOrdThreads = kOrdWaves * 64;
 constexpr int kAhead = 4;                                 // chunks a wave evaluates per round, all gathers in flight
@@ -383,17 +498,7 @@ __global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
     __syncthreads();
     const int total = s_pre[kCandThreads];
 
-    // chain state (wave 0), identical in every lane
-    bool prev_known = false;
-    int32_t prev1 = 0, prev2 = 0;
-    bool blk_has = false;
-    int emit_base = 0;
-    bool head_present = false;
-    int32_t head1 = 0, head2 = 0;
-    uint32_t head_info = 0, head_slot = kNoSlot;
-    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
+    Chain chain;                                         // wave 0 only
 
     for (int c0 = 0; c0 < total; c0 += kOrdRound) {
         // ---- evaluation, order free: chunk q = u * kOrdWaves + wave of the round goes to this wave's slot u, so a
@@ -444,13 +549,7 @@ __global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
                 if (c0 + q * 64 >= total) break;             // uniform in the wave
                 const Eval e = eval_record(a, in_range[u], c1[u], c2[u], r_tid[u], r_mtid[u], r_pos[u], r_mpos[u],
                                            r_flag[u], r_mapq[u]);
-                uint4 ent;
-                ent.x = (uint32_t)e.o1;
-                ent.y = (uint32_t)e.o2;
-                ent.z = e.n_min | ((e.bits & EV_REACH) ? 1u << 29 : 0u) | ((e.bits & EV_FISHY) ? 1u << 30 : 0u) |
-                        ((e.bits & EV_NONUNIQ) ? 1u << 31 : 0u);
-                ent.w = e.n_max | ((e.bits & EV_MAPQ0) ? 1u << 29 : 0u) | ((e.bits & EV_CASEA) ? 1u << 30 : 0u) |
-                        ((e.bits & EV_FIRSTMIN) ? 1u << 31 : 0u);
+                const uint4 ent = pack_entry(e);
                 s_ent[q * 64 + lane] = ent;
                 // the candidates' own coverage (the streaming pass credits only tid == mtid records)
                 wave_add_runs(aligned, r_tid[u], (e.bits & EV_COV) ? (int)r_qlen[u] : 0, lane);
@@ -460,97 +559,13 @@ __global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
         // ---- the order-dependent part, wave 0 over the round's entries in stream order
         if (wave == 0) {
             const int round_n = total - c0 < kOrdRound ? total - c0 : kOrdRound;
-            for (int q0 = 0; q0 < round_n; q0 += 64) {
-                const uint4 ent = s_ent[q0 + lane];          // entries past `total` were not written: masked below
-                const bool live = q0 + lane < round_n;
-                const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
-                const bool reach = live && ((ent.z >> 29) & 1u), fishy = live && ((ent.z >> 30) & 1u);
-                const bool nonuniq = live && ((ent.z >> 31) & 1u);
-                const bool mapq0 = (ent.w >> 29) & 1u, case_a = (ent.w >> 30) & 1u, first_min = (ent.w >> 31) & 1u;
-                const uint32_t n_min = ent.z & 0x1fffffffu, n_max = ent.w & 0x1fffffffu;
-                const bool dbl = case_a && a.extend_paths && !a.no_score;
-                c_nonuniq += nonuniq ? 1 : 0;
-                c_fishy += fishy ? 1 : 0;
-                c_reach += reach ? 1 : 0;
-                const unsigned long long has_mask = __ballot(reach);
-                bool pk = prev_known;
-                int32_t p1 = prev1, p2 = prev2;
-                {
-                    const unsigned long long below = has_mask & lt_mask;
-                    const int src = below ? 63 - __clzll((long long)below) : 0;
-                    const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
-                    if (below) { pk = true; p1 = q1; p2 = q2; }
-                }
-                const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
-                bool emit = fishy;
-                bool is_head = false;
-                if (reach) {
-                    if (!pk) {
-                        is_head = true;                      // first reaching record of the workgroup
-                        emit = accept;
-                    } else {
-                        const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
-                        c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
-                        emit = d.keep;
-                    }
-                }
-                const unsigned long long emit_mask = __ballot(emit);
-                const int slot = emit_base + __popcll(emit_mask & lt_mask);
-                if (emit) {
-                    const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
-                    const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
-                    const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
-                    seg_keys[block_base + slot] = ((((uint64_t)n_min << a.node_bits) | n_max) << 1) | (fishy ? 1u : 0u);
-                    seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
-                }
-                // the head is unique per workgroup; broadcast it to every lane
-                const unsigned long long head_mask = __ballot(is_head);
-                if (head_mask) {
-                    const int hl = __ffsll((long long)head_mask) - 1;
-                    head_present = true;
-                    head1 = __shfl(o1, hl, 64);
-                    head2 = __shfl(o2, hl, 64);
-                    const bool h_acc = __shfl((int)accept, hl, 64), h_dbl = __shfl((int)dbl, hl, 64);
-                    const bool h_mq0 = __shfl((int)mapq0, hl, 64);
-                    head_info = (h_acc ? 9u : 0u) | (h_dbl ? 2u : 0u) | (h_mq0 ? 4u : 0u);
-                    const int hs = __shfl(slot, hl, 64);
-                    head_slot = h_acc ? (uint32_t)hs : kNoSlot;
-                }
-                if (has_mask) {
-                    const int src = 63 - __clzll((long long)has_mask);
-                    blk_has = true;
-                    prev_known = true;
-                    prev1 = __shfl(o1, src, 64);
-                    prev2 = __shfl(o2, src, 64);
-                }
-                emit_base += __popcll(emit_mask);
-            }
+            for (int q0 = 0; q0 < round_n; q0 += 64)         // entries past `total` were not written: masked by `live`
+                chain.step(a, s_ent[q0 + lane], q0 + lane < round_n, lane, seg_keys, seg_payload, block_base);
         }
         if (c0 + kOrdRound < total) __syncthreads();         // the next round overwrites the entries (uniform)
     }
     if (wave != 0) return;
-
-    int tot[7];
-    {
-        const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
-#pragma unroll
-        for (int f = 0; f < 7; ++f) tot[f] = wave_sum(vals[f]);
-    }
-    {
-        uint32_t v = 0;                                      // lane f publishes plane f
-        if (lane == kSumEmit) v = (uint32_t)emit_base;
-        if (lane == kSumHas) v = blk_has ? 1u : 0u;
-        if (lane == kSumFirst1) v = head_present ? (uint32_t)head1 : 0u;
-        if (lane == kSumFirst2) v = head_present ? (uint32_t)head2 : 0u;
-        if (lane == kSumLast1) v = (uint32_t)prev1;
-        if (lane == kSumLast2) v = (uint32_t)prev2;
-        if (lane == kSumHeadInfo) v = head_present ? head_info : 0u;
-        if (lane == kSumHeadSlot) v = head_slot;
-#pragma unroll
-        for (int f = 0; f < 7; ++f)
-            if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
-        if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
-    }
+    chain.publish(summ, blockIdx.x, lane);
 }
 
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------
@@ -888,6 +903,10 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((a.n + kClsTile - 1) / kClsTile);
     const uint32_t stream_blocks = (uint32_t)((a.n + kStreamTile - 1) / kStreamTile);
+    // (A single fused pass for candidate-dense mate-pair libraries - coalesced loads of all seven columns, candidates
+    // compacted and evaluated in LDS, chain by wave 0 - was built and measured on a C3 slice: correct, but 0.70 ms
+    // against 0.16 + 0.42 ms for the two passes; at 135 VGPRs and a barrier-separated chain per 1024 records it is
+    // latency bound at 3 waves per SIMD.  The split design below serves every library.)
     {
         ProfScope ps(s, kProfClassify);
         hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
