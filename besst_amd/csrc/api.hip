@@ -456,6 +456,27 @@ int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const v
                          n_out, overflow);
 }
 
+int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
+                          const int32_t* len2, const uint32_t* row_n, const int64_t* row_sum, const uint32_t* row_offset,
+                          const int32_t* obs_lo, const int32_t* obs_hi, double mean, double sigma, double read_len,
+                          double* gap, double* sd0, int32_t* ks_h, uint8_t* flags, void* workspace,
+                          size_t workspace_bytes) {
+    BESST_REQUIRE(n_edges >= 0 && n_edges < ((int64_t)1 << 31), "dev_score_edges: edge count out of range");
+    if (n_edges == 0) return BESST_OK;
+    BESST_REQUIRE(row && swap && len1 && len2 && row_n && row_sum && row_offset && obs_lo && obs_hi && gap && sd0 &&
+                      ks_h && flags && workspace,
+                  "dev_score_edges: null pointer");
+    BESST_REQUIRE(sigma > 0.0, "dev_score_edges: sigma must be positive");
+    BESST_REQUIRE(workspace_bytes >= align_up((size_t)n_edges * 8, 256), "dev_score_edges: workspace too small");
+    ScoreArgs a;
+    a.row = row; a.swap = swap; a.len1 = len1; a.len2 = len2;
+    a.row_n = row_n; a.row_sum = row_sum; a.row_offset = row_offset;
+    a.obs_lo = obs_lo; a.obs_hi = obs_hi;
+    a.mean = mean; a.sigma = sigma; a.read_len = read_len;
+    a.n_edges = n_edges;
+    return launch_score(static_cast<hipStream_t>(stream), a, gap, sd0, ks_h, flags, workspace, workspace_bytes);
+}
+
 size_t besst_dev_metrics_workspace_bytes(int64_t n_records) { return metrics_workspace_bytes(n_records < 1 ? 1 : n_records); }
 
 int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* tlen,

@@ -272,6 +272,16 @@ class ShardedGraphBuild(object):
         dist.all_reduce(t, group=self.group)
         return int(t[0].item()), int(t[1].item())
 
+    def gather_edges(self, dst=0):
+        """Final gather of the owned edge rows to rank `dst`: returns the list of every rank's
+        ``backend.local_table()`` there (keys are disjoint: each key has one owner), None elsewhere.  Host side,
+        once per library; the rows' ``first_idx`` is the global emit index, so sorting the union by it restores the
+        reference's first-occurrence order."""
+        mine = self.backend.local_table()
+        out = [None] * self.world if self.rank == dst else None
+        dist.gather_object(mine, out, dst=dst, group=self.group)
+        return out
+
     def final_prev_obs(self):
         """counter.prev_obs1/2 after the last record of the global stream."""
         tails = self._tails.cpu().numpy().reshape(self.world, 4)

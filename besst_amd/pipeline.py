@@ -150,6 +150,36 @@ class DeviceGraphBuilder(object):
             _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
             _p(self.ws2), self.ws2.numel(), _p(first_map)), 'dev_reduce')
 
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+        """Score rows of the table this builder holds (besst_dev_score_edges) -> (gap, sd0, ks_h, flags) numpy arrays.
+        Not part of the timed graph build; synchronises (the scratch layout needs the link counts on the host)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        m = int(rows.shape[0])
+        if m == 0:
+            return (np.zeros(0), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.uint8))
+        dev = self.device
+        n_links = self.row_n.cpu().numpy().view(np.uint32)[rows].astype(np.int64)
+        if (n_links < 1).any():
+            raise _lib.BesstDeviceError('score_edges: empty row')
+        npow = np.where(n_links > 1, 1 << np.ceil(np.log2(np.maximum(n_links, 2))).astype(np.int64), 1)
+        big = np.where(npow > 8192, 2 * npow, 0)
+        big_off = (np.cumsum(big) - big).astype(np.uint64)
+        off_bytes = (m * 8 + 255) // 256 * 256
+        ws = torch.zeros(off_bytes + int(big.sum()) * 4 + 256, dtype=torch.uint8, device=dev)
+        ws[:m * 8] = torch.from_numpy(big_off.view(np.uint8)).to(dev)
+        d = [torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+             for a, dt in ((rows.view(np.int32), np.int32), (swap, np.uint8), (len1, np.int32), (len2, np.int32))]
+        gap = torch.zeros(m, dtype=torch.float64, device=dev)
+        sd0 = torch.zeros(m, dtype=torch.float64, device=dev)
+        ks = torch.zeros(m, dtype=torch.int32, device=dev)
+        flags = torch.zeros(m, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.lib.besst_dev_score_edges(
+            C.c_void_p(stream), m, _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(self.row_n), _p(self.row_sum),
+            _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), float(mean), float(sigma), float(read_len),
+            _p(gap), _p(sd0), _p(ks), _p(flags), _p(ws), ws.numel()), 'dev_score_edges')
+        return gap.cpu().numpy(), sd0.cpu().numpy(), ks.cpu().numpy(), flags.cpu().numpy()
+
     def step(self, rec):
         self.reset()
         self.classify(rec)

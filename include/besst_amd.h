@@ -293,6 +293,21 @@ int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, i
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table,
                             int64_t* aligned, const int32_t* tails, int32_t rank);
+/* Per-edge scoring on caller-owned device buffers (the device-pointer form of besst_ctx_score_edges;
+ * CreateGraph.py:498-614): ML gap by bisection, expected sigma, KS numerator h = max|#{l1 <= x} - #{l2 <= x}| on the
+ * centred per-end observations.  In the sharded build every rank scores the rows it owns.
+ *   row / swap / len1 / len2   one entry per scored edge (device): row index into the edge table, whether the
+ *                              edge's first scaffold is the key's max node, the two scaffold lengths
+ *   row_n .. obs_hi            the edge table of besst_dev_reduce
+ *   workspace                  [ uint64 big_off[n_edges] | int32 scratch ]: big_off[e] = start (in ints) of edge e's
+ *                              2 * next_pow2(n) scratch ints when next_pow2(n) > 8192, else ignored; the scratch
+ *                              part follows at the next 256-byte boundary after the offsets */
+int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                          const int32_t* len1, const int32_t* len2, const uint32_t* row_n,
+                          const int64_t* row_sum, const uint32_t* row_offset, const int32_t* obs_lo,
+                          const int32_t* obs_hi, double mean, double sigma, double read_len, double* gap,
+                          double* sd0, int32_t* ks_h, uint8_t* flags, void* workspace, size_t workspace_bytes);
+
 /* libmetrics sampling on caller-owned device columns (the device-pointer form of besst_ctx_metrics_sample;
  * libmetrics.py:63-84,293-303).  `state` is 6 x int64 on the device, in/out:
  *   [0] records so far that qualify for the insert-size sample   (is_proper_aligned_unique_innie/outie on a top contig)

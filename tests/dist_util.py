@@ -141,6 +141,9 @@ class OracleBackend(object):
     def sizes(self):
         return len(self.recv), len(self.rows)
 
+    def local_table(self):
+        return self.rows
+
 
 def rows_from_table(table):
     """{key: dict(n, s, s2, first, mask, lo, hi)} from a device EdgeTable (fishy rows keep empty lists)."""

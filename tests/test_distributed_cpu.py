@@ -53,6 +53,16 @@ def _worker(rank, port, out):
         mine = {k: r for k, r in want_rows.items()
                 if lib.besst_owner_of_scaffold(k >> (2 + wl['node_bits']), WORLD) == rank}
         assert backend.rows == mine
+        # final gather of the owned rows to rank 0: the union is the whole edge table, keys disjoint
+        tables = job.gather_edges(0)
+        if rank == 0:
+            union = {}
+            for t in tables:
+                assert not set(t) & set(union)
+                union.update(t)
+            assert union == want_rows
+        else:
+            assert tables is None
         out.put((rank, len(mine), want.nr_of_duplicates))
     finally:
         dist.destroy_process_group()

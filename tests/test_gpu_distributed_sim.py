@@ -142,3 +142,61 @@ def test_tail_search_on_short_and_linkless_slices(n_records):
             want = b.classify_tail().clone()
             assert int(want[0]) == 0
             assert torch.equal(b.classify_tail_early(), want)
+
+
+def test_simulated_ranks_score_their_own_edges():
+    """Edge scoring per owner rank (besst_dev_score_edges on each rank's rows) equals scoring the single-GPU table."""
+    import numpy as np
+    import torch
+    from besst_amd import device, distributed, workload
+    wl = workload.make('C2', 0, pairs=400000, nc=500)
+    asm, lib = wl['asm'], wl['lib']
+    dev = torch.device('cuda', 0)
+    world = 3
+    parts = DU.split_batch(wl['batch'], world)
+    backends = []
+    for r in range(world):
+        sub = dict(wl)
+        sub['batch'] = parts[r]
+        backends.append(distributed.HipBackend(dev, sub, r, world, 16384))
+    tails = []
+    for b in backends:
+        b.reset()
+        b.classify_scan()
+        tails.append(b.classify_tail().clone())
+    tails = torch.cat(tails)
+    sends = []
+    for b in backends:
+        b.classify_emit(tails)
+        sends.append(b.partition().clone())
+    region = backends[0].region
+    for r, b in enumerate(backends):
+        b.unpack(torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)]))
+        b.reduce()
+    torch.cuda.synchronize()
+
+    def pick(table):
+        rows = np.nonzero((~table.is_fishy) & ((table.mask & 1) != 0) & (table.n >= 5))[0].astype(np.uint32)
+        len1 = asm.lengths[(table.u[rows] >> 1) - 1].astype(np.int32)
+        len2 = asm.lengths[(table.v[rows] >> 1) - 1].astype(np.int32)
+        return rows, np.zeros(len(rows), np.uint8), len1, len2
+
+    got = {}
+    for b in backends:
+        table = b.local_table()
+        rows, swap, len1, len2 = pick(table)
+        gap, sd0, ks, flags = b.gb.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
+        for i, row in enumerate(rows):
+            got[int(table.key[row])] = (float(gap[i]), float(sd0[i]), int(ks[i]), int(flags[i]))
+    with device.GraphContext(0) as ctx:
+        ctx.set_contigs(**wl['table'])
+        ctx.set_library(lib['read_len'], lib['ins_size_threshold'], lib['min_mapq'], lib['orientation'],
+                        lib['detect_duplicate'], lib['extend_paths'], lib['no_score'])
+        ctx.push_records(wl['batch'])
+        table, _, _ = ctx.build_graph()
+        rows, swap, len1, len2 = pick(table)
+        res = ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'])
+        gap, sd0, ks, flags = res[0], res[1], res[2], res[3]
+        want = {int(table.key[row]): (float(gap[i]), float(sd0[i]), int(ks[i]), int(flags[i]))
+                for i, row in enumerate(rows)}
+    assert len(want) > 50 and got == want
