@@ -12,7 +12,9 @@ COLS = ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen', 'rlen', 'a
 
 
 def scenario_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.json')))
+    """The end-to-end scenarios (unit_golden.json holds the unit-level vectors of tests/test_unit_golden.py)."""
+    names = (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.json')))
+    return sorted(n for n in names if not n.startswith('unit_'))
 
 
 _streams = {}
