@@ -284,7 +284,7 @@ def main():
     cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
     # algorithmic bytes of one stream_kernel launch: tid, mtid (4 B each), mapq (1 B), qlen (2 B) per record;
-    # pos / mpos / flag are needed only for the ~1.5 % candidate records and belong to candidate_kernel
+    # pos / mpos / flag are needed only for the ~1.5 % candidate records and belong to ordered_kernel
     alg_bytes = n_rec * 11.0
     achieved = alg_bytes / cls_avg_s / 1e9 if cls_avg_s > 0 else 0.0
 

@@ -177,7 +177,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // stream_kernel: the bandwidth-bound pass.  Per record it needs only tid, mtid, mapq, qlen (11 B):
 //   * tid == mtid (98 % of a real stream): the record can only contribute coverage            [:138-139]
 //   * tid != mtid: "candidate" - everything else in the loop body requires contig1 != contig2 or
-//     different scaffolds (:141-169); its bit is published and candidate_kernel does the rest,
+//     different scaffolds (:141-169); its bit is published and ordered_kernel does the rest,
 //     including the candidate's own coverage contribution.
 // The stream is (tid,pos)-sorted, so the 256 records of a wave normally share one tid: coverage is a wave
 // reduction accumulated across the workgroup's sub-tiles and flushed with one 64-bit atomic per run.
