@@ -238,7 +238,9 @@ def main():
 
     if world > 1 or force_dist:
         from besst_amd import distributed
-        runner = distributed.ShardedGraphBuild(device, wl, rank, world)
+        # BESST_PAIR_CAPACITY: start from a given (too small) exchange-region capacity to exercise the grow-and-retry path
+        cap_env = os.environ.get('BESST_PAIR_CAPACITY')
+        runner = distributed.ShardedGraphBuild(device, wl, rank, world, pair_capacity=int(cap_env) if cap_env else None)
     else:
         runner = SingleGpu(device, wl, args.copies)
 

@@ -40,6 +40,7 @@ class HipBackend(object):
         self.lib = _lib.load()
         self.device = device
         self.rank, self.world = rank, world
+        self.wl = wl
         self.rec = pipeline.DeviceRecords(wl['batch'], device)
         self.pair_cap = int(pair_capacity + (pair_capacity & 1))
         self.recv_cap = self.pair_cap * world
@@ -216,9 +217,10 @@ class ShardedGraphBuild(object):
             # stream_kernel / ordered_kernel occupy the main one: the gather's latency is hidden.
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(b.device)
-                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
                 self._ev_main = torch.cuda.Event()
                 self._ev_side = torch.cuda.Event()
+            if self._tails is None:
+                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
             main, side = torch.cuda.current_stream(b.device), self._side_stream
             self._ev_main.record(main)                   # the previous step's stitch has read the old tails
             side.wait_event(self._ev_main)
@@ -261,9 +263,28 @@ class ShardedGraphBuild(object):
         summed.wait()
         b.unpack_after_allreduce()
 
-    def check_capacity(self):
-        if self.backend.overflowed():
-            raise _lib.BesstDeviceError('exchange region overflow: raise pair_capacity')
+    def check_capacity(self, grow=True):
+        """The exchange regions have a fixed capacity (sized from a probe pass with 1.5x slack).  If any rank
+        truncated a region in the last step, every rank learns it (all-reduce of the flag) and - with ``grow`` -
+        rebuilds its buffers with twice the capacity and repeats the step, so that a skewed owner distribution
+        costs a re-run of one step instead of the job."""
+        for _ in range(6):
+            flag = torch.tensor([1 if self.backend.overflowed() else 0], dtype=torch.int32,
+                                device=self.backend.aligned.device)
+            if dist.is_initialized():
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if not int(flag.item()):
+                return
+            if not grow or not isinstance(self.backend, HipBackend):
+                raise _lib.BesstDeviceError('exchange region overflow: raise pair_capacity')
+            old = self.backend
+            wl = dict(old.wl)
+            self.backend = HipBackend(old.device, wl, self.rank, self.world, old.pair_cap * 2, old.part_cap)
+            del old
+            self._tails = None
+            self._recv = None
+            self.step()
+        raise _lib.BesstDeviceError('exchange region overflow persists after growing the regions 64x')
 
     def sizes(self):
         """Global (tuples, edge rows) summed over ranks - synchronises."""
