@@ -85,9 +85,9 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
           '(filtered out from scaffolding): ', counter.non_unique, file=Information)
     print('Reads with too large insert size from "USEFUL READS" (filtered out): ',
           counter.reads_with_too_long_insert, file=Information)
-    print('Initial number of edges in G (the graph with large contigs): ', len(G.edges()), file=Information)
+    print('Initial number of edges in G (the graph with large contigs): ', G.number_of_edges(), file=Information)
     print('Initial number of edges in G_prime (the full graph of all contigs before removal of repats): ',
-          len(G_prime.edges()), file=Information)
+          G_prime.number_of_edges(), file=Information)
     if param.detect_duplicate:
         print('Number of duplicated reads indicated and removed: ', counter.nr_of_duplicates, file=Information)
 
@@ -108,12 +108,12 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
     if param.first_lib:
         Contigs, Scaffolds, G = RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs,
                                                small_scaffolds, Information)
-    print('Number of edges in G (after repeat removal): ', len(G.edges()), file=Information)
-    print('Number of edges in G_prime (after repeat removal): ', len(G_prime.edges()), file=Information)
+    print('Number of edges in G (after repeat removal): ', G.number_of_edges(), file=Information)
+    print('Number of edges in G_prime (after repeat removal): ', G_prime.number_of_edges(), file=Information)
 
     RemoveBugEdges(G, G_prime, fishy_rows, param, Information)
-    print('Number of edges in G (after filtering for buggy flag stats reporting): ', len(G.edges()), file=Information)
-    print('Number of edges in G_prime  (after filtering for buggy flag stats reporting): ', len(G_prime.edges()),
+    print('Number of edges in G (after filtering for buggy flag stats reporting): ', G.number_of_edges(), file=Information)
+    print('Number of edges in G_prime  (after filtering for buggy flag stats reporting): ', G_prime.number_of_edges(),
           file=Information)
 
     infer_spurious_link_count_threshold(G_prime, param)
@@ -135,7 +135,7 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
     if not param.no_score:
         GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, 'G', ctx)
     print('Number of edges in G_prime  (after removing edges under -e threshold (if not specified, default is '
-          '-e 3): ', len(G_prime.edges()), file=Information)
+          '-e 3): ', G_prime.number_of_edges(), file=Information)
     print('\n -------------------------------------------------------------\n', file=Information)
     print('Nr of contigs/scaffolds included in this pass: ' + str(len(Scaffolds) + len(small_scaffolds)),
           file=Information)

@@ -34,6 +34,14 @@ class Graph(_BaseGraph):
     def edges(self, nbunch=None, data=False):
         return list(_EdgeView(self)(nbunch=nbunch, data=data))
 
+    def number_of_edges(self, u=None, v=None):
+        """O(nodes) edge count (the base class goes through degree(), which this facade returns as a dict)."""
+        if u is not None:
+            return 1 if v in self._adj[u] else 0
+        total = sum(len(nbrs) for nbrs in self._adj.values())
+        loops = sum(1 for n, nbrs in self._adj.items() if n in nbrs)
+        return (total + loops) // 2
+
     def nodes_iter(self, data=False):
         return iter(_NodeView(self)(data=data))
 

@@ -19,3 +19,17 @@ G, Gp = CreateGraph.PE({}, {}, p.information_file, C_dict, p, {}, {}, batch); t4
 print('records %d  upload %.3f s  get_metrics %.3f s  PE %.3f s' % (len(batch), t1 - t0, t2 - t1, t4 - t3))
 print('G edges', len(G.edges()), 'Gp edges', len(Gp.edges()), 'mean/sd', p.mean_ins_size, p.std_dev_ins_size)
 import cProfile, pstats
+if os.environ.get('PROFILE_PE'):
+    p2 = Parameter.parameter()
+    for k, v in vars(p).items():
+        if k not in ('information_file',):
+            try:
+                setattr(p2, k, v)
+            except Exception:
+                pass
+    p2.scaffold_indexer = 1; p2.first_lib = True; p2.information_file = io.StringIO()
+    C2 = {n: 'A' * l for n, l in zip(batch.references, batch.lengths)}
+    pr = cProfile.Profile(); pr.enable()
+    CreateGraph.PE({}, {}, p2.information_file, C2, p2, {}, {}, batch)
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
