@@ -27,7 +27,7 @@ import numpy as np
 from . import Contig, Scaffold, e_nr_links, session
 from . import GenerateOutput as GO
 from .Parameter import counters
-from .device import CLS_ABSENT, CLS_LARGE, CLS_SMALL, MASK_G, MASK_GPRIME
+from .device import CLS_LARGE, CLS_SMALL, MASK_G, MASK_GPRIME
 from .mathstats_compat import MaxObsDistr
 from .nxcompat import Graph
 

@@ -1,7 +1,6 @@
 """Helpers shared by the GPU parity tests: run the device graph build and the oracle side by side."""
 import numpy as np
 
-from oracle import py_oracle as O
 from besst_amd import device
 
 

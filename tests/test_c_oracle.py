@@ -4,7 +4,6 @@ import pytest
 
 from oracle import c_oracle as CO
 from oracle import py_oracle as O
-from tests import dist_util as DU
 from tests import golden_util as GU
 from tests.test_gpu_graph_build import _oracle_inputs
 

@@ -7,7 +7,6 @@ fixed-capacity regions, source-ordered unpack, coverage/counter all-reduce - is 
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

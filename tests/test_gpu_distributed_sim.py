@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('world,orientation', [(2, 'fr'), (3, 'rf'), (8, 'fr')])
 def test_simulated_ranks_match_oracle(world, orientation):
     import torch
-    from besst_amd import distributed, synth, workload
+    from besst_amd import distributed, workload
     wl = workload.make('C2', 0, pairs=150000, nc=700)
     if orientation == 'rf':
         wl = workload.make('C3', 0, pairs=150000, nc=300)
