@@ -466,7 +466,10 @@ __device__ __forceinline__ uint4 pack_entry(const Eval& e) {
 
 constexpr int kOrdWaves = 4;                              // waves of an ordered_kernel workgroup
 constexpr int kOrdThreads = kOrdWaves * 64;
-constexpr int kAhead = 4;                                 // chunks a wave evaluates per round, all gathers in flight
+#ifndef BESST_ORD_AHEAD
+#define BESST_ORD_AHEAD 4
+#endif
+constexpr int kAhead = BESST_ORD_AHEAD;                                 // chunks a wave evaluates per round, all gathers in flight
 constexpr int kOrdRound = kOrdWaves * kAhead * 64;        // candidates per round (1024): 16 KB of entries in LDS
 
 __global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
