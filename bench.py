@@ -361,20 +361,15 @@ def overlapped_throughput(runner, wl, device, in_flight, steps):
     the kernel, so the roofline object always comes from the one-pass-at-a-time region."""
     import torch
     from besst_amd import pipeline
-    streams = [torch.cuda.Stream(device) for _ in range(in_flight)]
-    builders = []
-    for st in streams:
-        with torch.cuda.stream(st):
-            gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], runner.rec.n, runner.cap)
-            gb.set_contigs(**wl['table'])
-            builders.append(gb)
+    pool = pipeline.PassPool(device, wl['asm'].nc, wl['node_bits'], wl['lib'], runner.rec.n, runner.cap, in_flight)
+    pool.set_contigs(**wl['table'])
     torch.cuda.synchronize()
     recs = runner.recs
+    builders = pool.builders
 
     def run(k):
         for i in range(k):
-            with torch.cuda.stream(streams[i % in_flight]):
-                builders[i % in_flight].step(recs[i % len(recs)])
+            pool.submit(recs[i % len(recs)])
     run(2 * in_flight)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -260,6 +260,42 @@ class DeviceMetricsSampler(object):
         return self.samples, self.state
 
 
+class PassPool(object):
+    """Independent graph-build passes in flight on separate HIP streams (one builder and workspace per slot).
+
+    A pass over a sparse (paired-end) library is one bandwidth-bound kernel followed by a chain of short,
+    latency-bound ones; with several libraries to process (BASELINE configs 4 and 5 have two and three), the short
+    kernels of one pass run under the streaming kernel of another.  ``submit(rec)`` enqueues a pass on the next slot
+    and returns that slot's builder, whose outputs are valid once its stream - or the device - has been
+    synchronised and until the slot is reused ``in_flight`` submissions later."""
+
+    def __init__(self, device, n_contigs, node_bits, lib, record_capacity, tuple_capacity, in_flight=3):
+        self.device = device
+        self.streams = [torch.cuda.Stream(device) for _ in range(max(1, int(in_flight)))]
+        self.builders = []
+        for st in self.streams:
+            with torch.cuda.stream(st):
+                self.builders.append(DeviceGraphBuilder(device, n_contigs, node_bits, lib, record_capacity,
+                                                        tuple_capacity))
+        self._next = 0
+
+    def set_contigs(self, **table):
+        for st, gb in zip(self.streams, self.builders):
+            with torch.cuda.stream(st):
+                gb.set_contigs(**table)
+
+    def submit(self, rec):
+        slot = self._next % len(self.builders)
+        self._next += 1
+        with torch.cuda.stream(self.streams[slot]):
+            self.builders[slot].step(rec)
+        return self.builders[slot]
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+
 def prof_collect():
     lib = _lib.load()
     n = lib.besst_prof_slots()

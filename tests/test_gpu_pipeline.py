@@ -74,3 +74,33 @@ def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
     assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
     assert np.array_equal(get(gb.obs_hi, n, np.int32).astype(np.int64), want['obs_hi'])
+
+
+def test_pass_pool_overlapped_passes_are_independent():
+    """Three different record sets in flight on three streams, twice over: every slot ends with exactly the edge
+    table of the record set it processed last."""
+    import numpy as np
+    import torch
+    from besst_amd import pipeline, workload
+    from oracle import c_oracle as CO
+    dev = torch.device('cuda', 0)
+    wls = [workload.make('C2', 0, pairs=300000, nc=700, seed_offset=k) for k in range(3)]
+    base = wls[0]
+    recs = [pipeline.DeviceRecords(w['batch'], dev) for w in wls]
+    cap = max(r.n for r in recs)
+    pool = pipeline.PassPool(dev, base['asm'].nc, base['node_bits'], base['lib'], cap, cap, in_flight=3)
+    pool.set_contigs(**base['table'])
+    last = {}
+    for i in range(6):
+        k = (i * 2 + 1) % 3                      # slots see different record sets in the two rounds
+        gb = pool.submit(recs[k])
+        last[id(gb)] = (gb, k)
+    pool.synchronize()
+    assert len(last) == 3
+    for gb, k in last.values():
+        table = gb.fetch_table()
+        keys, payload, aligned, ctr = CO.record_loop(wls[k]['batch'], base['table'], base['lib'], base['node_bits'])
+        rows = CO.edge_rows(keys, payload)
+        assert np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
+        assert np.array_equal(table.obs_lo.astype(np.int64), rows['obs_lo'])
+        assert gb.aligned.cpu().numpy().tolist() == aligned.tolist()
