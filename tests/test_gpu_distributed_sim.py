@@ -200,3 +200,54 @@ def test_simulated_ranks_score_their_own_edges():
         want = {int(table.key[row]): (float(gap[i]), float(sd0[i]), int(ks[i]), int(flags[i]))
                 for i, row in enumerate(rows)}
     assert len(want) > 50 and got == want
+
+
+@pytest.mark.parametrize('flags', [dict(detect_duplicate=False), dict(extend_paths=False), dict(no_score=True),
+                                   dict(detect_duplicate=False, extend_paths=False)])
+def test_simulated_ranks_library_flags(flags):
+    """The slice-boundary carry with the other CreateEdge regimes: duplicates kept (-d off), no G' (second CreateEdge
+    call absent), no_score (G' only)."""
+    import torch
+    from besst_amd import distributed, workload
+    wl = workload.make('C2', 0, pairs=120000, nc=500)
+    wl['lib'] = dict(wl['lib'], **flags)
+    dev = torch.device('cuda', 0)
+    world = 3
+    parts = DU.split_batch(wl['batch'], world)
+    backends = []
+    for r in range(world):
+        sub = dict(wl)
+        sub['batch'] = parts[r]
+        backends.append(distributed.HipBackend(dev, sub, r, world, 8192))
+    tails = []
+    for b in backends:
+        b.reset()
+        b.classify_scan()
+        tails.append(b.classify_tail().clone())
+        assert torch.equal(b.classify_tail_early(), tails[-1])
+    tails = torch.cat(tails)
+    sends = []
+    for b in backends:
+        b.classify_emit(tails)
+        sends.append(b.partition().clone())
+    region = backends[0].region
+    for r, b in enumerate(backends):
+        b.unpack(torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)]))
+        b.reduce()
+    torch.cuda.synchronize()
+    want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+    counters = sum(b.counter_words.cpu() for b in backends)
+    assert counters.tolist() == [want.count, want.non_unique, want.non_unique_for_scaf, want.nr_of_duplicates,
+                                 want.too_long, want.fishy_reads, len(want.tuples), want.n_reach]
+    merged = {}
+    for b in backends:
+        rows = DU.rows_from_table(b.local_table())
+        for k in rows:
+            if k & 1:
+                rows[k]['lo'] = [0] * rows[k]['n']
+                rows[k]['hi'] = [0] * rows[k]['n']
+        merged.update(rows)
+    for k, r in want_rows.items():
+        if k & 1:
+            r['s'] = r['s2'] = 0
+    assert merged == want_rows
