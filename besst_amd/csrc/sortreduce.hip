@@ -326,13 +326,15 @@ __device__ __forceinline__ void bitonic_pairs(KP k, IP x, int np) {
     }
 }
 
+// kPacked: the words are key << idx_bits | stream index (unique), one compare per pair and no index array.
+template <bool kPacked>
 __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ n_ptr,
                                                           uint64_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ big_idx) {
     __shared__ uint64_t s_k[kBucketLds];
-    __shared__ uint32_t s_x[kBucketLds];
+    __shared__ uint32_t s_x[kPacked ? 1 : kBucketLds];
     // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
     const uint32_t n_all = *n_ptr;
     const uint32_t s0 = bucket_start[blockIdx.x], e0 = bucket_start[blockIdx.x + 1];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
     if (n <= kBucketLds) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             s_k[i] = keys[s0 + i];
-            s_x[i] = idx[s0 + i];
+            if (!kPacked) s_x[i] = idx[s0 + i];
         }
         __syncthreads();
         // rank sort: element i goes to position #{j : (key_j, idx_j) < (key_i, idx_i)}.  O(n^2) LDS broadcast reads
@@ -352,11 +354,16 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
         // that beats a bitonic network's 28-45 barrier-separated stages.
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t ki = s_k[i];
-            const uint32_t xi = s_x[i];
             int rank = 0;
-            for (int j = 0; j < n; ++j) rank += pair_less(s_k[j], s_x[j], ki, xi) ? 1 : 0;
-            keys[s0 + rank] = ki;
-            idx[s0 + rank] = xi;
+            if (kPacked) {
+                for (int j = 0; j < n; ++j) rank += s_k[j] < ki ? 1 : 0;
+                keys[s0 + rank] = ki;
+            } else {
+                const uint32_t xi = s_x[i];
+                for (int j = 0; j < n; ++j) rank += pair_less(s_k[j], s_x[j], ki, xi) ? 1 : 0;
+                keys[s0 + rank] = ki;
+                idx[s0 + rank] = xi;
+            }
         }
     } else {
         // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
@@ -364,13 +371,13 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
         uint32_t* gx = big_idx + 2 * (size_t)s0;
         for (int i = threadIdx.x; i < np; i += blockDim.x) {
             gk[i] = i < n ? keys[s0 + i] : ~0ull;
-            gx[i] = i < n ? idx[s0 + i] : ~0u;
+            gx[i] = kPacked ? 0u : (i < n ? idx[s0 + i] : ~0u);
         }
         __syncthreads();
         bitonic_pairs(gk, gx, np);
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             keys[s0 + i] = gk[i];
-            idx[s0 + i] = gx[i];
+            if (!kPacked) idx[s0 + i] = gx[i];
         }
     }
 }
@@ -693,12 +700,19 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         // small stream: one MSD pass on the top 11 significant bits, then every bucket sorts itself
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
         const DigitSel ds{0, shift, 0, 1u, kMsdBits};
+        int idx_bits = 1;
+        while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
+        packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;   // key and stream index in one word (always, in practice)
         launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
-                              row_n, zsum, zsq, w.bucket_start);
+                              row_n, zsum, zsq, w.bucket_start, packed_bits);
         if (shift > 0) {
             ProfScope ps(s, kProfBucketSort);
-            hipLaunchKernelGGL(bucket_sort_kernel, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0], w.idx[0],
-                               w.bucket_start, n_tuples, w.big_keys, w.big_idx);
+            if (packed_bits)
+                hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
+                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx);
+            else
+                hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
+                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx);
         }
         kin = w.keys[0];
         iin = w.idx[0];
