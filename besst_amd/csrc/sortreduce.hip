@@ -229,6 +229,30 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     __syncthreads();
 
+    // The MSD partition of packed words need not be stable (the words are unique and every bucket is fully sorted
+    // afterwards): an LDS atomic per key replaces the match-any ranking and the per-wave offset pass.
+    const bool unstable = packed_bits != 0 && bucket_start != nullptr;
+    if (unstable) {
+        uint32_t dig_rank[kSortItems];
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t i = wbase + r * 64 + lane;
+            dig_rank[r] = 0;
+            if (i < n) {
+                const uint32_t d = digit_of(key[r], ds);
+                dig_rank[r] = d | (atomicAdd(&s_whist[0][d], 1u) << BITS);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t i = wbase + r * 64 + lane;
+            if (i < n) {
+                const uint32_t dst = s_base[dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
+                keys_out[dst] = kFirst ? ((key[r] << packed_bits) | idx[r]) : key[r];
+            }
+        }
+        return;
+    }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t dig_rank[kSortItems];   // digit | rank << BITS
 #pragma unroll
@@ -705,7 +729,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;   // key and stream index in one word (always, in practice)
         launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
                               row_n, zsum, zsq, w.bucket_start, packed_bits);
-        if (shift > 0) {
+        if (shift > 0 || packed_bits) {   // the packed partition is unstable: buckets always need their sort
             ProfScope ps(s, kProfBucketSort);
             if (packed_bits)
                 hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
