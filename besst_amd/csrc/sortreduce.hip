@@ -356,17 +356,24 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ n_ptr,
                                                           uint64_t* __restrict__ big_keys,
-                                                          uint32_t* __restrict__ big_idx) {
+                                                          uint32_t* __restrict__ big_idx,
+                                                          uint32_t* __restrict__ bucket_rows, int packed_bits) {
     __shared__ uint64_t s_k[kBucketLds];
     __shared__ uint32_t s_x[kPacked ? 1 : kBucketLds];
+    __shared__ uint64_t s_sorted[kPacked ? kBucketLds : 1];   // packed: sorted copy, to count the bucket's distinct keys
+    __shared__ uint32_t s_heads;
     // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
     const uint32_t n_all = *n_ptr;
     const uint32_t s0 = bucket_start[blockIdx.x], e0 = bucket_start[blockIdx.x + 1];
-    if (n_all == 0) return;
-    const int n = (int)(e0 - s0);
-    if (n <= 1) return;
+    const int n = n_all == 0 ? 0 : (int)(e0 - s0);
+    if (n <= 1) {                     // nothing to sort; a single tuple is a single edge row
+        if (kPacked && threadIdx.x == 0) bucket_rows[blockIdx.x] = (uint32_t)n;
+        return;
+    }
+    if (threadIdx.x == 0) s_heads = 0;
     int np = 2;
     while (np < n) np <<= 1;
+    uint32_t heads = 0;               // packed: distinct keys of the bucket = its edge rows (bucket_reduce_kernel)
     if (n <= kBucketLds) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             s_k[i] = keys[s0 + i];
@@ -382,12 +389,18 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             if (kPacked) {
                 for (int j = 0; j < n; ++j) rank += s_k[j] < ki ? 1 : 0;
                 keys[s0 + rank] = ki;
+                s_sorted[rank] = ki;
             } else {
                 const uint32_t xi = s_x[i];
                 for (int j = 0; j < n; ++j) rank += pair_less(s_k[j], s_x[j], ki, xi) ? 1 : 0;
                 keys[s0 + rank] = ki;
                 idx[s0 + rank] = xi;
             }
+        }
+        if (kPacked) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x)
+                heads += (i == 0 || (s_sorted[i] >> packed_bits) != (s_sorted[i - 1] >> packed_bits)) ? 1u : 0u;
         }
     } else {
         // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
@@ -402,7 +415,111 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             keys[s0 + i] = gk[i];
             if (!kPacked) idx[s0 + i] = gx[i];
+            if (kPacked) heads += (i == 0 || (gk[i] >> packed_bits) != (gk[i - 1] >> packed_bits)) ? 1u : 0u;
         }
+    }
+    if (kPacked) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) heads += (uint32_t)__shfl_xor((int)heads, d, 64);
+        if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&s_heads, heads);
+        __syncthreads();
+        if (threadIdx.x == 0) bucket_rows[blockIdx.x] = s_heads;
+    }
+}
+
+// One workgroup per bucket of the packed MSD path: the bucket's tuples are sorted and complete (all tuples of a key
+// share the bucket), so its edge rows are local.  Row numbering needs only the row counts of the buckets before
+// it (bucket_rows, written by bucket_sort_kernel): no head-count launch, no cross-workgroup row accumulation.
+// Per chunk of 256 tuples: head flags -> row index (ballot scan), observation gather, run-segmented wave sums
+// (one atomic triple per row and wave, on accumulators cleared by the histogram pass).
+__global__ __launch_bounds__(256) void bucket_reduce_kernel(
+    const uint64_t* __restrict__ words, const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
+    const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_rows, int packed_bits,
+    uint32_t* __restrict__ n_rows, uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
+    uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
+    unsigned long long* __restrict__ row_sum_sq, uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset,
+    int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map) {
+    __shared__ uint32_t s_part[4];
+    __shared__ int s_wheads[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n_all = *n_ptr;
+    const uint32_t s0 = bucket_start[b], e0 = bucket_start[b + 1];
+    if (n_all == 0) {
+        if (b == 0 && t == 0) *n_rows = 0;
+        return;
+    }
+    uint32_t pre = 0;
+    for (uint32_t bb = t; bb < b; bb += 256) pre += bucket_rows[bb];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pre += (uint32_t)__shfl_xor((int)pre, d, 64);
+    if (lane == 0) s_part[wave] = pre;
+    __syncthreads();
+    const uint32_t base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (b == gridDim.x - 1 && t == 0) *n_rows = base + bucket_rows[b];
+    const int n = (int)(e0 - s0);
+    if (n == 0) return;
+    const uint64_t idx_mask = (1ull << packed_bits) - 1ull;
+    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    int64_t rows_done = (int64_t)base;            // rows that start before the current chunk
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int j = c0 + t;
+        const bool live = j < n;
+        const uint32_t i = s0 + (uint32_t)j;
+        const uint64_t w = live ? words[i] : ~0ull;
+        const uint64_t key = w >> packed_bits;
+        const uint32_t src = (uint32_t)(w & idx_mask);
+        const uint64_t pkey = (live && j > 0) ? words[i - 1] >> packed_bits : ~key;
+        const bool head = live && (j == 0 || key != pkey);
+        const unsigned long long hmask = __ballot(head);
+        if (lane == 0) s_wheads[wave] = __popcll(hmask);
+        __syncthreads();
+        int wpre = 0, ctot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < wave) wpre += s_wheads[q];
+            ctot += s_wheads[q];
+        }
+        // row of this item (rows are numbered by their heads; an item before the chunk's first head continues the
+        // last row of the previous chunk)
+        const int64_t row = rows_done + wpre + __popcll(hmask & le_mask) - 1;
+        uint64_t pl = 0;
+        if (live) pl = payload[src];
+        const uint32_t lo = (uint32_t)pl, hi = (uint32_t)(pl >> 32);
+        const int32_t o_lo = (int32_t)lo, o_hi = (int32_t)(hi & 0x3fffffffu);
+        if (live) {
+            obs_lo[i] = o_lo;
+            obs_hi[i] = o_hi;
+            if (head) {
+                row_key[row] = key;
+                row_mask[row] = hi >> 30;
+                row_first[row] = first_map ? first_map[src] : src;
+                row_offset[row] = i;
+            }
+        }
+        // run-segmented wave sums: a run = the lanes of one row inside this wave
+        {
+            const unsigned long long starts = hmask | 1ull;                 // lane 0 starts a run (maybe a continued row)
+            const int start = 63 - __clzll((long long)(starts & le_mask));
+            uint32_t cn = live ? 1u : 0u;
+            unsigned long long cs = live ? (unsigned long long)((long long)o_lo + o_hi) : 0ull;
+            unsigned long long cq = cs * cs;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t on = (uint32_t)__shfl_up((int)cn, d, 64);
+                const unsigned long long os = __shfl_up(cs, d, 64), oq = __shfl_up(cq, d, 64);
+                if (lane - d >= start) { cn += on; cs += os; cq += oq; }
+            }
+            const unsigned long long lmask = __ballot(live);
+            const bool tail = live && (lane == 63 || !((lmask >> (lane + 1)) & 1ull) || ((hmask >> (lane + 1)) & 1ull));
+            if (tail) {
+                atomicAdd(&row_n[row], cn);
+                atomicAdd(&row_sum[row], cs);
+                atomicAdd(&row_sum_sq[row], cq);
+            }
+        }
+        rows_done += ctot;
+        __syncthreads();                                                    // s_wheads is reused by the next chunk
     }
 }
 
@@ -628,6 +745,7 @@ struct RedWorkspace {
     uint32_t* blk_heads;
     uint32_t* blk_base;
     uint32_t* bucket_start;
+    uint32_t* bucket_rows;
     uint64_t* big_keys;
     uint32_t* big_idx;
     uint32_t stride;
@@ -654,6 +772,7 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up((kMaxRadix + 1) * 4, 256);
+    w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     // in-place scratch of the bucket sort (only streams that take the MSD path can use it)
     const size_t big = nb_sort <= (size_t)kScanFreeMaxBlocks ? 2 * (size_t)cap + 8 : 8;
     w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
@@ -733,10 +852,19 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             ProfScope ps(s, kProfBucketSort);
             if (packed_bits)
                 hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
-                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx);
+                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
             else
                 hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
-                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx);
+                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0);
+        }
+        if (packed_bits) {
+            // rows are local to a bucket: one launch instead of head counts + tile-based reduction
+            ProfScope ps(s, kProfRowReduce);
+            hipLaunchKernelGGL(bucket_reduce_kernel, dim3(1u << kMsdBits), dim3(256), 0, s, w.keys[0], payload, n_tuples,
+                               w.bucket_start, w.bucket_rows, packed_bits, n_rows, row_key, row_mask, row_n, zsum, zsq,
+                               row_first, row_offset, obs_lo, obs_hi, first_map);
+            BESST_HIP_TRY(hipGetLastError());
+            return BESST_OK;
         }
         kin = w.keys[0];
         iin = w.idx[0];
