@@ -967,6 +967,10 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((n + kClsTile - 1) / kClsTile);
     auto* ctr = reinterpret_cast<unsigned long long*>(counters);
+    // (Folding the stitch into compact_kernel - every workgroup working its own offset out from the summaries of the
+    // blocks before it - was built three ways (scans, scan-free with a walk-back, batched plane loads) and always
+    // landed at 15-17 us against 10 + 5 us for the two launches: 1221 workgroups re-reading the same 350 cache lines
+    // is an L2 hot spot.  The single-workgroup stitch stays.)
     {
         ProfScope ps(s, kProfStitch);
         hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
