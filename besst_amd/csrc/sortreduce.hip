@@ -350,17 +350,40 @@ __device__ __forceinline__ void bitonic_pairs(KP k, IP x, int np) {
     }
 }
 
+__device__ __forceinline__ void bitonic_words(uint64_t* k, int np) {          // unique 64-bit words, in LDS
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint64_t ka = k[i], kb = k[p];
+                    const bool up = (i & size) == 0;
+                    if ((kb < ka) == up) { k[i] = kb; k[p] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // kPacked: the words are key << idx_bits | stream index (unique), one compare per pair and no index array.
-template <bool kPacked>
+// kCap: LDS capacity in tuples.  512 serves the small streams (buckets of ~100: rank sort only, 8 KB of LDS, every
+// bucket of the launch resident at once); 4096 serves streams of up to 4 M tuples, whose buckets of a few hundred to
+// a few thousand words take an in-LDS bitonic network above 256 words (the O(n^2) rank sort loses there).
+template <bool kPacked, int kCap>
 __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ n_ptr,
                                                           uint64_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ big_idx,
                                                           uint32_t* __restrict__ bucket_rows, int packed_bits) {
-    __shared__ uint64_t s_k[kBucketLds];
-    __shared__ uint32_t s_x[kPacked ? 1 : kBucketLds];
-    __shared__ uint64_t s_sorted[kPacked ? kBucketLds : 1];   // packed: sorted copy, to count the bucket's distinct keys
+    // largest bucket the rank sort takes: n^2 / 256 LDS reads per thread beat the barrier-separated bitonic stages up
+    // to ~400 words (600 k tuples: 43 vs 60 us for the launch; 2 M tuples: 206 vs 152 us)
+    constexpr int kRank = kCap <= 512 ? kCap : 384;
+    static_assert(kPacked || kCap <= 512, "unpacked pairs are only sorted in the small-stream configuration");
+    __shared__ uint64_t s_k[kCap];
+    __shared__ uint32_t s_x[kPacked ? 1 : kCap];
+    __shared__ uint64_t s_sorted[kPacked ? kRank : 1];   // packed: sorted copy, to count the bucket's distinct keys
     __shared__ uint32_t s_heads;
     // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
     const uint32_t n_all = *n_ptr;
@@ -374,7 +397,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
     int np = 2;
     while (np < n) np <<= 1;
     uint32_t heads = 0;               // packed: distinct keys of the bucket = its edge rows (bucket_reduce_kernel)
-    if (n <= kBucketLds) {
+    if (n <= kRank) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             s_k[i] = keys[s0 + i];
             if (!kPacked) s_x[i] = idx[s0 + i];
@@ -401,6 +424,14 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             __syncthreads();
             for (int i = threadIdx.x; i < n; i += blockDim.x)
                 heads += (i == 0 || (s_sorted[i] >> packed_bits) != (s_sorted[i - 1] >> packed_bits)) ? 1u : 0u;
+        }
+    } else if (kPacked && n <= kCap) {
+        for (int i = threadIdx.x; i < np; i += blockDim.x) s_k[i] = i < n ? keys[s0 + i] : ~0ull;
+        __syncthreads();
+        bitonic_words(s_k, np);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            keys[s0 + i] = s_k[i];
+            heads += (i == 0 || (s_k[i] >> packed_bits) != (s_k[i - 1] >> packed_bits)) ? 1u : 0u;
         }
     } else {
         // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
@@ -753,6 +784,11 @@ struct RedWorkspace {
 };
 
 constexpr int kMaxRadix = 1 << 11;
+// Largest stream (in sort tiles) that takes the MSD + bucket path when its words can be packed: 1 M tuples, i.e.
+// buckets of ~500 words (measured: 300 k tuples 132 -> 53 us, 600 k 149 -> 83 us, 1 M 170 -> 130 us; at 2 M the
+// per-bucket LDS sorts cost what five LSD passes do).  Up to 64 tiles the partition uses the scan-free table,
+// beyond that the row scan.
+constexpr int kMsdMaxBlocks = 256;
 
 RedWorkspace carve(void* ws, int64_t cap) {
     RedWorkspace w;
@@ -764,7 +800,8 @@ RedWorkspace carve(void* ws, int64_t cap) {
     for (int j = 0; j < 2; ++j) { w.idx[j] = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)cap * 4, 256); }
     w.stride = (uint32_t)nb_sort;
     // the wide-digit path is only taken for small streams, the 8-bit path for any size
-    const size_t table_entries = nb_sort <= (size_t)kWideDigitMaxBlocks
+    const size_t wide_max = (size_t)(kWideDigitMaxBlocks > kMsdMaxBlocks ? kWideDigitMaxBlocks : kMsdMaxBlocks);
+    const size_t table_entries = nb_sort <= wide_max
                                      ? (nb_sort > (size_t)kScanFreeMaxBlocks ? nb_sort : (size_t)kScanFreeMaxBlocks) * kMaxRadix
                                      : nb_sort * kRadix;
     w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
@@ -774,7 +811,7 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up((kMaxRadix + 1) * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     // in-place scratch of the bucket sort (only streams that take the MSD path can use it)
-    const size_t big = nb_sort <= (size_t)kScanFreeMaxBlocks ? 2 * (size_t)cap + 8 : 8;
+    const size_t big = nb_sort <= (size_t)kMsdMaxBlocks ? 2 * (size_t)cap + 8 : 8;
     w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
     w.big_idx = reinterpret_cast<uint32_t*>(p + off); off += align_up(big * 4, 256);
     w.total = off;
@@ -839,23 +876,28 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;
     int packed_bits = 0;
-    if (nb_sort <= (uint32_t)kScanFreeMaxBlocks) {
-        // small stream: one MSD pass on the top 11 significant bits, then every bucket sorts itself
+    int cap_idx_bits = 1;
+    while (((int64_t)1 << cap_idx_bits) < cap) ++cap_idx_bits;
+    const bool packable = key_bits + cap_idx_bits <= 64;
+    if (nb_sort <= (uint32_t)kScanFreeMaxBlocks || (packable && nb_sort <= (uint32_t)kMsdMaxBlocks)) {
+        // one MSD pass on the top 11 significant bits, then every bucket sorts and reduces itself
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
         const DigitSel ds{0, shift, 0, 1u, kMsdBits};
-        int idx_bits = 1;
-        while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
-        packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;   // key and stream index in one word (always, in practice)
+        packed_bits = packable ? cap_idx_bits : 0;    // key and stream index in one word (always, in practice)
         launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
                               row_n, zsum, zsq, w.bucket_start, packed_bits);
         if (shift > 0 || packed_bits) {   // the packed partition is unstable: buckets always need their sort
             ProfScope ps(s, kProfBucketSort);
-            if (packed_bits)
-                hipLaunchKernelGGL(bucket_sort_kernel<true>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
-                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
+            const dim3 grid(1u << kMsdBits), block(kBucketThreads);
+            if (!packed_bits)
+                hipLaunchKernelGGL((bucket_sort_kernel<false, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0);
+            else if (nb_sort <= (uint32_t)kScanFreeMaxBlocks)
+                hipLaunchKernelGGL((bucket_sort_kernel<true, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
             else
-                hipLaunchKernelGGL(bucket_sort_kernel<false>, dim3(1u << kMsdBits), dim3(kBucketThreads), 0, s, w.keys[0],
-                                   w.idx[0], w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0);
+                hipLaunchKernelGGL((bucket_sort_kernel<true, 4096>), grid, block, 0, s, w.keys[0], w.idx[0],
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
         }
         if (packed_bits) {
             // rows are local to a bucket: one launch instead of head counts + tile-based reduction
