@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     // afterwards): an LDS atomic per key replaces the match-any ranking and the per-wave offset pass.
     const bool unstable = packed_bits != 0 && bucket_start != nullptr;
     if (unstable) {
+        const uint64_t low_mask = ds.shift > 0 ? ((1ull << ds.shift) - 1ull) : 0ull;
         uint32_t dig_rank[kSortItems];
 #pragma unroll
         for (int r = 0; r < kSortItems; ++r) {
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             const uint32_t i = wbase + r * 64 + lane;
             if (i < n) {
                 const uint32_t dst = s_base[dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
-                keys_out[dst] = kFirst ? ((key[r] << packed_bits) | idx[r]) : key[r];
+                // the bucket number IS the digit: only the key bits below it travel in the word, so that keys of
+                // up to 64 - index bits + 11 bits still pack (bucket_reduce_kernel puts the digit back)
+                keys_out[dst] = ((key[r] & low_mask) << packed_bits) | idx[r];
             }
         }
         return;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
 // (one atomic triple per row and wave, on accumulators cleared by the histogram pass).
 __global__ __launch_bounds__(256) void bucket_reduce_kernel(
     const uint64_t* __restrict__ words, const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
-    const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_rows, int packed_bits,
+    const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ bucket_rows, int packed_bits, int msd_shift,
     uint32_t* __restrict__ n_rows, uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
     uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
     unsigned long long* __restrict__ row_sum_sq, uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset,
@@ -498,9 +501,9 @@ __global__ __launch_bounds__(256) void bucket_reduce_kernel(
         const bool live = j < n;
         const uint32_t i = s0 + (uint32_t)j;
         const uint64_t w = live ? words[i] : ~0ull;
-        const uint64_t key = w >> packed_bits;
+        const uint64_t key = ((uint64_t)b << msd_shift) | (w >> packed_bits);   // digit (= bucket) | low key bits
         const uint32_t src = (uint32_t)(w & idx_mask);
-        const uint64_t pkey = (live && j > 0) ? words[i - 1] >> packed_bits : ~key;
+        const uint64_t pkey = (live && j > 0) ? (((uint64_t)b << msd_shift) | (words[i - 1] >> packed_bits)) : ~key;
         const bool head = live && (j == 0 || key != pkey);
         const unsigned long long hmask = __ballot(head);
         if (lane == 0) s_wheads[wave] = __popcll(hmask);
@@ -878,7 +881,8 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     int packed_bits = 0;
     int cap_idx_bits = 1;
     while (((int64_t)1 << cap_idx_bits) < cap) ++cap_idx_bits;
-    const bool packable = key_bits + cap_idx_bits <= 64;
+    // the MSD digit is implied by the bucket, so only the key bits below it have to fit next to the index
+    const bool packable = (key_bits > kMsdBits ? key_bits - kMsdBits : 0) + cap_idx_bits <= 64;
     if (nb_sort <= (uint32_t)kScanFreeMaxBlocks || (packable && nb_sort <= (uint32_t)kMsdMaxBlocks)) {
         // one MSD pass on the top 11 significant bits, then every bucket sorts and reduces itself
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
@@ -903,7 +907,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             // rows are local to a bucket: one launch instead of head counts + tile-based reduction
             ProfScope ps(s, kProfRowReduce);
             hipLaunchKernelGGL(bucket_reduce_kernel, dim3(1u << kMsdBits), dim3(256), 0, s, w.keys[0], payload, n_tuples,
-                               w.bucket_start, w.bucket_rows, packed_bits, n_rows, row_key, row_mask, row_n, zsum, zsq,
+                               w.bucket_start, w.bucket_rows, packed_bits, shift, n_rows, row_key, row_mask, row_n, zsum, zsq,
                                row_first, row_offset, obs_lo, obs_hi, first_map);
             BESST_HIP_TRY(hipGetLastError());
             return BESST_OK;
