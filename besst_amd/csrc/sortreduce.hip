@@ -353,40 +353,28 @@ __device__ __forceinline__ void bitonic_pairs(KP k, IP x, int np) {
     }
 }
 
-__device__ __forceinline__ void bitonic_words(uint64_t* k, int np) {          // unique 64-bit words, in LDS
-    for (int size = 2; size <= np; size <<= 1) {
-        for (int j = size >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const uint64_t ka = k[i], kb = k[p];
-                    const bool up = (i & size) == 0;
-                    if ((kb < ka) == up) { k[i] = kb; k[p] = ka; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // kPacked: the words are key << idx_bits | stream index (unique), one compare per pair and no index array.
 // kCap: LDS capacity in tuples.  512 serves the small streams (buckets of ~100: rank sort only, 8 KB of LDS, every
-// bucket of the launch resident at once); 4096 serves streams of up to 4 M tuples, whose buckets of a few hundred to
-// a few thousand words take an in-LDS bitonic network above 256 words (the O(n^2) rank sort loses there).
+// bucket of the launch resident at once); 4096 serves streams of up to 4 M tuples, whose buckets of several hundred
+// to a few thousand words are first split in LDS by the next 8 key bits (counting sort: histogram, scan, grouped
+// copy) and then rank-sorted inside each group - linear instead of the n^2 of a plain rank sort or the n log^2 n and
+// ~50 barriers of a bitonic network (2 M tuples: 150 us with the network, 206 us with the plain rank sort).
 template <bool kPacked, int kCap>
 __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                           const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ n_ptr,
                                                           uint64_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ big_idx,
-                                                          uint32_t* __restrict__ bucket_rows, int packed_bits) {
-    // largest bucket the rank sort takes: n^2 / 256 LDS reads per thread beat the barrier-separated bitonic stages up
-    // to ~400 words (600 k tuples: 43 vs 60 us for the launch; 2 M tuples: 206 vs 152 us)
-    constexpr int kRank = kCap <= 512 ? kCap : 384;
+                                                          uint32_t* __restrict__ bucket_rows, int packed_bits,
+                                                          int sub_bits /* key bits below the MSD digit */) {
+    constexpr int kRank = kCap <= 512 ? kCap : 256;     // largest bucket the plain rank sort takes
     static_assert(kPacked || kCap <= 512, "unpacked pairs are only sorted in the small-stream configuration");
-    __shared__ uint64_t s_k[kCap];
+    static_assert(kBucketThreads == 256 || kCap <= 512, "the group scan of the two-level sort uses one thread per group");
+    __shared__ uint64_t s_k[kCap <= 512 ? kCap : 256];   // rank-sort input (buckets up to kRank words)
     __shared__ uint32_t s_x[kPacked ? 1 : kCap];
-    __shared__ uint64_t s_sorted[kPacked ? kRank : 1];   // packed: sorted copy, to count the bucket's distinct keys
+    // packed: sorted copy, to count the bucket's distinct keys (and the grouped copy of the two-level sort)
+    __shared__ uint64_t s_sorted[kPacked ? (kCap <= 512 ? kRank : kCap) : 1];
+    __shared__ uint32_t s_cnt[kCap <= 512 ? 1 : 256], s_cur[kCap <= 512 ? 1 : 256];
     __shared__ uint32_t s_heads;
     // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
     const uint32_t n_all = *n_ptr;
@@ -428,13 +416,51 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             for (int i = threadIdx.x; i < n; i += blockDim.x)
                 heads += (i == 0 || (s_sorted[i] >> packed_bits) != (s_sorted[i - 1] >> packed_bits)) ? 1u : 0u;
         }
-    } else if (kPacked && n <= kCap) {
-        for (int i = threadIdx.x; i < np; i += blockDim.x) s_k[i] = i < n ? keys[s0 + i] : ~0ull;
+    } else if (kPacked && kCap > 512 && n <= kCap) {
+        // two levels: group by the next 8 key bits (the grouped copy is the only large LDS array; the words are read
+        // from memory twice, the second time from cache), then rank inside the group
+        const int sub_shift = packed_bits + (sub_bits > 8 ? sub_bits - 8 : 0);
+        const uint32_t sub_mask = sub_bits >= 8 ? 255u : ((1u << sub_bits) - 1u);
+        if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        bitonic_words(s_k, np);
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            atomicAdd(&s_cnt[(uint32_t)(keys[s0 + i] >> sub_shift) & sub_mask], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 group sizes (one per thread; kBucketThreads == 256)
+            const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+            const uint32_t c = s_cnt[t];
+            uint32_t x = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)x, d, 64);
+                if (lane >= d) x += o;
+            }
+            __shared__ uint32_t s_wt[4];
+            if (lane == 63) s_wt[wave] = x;
+            __syncthreads();
+            uint32_t pre = 0;
+            for (int w = 0; w < wave; ++w) pre += s_wt[w];
+            s_cur[t] = pre + x - c;                      // group start, then the running cursor of the grouped copy
+            __syncthreads();
+        }
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            keys[s0 + i] = s_k[i];
-            heads += (i == 0 || (s_k[i] >> packed_bits) != (s_k[i - 1] >> packed_bits)) ? 1u : 0u;
+            const uint64_t w = keys[s0 + i];
+            s_sorted[atomicAdd(&s_cur[(uint32_t)(w >> sub_shift) & sub_mask], 1u)] = w;
+        }
+        __syncthreads();                                 // now s_cur[d] = END of group d, s_cnt[d] its size
+        for (int p = threadIdx.x; p < n; p += blockDim.x) {
+            const uint64_t w = s_sorted[p];
+            const uint64_t key_floor = (w >> packed_bits) << packed_bits;    // smallest word with the same key
+            const uint32_t d = (uint32_t)(w >> sub_shift) & sub_mask;
+            const int hi = (int)s_cur[d], lo = hi - (int)s_cnt[d];
+            int rank = lo, below_key = lo;
+            for (int q = lo; q < hi; ++q) {
+                const uint64_t v = s_sorted[q];
+                rank += v < w ? 1 : 0;
+                below_key += v < key_floor ? 1 : 0;
+            }
+            keys[s0 + rank] = w;                         // every read of keys[] happened before the barrier above
+            heads += rank == below_key ? 1u : 0u;        // no word of the same key precedes it: first of its edge row
         }
     } else {
         // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
@@ -787,11 +813,11 @@ struct RedWorkspace {
 };
 
 constexpr int kMaxRadix = 1 << 11;
-// Largest stream (in sort tiles) that takes the MSD + bucket path when its words can be packed: 1 M tuples, i.e.
-// buckets of ~500 words (measured: 300 k tuples 132 -> 53 us, 600 k 149 -> 83 us, 1 M 170 -> 130 us; at 2 M the
-// per-bucket LDS sorts cost what five LSD passes do).  Up to 64 tiles the partition uses the scan-free table,
-// beyond that the row scan.
-constexpr int kMsdMaxBlocks = 256;
+// Largest stream (in sort tiles) that takes the MSD + bucket path when its words can be packed: 4 M tuples, i.e.
+// buckets of ~2000 words, which still fit the two-level in-LDS sort (measured against the LSD passes: 300 k tuples
+// 132 -> 47 us, 1 M 170 -> 78 us, 2 M 246 -> 132 us, 4 M 487 -> 249 us).  Up to 64 tiles the partition uses the
+// scan-free table, beyond that the row scan.
+constexpr int kMsdMaxBlocks = 1024;
 
 RedWorkspace carve(void* ws, int64_t cap) {
     RedWorkspace w;
@@ -895,13 +921,13 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             const dim3 grid(1u << kMsdBits), block(kBucketThreads);
             if (!packed_bits)
                 hipLaunchKernelGGL((bucket_sort_kernel<false, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0);
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0, shift);
             else if (nb_sort <= (uint32_t)kScanFreeMaxBlocks)
                 hipLaunchKernelGGL((bucket_sort_kernel<true, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift);
             else
                 hipLaunchKernelGGL((bucket_sort_kernel<true, 4096>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits);
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift);
         }
         if (packed_bits) {
             // rows are local to a bucket: one launch instead of head counts + tile-based reduction
