@@ -816,8 +816,14 @@ constexpr int kMaxRadix = 1 << 11;
 // Largest stream (in sort tiles) that takes the MSD + bucket path when its words can be packed: 4 M tuples, i.e.
 // buckets of ~2000 words, which still fit the two-level in-LDS sort (measured against the LSD passes: 300 k tuples
 // 132 -> 47 us, 1 M 170 -> 78 us, 2 M 246 -> 132 us, 4 M 487 -> 249 us).  Up to 64 tiles the partition uses the
-// scan-free table, beyond that the row scan.
-constexpr int kMsdMaxBlocks = 1024;
+// scan-free table, beyond that the row scan.  (The same idea one size up - a wide partition of 32 768-tuple tiles and
+// one workgroup per ~20 k-word bucket, counting sort into the ping-pong buffer + LDS rank batches - was built and is
+// exact, but on real mate-pair data a group of equal 19-bit prefixes is a whole scaffold end with hundreds of
+// links, and ranking inside such groups made full C3 10.5 ms against 5.3 ms with the LSD passes.)
+#ifndef BESST_MSD_MAX_BLOCKS
+#define BESST_MSD_MAX_BLOCKS 1024
+#endif
+constexpr int kMsdMaxBlocks = BESST_MSD_MAX_BLOCKS;
 
 RedWorkspace carve(void* ws, int64_t cap) {
     RedWorkspace w;

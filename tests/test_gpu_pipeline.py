@@ -32,12 +32,15 @@ def test_dev_layer_matches_oracle():
 @pytest.mark.parametrize('n,key_bits,hub', [(50_000, 31, 20_000), (3_000, 9, 0), (200_000, 41, 700), (1, 31, 0),
                                             (600_000, 33, 100_000), (700_000, 41, 0), (1_000_000, 41, 3_000),
                                             (1_000_000, 45, 0), (1_500_000, 41, 0), (200_000, 57, 500),
-                                            (700_000, 55, 0), (1_000_000, 59, 0)])
+                                            (700_000, 55, 0), (1_000_000, 59, 0), (5_000_000, 41, 0),
+                                            (6_000_000, 37, 150_000)])
 def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     """The sort/reduce stage alone, on skewed keys: a hub bucket larger than the LDS sort capacity, fewer key bits
     than one digit, the small-stream MSD path (scan-free table, rank sort), the mid-size MSD path (row-scanned table,
     rank sort / LDS bitonic / global bitonic buckets), 57- and 55-bit keys that only pack because the MSD digit is implied by the bucket, a
-    stream whose words do not fit 64 bits even so (59-bit keys: LSD passes with index arrays) and a large one (packed LSD passes)."""
+    stream whose words do not fit 64 bits even so (59-bit keys: LSD passes with index arrays), and streams beyond 4 M
+    tuples (wide partition + per-bucket two-level sort; the hub case puts 150 000 tuples in ONE group of one bucket,
+    which takes the global bitonic fallback) and a large one (packed LSD passes)."""
     import ctypes as C
     import numpy as np
     import torch
