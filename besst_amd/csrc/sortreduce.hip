@@ -353,6 +353,22 @@ __device__ __forceinline__ void bitonic_pairs(KP k, IP x, int np) {
     }
 }
 
+__device__ __forceinline__ void bitonic_words(uint64_t* k, int np) {          // unique 64-bit words, in LDS
+    for (int size = 2; size <= np; size <<= 1) {
+        for (int j = size >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint64_t ka = k[i], kb = k[p];
+                    const bool up = (i & size) == 0;
+                    if ((kb < ka) == up) { k[i] = kb; k[p] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // kPacked: the words are key << idx_bits | stream index (unique), one compare per pair and no index array.
 // kCap: LDS capacity in tuples.  512 serves the small streams (buckets of ~100: rank sort only, 8 KB of LDS, every
 // bucket of the launch resident at once); 4096 serves streams of up to 4 M tuples, whose buckets of several hundred
@@ -443,6 +459,25 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             s_cur[t] = pre + x - c;                      // group start, then the running cursor of the grouped copy
             __syncthreads();
         }
+        // Ranking inside a group costs its size per word: fine for the ~10-100 words that share 19 key bits on a
+        // paired-end library, ruinous when one scaffold end carries hundreds of links (mate pairs at high
+        // coverage: 0.6 ms for 1.7 M tuples).  Such a bucket takes a bitonic network over all its words instead.
+        // The choice is made per bucket on the rank sort's cost, the sum of the squared group sizes, against ~256
+        // LDS operations per word for the network.
+        __shared__ uint32_t s_sumsq;
+        if (threadIdx.x == 0) s_sumsq = 0;
+        __syncthreads();
+        if (s_cnt[threadIdx.x] > 1u) atomicAdd(&s_sumsq, s_cnt[threadIdx.x] * s_cnt[threadIdx.x]);
+        __syncthreads();
+        if (s_sumsq > 256u * (uint32_t)n) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) s_sorted[i] = i < n ? keys[s0 + i] : ~0ull;
+            __syncthreads();
+            bitonic_words(s_sorted, np);
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                keys[s0 + i] = s_sorted[i];
+                heads += (i == 0 || (s_sorted[i] >> packed_bits) != (s_sorted[i - 1] >> packed_bits)) ? 1u : 0u;
+            }
+        } else {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t w = keys[s0 + i];
             s_sorted[atomicAdd(&s_cur[(uint32_t)(w >> sub_shift) & sub_mask], 1u)] = w;
@@ -461,6 +496,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             }
             keys[s0 + rank] = w;                         // every read of keys[] happened before the barrier above
             heads += rank == below_key ? 1u : 0u;        // no word of the same key precedes it: first of its edge row
+        }
         }
     } else {
         // rare: bucket larger than LDS; padded copy at offset 2*s0 of a 2*capacity scratch (disjoint per bucket)
