@@ -370,8 +370,9 @@ __device__ __forceinline__ void bitonic_words(uint64_t* k, int np) {          //
 }
 
 // kPacked: the words are key << idx_bits | stream index (unique), one compare per pair and no index array.
-// kCap: LDS capacity in tuples.  512 serves the small streams (buckets of ~100: rank sort only, 8 KB of LDS, every
-// bucket of the launch resident at once); 4096 serves streams of up to 4 M tuples, whose buckets of several hundred
+// kCap: LDS capacity in tuples.  512 serves the rare streams whose (key, index) pairs do not fit one word (rank sort
+// only); 4096 serves every packed stream up to 4 M tuples (on C2's ~100-word buckets it is as fast as a dedicated
+// 512-word variant was, 11 vs 12.5 us for the launch), whose larger buckets of several hundred
 // to a few thousand words are first split in LDS by the next 8 key bits (counting sort: histogram, scan, grouped
 // copy) and then rank-sorted inside each group - linear instead of the n^2 of a plain rank sort or the n log^2 n and
 // ~50 barriers of a bitonic network (2 M tuples: 150 us with the network, 206 us with the plain rank sort).
@@ -964,9 +965,6 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             if (!packed_bits)
                 hipLaunchKernelGGL((bucket_sort_kernel<false, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
                                    w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0, shift);
-            else if (nb_sort <= (uint32_t)kScanFreeMaxBlocks)
-                hipLaunchKernelGGL((bucket_sort_kernel<true, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift);
             else
                 hipLaunchKernelGGL((bucket_sort_kernel<true, 4096>), grid, block, 0, s, w.keys[0], w.idx[0],
                                    w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift);
