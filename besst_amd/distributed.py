@@ -190,7 +190,10 @@ class ShardedGraphBuild(object):
         self._recv = None
         # the coverage/counter all-reduce overlaps the tuple exchange and the sort; it gets its own communicator so
         # that it is not serialised behind the all-to-all on the default one
-        self.side_group = dist.new_group() if dist.is_initialized() and group is None else group
+        # (BESST_SIDE_GROUP=0 keeps everything on the default communicator: a fallback should two communicators
+        # ever misbehave on some RCCL build)
+        want_side = dist.is_initialized() and group is None and os.environ.get('BESST_SIDE_GROUP', '1') != '0'
+        self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
     def _probe_pair_capacity(device, wl, world):
