@@ -68,6 +68,7 @@ constexpr int kStreamSubTile = kStreamThreads * kStreamVec;      // 1024 records
 constexpr int kStreamSubTiles = BESST_STREAM_SUBTILES;
 constexpr int kStreamTile = kStreamSubTile * kStreamSubTiles;    // 4096 records per workgroup
 constexpr int kGroup = 64 * kStreamVec;                          // 256 records per candidate-bit group
+constexpr int kGroupWords = 6;                                   // u64 per group record: 4 candidate words, coverage, pad
 // ordered_kernel: one workgroup per kCandGroups * 256 records (one lane of its first wave per group) -> one
 // block summary each.  With the evaluation spread over the workgroup's four waves the busiest block no longer
 // sets the kernel time, so the larger block wins (fewer summaries for the single-workgroup stitch): on C2
