@@ -42,6 +42,7 @@ _SIGNATURES = {
     'besst_last_error': (C.c_char_p, []),
     'besst_device_count': (C.c_int, []),
     'besst_prof_enable': (None, [C.c_uint32]),
+    'besst_prof_sample_every': (None, [C.c_uint32]),
     'besst_prof_slots': (C.c_int, []),
     'besst_prof_slot_name': (C.c_char_p, [C.c_int]),
     'besst_prof_collect': (C.c_int, [C.c_int, _P, _P]),

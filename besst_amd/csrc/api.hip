@@ -25,10 +25,13 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 static uint32_t g_prof_mask = 0;
+static uint32_t g_prof_every = 1;                  // record every n-th launch of an enabled slot
+static uint32_t g_prof_seen[kProfSlots] = {};
 static std::vector<ProfRec> g_prof;
 
 ProfScope::ProfScope(hipStream_t stream, int slot) : s(stream), idx(-1) {
     if (!((g_prof_mask >> slot) & 1u)) return;
+    if ((g_prof_seen[slot]++ % g_prof_every) != 0) return;
     ProfRec r;
     r.slot = slot;
     if (hipEventCreate(&r.a) != hipSuccess) return;
@@ -150,7 +153,12 @@ int besst_abi_version(void) { return BESST_ABI_VERSION; }
 
 const char* besst_last_error(void) { return g_error; }
 
-void besst_prof_enable(uint32_t slot_mask) { g_prof_mask = slot_mask; }
+void besst_prof_enable(uint32_t slot_mask) {
+    g_prof_mask = slot_mask;
+    for (int i = 0; i < kProfSlots; ++i) g_prof_seen[i] = 0;
+}
+
+void besst_prof_sample_every(uint32_t n) { g_prof_every = n ? n : 1; }
 
 int besst_prof_slots(void) { return kProfSlots; }
 

@@ -104,8 +104,11 @@ int besst_device_count(void);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline numbers).
  * Off by default; slot_mask selects the kernels to time (bit i = slot i, 0 = off).
  * besst_prof_collect synchronises the recorded events, sums elapsed milliseconds and
- * launch counts per slot (besst_prof_slots() entries, names from besst_prof_slot_name) and resets. */
+ * launch counts per slot (besst_prof_slots() entries, names from besst_prof_slot_name) and resets.
+ * besst_prof_sample_every(n) times only every n-th launch of an enabled slot: an event pair costs the stream
+ * ~3 us, which a 120 us step notices when every launch is timed. */
 void besst_prof_enable(uint32_t slot_mask);
+void besst_prof_sample_every(uint32_t n);
 int besst_prof_slots(void);
 const char* besst_prof_slot_name(int slot);
 int besst_prof_collect(int n_slots, double* ms, int64_t* launches);
