@@ -252,7 +252,9 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                        uint32_t* n_out, besst_counters* counters, void* workspace,
                        size_t workspace_bytes);
 
-/* Stage 2: stable radix sort of the tuples by key and segmented reduction into edge rows.
+/* Stage 2: sort of the tuples by (key, position in the stream) - observably a stable sort by key - and segmented
+ * reduction into edge rows (up to 4 M tuples: one MSD partition + per-bucket sort and reduction; beyond: LSD radix
+ * passes + tile-based reduction).
  *   n_tuples  uint32 device: number of valid tuples in keys/payload (<= capacity)
  *   key_bits  number of significant key bits (2 * node_bits + 1)
  * Outputs (capacity entries each): row_* arrays, obs_lo/obs_hi grouped by row, n_rows (uint32). */
