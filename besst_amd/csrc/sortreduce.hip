@@ -376,6 +376,11 @@ __device__ __forceinline__ void bitonic_words(uint64_t* k, int np) {          //
 // to a few thousand words are first split in LDS by the next 8 key bits (counting sort: histogram, scan, grouped
 // copy) and then rank-sorted inside each group - linear instead of the n^2 of a plain rank sort or the n log^2 n and
 // ~50 barriers of a bitonic network (2 M tuples: 150 us with the network, 206 us with the plain rank sort).
+#ifndef BESST_RANK_COST_LIMIT
+#define BESST_RANK_COST_LIMIT 256
+#endif
+constexpr uint32_t kRankCostLimit = BESST_RANK_COST_LIMIT;   // LDS reads per word above which a bucket takes the network
+
 template <bool kPacked, int kCap>
 __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                           const uint32_t* __restrict__ bucket_start,
@@ -418,6 +423,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             const uint64_t ki = s_k[i];
             int rank = 0;
             if (kPacked) {
+#pragma unroll 8
                 for (int j = 0; j < n; ++j) rank += s_k[j] < ki ? 1 : 0;
                 keys[s0 + rank] = ki;
                 s_sorted[rank] = ki;
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
         __syncthreads();
         if (s_cnt[threadIdx.x] > 1u) atomicAdd(&s_sumsq, s_cnt[threadIdx.x] * s_cnt[threadIdx.x]);
         __syncthreads();
-        if (s_sumsq > 256u * (uint32_t)n) {
+        if (s_sumsq > kRankCostLimit * (uint32_t)n) {
             for (int i = threadIdx.x; i < np; i += blockDim.x) s_sorted[i] = i < n ? keys[s0 + i] : ~0ull;
             __syncthreads();
             bitonic_words(s_sorted, np);
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
             const uint32_t d = (uint32_t)(w >> sub_shift) & sub_mask;
             const int hi = (int)s_cur[d], lo = hi - (int)s_cnt[d];
             int rank = lo, below_key = lo;
+#pragma unroll 8
             for (int q = lo; q < hi; ++q) {
                 const uint64_t v = s_sorted[q];
                 rank += v < w ? 1 : 0;
