@@ -114,3 +114,18 @@ def test_fragmented_assembly_many_contigs_per_wave():
     assert loop.count > 500 and sum(1 for x in loop.aligned if x) > 4000
     table, aligned, ctr = DU.device_build(batch, tab, p)
     DU.assert_matches_oracle(table, aligned, ctr, loop, asm.nc)
+
+
+def test_small_genome_high_coverage():
+    """A few dozen contigs at very high coverage: thousands of links per edge (MSD buckets beyond the LDS sort:
+    bitonic network in global scratch), and thousands of waves per contig (coverage through the group records)."""
+    asm = synth.make_assembly(40, 3000, 51)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 450.0, 40.0), 2500000, 52)
+    lens = asm.lengths.tolist()
+    tab = dict(cls=[1] * asm.nc, scaf=list(range(1, asm.nc + 1)), slen=lens, cpos=[0] * asm.nc, clen=lens,
+               cdir=[True] * asm.nc)
+    p = O.LibParams(read_len=100, ins_size_threshold=690.0)
+    loop = O.record_loop(GU.rec_lists(batch), tab, p)
+    assert max(r.n for r in loop.edges.values()) > 2000
+    table, aligned, ctr = DU.device_build(batch, tab, p)
+    DU.assert_matches_oracle(table, aligned, ctr, loop, asm.nc)
