@@ -456,15 +456,20 @@ __device__ __forceinline__ uint4 pack_entry(const Eval& e) {
     return ent;
 }
 
+// Occupancy over prefetch depth: two chunks in flight and a register cap for five workgroups per CU (the dense
+// mate-pair case is bound by gathers in flight: 0.43 -> 0.37 ms on a C3 slice; C2 is indifferent).
+#ifndef BESST_ORD_MIN_BLOCKS
+#define BESST_ORD_MIN_BLOCKS 5
+#endif
 constexpr int kOrdWaves = 4;                              // waves of an ordered_kernel workgroup
 constexpr int kOrdThreads = kOrdWaves * 64;
 #ifndef BESST_ORD_AHEAD
-#define BESST_ORD_AHEAD 4
+#define BESST_ORD_AHEAD 2
 #endif
 constexpr int kAhead = BESST_ORD_AHEAD;                                 // chunks a wave evaluates per round, all gathers in flight
 constexpr int kOrdRound = kOrdWaves * kAhead * 64;        // candidates per round (1024): 16 KB of entries in LDS
 
-__global__ __launch_bounds__(kOrdThreads) void ordered_kernel(
+__global__ __launch_bounds__(kOrdThreads, BESST_ORD_MIN_BLOCKS) void ordered_kernel(
     ClassifyArgs a, const unsigned long long* __restrict__ bitmask, int64_t n_groups,
     unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
     uint64_t* __restrict__ seg_payload, SummView summ) {
