@@ -219,6 +219,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no GPU visible; besst_amd has no CPU path)')
+    # BESST_DIST_BACKEND=gloo: the two-ranks-on-ONE-GPU check of the sharded path (RCCL refuses two ranks on one
+    # device); collectives are host-staged there, so its timings say nothing about a multi-GPU node.
+    backend = os.environ.get('BESST_DIST_BACKEND', 'nccl')
+    if backend == 'gloo':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     force_dist = os.environ.get('BESST_FORCE_DISTRIBUTED') == '1'   # exercise the RCCL path with one rank
@@ -226,7 +231,10 @@ def main():
         if 'MASTER_ADDR' not in os.environ:
             os.environ['MASTER_ADDR'] = '127.0.0.1'
             os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
@@ -268,7 +276,7 @@ def main():
     lib_h.besst_prof_enable(0)
     lib_h.besst_prof_sample_every(1)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -286,7 +294,7 @@ def main():
         verified = verify_full(runner, wl)
     elif world == 1 and force_dist and not args.no_verify:
         verified = verify_sharded_single_rank(runner, wl)
-    f = n_tuples / float(pairs)
+    f = n_tuples / float(pairs * world)                  # sizes() of the sharded runner are global sums
     cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
     # algorithmic bytes of one stream_kernel launch: tid, mtid (4 B each), mapq (1 B), qlen (2 B) per record;
@@ -323,10 +331,10 @@ def main():
                          'frac_of_measured_copy': round(achieved / copy_gbs, 4),
                          'algorithmic_bytes_per_launch': alg_bytes},
             # whole graph-build pass = 38 B/pair of records + each tuple written and read once
-            'graph_pass': {'algorithmic_bytes_per_step': pairs * (38.0 + 32.0 * f),
-                           'effective_GBps': round(pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9, 1),
-                           'frac_of_hbm_peak': round(pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9
-                                                     / HBM_PEAK_GBS, 4)},
+            'graph_pass': {'algorithmic_bytes_per_step': total_pairs * (38.0 + 32.0 * f),
+                           'effective_GBps': round(total_pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9, 1),
+                           'frac_of_hbm_peak': round(total_pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9
+                                                     / (HBM_PEAK_GBS * world), 4)},
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': verified,
         }

@@ -31,6 +31,45 @@ import torch.distributed as dist
 from . import _lib
 
 
+def _host_staged(t, group):
+    """True when a device tensor has to travel over a gloo group: the two-ranks-on-one-GPU check (RCCL refuses two
+    ranks on one device; tests/test_gpu_two_ranks.py, ``BESST_DIST_BACKEND=gloo python bench.py``).  The collectives
+    then go through host copies - a debugging transport, never what a multi-GPU node runs."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def _all_gather_into(out, x, group):
+    if _host_staged(x, group):
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, x.cpu(), group=group)
+        out.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+
+
+def _all_to_all(out, x, group):
+    if _host_staged(x, group):
+        host = torch.empty(x.shape, dtype=x.dtype)
+        dist.all_to_all_single(host, x.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, x, group=group)
+
+
+def _all_reduce(x, group, op=dist.ReduceOp.SUM, async_op=False):
+    if _host_staged(x, group):
+        host = x.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        x.copy_(host)
+        return _Done()
+    return dist.all_reduce(x, op=op, group=group, async_op=async_op)
+
+
 class HipBackend(object):
     """Kernel stages of one rank on its GPU."""
 
@@ -207,7 +246,7 @@ class ShardedGraphBuild(object):
         n_out, _ = probe.read_sizes()
         cap = torch.tensor([int(n_out * 1.5 / world) + 4096], dtype=torch.int64, device=device)
         if dist.is_initialized():
-            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+            _all_reduce(cap, None, op=dist.ReduceOp.MAX)
         return int(cap.item()), int(n_out * 1.25) + 4096
 
     def step(self):
@@ -229,7 +268,7 @@ class ShardedGraphBuild(object):
             side.wait_event(self._ev_main)
             tail = b.classify_tail_early(stream=side)
             with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(self._tails, tail, group=self.side_group)
+                _all_gather_into(self._tails, tail, self.side_group)
             self._ev_side.record(side)
             b.classify_scan()
             main.wait_event(self._ev_side)
@@ -238,7 +277,7 @@ class ShardedGraphBuild(object):
             if self._tails is None:
                 self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
             tail = b.classify_tail_early()
-            dist.all_gather_into_tensor(self._tails, tail, group=self.group)
+            _all_gather_into(self._tails, tail, self.group)
             b.classify_scan()
             tails = self._tails
         elif hasattr(b, 'classify_tail_early'):
@@ -246,7 +285,7 @@ class ShardedGraphBuild(object):
             if self._tails is None:
                 self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
             b.classify_scan()
-            dist.all_gather_into_tensor(self._tails, b.classify_tail(), group=self.group)
+            _all_gather_into(self._tails, b.classify_tail(), self.group)
             tails = self._tails
         else:                                            # CPU stand-in backends (gloo has no all_gather_into_tensor)
             b.classify_scan()
@@ -256,11 +295,11 @@ class ShardedGraphBuild(object):
             self._tails = tails = torch.cat(gathered)
         b.classify_emit(tails)
         # coverage numerators and counters are final here; sum them across ranks while tuples are exchanged
-        summed = dist.all_reduce(b.pack_for_allreduce(), group=self.side_group, async_op=True)
+        summed = _all_reduce(b.pack_for_allreduce(), self.side_group, async_op=True)
         send = b.partition()
         if self._recv is None:
             self._recv = torch.empty_like(send)
-        dist.all_to_all_single(self._recv, send, group=self.group)
+        _all_to_all(self._recv, send, self.group)
         b.unpack(self._recv)
         b.reduce()
         summed.wait()
@@ -275,7 +314,7 @@ class ShardedGraphBuild(object):
             flag = torch.tensor([1 if self.backend.overflowed() else 0], dtype=torch.int32,
                                 device=self.backend.aligned.device)
             if dist.is_initialized():
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                _all_reduce(flag, self.group, op=dist.ReduceOp.MAX)
             if not int(flag.item()):
                 return
             if not grow or not isinstance(self.backend, HipBackend):
@@ -293,7 +332,7 @@ class ShardedGraphBuild(object):
         """Global (tuples, edge rows) summed over ranks - synchronises."""
         n, r = self.backend.sizes()
         t = torch.tensor([n, r], dtype=torch.int64, device=self.backend.aligned.device)
-        dist.all_reduce(t, group=self.group)
+        _all_reduce(t, self.group)
         return int(t[0].item()), int(t[1].item())
 
     def gather_edges(self, dst=0):
@@ -334,15 +373,20 @@ class ShardedMetricsSample(object):
         from .pipeline import SAMPLE_CAP
         b = self.backend
         local = b.count(orientation, min_mapq, read_len).clone()
-        counts = [torch.empty_like(local) for _ in range(self.world)]
-        dist.all_gather(counts, local, group=self.group)
+        if _host_staged(local, self.group):
+            counts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.world)]
+            dist.all_gather(counts, local.cpu(), group=self.group)
+            counts = [c.to(local.device) for c in counts]
+        else:
+            counts = [torch.empty_like(local) for _ in range(self.world)]
+            dist.all_gather(counts, local, group=self.group)
         before = torch.zeros_like(local)
         for r in range(self.rank):
             before += counts[r]
         samples, state = b.emit(before, orientation, min_mapq, read_len, want_isize)
-        dist.all_reduce(samples, group=self.group)
+        _all_reduce(samples, self.group)
         tot = state[3:6].clone()
-        dist.all_reduce(tot, group=self.group)
+        _all_reduce(tot, self.group)
         total = torch.stack(counts).sum(0).cpu().numpy()
         tot = tot.cpu().numpy()
         n_isize = int(min(total[0], SAMPLE_CAP)) if want_isize else 0

@@ -1,0 +1,95 @@
+"""Two real processes, real HIP kernel stages, real torch.distributed groups - on the ONE GPU of the test box.
+
+RCCL refuses two ranks on one device, so the process group is gloo and besst_amd.distributed stages its
+collectives through host copies (distributed._host_staged).  Everything else is what a multi-GPU node runs:
+HipBackend on each rank's slice, tail gather, carry across the rank boundary, owner partition, equal-split
+all-to-all, unpack, reduce, coverage/counter all-reduce on the side group, capacity growth, the final gather of
+the edge rows.  The union must equal the single-process C oracle on the whole stream.
+"""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, port, config, tail_mode, pair_cap, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['BESST_TAIL_MODE'] = tail_mode
+    import torch
+    import torch.distributed as dist
+    from besst_amd import distributed, workload
+    from tests import dist_util as DU
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(dev)
+        wl = workload.make(config, 0, pairs=200000, nc=500)
+        sub = dict(wl)
+        sub['batch'] = DU.split_batch(wl['batch'], WORLD)[rank]
+        job = distributed.ShardedGraphBuild(dev, sub, rank, WORLD, pair_capacity=pair_cap)
+        assert job.side_group is not job.group            # the coverage all-reduce has its own group
+        for _ in range(2):
+            job.step()
+        torch.cuda.synchronize()
+        job.check_capacity()                              # small pair_cap: grows the regions and repeats the step
+        b = job.backend
+        want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+        assert b.aligned.cpu().tolist() == want.aligned
+        assert b.counter_words.cpu().tolist() == [want.count, want.non_unique, want.non_unique_for_scaf,
+                                                  want.nr_of_duplicates, want.too_long, want.fishy_reads,
+                                                  len(want.tuples), want.n_reach]
+        assert job.final_prev_obs() == want.prev
+        assert job.sizes() == (len(want.tuples), len(want_rows))
+        tables = job.gather_edges(0)
+        if rank == 0:
+            union = {}
+            for t in tables:
+                rows = DU.rows_from_table(t)
+                assert not set(rows) & set(union)
+                union.update(rows)
+            for k in union:
+                if k & 1:                                 # fishy rows carry no observations
+                    union[k]['lo'] = [0] * union[k]['n']
+                    union[k]['hi'] = [0] * union[k]['n']
+            for k, r in want_rows.items():
+                if k & 1:
+                    r['s'] = r['s2'] = 0
+            assert union == want_rows
+        out.put((rank, b.pair_cap, want.nr_of_duplicates))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('config,tail_mode,pair_cap', [('C2', 'late', 16384), ('C3', 'side', 65536),
+                                                       ('C2', 'inline', 512)])
+def test_two_processes_one_gpu(config, tail_mode, pair_cap):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, config, tail_mode, pair_cap, out)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(WORLD))
+    assert [g[0] for g in got] == [0, 1]
+    assert got[0][2] > 0
+    if pair_cap == 512:
+        assert got[0][1] > 512                            # the regions really grew
