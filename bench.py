@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument('--config', default='C2')
     ap.add_argument('--pairs', type=int, default=None, help='override pairs per GPU (smoke runs)')
     ap.add_argument('--contigs', type=int, default=None)
-    ap.add_argument('--cpu-sample-records', type=int, default=20_000_000)
+    ap.add_argument('--cpu-sample-records', type=int, default=20_000_000,
+                    help='records of the stream the Python port is timed on; 0 skips it (C port + check only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown-steps', type=int, default=3)
     ap.add_argument('--copies', type=int, default=3,
@@ -108,7 +109,8 @@ C_PORT_TIMING = {}
 
 
 def verify_full(runner, wl):
-    """Full-size parity: device edge table == C oracle on the whole workload (rank 0, N=1)."""
+    """Second half of the cpu_baseline leg (rank 0, N=1): the C restatement is timed over the WHOLE workload, on one
+    thread and on all host cores, and its edge table doubles as the full-size parity check of the device's."""
     import numpy as np
     from oracle import c_oracle as CO
     table = runner.gb.fetch_table()
@@ -290,10 +292,9 @@ def main():
 
     n_tuples, n_rows = runner.sizes()
     verified = None
-    if world == 1 and not args.no_verify and not force_dist:
-        verified = verify_full(runner, wl)
-    elif world == 1 and force_dist and not args.no_verify:
-        verified = verify_sharded_single_rank(runner, wl)
+    # the oracle is touched only in the cpu_baseline leg (--no-cpu-baseline: no oracle at all in this process)
+    if world == 1 and not args.no_verify and not args.no_cpu_baseline:
+        verified = verify_sharded_single_rank(runner, wl) if force_dist else verify_full(runner, wl)
     f = n_tuples / float(pairs * world)                  # sizes() of the sharded runner are global sums
     cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
@@ -345,7 +346,10 @@ def main():
             torch.cuda.empty_cache()
             out['stages'] = stage_timings(wl)
         if not args.no_cpu_baseline:
-            base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
+            if args.cpu_sample_records > 0:
+                base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
+            else:                    # --cpu-sample-records 0: skip the Python port, keep the C port + full-size check
+                base = dict(value=None, unit='read-pairs/s', cores=1, kind='port', sample='python port skipped')
             if C_PORT_TIMING:      # the C restatement (oracle/besst_oracle.c), one thread, whole stream: record loop only
                 base['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'],
                                   'unit': 'read-pairs/s', 'cores': 1,

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 for flags in "$@"; do
   BESST_EXTRA_FLAGS="$flags" besst_amd/csrc/build.sh > /dev/null 2>&1
-  python bench.py ${BENCH_ARGS:---steps 21 --warmup 3} --no-stages --no-cpu-baseline --breakdown-steps 3 --in-flight 0 2>/dev/null | python -c "
+  python bench.py ${BENCH_ARGS:---steps 21 --warmup 3} --no-stages --cpu-sample-records 0 --breakdown-steps 3 --in-flight 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print('$flags', round(d['ms_per_step']*1000,1), k, d['verified_vs_c_oracle'])"
 done
