@@ -125,7 +125,10 @@ struct ClassifyArgs {
 
 // ---- sort / reduce geometry -------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 16;
+#ifndef BESST_SORT_ITEMS
+#define BESST_SORT_ITEMS 16
+#endif
+constexpr int kSortItems = BESST_SORT_ITEMS;
 constexpr int kSortTile = kSortThreads * kSortItems;   // 4096 keys per block
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;

@@ -41,7 +41,10 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
 //   scanned   (many blocks): table[digit][block], exclusive-scanned along blocks by radix_rowscan_kernel
 // Every kernel loads its keys speculatively (guarded by the caller's capacity, not by the device-side count)
 // so that the count, the table and the keys arrive after ONE memory latency instead of three.
-constexpr int kScanFreeMaxBlocks = 64;
+#ifndef BESST_SCAN_FREE_MAX_BLOCKS
+#define BESST_SCAN_FREE_MAX_BLOCKS 64
+#endif
+constexpr int kScanFreeMaxBlocks = BESST_SCAN_FREE_MAX_BLOCKS;
 // Largest stream (in sort tiles) that still gets 11-bit LSD digits.  Measured on C3 slices of 0.5 - 8.5 M tuples:
 // the per-tile table of 2048 counters then holds as many entries as a quarter to a half of the keys, written
 // and read as scattered 4-byte words, and 8-bit digits win at every size (8.5 M tuples: 0.45 vs 0.63 ms for the
