@@ -1,0 +1,211 @@
+"""Scaffold-graph linearisation (steps 1-4 of the reference's MakeScaffolds.Algorithm) on the MI355X.
+
+Mirror of the reference's functions of the same names (BESST/MakeScaffolds.py):
+
+    RemoveIsolatedContigs(G, Information)                                       :134-144   step 1 / 3
+    RemoveAmbiguousRegionsUsingScore(G, G_prime, Information, param, plot)      :206-241   step 2 (+ remove_edges :156-204)
+    RemoveLoops(G, G_prime, Scaffolds, Contigs, Information, param)             :248-274   step 4
+    LinearizeGraph(...)   steps 1, 2, 3, 4 in the order of Algorithm (:75-82) with ONE device call
+
+They take and mutate the same ``networkx``-1.x style graphs CreateGraph.PE returns (``besst_amd.nxcompat.Graph``),
+print the same lines to ``Information`` and leave the same graphs behind; the work itself runs in
+``besst_linearize`` (besst_amd/csrc/linearize.hip) on arrays extracted from the graph.  There is no CPU path:
+without libbesst_amd.so or a GPU the calls raise ``besst_amd._lib.BesstDeviceError``.
+
+Not mirrored: the ``param.plots`` histograms of the decision scores (:231-234), and the text of the
+'A cycle in the scaffold graph' lines lists a cycle's nodes in walking order rather than networkx's.
+"""
+from __future__ import print_function
+
+import numpy as np
+
+from . import _lib
+
+STEP1, STEP2, STEP3, STEP4 = 1, 2, 4, 8
+
+
+def linearize_arrays(n_scaffolds, a, b, score, steps=STEP1 | STEP2 | STEP3 | STEP4, device=0):
+    """besst_linearize on host arrays.  Nodes are compact ids (scaffold k: 2k = 'L', 2k+1 = 'R'); a/b/score are the
+    link edges in G.edges() order.  Returns a dict: alive2 (per edge), removed_by (per scaffold: 0 kept, else the
+    step that removed it), present (= removed_by == 0), isolated [step 1, step 3], cycles, rounds, ambivalent
+    [(top, second)] in the reference's visiting order."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(a, np.int32)
+    b = np.ascontiguousarray(b, np.int32)
+    score = np.ascontiguousarray(score, np.float64)
+    m, n = int(a.shape[0]), int(n_scaffolds)
+    if b.shape[0] != m or score.shape[0] != m:
+        raise ValueError('a, b and score must have one entry per edge')
+    if m and (min(int(a.min()), int(b.min())) < 0 or max(int(a.max()), int(b.max())) >= 2 * n):
+        raise ValueError('node id out of range')
+    alive = np.zeros(max(m, 1), np.uint8)
+    removed_by = np.zeros(max(n, 1), np.uint8)
+    amb = np.zeros(max(2 * n, 1), np.uint8)
+    top = np.zeros(max(2 * n, 1), np.float64)
+    second = np.zeros(max(2 * n, 1), np.float64)
+    best = np.zeros(max(2 * n, 1), np.uint32)
+    counters = np.zeros(8, np.int64)
+    _lib.check(lib.besst_linearize(device, steps, n, m, _lib.ptr(a), _lib.ptr(b), _lib.ptr(score), _lib.ptr(alive),
+                                   _lib.ptr(removed_by), _lib.ptr(amb), _lib.ptr(top), _lib.ptr(second), _lib.ptr(best),
+                                   _lib.ptr(counters)), 'besst_linearize')
+    events = []
+    nodes = np.nonzero(amb[:2 * n])[0]
+    if nodes.shape[0]:
+        # visiting order of the reference: the node's best edge by (score desc, edge index asc), edge[0] first
+        be = best[nodes].astype(np.int64)
+        is_b = (b[be] == nodes).astype(np.int64)
+        order = np.lexsort((is_b, be, -score[be]))
+        events = [(float(top[x]), float(second[x])) for x in nodes[order]]
+    return dict(alive2=alive[:m].astype(bool), removed_by=removed_by[:n].copy(), present=removed_by[:n] == 0,
+                isolated=[int(counters[0]), int(counters[1])], cycles=int(counters[2]), rounds=int(counters[4]),
+                ambivalent=events)
+
+
+class _GraphArrays(object):
+    """Link edges of a graph as arrays.  Scaffold k = k-th distinct scaffold in node order."""
+
+    def __init__(self, G, scored_only):
+        self.index = {}
+        for s, _ in G.nodes():
+            self.index.setdefault(s, len(self.index))
+        self.scaffolds = list(self.index)
+        a, b, score, edges = [], [], [], []
+        unscored = 0
+        for u, v, d in G.edges(data=True):
+            if d['nr_links'] is None:
+                continue
+            if 'score' not in d:
+                unscored += 1
+                if scored_only:
+                    continue
+            a.append(self.node(u))
+            b.append(self.node(v))
+            score.append(d.get('score', 1.0))
+            edges.append((u, v))
+        self.a, self.b, self.score, self.edges, self.unscored = a, b, score, edges, unscored
+
+    def node(self, n):
+        return 2 * self.index[n[0]] + (n[1] == 'R')
+
+    @property
+    def n_scaffolds(self):
+        return len(self.index)
+
+
+def _remove_scaffolds(G, arrays, present):
+    gone = [s for s, keep in zip(arrays.scaffolds, present) if not keep]
+    for s in gone:
+        G.remove_nodes_from([(s, 'L'), (s, 'R')])
+    return gone
+
+
+def RemoveIsolatedContigs(G, Information, device=0):
+    print('Remove isolated nodes.', file=Information)
+    arr = _GraphArrays(G, scored_only=False)
+    res = linearize_arrays(arr.n_scaffolds, arr.a, arr.b, arr.score, STEP1, device)
+    _remove_scaffolds(G, arr, res['present'])
+    print(str(res['isolated'][0]) + ' isolated contigs removed from graph.', file=Information)
+    return G
+
+
+def _apply_step2(G, G_prime, Information, param, arr, res, nr_edges_before):
+    for top, second in res['ambivalent']:
+        print('SCORES AMBVIVALENT', top, second, file=Information)
+    dropped = [e for e, keep in zip(arr.edges, res['alive2']) if not keep]
+    G.remove_edges_from(dropped)
+    if param.extend_paths:
+        G_prime.remove_edges_from(dropped)                  # edges G_prime never had are ignored (:174-177)
+    nr_edges_after = len(G.edges())
+    print(' Number of edges in G before:', nr_edges_before, file=Information)
+    print(' Number of edges in G after:', nr_edges_after, file=Information)
+    try:
+        print(' %-age removed edges:', 100 * (1 - (nr_edges_after / float(nr_edges_before))), file=Information)
+    except ZeroDivisionError:
+        pass
+
+
+def _scored_arrays(G):
+    arr = _GraphArrays(G, scored_only=True)
+    if arr.unscored and arr.edges:
+        # the reference reads G[node][nbr]['score'] of every link edge at a visited node (:161)
+        raise KeyError('score')
+    return arr
+
+
+def RemoveAmbiguousRegionsUsingScore(G, G_prime, Information, param, plot, device=0):
+    nr_edges_before = len(G.edges())
+    print('Remove edges from node if more than two edges', file=Information)
+    arr = _scored_arrays(G)
+    res = linearize_arrays(arr.n_scaffolds, arr.a, arr.b, arr.score, STEP2, device)
+    _apply_step2(G, G_prime, Information, param, arr, res, nr_edges_before)
+    return ()
+
+
+def _cycles_of(arr, alive, gone_scaffolds):
+    """Node lists of the cycles among the removed scaffolds (for the log lines only)."""
+    gone = set(gone_scaffolds)
+    mate = {}
+    for (u, v), keep in zip(arr.edges, alive):
+        if keep and u[0] in gone and v[0] in gone:
+            mate[u], mate[v] = v, u
+    cycles, seen = [], set()
+    for s in gone_scaffolds:
+        if s in seen:
+            continue
+        cyc, x = [], (s, 'L')
+        while x[0] not in seen:
+            seen.add(x[0])
+            other = (x[0], 'R' if x[1] == 'L' else 'L')
+            cyc += [x, other]
+            x = mate[other]
+        cycles.append(cyc)
+    return cycles
+
+
+def _apply_step4(G, G_prime, Information, param, arr, alive, present_before, res):
+    gone = [s for s, was, keep in zip(arr.scaffolds, present_before, res['present']) if was and not keep]
+    cycles = _cycles_of(arr, alive, gone)
+    for cycle in cycles:
+        print('A cycle in the scaffold graph: ' + str(cycle) + '\n', file=Information)
+        print('A cycle in the scaffold graph: ' + str(cycle), file=Information)
+    for s in gone:
+        G.remove_nodes_from([(s, 'L'), (s, 'R')])
+        if param.extend_paths:
+            G_prime.remove_nodes_from([(s, 'L'), (s, 'R')])
+    print(str(res['cycles']) + ' cycles removed from graph.', file=Information)
+
+
+def RemoveLoops(G, G_prime, Scaffolds, Contigs, Information, param, device=0):
+    print('Contigs/scaffolds left:', len(G.nodes()) / 2, file=Information)
+    print('Remove remaining cycles...', file=Information)
+    arr = _GraphArrays(G, scored_only=False)
+    res = linearize_arrays(arr.n_scaffolds, arr.a, arr.b, arr.score, STEP4, device)
+    _apply_step4(G, G_prime, Information, param, arr, [True] * len(arr.edges), [True] * arr.n_scaffolds, res)
+    return (G, Contigs, Scaffolds)
+
+
+def LinearizeGraph(G, G_prime, Contigs, Scaffolds, Information, param, device=0):
+    """Steps 1-4 as MakeScaffolds.Algorithm runs them when scoring is on (:75-82), with one device call.
+    Returns (G, Contigs, Scaffolds) like RemoveLoops."""
+    arr = _scored_arrays(G)
+    res = linearize_arrays(arr.n_scaffolds, arr.a, arr.b, arr.score, STEP1 | STEP2 | STEP3 | STEP4, device)
+    alive = res['alive2']
+    # step 1
+    print('Remove isolated nodes.', file=Information)
+    after1 = (res['removed_by'] != 1).tolist()
+    _remove_scaffolds(G, arr, after1)
+    print(str(res['isolated'][0]) + ' isolated contigs removed from graph.', file=Information)
+    # step 2
+    nr_edges_before = len(G.edges())
+    print('Remove edges from node if more than two edges', file=Information)
+    _apply_step2(G, G_prime, Information, param, arr, res, nr_edges_before)
+    # step 3
+    print('Remove isolated nodes.', file=Information)
+    after3 = [r != 1 and r != 3 for r in res['removed_by'].tolist()]
+    _remove_scaffolds(G, arr, after3)
+    print(str(res['isolated'][1]) + ' isolated contigs removed from graph.', file=Information)
+    # step 4
+    print('Contigs/scaffolds left:', len(G.nodes()) / 2, file=Information)
+    print('Remove remaining cycles...', file=Information)
+    _apply_step4(G, G_prime, Information, param, arr, alive, after3, res)
+    return (G, Contigs, Scaffolds)

@@ -339,6 +339,36 @@ int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples
 int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
                      uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow);
 
+/* ---- Scaffold-graph linearisation on the scored edge table -----------------------------------
+ * Steps 1-4 of MakeScaffolds.Algorithm (MakeScaffolds.py:75-82) in one call:
+ *   step 1/3  RemoveIsolatedContigs            (MakeScaffolds.py:134-144)
+ *   step 2    RemoveAmbiguousRegionsUsingScore (MakeScaffolds.py:206-241) with remove_edges (:156-204)
+ *   step 4    RemoveLoops                      (MakeScaffolds.py:248-274)
+ * Nodes are compact ids: scaffold k has the nodes 2k ('L') and 2k+1 ('R').
+ *   steps            mask of the steps to run: 1 = step 1, 2 = step 2, 4 = step 3, 8 = step 4 (15 = all, in the order of
+ *                    MakeScaffolds.Algorithm).  Without step 2 every edge counts as a link edge whatever its score;
+ *                    step 4 then requires at most one link edge per node (BESST_ERR_STATE otherwise)
+ *   a, b, score      the link edges of G that carry a score, in G.edges() order (a = edge[0], b = edge[1]); the
+ *                    order decides ties between equal scores exactly as Python's stable sort does (:216-217)
+ *   edge_alive       out, n_edges: 1 = the edge survives step 2
+ *   scaffold_removed_by  out, n_scaffolds: 0 = the scaffold survives; 1 / 3 / 4 = the step that removed it
+ *   node_ambivalent  out, 2 * n_scaffolds: 1 = the node printed 'SCORES AMBVIVALENT' (:183); node_top / node_second
+ *                    hold the two scores it printed, node_best_edge the edge of the node's first visit (events are
+ *                    replayed in visiting order by sorting on (score desc, node_best_edge asc, is-edge[1]))
+ *   counters         out, HOST array of 8: [0] scaffolds removed by step 1, [1] by step 3, [2] cycles found by
+ *                    step 4, [3] ambivalent nodes, [4] rounds step 2 took
+ * besst_linearize takes host pointers (copies in, runs, copies out, like the besst_ctx_* calls);
+ * besst_dev_linearize takes device pointers for everything but `counters` and synchronises the stream. */
+int besst_linearize(int device, int32_t steps, int64_t n_scaffolds, int64_t n_edges, const int32_t* a, const int32_t* b,
+                    const double* score, uint8_t* edge_alive, uint8_t* scaffold_removed_by,
+                    uint8_t* node_ambivalent, double* node_top, double* node_second,
+                    uint32_t* node_best_edge, int64_t* counters);
+size_t besst_dev_linearize_workspace_bytes(int64_t n_scaffolds, int64_t n_edges);
+int besst_dev_linearize(void* stream, int32_t steps, int64_t n_scaffolds, int64_t n_edges, const int32_t* a, const int32_t* b,
+                        const double* score, void* workspace, size_t workspace_bytes, uint8_t* edge_alive,
+                        uint8_t* scaffold_removed_by, uint8_t* node_ambivalent, double* node_top,
+                        double* node_second, uint32_t* node_best_edge, int64_t* counters);
+
 #ifdef __cplusplus
 }
 #endif

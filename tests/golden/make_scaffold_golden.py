@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 
+from tests import scaffold_util as SU  # noqa: E402
 from tests.refharness import driver, loader  # noqa: E402
 
 OUT = os.path.join(HERE, 'scaffold_steps.json.gz')
@@ -31,18 +32,7 @@ SCORE_POOL = (0.0, 0.0, 0.0, 0.4, 0.5, 0.8, 1.0, 1.0, 1.25, 1.6, 2.0)
 
 
 def build_graph(nxg, nodes, links):
-    """nodes: [(scaf, side)] in insertion order (both sides of every scaffold present); links: [(u, v, score)]."""
-    G = nxg()
-    for n in nodes:
-        G.add_node(tuple(n), length=1000)
-    seen = set()
-    for s, _ in nodes:
-        if s not in seen:
-            seen.add(s)
-            G.add_edge((s, 'L'), (s, 'R'), nr_links=None)
-    for u, v, sc in links:
-        G.add_edge(tuple(u), tuple(v), nr_links=7, obs=700, obs_sq=70000, observations=[100] * 7, gap=0, score=sc)
-    return G
+    return SU.build_graph(nodes, links)
 
 
 def random_case(rng, n_scaf, mean_deg, kind):
@@ -93,14 +83,7 @@ def random_case(rng, n_scaf, mean_deg, kind):
     return nodes, links
 
 
-def link_rows(G):
-    out = []
-    for u, v in G.edges():
-        d = G[u][v]
-        if d['nr_links'] is None:
-            continue
-        out.append([list(u), list(v), d.get('score')])
-    return out
+link_rows = SU.link_rows
 
 
 def run_reference(ms, mods, nxg, nodes, links, prime_links, extend_paths):

@@ -52,3 +52,36 @@ def check_result(case, res):
     assert [int(x) for x in res['isolated']] == case['isolated_removed']
     assert int(res['cycles']) == case['cycles_removed']
     assert [[float(t), float(s)] for t, s in res['ambivalent']] == case['ambivalent']
+
+
+def build_graph(nodes, links):
+    """The facade graph of a case: nodes [(scaf, side)] in insertion order, the intra-scaffold edges, then the link
+    edges [(u, v, score)] in listing order (which reproduces the listing as G.edges() order)."""
+    from besst_amd import nxcompat
+    G = nxcompat.Graph()
+    for n in nodes:
+        G.add_node(tuple(n), length=1000)
+    seen = set()
+    for s, _ in nodes:
+        if s not in seen:
+            seen.add(s)
+            G.add_edge((s, 'L'), (s, 'R'), nr_links=None)
+    for u, v, sc in links:
+        G.add_edge(tuple(u), tuple(v), nr_links=7, obs=700, obs_sq=70000, observations=[100] * 7, gap=0, score=sc)
+    return G
+
+
+def link_rows(G):
+    out = []
+    for u, v in G.edges():
+        d = G[u][v]
+        if d['nr_links'] is None:
+            continue
+        out.append([list(u), list(v), d.get('score')])
+    return out
+
+
+class Param(object):
+    def __init__(self, extend_paths):
+        self.extend_paths = extend_paths
+        self.plots = False
