@@ -200,9 +200,82 @@ def stage_timings(wl):
             out['scored_edges'] = int(rows.shape[0])
             out['score_edges_per_s'] = rows.shape[0] / dt
         lib_h.besst_prof_enable(0)
+        out.update(linearize_timing())
         pairs = len(batch) // 2
         out['pcie_inclusive_pairs_per_s'] = pairs / ((out['h2d_push_ms'] + out['ctx_build_graph_ms']) * 1e-3)
     return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}
+
+
+def linearize_workload(n_scaf, n_edges, seed=20240929):
+    """Seeded scored scaffold graph for the linearisation stage: random link edges, half of
+    the scores from a small pool (ties, zeros, 0.8 ratios), half uniform in [0, 2]."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 2 * n_scaf, n_edges).astype(np.int32)
+    b = rng.integers(0, 2 * n_scaf, n_edges).astype(np.int32)
+    keep = (a >> 1) != (b >> 1)
+    a, b = a[keep], b[keep]
+    lo, hi = np.minimum(a, b).astype(np.int64), np.maximum(a, b).astype(np.int64)
+    _, first = np.unique(lo * (2 * n_scaf) + hi, return_index=True)
+    first.sort()
+    a, b = a[first], b[first]
+    pool = np.array([0.0, 0.5, 0.8, 1.0, 1.0, 1.25, 2.0])
+    score = np.where(rng.random(a.shape[0]) < 0.5, rng.choice(pool, a.shape[0]), np.round(rng.random(a.shape[0]) * 2, 2))
+    return a, b, score.astype(np.float64)
+
+
+def linearize_timing(n_scaf=2_000_000, n_edges=3_000_000):
+    """MakeScaffolds steps 1-4 on a C5-sized scored edge table: wall time through the host-pointer call (copies
+    included) and with the table resident in HBM."""
+    import torch
+    from besst_amd import MakeScaffolds as MS, _lib
+    a, b, score = linearize_workload(n_scaf, n_edges)
+    m = int(a.shape[0])
+    MS.linearize_arrays(n_scaf, a, b, score)
+    t0 = time.perf_counter()
+    res = MS.linearize_arrays(n_scaf, a, b, score)
+    host_ms = (time.perf_counter() - t0) * 1e3
+    lib_h = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    da, db, ds = (torch.from_numpy(x).to(dev) for x in (a, b, score))
+    ws = torch.empty(lib_h.besst_dev_linearize_workspace_bytes(n_scaf, m), dtype=torch.uint8, device=dev)
+    alive = torch.empty(m, dtype=torch.uint8, device=dev)
+    removed = torch.empty(n_scaf, dtype=torch.uint8, device=dev)
+    amb = torch.empty(2 * n_scaf, dtype=torch.uint8, device=dev)
+    top = torch.empty(2 * n_scaf, dtype=torch.float64, device=dev)
+    sec = torch.empty(2 * n_scaf, dtype=torch.float64, device=dev)
+    best = torch.empty(2 * n_scaf, dtype=torch.int32, device=dev)
+    counters = np.zeros(8, np.int64)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        _lib.check(lib_h.besst_dev_linearize(stream, 15, n_scaf, m, da.data_ptr(), db.data_ptr(), ds.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), alive.data_ptr(), removed.data_ptr(),
+                                             amb.data_ptr(), top.data_ptr(), sec.data_ptr(), best.data_ptr(),
+                                             _lib.ptr(counters)), 'besst_dev_linearize')
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    dev_ms = (time.perf_counter() - t0) * 1e3
+    same = bool(np.array_equal(alive.cpu().numpy().astype(bool), res['alive2'])
+                and np.array_equal(removed.cpu().numpy(), res['removed_by']))
+    return {'linearize_scaffolds': n_scaf, 'linearize_edges': m, 'linearize_rounds': int(counters[4]),
+            'linearize_host_call_ms': host_ms, 'linearize_resident_ms': dev_ms,
+            'linearize_edges_per_s': m / (dev_ms * 1e-3), 'linearize_calls_agree': same}
+
+
+def linearize_cpu_baseline(n_scaf=200_000, n_edges=300_000):
+    """cpu_baseline leg: the sequential restatement of steps 1-4 (oracle/scaffold_oracle.py, one thread) on a
+    bounded graph of the same shape."""
+    from oracle import scaffold_oracle as SO
+    a, b, score = linearize_workload(n_scaf, n_edges)
+    la, lb, ls = a.tolist(), b.tolist(), score.tolist()
+    t0 = time.perf_counter()
+    SO.linearize(n_scaf, la, lb, ls)
+    dt = time.perf_counter() - t0
+    return {'value': len(la) / dt, 'unit': 'edges/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d scaffolds / %d scored link edges, oracle/scaffold_oracle.linearize, %.1f s'
+                      % (n_scaf, len(la), dt)}
 
 
 def main():
@@ -360,6 +433,8 @@ def main():
                                             'equals_sequential': C_PORT_TIMING['mt_equal'],
                                             'sample': 'whole stream, contiguous slices, %.3f s (includes numpy column '
                                                       'setup and thread start)' % C_PORT_TIMING['mt_seconds']}
+            if not args.no_stages:
+                base['linearize_port'] = linearize_cpu_baseline()
             out['cpu_baseline'] = base
         else:
             out['cpu_baseline'] = None

@@ -164,3 +164,39 @@ def test_cli_end_to_end(tmp_path):
     want = [(e['u'][0], e['u'][1], e['v'][0], e['v'][1], e['nr_links'], e['obs'], e['obs_sq']) for e in doc['final']['G']]
     assert got == want
     assert (tmp_path / 'BESST_output' / 'Statistics.txt').exists()
+
+
+@pytest.mark.parametrize('name', ['fr_infer', 'rf_contam', 'rf_second_lib'])
+def test_linearize_the_graph_pe_returns(name):
+    """CreateGraph.PE -> MakeScaffolds.LinearizeGraph (steps 1-4) on the real scored graph: the surviving nodes and
+    link edges equal the sequential CPU restatement run on the same graph's edge list."""
+    from besst_amd import MakeScaffolds as MS
+    from oracle import scaffold_oracle as SO
+    doc, batch = GU.load(name)
+    param = make_param(doc['overrides'])
+    info = param.information_file
+    libmetrics.get_metrics(batch, param, info)
+    if doc['layout'] is not None:
+        Contigs, Scaffolds, small_contigs, small_scaffolds = state_from_layout(doc, batch, doc['layout_threshold'])
+        param.scaffold_indexer = doc['layout']['next_scaffold_id']
+        param.tot_assembly_length = sum(batch.lengths)
+    else:
+        Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+    lens = dict(zip(batch.references, batch.lengths))
+    C_dict = {n: 'A' * int(lens.get(n, 10)) for n in doc['fasta_names']}
+    G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, batch)
+    session.close_session(batch)
+    arr = MS._GraphArrays(G, scored_only=True)
+    assert len(arr.edges) > 20
+    want = SO.linearize(arr.n_scaffolds, arr.a, arr.b, arr.score)
+    keep_nodes = [n for n in G.nodes() if want['present'][arr.index[n[0]]]]
+    keep_edges = [e for e, k in zip(arr.edges, want['alive2'])
+                  if k and want['present'][arr.index[e[0][0]]] and want['present'][arr.index[e[1][0]]]]
+    nodes_before = len(G.nodes())
+    G, _, _ = MS.LinearizeGraph(G, G_prime, Contigs, Scaffolds, info, param)
+    assert list(G.nodes()) == keep_nodes
+    assert [(u, v) for u, v in G.edges() if G[u][v]['nr_links'] is not None] == keep_edges
+    assert len(keep_nodes) < nodes_before or len(keep_edges) < len(arr.edges)
+    # every remaining node has at most one link edge: the graph is a set of paths
+    for n in G.nodes():
+        assert sum(1 for m in G.neighbors(n) if G[n][m]['nr_links'] is not None) <= 1
