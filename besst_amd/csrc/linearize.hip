@@ -56,10 +56,11 @@ struct LinArgs {
     int32_t* lab[2];
     // per edge
     uint8_t* alive;
+    uint32_t* list[2];                // pending edges (an undecided endpoint), rebuilt every round; round 0 reads all edges
     // per scaffold
     uint8_t* removed_by;              // 0: still there; 1 / 3 / 4: the step that removed the scaffold
-    // [0] isolated step 1, [1] isolated step 3, [2] directed cycles, [3] ambivalent nodes, [4..5] pending edges
-    // (ping-pong), [6] link edges at nodes with more than one (step 4 without step 2)
+    // [0] isolated step 1, [1] isolated step 3, [2] directed cycles, [3] ambivalent nodes, [4..5] lengths of the two
+    // pending-edge lists, [6] link edges at nodes with more than one (step 4 without step 2)
     unsigned long long* counters;
 };
 
@@ -116,24 +117,43 @@ __device__ __forceinline__ bool is_ready(const LinArgs& g, uint32_t x, int round
     return !is_done(g, x, round) && g.blocked_at[x] != round;
 }
 
+// The edges a round has to look at: those with an undecided endpoint when the round began.  lin_block_kernel of
+// round r reads the list of round r - 1 (all edges in round 0) and writes the list the other three phases of
+// round r - and the block phase of round r + 1 - iterate; counters[4 + parity] hold the list lengths.  Most nodes
+// decide in the first two rounds, so later rounds touch a small fraction of the edges.
+__device__ __forceinline__ uint32_t list_len(const LinArgs& g, int which) { return (uint32_t)g.counters[4 + which]; }
+
 // round, phase 1: the later endpoint of an edge between two undecided nodes has to wait
 __global__ __launch_bounds__(kLinThreads) void lin_block_kernel(LinArgs g, int round) {
-    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
+    const uint32_t j = blockIdx.x * kLinThreads + threadIdx.x;
+    const int cur = round & 1, next = cur ^ 1;
+    const uint32_t n_cur = round == 0 ? g.m : list_len(g, cur);
     bool pending = false;
-    if (i < g.m && g.alive[i]) {
-        const uint32_t a = g.a[i], b = g.b[i];
-        const bool da = is_done(g, a, round), db = is_done(g, b, round);
-        pending = !da || !db;
-        if (!da && !db) g.blocked_at[earlier(g, a, b) ? b : a] = round;
+    uint32_t i = 0;
+    if (j < n_cur) {
+        i = round == 0 ? j : g.list[cur][j];
+        if (g.alive[i]) {
+            const uint32_t a = g.a[i], b = g.b[i];
+            const bool da = is_done(g, a, round), db = is_done(g, b, round);
+            pending = !da || !db;
+            if (!da && !db) g.blocked_at[earlier(g, a, b) ? b : a] = round;
+        }
     }
     const unsigned long long mask = __ballot(pending);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&g.counters[4 + (round & 1)], (unsigned long long)__popcll(mask));
+    if (mask) {                                   // wave-aggregated append
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&g.counters[4 + next], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (pending) g.list[next][(uint32_t)base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    }
 }
 
 // phase 2: best score and number of live scoring edges of every ready node
 __global__ __launch_bounds__(kLinThreads) void lin_top_kernel(LinArgs g, int round) {
-    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
-    if (i >= g.m || !g.alive[i]) return;
+    const uint32_t j = blockIdx.x * kLinThreads + threadIdx.x;
+    if (j >= list_len(g, (round & 1) ^ 1)) return;
+    const uint32_t i = g.list[(round & 1) ^ 1][j];
     const unsigned long long sb = score_bits(g.score[i]);
     const uint32_t ends[2] = {(uint32_t)g.a[i], (uint32_t)g.b[i]};
 #pragma unroll
@@ -147,8 +167,9 @@ __global__ __launch_bounds__(kLinThreads) void lin_top_kernel(LinArgs g, int rou
 
 // phase 3: how many edges share the best score, and the best score below it
 __global__ __launch_bounds__(kLinThreads) void lin_second_kernel(LinArgs g, int round) {
-    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
-    if (i >= g.m || !g.alive[i]) return;
+    const uint32_t j = blockIdx.x * kLinThreads + threadIdx.x;
+    if (j >= list_len(g, (round & 1) ^ 1)) return;
+    const uint32_t i = g.list[(round & 1) ^ 1][j];
     const unsigned long long sb = score_bits(g.score[i]);
     const uint32_t ends[2] = {(uint32_t)g.a[i], (uint32_t)g.b[i]};
 #pragma unroll
@@ -162,8 +183,9 @@ __global__ __launch_bounds__(kLinThreads) void lin_second_kernel(LinArgs g, int 
 
 // phase 4: the ready nodes decide (MakeScaffolds.py:181-188) and are done from the next round on
 __global__ __launch_bounds__(kLinThreads) void lin_decide_kernel(LinArgs g, int round) {
-    const uint32_t i = blockIdx.x * kLinThreads + threadIdx.x;
-    if (i >= g.m || !g.alive[i]) return;
+    const uint32_t j = blockIdx.x * kLinThreads + threadIdx.x;
+    if (j >= list_len(g, (round & 1) ^ 1)) return;
+    const uint32_t i = g.list[(round & 1) ^ 1][j];
     const unsigned long long sb = score_bits(g.score[i]);
     const uint32_t ends[2] = {(uint32_t)g.a[i], (uint32_t)g.b[i]};
     bool drop = false;
@@ -258,7 +280,7 @@ size_t carve(size_t& off, size_t bytes) {
 
 struct LinLayout {
     size_t best_bits, best_i, deg, done_at, blocked_at, top1, top2, cnt, ntop, amb, mate, jump0, jump1, lab0, lab1,
-        alive, present, counters, total;
+        alive, present, counters, list0, list1, total;
 };
 
 LinLayout lin_layout(int64_t n_scaf, int64_t m) {
@@ -286,6 +308,8 @@ LinLayout lin_layout(int64_t n_scaf, int64_t m) {
     L.lab1 = carve(off, n * 4);
     L.alive = carve(off, e);
     L.present = carve(off, n / 2);
+    L.list0 = carve(off, e * 4);
+    L.list1 = carve(off, e * 4);
     L.total = off;
     return L;
 }
@@ -340,6 +364,7 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
     g.jump[0] = (int32_t*)(w + L.jump0); g.jump[1] = (int32_t*)(w + L.jump1);
     g.lab[0] = (int32_t*)(w + L.lab0); g.lab[1] = (int32_t*)(w + L.lab1);
     g.alive = (uint8_t*)(w + L.alive);
+    g.list[0] = (uint32_t*)(w + L.list0); g.list[1] = (uint32_t*)(w + L.list1);
     g.removed_by = (uint8_t*)(w + L.present);
     g.counters = (unsigned long long*)(w + L.counters);
 
@@ -359,18 +384,21 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
         if (steps & 1) hipLaunchKernelGGL(lin_isolated_kernel, dim3(nb_s), dim3(kLinThreads), 0, s, g, 0);
         // step 2: rounds until no live edge has an undecided endpoint (checked every kBatch rounds)
         constexpr int kBatch = 4;
+        uint32_t bound = g.m;                          // upper bound of the pending list (lists only shrink)
         while (g.m && (steps & 2)) {
+            const uint32_t nb_l = (bound + kLinThreads - 1) / kLinThreads;
             for (int r = 0; r < kBatch; ++r, ++rounds) {
-                BESST_HIP_TRY(hipMemsetAsync(&g.counters[4 + (rounds & 1)], 0, 8, s));
-                hipLaunchKernelGGL(lin_block_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g, rounds);
-                hipLaunchKernelGGL(lin_top_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g, rounds);
-                hipLaunchKernelGGL(lin_second_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g, rounds);
-                hipLaunchKernelGGL(lin_decide_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g, rounds);
+                BESST_HIP_TRY(hipMemsetAsync(&g.counters[4 + ((rounds & 1) ^ 1)], 0, 8, s));
+                hipLaunchKernelGGL(lin_block_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
+                hipLaunchKernelGGL(lin_top_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
+                hipLaunchKernelGGL(lin_second_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
+                hipLaunchKernelGGL(lin_decide_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
             }
-            // pending count of the batch's LAST round: edges that still had an undecided endpoint when it began
+            // list of the batch's LAST round: the edges that still had an undecided endpoint when it began
             BESST_HIP_TRY(hipMemcpyAsync(host_counters, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
             BESST_HIP_TRY(hipStreamSynchronize(s));
-            if (host_counters[4 + ((rounds - 1) & 1)] == 0) break;
+            bound = (uint32_t)host_counters[4 + (rounds & 1)];
+            if (bound == 0) break;
             BESST_REQUIRE(rounds < (1 << 24), "linearize: step 2 did not converge");
         }
         if (steps & 2) hipLaunchKernelGGL(lin_count_amb_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g);
