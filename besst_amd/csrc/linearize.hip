@@ -60,9 +60,26 @@ struct LinArgs {
     // per scaffold
     uint8_t* removed_by;              // 0: still there; 1 / 3 / 4: the step that removed the scaffold
     // [0] isolated step 1, [1] isolated step 3, [2] directed cycles, [3] ambivalent nodes, [4..5] lengths of the two
-    // pending-edge lists, [6] link edges at nodes with more than one (step 4 without step 2)
+    // pending-edge lists, [7] changes of the last counted doubling pass, [6] link edges at nodes with more than one (step 4 without step 2)
     unsigned long long* counters;
 };
+
+// Sum of v over the workgroup, added to *counter by ONE atomic (every thread of the workgroup must call it).
+// Per-wave atomics on one address serialise device-wide: with a wave per 64 nodes the counting kernels spent
+// 0.3 - 0.7 ms in them on a 4 M-node graph.
+__device__ __forceinline__ void block_add(uint32_t v, unsigned long long* counter) {
+    __shared__ uint32_t s_part[kLinThreads / 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kLinThreads / 64; ++w) tot += s_part[w];
+        if (tot) atomicAdd(counter, (unsigned long long)tot);
+    }
+}
 
 __device__ __forceinline__ unsigned long long score_bits(double s) { return (unsigned long long)__double_as_longlong(s); }
 
@@ -102,14 +119,13 @@ __global__ __launch_bounds__(kLinThreads) void lin_best_index_kernel(LinArgs g) 
 
 // steps 1 and 3: which = 0 / 1
 __global__ __launch_bounds__(kLinThreads) void lin_isolated_kernel(LinArgs g, int which) {
-    const uint32_t k = blockIdx.x * kLinThreads + threadIdx.x;
-    bool gone = false;
-    if (k < g.n_scaf && !g.removed_by[k] && g.deg[2 * k] == 0 && g.deg[2 * k + 1] == 0) {
-        g.removed_by[k] = which ? 3 : 1;
-        gone = true;
-    }
-    const unsigned long long mask = __ballot(gone);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&g.counters[which], (unsigned long long)__popcll(mask));
+    uint32_t gone = 0;
+    for (uint32_t k = blockIdx.x * kLinThreads + threadIdx.x; k < g.n_scaf; k += gridDim.x * kLinThreads)
+        if (!g.removed_by[k] && g.deg[2 * k] == 0 && g.deg[2 * k + 1] == 0) {
+            g.removed_by[k] = which ? 3 : 1;
+            ++gone;
+        }
+    block_add(gone, &g.counters[which]);
 }
 
 __device__ __forceinline__ bool is_done(const LinArgs& g, uint32_t x, int round) { return g.done_at[x] < round; }
@@ -123,30 +139,52 @@ __device__ __forceinline__ bool is_ready(const LinArgs& g, uint32_t x, int round
 // decide in the first two rounds, so later rounds touch a small fraction of the edges.
 __device__ __forceinline__ uint32_t list_len(const LinArgs& g, int which) { return (uint32_t)g.counters[4 + which]; }
 
-// round, phase 1: the later endpoint of an edge between two undecided nodes has to wait
+// round, phase 1: the later endpoint of an edge between two undecided nodes has to wait.  A workgroup looks at
+// kBlockItems * 256 list entries and reserves its share of the next list with one atomic.
+constexpr int kBlockItems = 8;
 __global__ __launch_bounds__(kLinThreads) void lin_block_kernel(LinArgs g, int round) {
-    const uint32_t j = blockIdx.x * kLinThreads + threadIdx.x;
+    __shared__ uint32_t s_wave[kLinThreads / 64];
+    __shared__ uint32_t s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cur = round & 1, next = cur ^ 1;
     const uint32_t n_cur = round == 0 ? g.m : list_len(g, cur);
-    bool pending = false;
-    uint32_t i = 0;
-    if (j < n_cur) {
-        i = round == 0 ? j : g.list[cur][j];
-        if (g.alive[i]) {
-            const uint32_t a = g.a[i], b = g.b[i];
-            const bool da = is_done(g, a, round), db = is_done(g, b, round);
-            pending = !da || !db;
-            if (!da && !db) g.blocked_at[earlier(g, a, b) ? b : a] = round;
-        }
+    const uint32_t base = blockIdx.x * (kLinThreads * kBlockItems);
+    uint32_t idx[kBlockItems];
+    uint32_t mine = 0, flags = 0;
+#pragma unroll
+    for (int r = 0; r < kBlockItems; ++r) {
+        const uint32_t j = base + r * kLinThreads + t;
+        idx[r] = 0;
+        if (j >= n_cur) continue;
+        const uint32_t i = round == 0 ? j : g.list[cur][j];
+        idx[r] = i;
+        if (!g.alive[i]) continue;
+        const uint32_t a = g.a[i], b = g.b[i];
+        const bool da = is_done(g, a, round), db = is_done(g, b, round);
+        if (!da && !db) g.blocked_at[earlier(g, a, b) ? b : a] = round;
+        if (!da || !db) { flags |= 1u << r; ++mine; }
     }
-    const unsigned long long mask = __ballot(pending);
-    if (mask) {                                   // wave-aggregated append
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&g.counters[4 + next], (unsigned long long)__popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (pending) g.list[next][(uint32_t)base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    // exclusive scan of the per-thread counts over the workgroup
+    uint32_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(x, d, 64);
+        if (lane >= d) x += o;
     }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t before = x - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < kLinThreads / 64; ++w) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+    }
+    if (t == 0) s_base = total ? (uint32_t)atomicAdd(&g.counters[4 + next], (unsigned long long)total) : 0u;
+    __syncthreads();
+    uint32_t out = s_base + before;
+#pragma unroll
+    for (int r = 0; r < kBlockItems; ++r)
+        if (flags & (1u << r)) g.list[next][out++] = idx[r];
 }
 
 // phase 2: best score and number of live scoring edges of every ready node
@@ -212,10 +250,10 @@ __global__ __launch_bounds__(kLinThreads) void lin_decide_kernel(LinArgs g, int 
 }
 
 __global__ __launch_bounds__(kLinThreads) void lin_count_amb_kernel(LinArgs g) {
-    const uint32_t x = blockIdx.x * kLinThreads + threadIdx.x;
-    const bool amb = x < g.n_nodes && g.amb[x];
-    const unsigned long long mask = __ballot(amb);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&g.counters[3], (unsigned long long)__popcll(mask));
+    uint32_t amb = 0;
+    for (uint32_t x = blockIdx.x * kLinThreads + threadIdx.x; x < g.n_nodes; x += gridDim.x * kLinThreads)
+        amb += g.amb[x] ? 1u : 0u;
+    block_add(amb, &g.counters[3]);
 }
 
 __global__ __launch_bounds__(kLinThreads) void lin_degree_kernel(LinArgs g) {
@@ -261,15 +299,35 @@ __global__ __launch_bounds__(kLinThreads) void lin_walk_double_kernel(LinArgs g,
     g.lab[from ^ 1][x] = l;
 }
 
-__global__ __launch_bounds__(kLinThreads) void lin_cycle_kernel(LinArgs g, int from) {
-    const uint32_t x = blockIdx.x * kLinThreads + threadIdx.x;
-    bool head = false;
-    if (x < g.n_nodes && g.jump[from][x] >= 0) {      // the walk from x never ends: x is on a cycle
-        g.removed_by[x >> 1] = 4;
-        head = g.lab[from][x] == (int32_t)x;          // one head per directed cycle, two directions per cycle
+// Same pass, counting what it changed (a walk that ended, a label that fell).  A pass that changes nothing proves
+// that every finite walk has ended (a longer one would have a suffix ending in this pass) and that every cycle's
+// minimum has gone all the way round, so the host stops doubling there instead of after ceil(log2 n) + 1 passes.
+__global__ __launch_bounds__(kLinThreads) void lin_walk_double_count_kernel(LinArgs g, int from) {
+    uint32_t changed = 0;
+    for (uint32_t x = blockIdx.x * kLinThreads + threadIdx.x; x < g.n_nodes; x += gridDim.x * kLinThreads) {
+        const int32_t j = g.jump[from][x];
+        const int32_t l0 = g.lab[from][x];
+        int32_t l = l0, jj = -1;
+        if (j >= 0) {
+            jj = g.jump[from][j];
+            const int32_t lj = g.lab[from][j];
+            l = lj < l ? lj : l;
+        }
+        g.jump[from ^ 1][x] = jj;
+        g.lab[from ^ 1][x] = l;
+        changed += ((j >= 0 && jj < 0) || l != l0) ? 1u : 0u;
     }
-    const unsigned long long mask = __ballot(head);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&g.counters[2], (unsigned long long)__popcll(mask));
+    block_add(changed, &g.counters[7]);
+}
+
+__global__ __launch_bounds__(kLinThreads) void lin_cycle_kernel(LinArgs g, int from) {
+    uint32_t heads = 0;
+    for (uint32_t x = blockIdx.x * kLinThreads + threadIdx.x; x < g.n_nodes; x += gridDim.x * kLinThreads)
+        if (g.jump[from][x] >= 0) {                   // the walk from x never ends: x is on a cycle
+            g.removed_by[x >> 1] = 4;
+            heads += g.lab[from][x] == (int32_t)x;    // one head per directed cycle, two directions per cycle
+        }
+    block_add(heads, &g.counters[2]);
 }
 
 size_t carve(size_t& off, size_t bytes) {
@@ -373,6 +431,9 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
     BESST_HIP_TRY(hipMemsetAsync(w + L.present, 0, (size_t)(n_scaffolds > 0 ? n_scaffolds : 1), s));
     const uint32_t nb_e = (g.m + kLinThreads - 1) / kLinThreads, nb_n = (g.n_nodes + kLinThreads - 1) / kLinThreads;
     const uint32_t nb_s = (g.n_scaf + kLinThreads - 1) / kLinThreads;
+    // the counting kernels stride over their range with at most this many workgroups: one atomic each
+    constexpr uint32_t kCountBlocks = 1024;
+    const uint32_t nb_sc = nb_s < kCountBlocks ? nb_s : kCountBlocks, nb_nc = nb_n < kCountBlocks ? nb_n : kCountBlocks;
     unsigned long long host_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rounds = 0;
     if (g.n_scaf) {
@@ -381,7 +442,7 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
             hipLaunchKernelGGL(lin_best_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g);
             hipLaunchKernelGGL(lin_best_index_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g);
         }
-        if (steps & 1) hipLaunchKernelGGL(lin_isolated_kernel, dim3(nb_s), dim3(kLinThreads), 0, s, g, 0);
+        if (steps & 1) hipLaunchKernelGGL(lin_isolated_kernel, dim3(nb_sc), dim3(kLinThreads), 0, s, g, 0);
         // step 2: rounds until no live edge has an undecided endpoint (checked every kBatch rounds)
         constexpr int kBatch = 4;
         uint32_t bound = g.m;                          // upper bound of the pending list (lists only shrink)
@@ -389,7 +450,8 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
             const uint32_t nb_l = (bound + kLinThreads - 1) / kLinThreads;
             for (int r = 0; r < kBatch; ++r, ++rounds) {
                 BESST_HIP_TRY(hipMemsetAsync(&g.counters[4 + ((rounds & 1) ^ 1)], 0, 8, s));
-                hipLaunchKernelGGL(lin_block_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
+                hipLaunchKernelGGL(lin_block_kernel, dim3((nb_l + kBlockItems - 1) / kBlockItems), dim3(kLinThreads), 0, s, g,
+                                   rounds);
                 hipLaunchKernelGGL(lin_top_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
                 hipLaunchKernelGGL(lin_second_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
                 hipLaunchKernelGGL(lin_decide_kernel, dim3(nb_l), dim3(kLinThreads), 0, s, g, rounds);
@@ -401,21 +463,32 @@ int besst_dev_linearize(void* stream_, int32_t steps, int64_t n_scaffolds, int64
             if (bound == 0) break;
             BESST_REQUIRE(rounds < (1 << 24), "linearize: step 2 did not converge");
         }
-        if (steps & 2) hipLaunchKernelGGL(lin_count_amb_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g);
+        if (steps & 2) hipLaunchKernelGGL(lin_count_amb_kernel, dim3(nb_nc), dim3(kLinThreads), 0, s, g);
         if (steps & 12) {                              // degrees over the surviving link edges
             BESST_HIP_TRY(hipMemsetAsync(g.deg, 0, (size_t)g.n_nodes * 4, s));
             if (g.m) hipLaunchKernelGGL(lin_degree_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g);
         }
-        if (steps & 4) hipLaunchKernelGGL(lin_isolated_kernel, dim3(nb_s), dim3(kLinThreads), 0, s, g, 1);
+        if (steps & 4) hipLaunchKernelGGL(lin_isolated_kernel, dim3(nb_sc), dim3(kLinThreads), 0, s, g, 1);
         if (steps & 8) {
             if (g.m) hipLaunchKernelGGL(lin_mate_kernel, dim3(nb_e), dim3(kLinThreads), 0, s, g);
             hipLaunchKernelGGL(lin_walk_init_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g);
-            int from = 0;
-            for (uint64_t reach = 1; reach < 2ull * g.n_scaf; reach <<= 1) {   // walks longer than n_scaf steps are cycles
-                hipLaunchKernelGGL(lin_walk_double_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g, from);
-                from ^= 1;
+            int from = 0, passes = 0;
+            // walks longer than n_scaf steps are cycles: ceil(log2 n) + 1 passes at most, fewer when a pass (checked
+            // every other one) changes nothing
+            for (uint64_t reach = 1; reach < 2ull * g.n_scaf; reach <<= 1, ++passes) {
+                if (passes & 1) {
+                    BESST_HIP_TRY(hipMemsetAsync(&g.counters[7], 0, 8, s));
+                    hipLaunchKernelGGL(lin_walk_double_count_kernel, dim3(nb_nc), dim3(kLinThreads), 0, s, g, from);
+                    from ^= 1;
+                    BESST_HIP_TRY(hipMemcpyAsync(host_counters, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+                    BESST_HIP_TRY(hipStreamSynchronize(s));
+                    if (host_counters[7] == 0) break;
+                } else {
+                    hipLaunchKernelGGL(lin_walk_double_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g, from);
+                    from ^= 1;
+                }
             }
-            hipLaunchKernelGGL(lin_cycle_kernel, dim3(nb_n), dim3(kLinThreads), 0, s, g, from);
+            hipLaunchKernelGGL(lin_cycle_kernel, dim3(nb_nc), dim3(kLinThreads), 0, s, g, from);
         }
         BESST_HIP_TRY(hipGetLastError());
     }
