@@ -17,6 +17,8 @@
 //
 // All sizes are read from device memory (n_tuples), so the whole stage is enqueued without a host
 // round trip; grids are sized by the caller's capacity bound and surplus workgroups exit at once.
+#include <type_traits>
+
 #include "common.h"
 
 namespace besst {
@@ -55,7 +57,7 @@ constexpr int kScanFreeMaxBlocks = BESST_SCAN_FREE_MAX_BLOCKS;
 #endif
 constexpr int kWideDigitMaxBlocks = BESST_WIDE_DIGIT_MAX_BLOCKS;
 
-template <int BITS>
+template <int BITS, int ITEMS = kSortItems>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds,
     uint32_t* __restrict__ table, uint32_t stride, int scanned, uint32_t* __restrict__ zero_n,
@@ -64,16 +66,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     __shared__ uint32_t s_hist[RADIX];
     const int t = threadIdx.x;
     const uint32_t b = blockIdx.x;
-    const uint32_t base = b * kSortTile;
-    uint64_t k[kSortItems];
+    const uint32_t base = b * (kSortThreads * ITEMS);
+    uint64_t k[ITEMS];
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = base + r * kSortThreads + t;
         k[r] = i < cap ? keys[i] : 0ull;
     }
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
-    if (b >= nblocks_of(n, kSortTile)) return;
+    if (b >= nblocks_of(n, (kSortThreads * ITEMS))) return;
     for (int d = t; d < RADIX; d += kSortThreads) s_hist[d] = 0;
     __syncthreads();
     // Later passes see nearly sorted keys: whole waves share one digit and per-lane LDS atomics on one bin
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     // with the run length.
     const int lane = t & 63;
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = base + r * kSortThreads + t;
         const bool valid = i < n;
         const uint32_t d = valid ? digit_of(k[r], ds) : 0xffffffffu;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     }
     if (zero_n) {   // last pass: clear the edge-row accumulators this tile can reach (rows <= tuples)
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * kSortThreads + t;
             if (i < n) { zero_n[i] = 0; zero_sum[i] = 0; zero_sum_sq[i] = 0; }
         }
@@ -112,10 +114,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total to row_total[d]
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                             uint32_t* __restrict__ table, uint32_t stride,
-                                                            uint32_t* __restrict__ row_total) {
+                                                            uint32_t* __restrict__ row_total, uint32_t tile = kSortTile) {
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
-    const uint32_t nb = nblocks_of(n, kSortTile);
+    const uint32_t nb = nblocks_of(n, tile);
     uint32_t* row = table + (size_t)blockIdx.x * stride;
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry;
@@ -1047,6 +1049,7 @@ namespace {
 // (wave match-any on the owner byte, per-wave counters in LDS, per-tile counts from radix_hist_kernel in owner
 // mode), but a tuple's destination is its rank INSIDE its owner's region, and the payload travels with the key:
 // the thread that ranks tuple i copies payload[i] (coalesced), so no sorted copy and no gather are needed.
+template <int ITEMS>
 __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
     uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
@@ -1057,17 +1060,17 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     __shared__ uint32_t s_base[RADIX];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
-    uint64_t key[kSortItems], pl[kSortItems];
+    const uint32_t wbase = b * (kSortThreads * ITEMS) + wave * (ITEMS * 64);
+    uint64_t key[ITEMS], pl[ITEMS];
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         key[r] = i < cap ? keys_in[i] : ~0ull;
         pl[r] = i < cap ? payload[i] : 0ull;
     }
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
-    const uint32_t nb = nblocks_of(n, kSortTile);
+    const uint32_t nb = nblocks_of(n, (kSortThreads * ITEMS));
     if (nb == 0 && b == 0 && (uint32_t)t < world) {          // empty stream: headers only
         uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)t * region_bytes);
         hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0;
@@ -1098,9 +1101,9 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     }
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t dig_rank[kSortItems];   // owner | rank << 8
+    uint32_t dig_rank[ITEMS];   // owner | rank << 8
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = valid ? digit_of(key[r], ds) : (uint32_t)(RADIX - 1);
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
             const uint32_t d = dig_rank[r] & (RADIX - 1);
@@ -1191,18 +1194,30 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
     const RedWorkspace w = carve(ws, cap > 0 ? cap : 1);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "partition: workspace too small");
     const size_t region = exchange_region_bytes(pair_cap);
+    // Tiles of 1024 tuples instead of the sort's 4096 for streams of up to 4 M tuples: a C2-sized slice emits ~140 k
+    // tuples, i.e. 34 sort tiles on a 256-CU chip; with 135 small ones the two launches take 14 instead of 22 us
+    // (one rank over RCCL, whole step 190 -> 173 us).  Their [owner][tile] table (256 x 4 x sort tiles) fits the
+    // MSD table of the same workspace; larger streams keep the sort's tile.
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const DigitSel ds{1, 0, node_bits, (uint32_t)world, kRadixBits};
-    const uint32_t nb_launch = nb_sort ? nb_sort : 1;
-    const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
-    hipLaunchKernelGGL((radix_hist_kernel<kRadixBits>), dim3(nb_launch), dim3(kSortThreads), 0, s, keys, n_tuples,
-                       (uint32_t)cap, ds, w.table, w.stride, scanned, nullptr, nullptr, nullptr);
-    if (scanned)
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.table,
-                           w.stride, w.row_total);
-    hipLaunchKernelGGL(partition_scatter_kernel, dim3(nb_launch), dim3(kSortThreads), 0, s, keys, payload, n_tuples,
-                       (uint32_t)cap, ds, w.table, w.stride, w.row_total, scanned, (uint32_t)world, (uint32_t)pair_cap,
-                       static_cast<char*>(send), region);
+    auto run = [&](auto items_tag) {
+        constexpr int kItems = decltype(items_tag)::value;
+        constexpr uint32_t kTile = kSortThreads * kItems;
+        const uint32_t nb = (uint32_t)((cap + kTile - 1) / kTile);
+        const uint32_t nb_launch = nb ? nb : 1;
+        const int scanned = nb > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
+        const uint32_t stride = nb_launch;                   // rows of the scanned layout: [owner][tile]
+        hipLaunchKernelGGL((radix_hist_kernel<kRadixBits, kItems>), dim3(nb_launch), dim3(kSortThreads), 0, s, keys,
+                           n_tuples, (uint32_t)cap, ds, w.table, stride, scanned, nullptr, nullptr, nullptr);
+        if (scanned)
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.table,
+                               stride, w.row_total, kTile);
+        hipLaunchKernelGGL((partition_scatter_kernel<kItems>), dim3(nb_launch), dim3(kSortThreads), 0, s, keys,
+                           payload, n_tuples, (uint32_t)cap, ds, w.table, stride, w.row_total, scanned, (uint32_t)world,
+                           (uint32_t)pair_cap, static_cast<char*>(send), region);
+    };
+    if (nb_sort <= (uint32_t)kMsdMaxBlocks) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, kSortItems>{});
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -227,11 +227,12 @@ class ShardedGraphBuild(object):
         # not be measured on the single-GPU development box.
         self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'late')      # 'late' | 'side' | 'inline'
         self._recv = None
-        # the coverage/counter all-reduce overlaps the tuple exchange and the sort; it gets its own communicator so
-        # that it is not serialised behind the all-to-all on the default one
-        # (BESST_SIDE_GROUP=0 keeps everything on the default communicator: a fallback should two communicators
-        # ever misbehave on some RCCL build)
-        want_side = dist.is_initialized() and group is None and os.environ.get('BESST_SIDE_GROUP', '1') != '0'
+        # BESST_ALLREDUCE_ASYNC=1: the coverage/counter all-reduce overlaps the tuple exchange and the sort on its own
+        # communicator (so that it is not serialised behind the all-to-all); BESST_SIDE_GROUP=0 keeps even that on
+        # the default communicator.  See step() for why the default is the plain in-order all-reduce.
+        self.allreduce_async = os.environ.get('BESST_ALLREDUCE_ASYNC', '0') == '1'
+        want_side = (dist.is_initialized() and group is None and os.environ.get('BESST_SIDE_GROUP', '1') != '0'
+                     and (self.allreduce_async or self.tail_mode == 'side'))
         self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
@@ -294,10 +295,17 @@ class ShardedGraphBuild(object):
             dist.all_gather(gathered, tail, group=self.group)
             self._tails = tails = torch.cat(gathered)
         b.classify_emit(tails)
-        # coverage numerators and counters are final here; sum them across ranks while tuples are exchanged
-        # (issuing it after the sort instead, from a side stream that only waits for the emit stage, was 28 us
-        # SLOWER with one rank over RCCL: the extra event and stream waits cost more than the host time it frees)
-        summed = _all_reduce(b.pack_for_allreduce(), self.side_group, async_op=True)
+        # Coverage numerators and counters are final here.  Default: a plain all-reduce in stream order on the main
+        # communicator.  BESST_ALLREDUCE_ASYNC=1 issues it asynchronously on a second communicator instead, so that
+        # it overlaps the tuple exchange and the sort; with one rank over RCCL that was 17 us SLOWER per step (192
+        # vs 175 us: the event hand-overs between the streams cost more than the 80 KB all-reduce), and issuing it
+        # after the sort from a side stream another 28 us slower, so overlap stays opt-in until it can be measured
+        # across xGMI.
+        if self.allreduce_async:
+            summed = _all_reduce(b.pack_for_allreduce(), self.side_group, async_op=True)
+        else:
+            _all_reduce(b.pack_for_allreduce(), self.group)
+            summed = _Done()
         send = b.partition()
         if self._recv is None:
             self._recv = torch.empty_like(send)

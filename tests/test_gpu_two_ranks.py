@@ -3,7 +3,8 @@
 RCCL refuses two ranks on one device, so the process group is gloo and besst_amd.distributed stages its
 collectives through host copies (distributed._host_staged).  Everything else is what a multi-GPU node runs:
 HipBackend on each rank's slice, tail gather, carry across the rank boundary, owner partition, equal-split
-all-to-all, unpack, reduce, coverage/counter all-reduce on the side group, capacity growth, the final gather of
+all-to-all, unpack, reduce, coverage/counter all-reduce (in order, and asynchronously on the side group),
+capacity growth, the final gather of
 the edge rows.  The union must equal the single-process C oracle on the whole stream.
 """
 import os
@@ -28,6 +29,7 @@ def _worker(rank, port, config, tail_mode, pair_cap, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['BESST_TAIL_MODE'] = tail_mode
+    os.environ['BESST_ALLREDUCE_ASYNC'] = '1' if tail_mode == 'inline' else '0'
     import torch
     import torch.distributed as dist
     from besst_amd import distributed, workload
@@ -40,7 +42,8 @@ def _worker(rank, port, config, tail_mode, pair_cap, out):
         sub = dict(wl)
         sub['batch'] = DU.split_batch(wl['batch'], WORLD)[rank]
         job = distributed.ShardedGraphBuild(dev, sub, rank, WORLD, pair_capacity=pair_cap)
-        assert job.side_group is not job.group            # the coverage all-reduce has its own group
+        # the side communicator exists only where something runs beside the main one
+        assert (job.side_group is not job.group) == (tail_mode in ('side', 'inline'))
         for _ in range(2):
             job.step()
         torch.cuda.synchronize()
