@@ -99,6 +99,8 @@ _SIGNATURES = {
                                       C.c_size_t]),
     'besst_dev_unpack': (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
     'besst_linearize': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_score_paths': (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P]),
+    'besst_dev_score_paths': (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P]),
     'besst_dev_linearize_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
     'besst_dev_linearize': (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, _P,
                                       _P]),

@@ -369,6 +369,23 @@ int besst_dev_linearize(void* stream, int32_t steps, int64_t n_scaffolds, int64_
                         uint8_t* scaffold_removed_by, uint8_t* node_ambivalent, double* node_top,
                         double* node_second, uint32_t* node_best_edge, int64_t* counters);
 
+/* ---- ScorePaths on the link graph -------------------------------------------------------------
+ * Connectivity weights of a batch of candidate paths: calculate_connectivity / calculate_connectivity_contamination
+ * of ScorePaths (ExtendLargeScaffolds.py:29-130); the path search itself stays on the host.
+ *   n_nodes, row_ptr, col, weight   CSR of the LINK edges of the graph in both directions (node = 2 * scaffold +
+ *                                   (side == 'R'); weight = nr_links); row_ptr has n_nodes + 1 entries
+ *   n_paths, path_ptr, path_nodes   CSR of the paths (lists of nodes), path_ptr has n_paths + 1 entries
+ *   contamination                   0: calculate_connectivity (:33-69), 1: the contamination variant (:72-105)
+ *   good, bad                       out, n_paths: good_link_weight (BEFORE the division by two of :94) and
+ *                                   bad_link_weight; score = good / float(bad) is formed by the caller (:63-67)
+ * besst_score_paths takes host pointers; besst_dev_score_paths device pointers and only enqueues on `stream`. */
+int besst_score_paths(int device, int64_t n_nodes, const int64_t* row_ptr, const int32_t* col,
+                      const int32_t* weight, int64_t n_paths, const int64_t* path_ptr, const int32_t* path_nodes,
+                      int32_t contamination, int64_t* good, int64_t* bad);
+int besst_dev_score_paths(void* stream, int64_t n_nodes, const int64_t* row_ptr, const int32_t* col,
+                          const int32_t* weight, int64_t n_paths, const int64_t* path_ptr,
+                          const int32_t* path_nodes, int32_t contamination, int64_t* good, int64_t* bad);
+
 #ifdef __cplusplus
 }
 #endif
