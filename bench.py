@@ -201,6 +201,7 @@ def stage_timings(wl):
             out['score_edges_per_s'] = rows.shape[0] / dt
         lib_h.besst_prof_enable(0)
         out.update(linearize_timing())
+        out.update(scorepaths_timing())
         pairs = len(batch) // 2
         out['pcie_inclusive_pairs_per_s'] = pairs / ((out['h2d_push_ms'] + out['ctx_build_graph_ms']) * 1e-3)
     return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}
@@ -262,6 +263,81 @@ def linearize_timing(n_scaf=2_000_000, n_edges=3_000_000):
     return {'linearize_scaffolds': n_scaf, 'linearize_edges': m, 'linearize_rounds': int(counters[4]),
             'linearize_host_call_ms': host_ms, 'linearize_resident_ms': dev_ms,
             'linearize_edges_per_s': m / (dev_ms * 1e-3), 'linearize_calls_agree': same}
+
+
+def scorepaths_workload(n_scaf=50_000, n_links=150_000, n_paths=200_000, seed=11):
+    """Seeded link graph (CSR) and a batch of alternating random walks over it for the ScorePaths stage."""
+    rng = np.random.default_rng(seed)
+    n_nodes = 2 * n_scaf
+    a = rng.integers(0, n_nodes, n_links)
+    b = rng.integers(0, n_nodes, n_links)
+    keep = (a >> 1) != (b >> 1)
+    a, b = a[keep], b[keep]
+    w = rng.integers(1, 50, a.shape[0])
+    src = np.concatenate([a, b])
+    order = np.argsort(src, kind='stable')
+    col = np.ascontiguousarray(np.concatenate([b, a]).astype(np.int32)[order])
+    weight = np.ascontiguousarray(np.concatenate([w, w]).astype(np.int32)[order])
+    row_ptr = np.zeros(n_nodes + 1, np.int64)
+    np.cumsum(np.bincount(src, minlength=n_nodes), out=row_ptr[1:])
+    lens = rng.choice([2, 3, 4, 6, 8, 12, 20, 40], n_paths)
+    path_ptr = np.zeros(n_paths + 1, np.int64)
+    np.cumsum(lens, out=path_ptr[1:])
+    nodes = np.empty(int(path_ptr[-1]), np.int32)
+    cur = rng.integers(0, n_nodes, n_paths)
+    for step in range(int(lens.max())):
+        live = np.nonzero(lens > step)[0]
+        nodes[path_ptr[live] + step] = cur[live]
+        if step % 2 == 0:
+            deg = row_ptr[cur[live] + 1] - row_ptr[cur[live]]
+            pick = row_ptr[cur[live]] + (rng.integers(0, 1 << 30, live.shape[0]) % np.maximum(deg, 1))
+            nxt = np.where(deg > 0, col[np.minimum(pick, col.shape[0] - 1)], rng.integers(0, n_nodes, live.shape[0]))
+        else:
+            nxt = cur[live] ^ 1
+        cur[live] = nxt
+    return n_nodes, row_ptr, col, weight, path_ptr, nodes
+
+
+def scorepaths_timing():
+    """ScorePaths weights of 200 k candidate paths (mean 12 ends) on a 50 k-scaffold link graph, everything resident."""
+    import torch
+    from besst_amd import _lib
+    n_nodes, row_ptr, col, weight, path_ptr, nodes = scorepaths_workload()
+    n_paths = path_ptr.shape[0] - 1
+    lib_h = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    d = [torch.from_numpy(x).to(dev) for x in (row_ptr, col, weight, path_ptr, nodes)]
+    good = torch.zeros(n_paths, dtype=torch.int64, device=dev)
+    bad = torch.zeros(n_paths, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        _lib.check(lib_h.besst_dev_score_paths(stream, n_nodes, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                               n_paths, d[3].data_ptr(), d[4].data_ptr(), 0, good.data_ptr(),
+                                               bad.data_ptr()), 'besst_dev_score_paths')
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    return {'scorepaths_paths': int(n_paths), 'scorepaths_path_ends': int(path_ptr[-1]), 'scorepaths_ms': ms,
+            'scorepaths_paths_per_s': n_paths / (ms * 1e-3)}
+
+
+def scorepaths_cpu_baseline(n_sample=20_000):
+    """cpu_baseline leg: the restatement of ScorePaths' weights (oracle/scorepaths_oracle.py, one thread) on the
+    first paths of the same batch."""
+    from oracle import scorepaths_oracle as PO
+    _, row_ptr, col, weight, path_ptr, nodes = scorepaths_workload()
+    rp, cl, wl, nl, pp = row_ptr.tolist(), col.tolist(), weight.tolist(), nodes.tolist(), path_ptr.tolist()
+    t0 = time.perf_counter()
+    for p in range(n_sample):
+        PO.link_weights(rp, cl, wl, nl[pp[p]:pp[p + 1]], False)
+    dt = time.perf_counter() - t0
+    return {'value': n_sample / dt, 'unit': 'paths/s', 'cores': 1, 'kind': 'port',
+            'sample': 'first %d paths of the batch, oracle/scorepaths_oracle.link_weights, %.1f s' % (n_sample, dt)}
 
 
 def linearize_cpu_baseline(n_scaf=200_000, n_edges=300_000):
@@ -435,6 +511,7 @@ def main():
                                                       'setup and thread start)' % C_PORT_TIMING['mt_seconds']}
             if not args.no_stages:
                 base['linearize_port'] = linearize_cpu_baseline()
+                base['scorepaths_port'] = scorepaths_cpu_baseline()
             out['cpu_baseline'] = base
         else:
             out['cpu_baseline'] = None

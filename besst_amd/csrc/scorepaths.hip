@@ -8,9 +8,10 @@
 //                                          at an even one that is still to come -> bad as well (:46-58)
 //   calculate_connectivity_contamination   partner at a position of the other parity -> good, otherwise bad (:84-93);
 //                                          the good weight is halved afterwards (:94)
-// One wavefront per path: the path sits in LDS, the lanes take the (end, link edge) pairs of the path in turn, and
-// each looks its partner up by scanning the path (all lanes read the same LDS word per step: a broadcast, no bank
-// conflict).  Work per path is (sum of degrees) x (path length) compares - paths are tens of ends long, the search
+// Sixteen lanes per path (four paths per wavefront): the path sits in LDS, the lanes take its ends in turn, walk
+// that end's link edges and look every partner up by scanning the path (the lanes of a group read the same LDS word
+// per step: a broadcast).  With a whole wavefront per path and the lanes spread over one end's edges, three of 64
+// lanes had work (200 k paths: 5.3 ms).  Work per path is (sum of degrees) x (path length) compares - paths are tens of ends long, the search
 // caps them at 100 (:559) - and the sums are exact integers, so the score (a float division of the two sums, :63-67)
 // is formed on the host exactly as Python does.
 #include <hip/hip_runtime.h>
@@ -24,38 +25,39 @@ namespace besst {
 
 namespace {
 
-constexpr int kPathWaves = 4;                 // paths per workgroup
-constexpr int kPathLds = 512;                 // ends of a path kept in LDS; longer paths are scanned from global memory
+constexpr int kGroup = 16;                    // lanes per path: candidate paths are tens of ends long
+constexpr int kPathThreads = 256;
+constexpr int kPathsPerBlock = kPathThreads / kGroup;
+constexpr int kPathLds = 256;                 // ends of a path kept in LDS; longer paths are scanned from global memory
 
-__global__ __launch_bounds__(kPathWaves * 64) void score_paths_kernel(
+__global__ __launch_bounds__(kPathThreads) void score_paths_kernel(
     const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const int32_t* __restrict__ weight,
     const int64_t* __restrict__ path_ptr, const int32_t* __restrict__ path_nodes, int64_t n_paths, int contamination,
     long long* __restrict__ good_out, long long* __restrict__ bad_out) {
-    __shared__ int32_t s_path[kPathWaves][kPathLds];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t p = (int64_t)blockIdx.x * kPathWaves + wave;
-    if (p >= n_paths) return;                                  // whole waves leave; no workgroup barrier is used
-    const int64_t begin = path_ptr[p];
-    const int len = (int)(path_ptr[p + 1] - begin);
+    __shared__ int32_t s_path[kPathsPerBlock][kPathLds];
+    const int sub = threadIdx.x % kGroup, grp = threadIdx.x / kGroup;
+    const int64_t p = (int64_t)blockIdx.x * kPathsPerBlock + grp;
+    const bool live = p < n_paths;
+    const int64_t begin = live ? path_ptr[p] : 0;
+    const int len = live ? (int)(path_ptr[p + 1] - begin) : 0;
     const int32_t* path = path_nodes + begin;
     const bool in_lds = len <= kPathLds;
     if (in_lds)
-        for (int j = lane; j < len; j += 64) s_path[wave][j] = path[j];
-    // (the wave is the only reader of its row: its own LDS writes are visible to it after the implicit wave-level
-    //  ordering of ds_write / ds_read, made explicit here)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int j = sub; j < len; j += kGroup) s_path[grp][j] = path[j];
+    __syncthreads();
     long long good = 0, bad = 0;
-    for (int i = 0; i < len; ++i) {
-        const int32_t node = in_lds ? s_path[wave][i] : path[i];
-        const int64_t e0 = row_ptr[node], e1 = row_ptr[node + 1];
-        for (int64_t e = e0 + lane; e < e1; e += 64) {
+    // the lanes of a group take the ends of the path in turn; each walks that end's link edges and looks the partner
+    // up by scanning the path (the lanes of a group read the same LDS word per step: a broadcast)
+    for (int i = sub; i < len; i += kGroup) {
+        const int32_t node = in_lds ? s_path[grp][i] : path[i];
+        const int64_t e1 = row_ptr[node + 1];
+        for (int64_t e = row_ptr[node]; e < e1; ++e) {
             const int32_t nbr = col[e];
             if ((nbr >> 1) == (node >> 1)) continue;           // the scaffold's own other end (:45, node[0] != nbr[0])
             const long long w = weight[e];
             bool at_odd = false, at_even = false, visited = false;
             for (int j = 0; j < len; ++j) {
-                const int32_t x = in_lds ? s_path[wave][j] : path[j];
+                const int32_t x = in_lds ? s_path[grp][j] : path[j];
                 if (x == nbr) {
                     if (j & 1) at_odd = true; else at_even = true;
                     if (j < i) visited = true;
@@ -73,11 +75,11 @@ __global__ __launch_bounds__(kPathWaves * 64) void score_paths_kernel(
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        good += __shfl_xor(good, d, 64);
-        bad += __shfl_xor(bad, d, 64);
+    for (int d = kGroup / 2; d >= 1; d >>= 1) {
+        good += __shfl_xor(good, d, kGroup);
+        bad += __shfl_xor(bad, d, kGroup);
     }
-    if (lane == 0) { good_out[p] = good; bad_out[p] = bad; }
+    if (live && sub == 0) { good_out[p] = good; bad_out[p] = bad; }
 }
 
 }  // namespace
@@ -93,11 +95,11 @@ int besst_dev_score_paths(void* stream_, int64_t n_nodes, const int64_t* row_ptr
                           int32_t contamination, int64_t* good, int64_t* bad) {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     BESST_REQUIRE(n_nodes >= 0 && n_nodes < ((int64_t)1 << 31), "score_paths: node count out of range");
-    BESST_REQUIRE(n_paths >= 0 && n_paths < ((int64_t)1 << 31) * kPathWaves, "score_paths: path count out of range");
+    BESST_REQUIRE(n_paths >= 0 && n_paths < ((int64_t)1 << 31) * kPathsPerBlock, "score_paths: path count out of range");
     if (n_paths == 0) return BESST_OK;
     BESST_REQUIRE(row_ptr && path_ptr && path_nodes && good && bad, "score_paths: null pointer");
-    const uint32_t blocks = (uint32_t)((n_paths + kPathWaves - 1) / kPathWaves);
-    hipLaunchKernelGGL(score_paths_kernel, dim3(blocks), dim3(kPathWaves * 64), 0, s, row_ptr, col, weight, path_ptr,
+    const uint32_t blocks = (uint32_t)((n_paths + kPathsPerBlock - 1) / kPathsPerBlock);
+    hipLaunchKernelGGL(score_paths_kernel, dim3(blocks), dim3(kPathThreads), 0, s, row_ptr, col, weight, path_ptr,
                        path_nodes, n_paths, contamination ? 1 : 0, reinterpret_cast<long long*>(good),
                        reinterpret_cast<long long*>(bad));
     BESST_HIP_TRY(hipGetLastError());
