@@ -494,7 +494,7 @@ def main():
             del runner
             torch.cuda.empty_cache()
             out['stages'] = stage_timings(wl)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU legs run on rank 0 at N = 1 only
             if args.cpu_sample_records > 0:
                 base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
             else:                    # --cpu-sample-records 0: skip the Python port, keep the C port + full-size check
