@@ -446,22 +446,26 @@ int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, i
 }
 
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity) { return exchange_region_bytes(pair_capacity); }
+size_t besst_dev_exchange_stride_bytes(int64_t pair_capacity, int64_t rider_bytes) {
+    return exchange_stride_bytes(pair_capacity, rider_bytes < 0 ? 0 : rider_bytes);
+}
 
 uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world) { return owner_of_scaffold(scaffold_id, world ? world : 1); }
 
 int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits, int32_t world,
                         const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity, void* send_buffer,
-                        void* workspace, size_t workspace_bytes) {
+                        void* workspace, size_t workspace_bytes, const void* rider, int64_t rider_bytes) {
     BESST_REQUIRE(n_tuples && keys && payload && send_buffer, "partition: null pointer");
     return launch_partition(static_cast<hipStream_t>(stream), capacity, n_tuples, node_bits, world, keys, payload,
-                            pair_capacity, send_buffer, workspace, workspace_bytes);
+                            pair_capacity, send_buffer, workspace, workspace_bytes, rider, rider_bytes);
 }
 
 int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
-                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow) {
+                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum,
+                     int64_t rider_bytes) {
     BESST_REQUIRE(recv_buffer && keys && payload && gidx && n_out && overflow, "unpack: null pointer");
     return launch_unpack(static_cast<hipStream_t>(stream), world, pair_capacity, recv_buffer, keys, payload, gidx,
-                         n_out, overflow);
+                         n_out, overflow, rider_sum, rider_bytes);
 }
 
 int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,

@@ -176,11 +176,12 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr);
 size_t exchange_region_bytes(int64_t pair_cap);
+size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes);
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
                      const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
-                     size_t ws_bytes);
+                     size_t ws_bytes, const void* rider, int64_t rider_bytes);
 int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
-                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow);
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes);
 
 struct MetricsArgs {
     const int32_t* tid;

@@ -1054,11 +1054,23 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint64_t* __restrict__ payload, const uint32_t* __restrict__ n_ptr,
     uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
     const uint32_t* __restrict__ row_total, int scanned, uint32_t world, uint32_t pair_cap,
-    char* __restrict__ send, size_t region_bytes) {
+    char* __restrict__ send, size_t region_bytes, uint32_t tile_blocks, const uint64_t* __restrict__ rider,
+    uint32_t rider_words, size_t rider_offset) {
     constexpr int RADIX = kRadix;                 // one counter per thread (world <= 256)
     __shared__ uint32_t s_whist[4][RADIX];
     __shared__ uint32_t s_base[RADIX];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (blockIdx.x >= tile_blocks) {
+        // the blocks behind the tiles copy the rider (coverage numerators + counters of this rank) behind the
+        // tuples of EVERY region: the receivers sum the riders of all sources, which saves the all-reduce
+        const uint32_t nb_r = gridDim.x - tile_blocks;
+        for (uint32_t i = (blockIdx.x - tile_blocks) * kSortThreads + t; i < rider_words; i += nb_r * kSortThreads) {
+            const uint64_t v = rider[i];
+            for (uint32_t d = 0; d < world; ++d)
+                reinterpret_cast<uint64_t*>(send + (size_t)d * region_bytes + rider_offset)[i] = v;
+        }
+        return;
+    }
     const uint32_t b = blockIdx.x;
     const uint32_t wbase = b * (kSortThreads * ITEMS) + wave * (ITEMS * 64);
     uint64_t key[ITEMS], pl[ITEMS];
@@ -1154,8 +1166,22 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
 __global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ recv, uint32_t world, uint32_t pair_cap,
                                                      size_t region_bytes, uint64_t* __restrict__ keys,
                                                      uint64_t* __restrict__ payload, uint32_t* __restrict__ gidx,
-                                                     uint32_t* __restrict__ n_out, uint32_t* __restrict__ overflow) {
+                                                     uint32_t* __restrict__ n_out, uint32_t* __restrict__ overflow,
+                                                     uint32_t tuple_blocks, unsigned long long* __restrict__ rider_sum,
+                                                     uint32_t rider_words, size_t rider_offset) {
     __shared__ uint32_t s_off[257], s_base[257];
+    if (blockIdx.x >= tuple_blocks) {             // riders: sum over the sources, written over the local values
+        if (blockIdx.y != 0) return;
+        const uint32_t nb_r = gridDim.x - tuple_blocks;
+        for (uint32_t i = (blockIdx.x - tuple_blocks) * blockDim.x + threadIdx.x; i < rider_words;
+             i += nb_r * blockDim.x) {
+            unsigned long long acc = 0;
+            for (uint32_t sidx = 0; sidx < world; ++sidx)
+                acc += reinterpret_cast<const unsigned long long*>(recv + (size_t)sidx * region_bytes + rider_offset)[i];
+            rider_sum[i] = acc;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         uint32_t run = 0, gb = 0, over = 0;
         for (uint32_t sidx = 0; sidx < world; ++sidx) {
@@ -1184,16 +1210,25 @@ __global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ re
 }  // namespace
 
 size_t exchange_region_bytes(int64_t pair_cap) { return 64 + (size_t)pair_cap * 20; }
+// a region followed by a rider of `rider_bytes` (0: none); the rider starts 8-byte aligned behind the tuples
+size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes) {
+    return align_up(exchange_region_bytes(pair_cap), 8) + align_up((size_t)rider_bytes, 8);
+}
 
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
                      const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
-                     size_t ws_bytes) {
+                     size_t ws_bytes, const void* rider, int64_t rider_bytes) {
+    BESST_REQUIRE(rider_bytes >= 0 && (rider_bytes & 7) == 0 && rider_bytes < ((int64_t)1 << 31) &&
+                      (rider_bytes == 0 || rider), "partition: bad rider");
     BESST_REQUIRE(world >= 1 && world <= 256, "partition: world size must be in [1, 256]");
     BESST_REQUIRE(pair_cap > 0 && (pair_cap & 1) == 0, "partition: pair capacity must be a positive even number");
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "partition: capacity out of range");
     const RedWorkspace w = carve(ws, cap > 0 ? cap : 1);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "partition: workspace too small");
-    const size_t region = exchange_region_bytes(pair_cap);
+    const size_t region = exchange_stride_bytes(pair_cap, rider_bytes);
+    const size_t rider_offset = align_up(exchange_region_bytes(pair_cap), 8);
+    const uint32_t rider_words = (uint32_t)(rider_bytes / 8);
+    const uint32_t rider_blocks = rider_words ? (rider_words + kSortThreads - 1) / kSortThreads : 0;
     // Tiles of 1024 tuples instead of the sort's 4096 for streams of up to 4 M tuples: a C2-sized slice emits ~140 k
     // tuples, i.e. 34 sort tiles on a 256-CU chip; with 135 small ones the two launches take 14 instead of 22 us
     // (one rank over RCCL, whole step 190 -> 173 us).  Their [owner][tile] table (256 x 4 x sort tiles) fits the
@@ -1212,9 +1247,10 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
         if (scanned)
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.table,
                                stride, w.row_total, kTile);
-        hipLaunchKernelGGL((partition_scatter_kernel<kItems>), dim3(nb_launch), dim3(kSortThreads), 0, s, keys,
-                           payload, n_tuples, (uint32_t)cap, ds, w.table, stride, w.row_total, scanned, (uint32_t)world,
-                           (uint32_t)pair_cap, static_cast<char*>(send), region);
+        hipLaunchKernelGGL((partition_scatter_kernel<kItems>), dim3(nb_launch + rider_blocks), dim3(kSortThreads), 0, s,
+                           keys, payload, n_tuples, (uint32_t)cap, ds, w.table, stride, w.row_total, scanned,
+                           (uint32_t)world, (uint32_t)pair_cap, static_cast<char*>(send), region, nb_launch,
+                           static_cast<const uint64_t*>(rider), rider_words, rider_offset);
     };
     if (nb_sort <= (uint32_t)kMsdMaxBlocks) run(std::integral_constant<int, 4>{});
     else run(std::integral_constant<int, kSortItems>{});
@@ -1223,13 +1259,19 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
 }
 
 int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
-                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow) {
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes) {
     BESST_REQUIRE(world >= 1 && world <= 256, "unpack: world size must be in [1, 256]");
     BESST_REQUIRE(pair_cap > 0, "unpack: pair capacity must be positive");
-    const size_t region = exchange_region_bytes(pair_cap);
-    hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)((pair_cap + 255) / 256), (uint32_t)world), dim3(256), 0, s,
+    BESST_REQUIRE(rider_bytes >= 0 && (rider_bytes & 7) == 0 && rider_bytes < ((int64_t)1 << 31) &&
+                      (rider_bytes == 0 || rider_sum), "unpack: bad rider");
+    const size_t region = exchange_stride_bytes(pair_cap, rider_bytes);
+    const uint32_t tuple_blocks = (uint32_t)((pair_cap + 255) / 256);
+    const uint32_t rider_words = (uint32_t)(rider_bytes / 8);
+    const uint32_t rider_blocks = rider_words ? (rider_words + 255) / 256 : 0;
+    hipLaunchKernelGGL(unpack_kernel, dim3(tuple_blocks + rider_blocks, (uint32_t)world), dim3(256), 0, s,
                        static_cast<const char*>(recv), (uint32_t)world, (uint32_t)pair_cap, region, keys, payload,
-                       gidx, n_out, overflow);
+                       gidx, n_out, overflow, tuple_blocks, static_cast<unsigned long long*>(rider_sum), rider_words,
+                       align_up(exchange_region_bytes(pair_cap), 8));
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

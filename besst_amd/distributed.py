@@ -70,6 +70,9 @@ def _all_reduce(x, group, op=dist.ReduceOp.SUM, async_op=False):
     return dist.all_reduce(x, op=op, group=group, async_op=async_op)
 
 
+RIDER_MAX_BYTES = 256 * 1024
+
+
 class HipBackend(object):
     """Kernel stages of one rank on its GPU."""
 
@@ -89,7 +92,14 @@ class HipBackend(object):
         # coverage numerators and the 8 summable counter words are adjacent in the builder's state block, so ONE
         # in-place all-reduce sums both
         self._sum_buf = self.gb.state[:self.gb.n_contigs + 8]
-        self.region = self.lib.besst_dev_exchange_region_bytes(self.pair_cap)
+        # Small assemblies send that block as a RIDER behind the tuples of every exchange region and the receivers
+        # sum the riders of their sources: the all-reduce disappears from the step.  World copies of the block travel,
+        # so beyond RIDER_MAX_BYTES (32 k contigs) the all-reduce moves fewer bytes and stays.
+        mode = os.environ.get('BESST_COVERAGE_EXCHANGE', 'auto')          # 'auto' | 'rider' | 'allreduce'
+        sum_bytes = int(self._sum_buf.numel()) * 8
+        self.rider_bytes = sum_bytes if mode == 'rider' or (mode == 'auto' and sum_bytes <= RIDER_MAX_BYTES) else 0
+        self.sums_ride_exchange = self.rider_bytes > 0
+        self.region = self.lib.besst_dev_exchange_stride_bytes(self.pair_cap, self.rider_bytes)
         u8 = dict(dtype=torch.uint8, device=device)
         self.send = torch.zeros(world * self.region, **u8)
         self.part_cap = int(tuple_capacity) if tuple_capacity else self.rec.n
@@ -161,7 +171,8 @@ class HipBackend(object):
         g, p = self.gb, self.pipeline._p
         self._call('partition', self.lib.besst_dev_partition, lambda: (
             self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
-            p(self.send), p(self.ws_part), self.ws_part.numel()))
+            p(self.send), p(self.ws_part), self.ws_part.numel(),
+            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes))
         return self.send
 
     def unpack(self, recv):
@@ -171,7 +182,8 @@ class HipBackend(object):
             self._args['recv_ptr'] = recv.data_ptr()
         self._call('unpack', self.lib.besst_dev_unpack, lambda: (
             self.world, self.pair_cap, p(recv), p(self.rkeys), p(self.rpayload), p(self.gidx),
-            C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4)))
+            C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4),
+            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes))
 
     def reduce(self):
         g, p = self.gb, self.pipeline._p
@@ -232,7 +244,8 @@ class ShardedGraphBuild(object):
         # the default communicator.  See step() for why the default is the plain in-order all-reduce.
         self.allreduce_async = os.environ.get('BESST_ALLREDUCE_ASYNC', '0') == '1'
         want_side = (dist.is_initialized() and group is None and os.environ.get('BESST_SIDE_GROUP', '1') != '0'
-                     and (self.allreduce_async or self.tail_mode == 'side'))
+                     and ((self.allreduce_async and not getattr(backend, 'sums_ride_exchange', False))
+                          or self.tail_mode == 'side'))
         self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
@@ -301,7 +314,9 @@ class ShardedGraphBuild(object):
         # vs 175 us: the event hand-overs between the streams cost more than the 80 KB all-reduce), and issuing it
         # after the sort from a side stream another 28 us slower, so overlap stays opt-in until it can be measured
         # across xGMI.
-        if self.allreduce_async:
+        if getattr(b, 'sums_ride_exchange', False):
+            summed = _Done()                       # the block rides the all-to-all (HipBackend.rider_bytes)
+        elif self.allreduce_async:
             summed = _all_reduce(b.pack_for_allreduce(), self.side_group, async_op=True)
         else:
             _all_reduce(b.pack_for_allreduce(), self.group)

@@ -331,13 +331,22 @@ int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const 
                              int32_t min_mapq, double read_len, int32_t count_only, int32_t* isize_out,
                              int32_t* contam_out, int64_t* state, void* workspace, size_t workspace_bytes);
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity);
+/* A region may be followed by a RIDER: `rider_bytes` (multiple of 8) of 64-bit words that every source copies behind
+ * the tuples of each of its regions (besst_dev_partition) and every receiver sums over its sources
+ * (besst_dev_unpack, written to `rider_sum`).  The sharded build sends the coverage numerators and counters of
+ * small assemblies this way instead of all-reducing them: one collective less per step.  The exchange
+ * then moves besst_dev_exchange_stride_bytes(pair_capacity, rider_bytes) bytes per (source, destination) pair;
+ * rider_bytes = 0: no rider, stride = region. */
+size_t besst_dev_exchange_stride_bytes(int64_t pair_capacity, int64_t rider_bytes);
 uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world);
 /* workspace: besst_dev_reduce_workspace_bytes(capacity) */
 int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits,
                         int32_t world, const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity,
-                        void* send_buffer, void* workspace, size_t workspace_bytes);
+                        void* send_buffer, void* workspace, size_t workspace_bytes, const void* rider,
+                        int64_t rider_bytes);
 int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
-                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow);
+                     uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum,
+                     int64_t rider_bytes);
 
 /* ---- Scaffold-graph linearisation on the scored edge table -----------------------------------
  * Steps 1-4 of MakeScaffolds.Algorithm (MakeScaffolds.py:75-82) in one call:

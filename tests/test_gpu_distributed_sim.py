@@ -11,10 +11,14 @@ from tests import dist_util as DU
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world,orientation', [(2, 'fr'), (3, 'rf'), (8, 'fr')])
-def test_simulated_ranks_match_oracle(world, orientation):
+@pytest.mark.parametrize('world,orientation,coverage', [(2, 'fr', 'rider'), (3, 'rf', 'allreduce'), (8, 'fr', 'auto'),
+                                                        (2, 'fr', 'allreduce')])
+def test_simulated_ranks_match_oracle(world, orientation, coverage, monkeypatch):
+    """coverage: how the coverage numerators and counters are summed - as a rider of the exchange regions (the
+    receivers sum their sources' copies; 'auto' picks it for these small assemblies) or by the all-reduce."""
     import torch
     from besst_amd import distributed, workload
+    monkeypatch.setenv('BESST_COVERAGE_EXCHANGE', coverage)
     wl = workload.make('C2', 0, pairs=150000, nc=700)
     if orientation == 'rf':
         wl = workload.make('C3', 0, pairs=150000, nc=300)
@@ -48,8 +52,18 @@ def test_simulated_ranks_match_oracle(world, orientation):
     assert not any(b.overflowed() for b in backends)
     want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
     assert want.nr_of_duplicates > 0 and want.fishy_reads > 0
-    aligned = sum(b.aligned.cpu() for b in backends)
-    counters = sum(b.counter_words.cpu() for b in backends)
+    if backends[0].sums_ride_exchange:
+        assert coverage != 'allreduce'
+        # the riders were summed by every receiver: each rank already holds the global values
+        for b in backends[1:]:
+            assert torch.equal(b.aligned, backends[0].aligned)
+            assert torch.equal(b.counter_words[:8], backends[0].counter_words[:8])
+        aligned = backends[0].aligned.cpu()
+        counters = backends[0].counter_words.cpu()
+    else:
+        assert coverage == 'allreduce'
+        aligned = sum(b.aligned.cpu() for b in backends)          # what the all-reduce computes
+        counters = sum(b.counter_words.cpu() for b in backends)
     assert aligned.tolist() == want.aligned
     assert counters.tolist() == [want.count, want.non_unique, want.non_unique_for_scaf, want.nr_of_duplicates,
                                  want.too_long, want.fishy_reads, len(want.tuples), want.n_reach]
@@ -236,9 +250,11 @@ def test_simulated_ranks_library_flags(flags):
         b.reduce()
     torch.cuda.synchronize()
     want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
-    counters = sum(b.counter_words.cpu() for b in backends)
-    assert counters.tolist() == [want.count, want.non_unique, want.non_unique_for_scaf, want.nr_of_duplicates,
-                                 want.too_long, want.fishy_reads, len(want.tuples), want.n_reach]
+    assert backends[0].sums_ride_exchange            # 500 contigs: the counters were summed by the unpack stage
+    for b in backends:
+        assert b.counter_words.cpu().tolist() == [want.count, want.non_unique, want.non_unique_for_scaf,
+                                                  want.nr_of_duplicates, want.too_long, want.fishy_reads,
+                                                  len(want.tuples), want.n_reach]
     merged = {}
     for b in backends:
         rows = DU.rows_from_table(b.local_table())

@@ -3,7 +3,8 @@
 RCCL refuses two ranks on one device, so the process group is gloo and besst_amd.distributed stages its
 collectives through host copies (distributed._host_staged).  Everything else is what a multi-GPU node runs:
 HipBackend on each rank's slice, tail gather, carry across the rank boundary, owner partition, equal-split
-all-to-all, unpack, reduce, coverage/counter all-reduce (in order, and asynchronously on the side group),
+all-to-all, unpack, reduce, coverage/counter sums (as riders of the exchange, all-reduced in order, and
+asynchronously on the side group),
 capacity growth, the final gather of
 the edge rows.  The union must equal the single-process C oracle on the whole stream.
 """
@@ -25,11 +26,12 @@ def _free_port():
     return port
 
 
-def _worker(rank, port, config, tail_mode, pair_cap, out):
+def _worker(rank, port, config, tail_mode, pair_cap, coverage, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['BESST_TAIL_MODE'] = tail_mode
     os.environ['BESST_ALLREDUCE_ASYNC'] = '1' if tail_mode == 'inline' else '0'
+    os.environ['BESST_COVERAGE_EXCHANGE'] = coverage
     import torch
     import torch.distributed as dist
     from besst_amd import distributed, workload
@@ -44,6 +46,7 @@ def _worker(rank, port, config, tail_mode, pair_cap, out):
         job = distributed.ShardedGraphBuild(dev, sub, rank, WORLD, pair_capacity=pair_cap)
         # the side communicator exists only where something runs beside the main one
         assert (job.side_group is not job.group) == (tail_mode in ('side', 'inline'))
+        assert job.backend.sums_ride_exchange == (coverage != 'allreduce')
         for _ in range(2):
             job.step()
         torch.cuda.synchronize()
@@ -76,14 +79,16 @@ def _worker(rank, port, config, tail_mode, pair_cap, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('config,tail_mode,pair_cap', [('C2', 'late', 16384), ('C3', 'side', 65536),
-                                                       ('C2', 'inline', 512)])
-def test_two_processes_one_gpu(config, tail_mode, pair_cap):
+@pytest.mark.parametrize('config,tail_mode,pair_cap,coverage', [('C2', 'late', 16384, 'auto'),
+                                                                ('C3', 'side', 65536, 'rider'),
+                                                                ('C2', 'inline', 512, 'allreduce'),
+                                                                ('C2', 'late', 512, 'rider')])
+def test_two_processes_one_gpu(config, tail_mode, pair_cap, coverage):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, config, tail_mode, pair_cap, out)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, port, config, tail_mode, pair_cap, coverage, out)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
