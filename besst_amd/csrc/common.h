@@ -125,6 +125,10 @@ struct ClassifyArgs {
 
 // ---- sort / reduce geometry -------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
+// Keys per thread of a sort tile (build knob).  Swept on C2 (~140 k tuples): 8 and 4 make the MSD scatter faster
+// (15 -> 10 us) but push the stream past the scan-free table limit, and the row-scan launch they then need costs
+// what they saved (step 112-113 vs 113-115 us); the owner partition of the sharded build, whose table is 8x smaller,
+// does use 1024-tuple tiles (launch_partition).
 #ifndef BESST_SORT_ITEMS
 #define BESST_SORT_ITEMS 16
 #endif
