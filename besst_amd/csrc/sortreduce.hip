@@ -875,6 +875,14 @@ constexpr int kMaxRadix = 1 << 11;
 #define BESST_MSD_MAX_BLOCKS 1024
 #endif
 constexpr int kMsdMaxBlocks = BESST_MSD_MAX_BLOCKS;
+// Digit width of the LSD passes large streams take (build knob).  C3 slice of 8.5 M tuples (37-bit keys): 10 bits
+// = 4 passes instead of 5, but the per-tile table of 1024 counters is written as scattered 4-byte words and the
+// histogram launches go from 0.127 to 0.174 ms in total, the scatter stays at 0.22: step 1.24 -> 1.29 ms (11 bits:
+// 1.44 ms).  Fewer passes only pay once the per-tile table goes (single-pass chained scan).
+#ifndef BESST_LSD_BITS
+#define BESST_LSD_BITS 8
+#endif
+constexpr int kLsdBits = BESST_LSD_BITS;
 
 RedWorkspace carve(void* ws, int64_t cap) {
     RedWorkspace w;
@@ -889,7 +897,7 @@ RedWorkspace carve(void* ws, int64_t cap) {
     const size_t wide_max = (size_t)(kWideDigitMaxBlocks > kMsdMaxBlocks ? kWideDigitMaxBlocks : kMsdMaxBlocks);
     const size_t table_entries = nb_sort <= wide_max
                                      ? (nb_sort > (size_t)kScanFreeMaxBlocks ? nb_sort : (size_t)kScanFreeMaxBlocks) * kMaxRadix
-                                     : nb_sort * kRadix;
+                                     : nb_sort * (size_t)(1 << kLsdBits);
     w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
     w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
     w.blk_heads = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
@@ -955,7 +963,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
     // wide digits (fewer dependent launches) while the stage is latency bound, 8-bit digits for large streams
-    const int bits = nb_sort <= (uint32_t)kWideDigitMaxBlocks ? 11 : kRadixBits;
+    const int bits = nb_sort <= (uint32_t)kWideDigitMaxBlocks ? 11 : kLsdBits;
     const int passes = (key_bits + bits - 1) / bits;
     auto* zsum = reinterpret_cast<unsigned long long*>(row_sum);
     auto* zsq = reinterpret_cast<unsigned long long*>(row_sum_sq);
@@ -1009,8 +1017,8 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                 launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
                                 last ? row_n : nullptr, zsum, zsq, nullptr, packed_bits);
             else
-                launch_pass<kRadixBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
-                                        last ? row_n : nullptr, zsum, zsq, nullptr, packed_bits);
+                launch_pass<kLsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
+                                      last ? row_n : nullptr, zsum, zsq, nullptr, packed_bits);
             kin = kout;
             iin = iout;
         }
