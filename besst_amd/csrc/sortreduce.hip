@@ -114,6 +114,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total to row_total[d]
+// (A tile-major table - coalesced rows from the histogram kernel, a workgroup per 64 tiles x 256 digits scanning its
+// columns in place, the last workgroup scanning the chunk totals - was built to get rid of the one-word-per-cache-line
+// accesses of this layout: the histogram launches got 16 % faster, the scan three times slower (few, serial
+// workgroups), a C3 slice went from 1.24 to 1.34 ms and 1 M tuples from 78 to 82 us.)
 __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                             uint32_t* __restrict__ table, uint32_t stride,
                                                             uint32_t* __restrict__ row_total, uint32_t tile = kSortTile) {
