@@ -102,7 +102,9 @@ class HipBackend(object):
         self.region = self.lib.besst_dev_exchange_stride_bytes(self.pair_cap, self.rider_bytes)
         u8 = dict(dtype=torch.uint8, device=device)
         self.send = torch.zeros(world * self.region, **u8)
-        self.part_cap = int(tuple_capacity) if tuple_capacity else self.rec.n
+        # the partition reads its input speculatively up to this capacity: never beyond the emit buffers (one tuple per
+        # record at most)
+        self.part_cap = min(int(tuple_capacity), self.rec.n) if tuple_capacity else self.rec.n
         self.ws_part = torch.empty(self.lib.besst_dev_reduce_workspace_bytes(self.part_cap), **u8)
         self.tail = torch.zeros(4, dtype=torch.int32, device=device)
         self.tail_scratch = torch.zeros(2, dtype=torch.int64, device=device)
