@@ -441,6 +441,13 @@ def main():
 
     n_tuples, n_rows = runner.sizes()
     verified = None
+    exchange_ok = None
+    if world > 1 or force_dist:
+        # size-independent check of the exchange at any N: the tuples the owners received are the tuples the slices
+        # emitted (the emitted count is one of the summed counter words), and no region overflowed
+        b = runner.backend
+        emitted = int(b.counter_words.cpu()[6].item())
+        exchange_ok = bool(emitted == n_tuples and not b.overflowed())
     # the oracle is touched only in the cpu_baseline leg (--no-cpu-baseline: no oracle at all in this process)
     if world == 1 and not args.no_verify and not args.no_cpu_baseline:
         verified = verify_sharded_single_rank(runner, wl) if force_dist else verify_full(runner, wl)
@@ -487,6 +494,7 @@ def main():
                                                      / (HBM_PEAK_GBS * world), 4)},
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': verified,
+            'exchange_consistent': exchange_ok,
         }
         if world == 1 and args.in_flight > 1 and not force_dist:
             out['overlapped'] = overlapped_throughput(runner, wl, device, args.in_flight, max(args.steps, 30))
