@@ -158,6 +158,78 @@ def verify_sharded_single_rank(job, wl):
                 and job.final_prev_obs() == (int(c_ctr[8]), int(c_ctr[9])))
 
 
+def _make_slice(job):
+    from besst_amd import workload
+    config, pairs, contigs, r = job
+    return workload.make(config, 0, pairs=pairs, nc=contigs, reads_seed_offset=r)['batch']
+
+
+def _other_slices(args, world):
+    """The record slices of ranks 1 .. world-1, regenerated on rank 0 (same seeds): in worker processes when that
+    works (numpy only, spawned so that they never see this process' HIP state), one after the other otherwise."""
+    jobs = [(args.config, args.pairs, args.contigs, r) for r in range(1, world)]
+    try:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=min(len(jobs), 8), mp_context=mp.get_context('spawn')) as pool:
+            return list(pool.map(_make_slice, jobs))
+    except Exception:                                     # noqa: BLE001 - any pool problem: do it serially
+        return [_make_slice(j) for j in jobs]
+
+
+def verify_sharded_vs_single_gpu(runner, wl, args, rank, world, device):
+    """N > 1: the union of the owners' edge rows must equal what the single-GPU path builds from the whole stream
+    (all slices one after the other) - the product checked against itself, no oracle involved; the single-GPU path
+    is what the N = 1 run of the same bench checks against the C oracle.  Every rank takes part in the gather,
+    rank 0 rebuilds the other slices (same seeds) and runs the single-GPU pass."""
+    import torch
+    import torch.distributed as dist
+    from besst_amd import distributed, workload
+    from besst_amd.records import RecordBatch
+    b = runner.backend
+    t = b.local_table()
+    n_rows = torch.tensor([len(t)], dtype=torch.int64, device=device)
+    distributed._all_reduce(n_rows, None, op=dist.ReduceOp.MAX)
+    cap = int(n_rows.item()) + 1
+    # fixed-size block per rank: [rows, key..., n..., first_idx..., sum_obs...] as int64
+    block = np.zeros(1 + 4 * cap, np.int64)
+    block[0] = len(t)
+    block[1:1 + len(t)] = t.key.view(np.int64)
+    block[1 + cap:1 + cap + len(t)] = t.n
+    block[1 + 2 * cap:1 + 2 * cap + len(t)] = t.first_idx
+    block[1 + 3 * cap:1 + 3 * cap + len(t)] = t.sum_obs
+    mine = torch.from_numpy(block).to(device)
+    everything = torch.empty(world * block.shape[0], dtype=torch.int64, device=device)
+    distributed._all_gather_into(everything, mine, None)
+    if rank != 0:
+        return None
+    got = everything.cpu().numpy().reshape(world, -1)
+    parts = []
+    for r in range(world):
+        k = int(got[r, 0])
+        parts.append((got[r, 1:1 + k].view(np.uint64), got[r, 1 + cap:1 + cap + k], got[r, 1 + 2 * cap:1 + 2 * cap + k],
+                      got[r, 1 + 3 * cap:1 + 3 * cap + k]))
+    key = np.concatenate([p[0] for p in parts])
+    order = np.argsort(key, kind='stable')
+    batches = [wl['batch']] + _other_slices(args, world)
+    whole = dict(wl)
+    whole['batch'] = RecordBatch.concatenate(batches)
+    single = SingleGpu(device, whole, 1)
+    single.step()
+    ref = single.gb.fetch_table()
+    link = ~ref.is_fishy
+    ok = (np.array_equal(key[order], ref.key)
+          and np.array_equal(np.concatenate([p[1] for p in parts])[order], ref.n.astype(np.int64))
+          and np.array_equal(np.concatenate([p[2] for p in parts])[order], ref.first_idx.astype(np.int64))
+          and np.array_equal(np.concatenate([p[3] for p in parts])[order][link], ref.sum_obs[link])
+          and b.aligned.cpu().numpy().tolist() == single.gb.aligned.cpu().numpy().tolist())
+    ctr = single.gb.read_counters()
+    ok = ok and b.counter_words.cpu().numpy().tolist() == [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf,
+                                                            ctr.nr_of_duplicates, ctr.reads_with_too_long_insert,
+                                                            ctr.fishy_reads, ctr.n_tuples, ctr.n_reach]
+    return bool(ok)
+
+
 def stage_timings(wl):
     """Wall time of the other stages through the host-buffer C ABI (reported separately)."""
     import numpy as np
@@ -390,7 +462,8 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
     # ---- workload: one C2-sized slice per rank (weak scaling) -------------------------------------------
-    wl = workload.make(args.config, 0, pairs=args.pairs, nc=args.contigs, seed_offset=rank)
+    # one assembly, one library; rank r holds the r-th slice of its stream (independent reads per slice)
+    wl = workload.make(args.config, 0, pairs=args.pairs, nc=args.contigs, reads_seed_offset=rank)
     batch, table, lib = wl['batch'], wl['table'], wl['lib']
     n_rec = len(batch)
     pairs = n_rec // 2
@@ -442,12 +515,18 @@ def main():
     n_tuples, n_rows = runner.sizes()
     verified = None
     exchange_ok = None
+    sharded_ok = None
     if world > 1 or force_dist:
         # size-independent check of the exchange at any N: the tuples the owners received are the tuples the slices
         # emitted (the emitted count is one of the summed counter words), and no region overflowed
         b = runner.backend
         emitted = int(b.counter_words.cpu()[6].item())
         exchange_ok = bool(emitted == n_tuples and not b.overflowed())
+    if world > 1 and not args.no_verify:
+        try:
+            sharded_ok = verify_sharded_vs_single_gpu(runner, wl, args, rank, world, device)
+        except Exception as e:                           # noqa: BLE001 - the bench line must still be printed
+            sharded_ok = 'error: %s' % (str(e).splitlines()[0][:200] if str(e) else type(e).__name__)
     # the oracle is touched only in the cpu_baseline leg (--no-cpu-baseline: no oracle at all in this process)
     if world == 1 and not args.no_verify and not args.no_cpu_baseline:
         verified = verify_sharded_single_rank(runner, wl) if force_dist else verify_full(runner, wl)
@@ -495,6 +574,7 @@ def main():
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': verified,
             'exchange_consistent': exchange_ok,
+            'sharded_equals_single_gpu': sharded_ok,
         }
         if world == 1 and args.in_flight > 1 and not force_dist:
             out['overlapped'] = overlapped_throughput(runner, wl, device, args.in_flight, max(args.steps, 30))

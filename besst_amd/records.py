@@ -135,6 +135,13 @@ class RecordBatch(object):
         return RecordBatch(self.references, self.lengths, rlen=rlen, alen=alen, **kw)
 
     @classmethod
+    def concatenate(cls, batches):
+        """The batches' records one after the other (same reference table)."""
+        first = batches[0]
+        kw = {name: np.concatenate([getattr(b, name) for b in batches]) for name, _ in _COLUMNS}
+        return cls(first.references, first.lengths, **kw)
+
+    @classmethod
     def from_pysam_like(cls, bam_file):
         """Materialise any pysam-like iterable (slow host loop; compatibility path only)."""
         if isinstance(bam_file, RecordBatch):

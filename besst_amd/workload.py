@@ -26,14 +26,16 @@ def node_bits_for(table):
     return max(1, int(max_id * 2 + 1).bit_length())
 
 
-def make(config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, tid_offset=0):
+def make(config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, tid_offset=0, reads_seed_offset=0):
+    """seed_offset: a different assembly AND different reads; reads_seed_offset: the same assembly (contig table),
+    an independent set of read pairs - what rank r of a sharded run holds: its slice of one library's stream."""
     cfg = synth.CONFIGS[config]
     spec = cfg['libs'][lib_index]
     n_pairs = int(pairs if pairs is not None else cfg['pairs'] // len(cfg['libs']))
     n_ctg = int(nc if nc is not None else cfg['nc'])
     seed = synth.config_seed(config) + 1000 * seed_offset
     asm = synth.make_assembly(n_ctg, cfg['median'], seed)
-    batch = synth.simulate_library(asm, spec, n_pairs, seed + 100 + lib_index)
+    batch = synth.simulate_library(asm, spec, n_pairs, seed + 100 + lib_index + 7919 * reads_seed_offset)
     lib = dict(read_len=float(spec.read_len), ins_size_threshold=spec.mean + 6 * spec.sd, min_mapq=11,
                orientation=spec.orientation, detect_duplicate=True, extend_paths=True, no_score=False,
                mean=spec.mean, sd=spec.sd)
