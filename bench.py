@@ -5,7 +5,8 @@ A step = one pass of the hot path over one resident batch: record loop (classify
 chain, ordered tuple emission, radix sort and edge-table reduction, all enqueued on one HIP stream
 through the besst_dev_* C ABI with the record columns already in HBM.  No host round trip happens
 inside a step.  At N > 1 every rank owns a contiguous slice of the (tid,pos)-sorted stream
-(weak scaling: one C2-sized slice per GPU); see besst_amd/distributed.py.
+(weak scaling: one C2-sized slice per GPU, all of one assembly) and the result is checked against the
+single-GPU build of the whole stream (sharded_equals_single_gpu); see besst_amd/distributed.py.
 
 Prints ONE JSON line on rank 0 (see the repo prompt for the contract) with two extra objects:
   roofline     - dominant kernel (stream_kernel): algorithmic bytes per launch / mean launch
