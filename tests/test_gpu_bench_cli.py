@@ -1,0 +1,54 @@
+"""bench.py end to end on the GPU box: the default single-GPU line and the driver's N = 2 command line (torchrun,
+both ranks on the box's one GPU over the gloo transport), at reduced sizes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['--pairs', '400000', '--contigs', '3000', '--steps', '5', '--warmup', '2', '--cpu-sample-records', '200000']
+
+
+def _last_json_line(text):
+    lines = [l for l in text.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + SMALL, cwd=REPO, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['higher_is_better'] is True
+    assert d['verified_vs_c_oracle'] is True
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline'])
+    assert d['stages']['linearize_calls_agree'] is True
+    assert abs(d['value'] - 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
+def test_two_ranks_over_gloo_on_one_gpu():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2'] + SMALL
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert d['exchange_consistent'] is True
+    assert d['sharded_equals_single_gpu'] is True
+    assert d['cpu_baseline'] is None                      # the CPU legs run at N = 1 only
+    assert abs(d['value'] - 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
