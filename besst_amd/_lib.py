@@ -87,7 +87,7 @@ _SIGNATURES = {
     'besst_dev_classify_tail_search': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                                  C.POINTER(LibParams), C.c_int32, _P, _P]),
     'besst_dev_classify_emit': (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_size_t, C.c_int64,
-                                          _P, _P, _P, C.c_int32]),
+                                          _P, _P, _P, C.c_int32, _P]),
     'besst_dev_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                         C.c_double, _P, _P, _P, _P, _P, C.c_size_t]),
     'besst_dev_metrics_workspace_bytes': (C.c_size_t, [C.c_int64]),
@@ -97,8 +97,9 @@ _SIGNATURES = {
     'besst_owner_of_scaffold': (C.c_uint32, [C.c_uint32, C.c_uint32]),
     'besst_dev_exchange_stride_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
     'besst_dev_partition': (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, _P,
-                                      C.c_size_t, _P, C.c_int64]),
-    'besst_dev_unpack': (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64]),
+                                      C.c_size_t, _P, C.c_int64, _P]),
+    'besst_dev_unpack': (C.c_int, [_P, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32,
+                                   C.c_int32, C.c_int32, _P, _P]),
     'besst_linearize': (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_score_paths': (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P]),
     'besst_dev_score_paths': (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, C.c_int32, _P, _P]),

@@ -435,14 +435,16 @@ int besst_dev_classify_tail_search(void* stream, int64_t n, const int32_t* tid, 
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table, int64_t* aligned,
-                            const int32_t* tails, int32_t rank) {
+                            const int32_t* tails, int32_t rank, int32_t* slice_info) {
+    BESST_REQUIRE(!(tails && slice_info), "classify_emit: tails and slice_info exclude each other");
     BESST_REQUIRE(carry && keys && payload && n_out && counters && contig_table && aligned,
                   "classify_emit: null pointer");
     BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "classify_emit: n_contigs out of range");
     BESST_REQUIRE(rank >= 0 && rank <= 65536, "classify_emit: rank out of range");
     const uint8_t* cls8 = static_cast<const uint8_t*>(contig_table) + (size_t)n_contigs * sizeof(ContigRow);
     return launch_classify_emit(static_cast<hipStream_t>(stream), n, detect_duplicate, carry, keys, payload, n_out,
-                                counters, workspace, workspace_bytes, cls8, (int32_t)n_contigs, aligned, tails, rank);
+                                counters, workspace, workspace_bytes, cls8, (int32_t)n_contigs, aligned, tails, rank,
+                                slice_info);
 }
 
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity) { return exchange_region_bytes(pair_capacity); }
@@ -454,18 +456,21 @@ uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world) { return 
 
 int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits, int32_t world,
                         const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity, void* send_buffer,
-                        void* workspace, size_t workspace_bytes, const void* rider, int64_t rider_bytes) {
+                        void* workspace, size_t workspace_bytes, const void* rider, int64_t rider_bytes,
+                        const int32_t* slice_info) {
     BESST_REQUIRE(n_tuples && keys && payload && send_buffer, "partition: null pointer");
     return launch_partition(static_cast<hipStream_t>(stream), capacity, n_tuples, node_bits, world, keys, payload,
-                            pair_capacity, send_buffer, workspace, workspace_bytes, rider, rider_bytes);
+                            pair_capacity, send_buffer, workspace, workspace_bytes, rider, rider_bytes, slice_info);
 }
 
 int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
                      uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum,
-                     int64_t rider_bytes) {
+                     int64_t rider_bytes, int32_t speculative_heads, int32_t rank, int32_t detect_duplicate,
+                     int32_t* all_slice_info, besst_counters* counters) {
     BESST_REQUIRE(recv_buffer && keys && payload && gidx && n_out && overflow, "unpack: null pointer");
     return launch_unpack(static_cast<hipStream_t>(stream), world, pair_capacity, recv_buffer, keys, payload, gidx,
-                         n_out, overflow, rider_sum, rider_bytes);
+                         n_out, overflow, rider_sum, rider_bytes, speculative_heads, rank, detect_duplicate,
+                         all_slice_info, counters);
 }
 
 int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,

@@ -40,38 +40,6 @@ struct Eval {
     uint32_t n_min, n_max;   // node codes (scaffold * 2 + side) of the edge this record may support
 };
 
-struct CEDelta {
-    int count, too_long, dup, nus;
-    bool keep;
-};
-
-// CreateEdge call sequence for one record (CreateGraph.py:176-183,812-871): first call against the
-// running prev_obs, optional second call (G_prime) with prev_obs reset to (-1,-1).
-__device__ __forceinline__ CEDelta create_edge(int o1, int o2, int p1, int p2, bool accept, bool dbl,
-                                               bool mapq0, bool detect) {
-    CEDelta d{0, 0, 0, 0, false};
-    d.nus += mapq0 ? 1 : 0;
-    if (o1 == p1 && o2 == p2) {
-        d.dup++;
-        if (detect) return d;
-    }
-    if (accept) {
-        d.count++;
-        d.keep = true;
-    } else {
-        d.too_long++;
-    }
-    if (dbl) {
-        d.nus += mapq0 ? 1 : 0;
-        if (o1 == -1 && o2 == -1) {
-            d.dup++;
-            if (detect) return d;
-        }
-        if (accept) d.count++; else d.too_long++;
-    }
-    return d;
-}
-
 // One end of PosDirCalculatorPE / PosDirCalculatorMP (CreateGraph.py:1024-1076).  The MP calculator is
 // the PE one with the read strand inverted.  read_len may be fractional: Python evaluates
 // `cpos + rpos + read_len` and `slen - cpos - (clen - rpos - read_len)` left to right in float and
@@ -588,8 +556,16 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                                                       uint32_t* __restrict__ skip_slot,
                                                       uint32_t* n_out,
                                                       unsigned long long* counters,
-                                                      const int32_t* __restrict__ tails, int rank) {
+                                                      const int32_t* __restrict__ tails, int rank,
+                                                      int32_t* __restrict__ slice_info) {
+    // slice_info != nullptr (sharded build without a tail exchange): the slice's FIRST reaching record is left
+    // unresolved - its provisional tuple stays, its CreateEdge call is not counted - and described in slice_info
+    // { any reaching, last obs1, last obs2, head present, head obs1, head obs2, head info, head tuple position },
+    // which travels in the exchange headers; the owners resolve it against the slices before (unpack_kernel).
     __shared__ int32_t s_l1[1024 * kStitchRounds], s_l2[1024 * kStitchRounds];
+    __shared__ int s_any;            // a block before this iteration reached CreateEdge
+    __shared__ int s_head_block;     // block of the slice head (speculative mode), -1 before it is found
+    __shared__ int32_t s_head[4];    // its obs1, obs2, info, slot
     __shared__ int s_tab[64];
     __shared__ int s_total;
     __shared__ int32_t s_carry[2];
@@ -603,6 +579,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
             for (int j = 0; j < rank; ++j)
                 if (tails[j * 4]) { p1 = tails[j * 4 + 1]; p2 = tails[j * 4 + 2]; }
         s_carry[0] = p1; s_carry[1] = p2; s_base = 0;
+        s_any = 0; s_head_block = -1;
     }
     __syncthreads();
     int c_count = 0, c_long = 0, c_dup = 0, c_nus = 0, c_nonuniq = 0, c_fishy = 0, c_reach = 0;
@@ -664,7 +641,10 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
             const int32_t p2 = pi >= 0 ? s_l2[pi] : s_carry[1];
             n_final[r] = n_emit[r];
             skip[r] = kNoSlot;
-            if (has[r]) {
+            if (has[r] && slice_info && pi < 0 && !s_any) {        // the slice head: resolved by the owners
+                s_head_block = (int)(c0 + (uint32_t)r * 1024u + (uint32_t)t);
+                s_head[0] = f1[r]; s_head[1] = f2[r]; s_head[2] = (int32_t)head_info[r]; s_head[3] = (int32_t)head_slot[r];
+            } else if (has[r]) {
                 const CEDelta d = create_edge(f1[r], f2[r], p1, p2, head_info[r] & 1u, head_info[r] & 2u,
                                               head_info[r] & 4u, detect != 0);
                 c_count += d.count; c_long += d.too_long; c_dup += d.dup; c_nus += d.nus;
@@ -711,7 +691,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
         __syncthreads();
         if (t == 0) {
             s_base = base + iter_total;
-            if (last_idx >= 0) { s_carry[0] = s_l1[last_idx]; s_carry[1] = s_l2[last_idx]; }
+            if (last_idx >= 0) { s_carry[0] = s_l1[last_idx]; s_carry[1] = s_l2[last_idx]; s_any = 1; }
         }
         __syncthreads();
     }
@@ -735,6 +715,15 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
         carry[1] = s_carry[1];
         *n_out = (uint32_t)s_base;
         atomicAdd(&counters[6], (unsigned long long)s_base);
+        if (slice_info) {
+            const bool head = s_head_block >= 0;
+            slice_info[0] = s_any; slice_info[1] = s_carry[0]; slice_info[2] = s_carry[1];
+            slice_info[3] = head ? 1 : 0;
+            slice_info[4] = head ? s_head[0] : 0; slice_info[5] = head ? s_head[1] : 0;
+            slice_info[6] = head ? s_head[2] : 0;
+            // position of the head's provisional tuple in the slice's compacted stream (-1: none was emitted)
+            slice_info[7] = head && (s_head[2] & 8) ? (int32_t)(offsets[s_head_block] + (uint32_t)s_head[3]) : -1;
+        }
     }
 }
 
@@ -961,9 +950,10 @@ int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* t
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,
-                         const int32_t* tails, int rank) {
+                         const int32_t* tails, int rank, int32_t* slice_info) {
     if (n <= 0) {
         BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
+        if (slice_info) BESST_HIP_TRY(hipMemsetAsync(slice_info, 0, 8 * sizeof(int32_t), s));
         return BESST_OK;
     }
     const ClsWorkspace w = carve(ws, n);
@@ -977,7 +967,7 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     {
         ProfScope ps(s, kProfStitch);
         hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
-                           w.skip, n_out, ctr, tails, rank);
+                           w.skip, n_out, ctr, tails, rank, slice_info);
     }
     {
         ProfScope ps(s, kProfCompact);
@@ -993,7 +983,7 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
     int rc = launch_classify_scan(s, a, aligned, counters, ws, ws_bytes);
     if (rc) return rc;
     return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
-                                a.n_contigs, aligned, nullptr, 0);
+                                a.n_contigs, aligned, nullptr, 0, nullptr);
 }
 
 }  // namespace besst

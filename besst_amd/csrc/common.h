@@ -143,6 +143,39 @@ constexpr int kRedTile = kRedThreads * kRedItems;      // 2048 tuples per block
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+struct CEDelta {
+    int count, too_long, dup, nus;
+    bool keep;
+};
+
+// CreateEdge call sequence for one record (shared by the record loop, the stitch and - sharded build - the unpack
+// stage, which resolves slice heads).  One record (CreateGraph.py:176-183,812-871): first call against the
+// running prev_obs, optional second call (G_prime) with prev_obs reset to (-1,-1).
+__device__ __forceinline__ CEDelta create_edge(int o1, int o2, int p1, int p2, bool accept, bool dbl,
+                                               bool mapq0, bool detect) {
+    CEDelta d{0, 0, 0, 0, false};
+    d.nus += mapq0 ? 1 : 0;
+    if (o1 == p1 && o2 == p2) {
+        d.dup++;
+        if (detect) return d;
+    }
+    if (accept) {
+        d.count++;
+        d.keep = true;
+    } else {
+        d.too_long++;
+    }
+    if (dbl) {
+        d.nus += mapq0 ? 1 : 0;
+        if (o1 == -1 && o2 == -1) {
+            d.dup++;
+            if (detect) return d;
+        }
+        if (accept) d.count++; else d.too_long++;
+    }
+    return d;
+}
+
 // digit selector of the radix kernels: mode 0 = 8-bit digit at `shift`, mode 1 = owner rank of the key
 struct DigitSel {
     int mode;
@@ -171,7 +204,7 @@ int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* t
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,
-                         const int32_t* tails, int rank);
+                         const int32_t* tails, int rank, int32_t* slice_info);
 
 size_t reduce_workspace_bytes(int64_t cap);
 int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
@@ -183,9 +216,10 @@ size_t exchange_region_bytes(int64_t pair_cap);
 size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes);
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
                      const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
-                     size_t ws_bytes, const void* rider, int64_t rider_bytes);
+                     size_t ws_bytes, const void* rider, int64_t rider_bytes, const int32_t* slice_info);
 int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
-                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes);
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes,
+                  int speculative, int rank, int detect_dup, int32_t* all_info, besst_counters* counters);
 
 struct MetricsArgs {
     const int32_t* tid;

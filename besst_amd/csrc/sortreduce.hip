@@ -1069,7 +1069,10 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table, uint32_t stride,
     const uint32_t* __restrict__ row_total, int scanned, uint32_t world, uint32_t pair_cap,
     char* __restrict__ send, size_t region_bytes, uint32_t tile_blocks, const uint64_t* __restrict__ rider,
-    uint32_t rider_words, size_t rider_offset) {
+    uint32_t rider_words, size_t rider_offset, const int32_t* __restrict__ slice_info) {
+    // slice_info (stitch_kernel's speculative mode): copied into words 4..11 of every region header; the thread that
+    // places the slice head's provisional tuple tells every destination where it went (words 12, 13: owner, position
+    // inside the owner's region), so that the owner can drop it without a search if it turns out to be a duplicate.
     constexpr int RADIX = kRadix;                 // one counter per thread (world <= 256)
     __shared__ uint32_t s_whist[4][RADIX];
     __shared__ uint32_t s_base[RADIX];
@@ -1100,6 +1103,8 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     if (nb == 0 && b == 0 && (uint32_t)t < world) {          // empty stream: headers only
         uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)t * region_bytes);
         hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0;
+        if (slice_info)
+            for (int k = 0; k < 8; ++k) hdr[4 + k] = (uint32_t)slice_info[k];
     }
     if (b >= nb) return;
 #pragma unroll
@@ -1123,6 +1128,8 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
             hdr[1] = tot;                                    // tuples the source wanted to send (overflow check)
             hdr[2] = n;                                      // the source's total: base of the next source's indexes
             hdr[3] = 0;
+            if (slice_info)
+                for (int k = 0; k < 8; ++k) hdr[4 + k] = (uint32_t)slice_info[k];
         }
     }
     __syncthreads();
@@ -1167,6 +1174,11 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
         if (i < n) {
             const uint32_t d = dig_rank[r] & (RADIX - 1);
             const uint32_t p = s_whist[wave][d] + (dig_rank[r] >> kRadixBits);
+            if (slice_info && (int32_t)i == slice_info[7])   // the slice head's provisional tuple
+                for (uint32_t d2 = 0; d2 < world; ++d2) {
+                    uint32_t* hdr = reinterpret_cast<uint32_t*>(send + (size_t)d2 * region_bytes);
+                    hdr[12] = d; hdr[13] = p;
+                }
             if (p < pair_cap) {                              // overflow is reported through hdr[1] > hdr[0]
                 char* region = send + (size_t)d * region_bytes + 64;
                 reinterpret_cast<uint64_t*>(region)[p] = key[r];
@@ -1177,13 +1189,72 @@ __global__ __launch_bounds__(kSortThreads) void partition_scatter_kernel(
     }
 }
 
+// Speculative heads (spec != 0, stitch_kernel's slice_info in the headers): no tail exchange ran before the emit
+// stage, so every source left its first reaching record unresolved.  Each receiver replays the chain over the
+// sources - the prev_obs entering source s is the tail of the nearest earlier source that reached CreateEdge, the
+// reference's initial (-1, -1) for the first - applies CreateEdge to each head (CreateGraph.py:835-870), corrects
+// the (already summed) counters by the heads' contributions and, where a head turns out to be a duplicate, drops its
+// provisional tuple: the owner finds it at the position the source wrote into the header, every receiver shifts the
+// global emit indexes behind it.  All ranks compute the same corrections from the same headers.
 __global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ recv, uint32_t world, uint32_t pair_cap,
                                                      size_t region_bytes, uint64_t* __restrict__ keys,
                                                      uint64_t* __restrict__ payload, uint32_t* __restrict__ gidx,
                                                      uint32_t* __restrict__ n_out, uint32_t* __restrict__ overflow,
                                                      uint32_t tuple_blocks, unsigned long long* __restrict__ rider_sum,
-                                                     uint32_t rider_words, size_t rider_offset) {
-    __shared__ uint32_t s_off[257], s_base[257];
+                                                     uint32_t rider_words, size_t rider_offset, int spec,
+                                                     uint32_t my_rank, int detect, int32_t* __restrict__ all_info,
+                                                     unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_off[257], s_base[257], s_cnt[256];
+    __shared__ int32_t s_drop_local[256], s_drop_src[256];
+    __shared__ long long s_delta[8];              // corrections of the 8 summed counter words
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, gb = 0, over = 0;
+        int32_t p1 = -1, p2 = -1;                 // Parameter.counters: prev_obs1 = prev_obs2 = -1
+        long long dc = 0, dl = 0, dd = 0, dn = 0, dt = 0;
+        for (uint32_t sidx = 0; sidx < world; ++sidx) {
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(recv + (size_t)sidx * region_bytes);
+            uint32_t cnt = hdr[0], tot = hdr[2];
+            int32_t drop_local = -1, drop_src = -1;
+            if (spec) {
+                const bool any = hdr[4] != 0, head = hdr[7] != 0;
+                const uint32_t info = hdr[10];
+                if (head) {
+                    const CEDelta d = create_edge((int32_t)hdr[8], (int32_t)hdr[9], p1, p2, info & 1u, info & 2u,
+                                                  info & 4u, detect != 0);
+                    dc += d.count; dl += d.too_long; dd += d.dup; dn += d.nus;
+                    if ((info & 8u) && !d.keep) {            // the provisional tuple has to go
+                        drop_src = (int32_t)hdr[11];
+                        if (hdr[12] == my_rank && hdr[13] < cnt) drop_local = (int32_t)hdr[13];
+                        dt -= 1;
+                    }
+                }
+                if (any) { p1 = (int32_t)hdr[5]; p2 = (int32_t)hdr[6]; }
+                if (all_info && blockIdx.x == 0 && blockIdx.y == 0)
+                    for (int k = 0; k < 8; ++k) all_info[sidx * 8 + k] = (int32_t)hdr[4 + k];
+            }
+            s_off[sidx] = run;
+            s_base[sidx] = gb;
+            s_cnt[sidx] = cnt;
+            s_drop_local[sidx] = drop_local;
+            s_drop_src[sidx] = drop_src;
+            run += cnt - (drop_local >= 0 ? 1u : 0u);
+            gb += tot - (drop_src >= 0 ? 1u : 0u);
+            over |= hdr[1] > hdr[0] ? 1u : 0u;
+        }
+        s_off[world] = run;
+        // besst_counters words: count 0, non_unique 1, non_unique_for_scaf 2, nr_of_duplicates 3, too_long 4, fishy 5,
+        // n_tuples 6, n_reach 7
+        s_delta[0] = dc; s_delta[1] = 0; s_delta[2] = dn; s_delta[3] = dd; s_delta[4] = dl; s_delta[5] = 0;
+        s_delta[6] = dt; s_delta[7] = 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            *n_out = run;
+            if (over) *overflow = 1u;
+            if (spec && !rider_words)              // counters were all-reduced before: add the corrections here
+                for (int k = 0; k < 8; ++k)
+                    if (s_delta[k]) atomicAdd(&counters[k], (unsigned long long)s_delta[k]);
+        }
+    }
+    __syncthreads();
     if (blockIdx.x >= tuple_blocks) {             // riders: sum over the sources, written over the local values
         if (blockIdx.y != 0) return;
         const uint32_t nb_r = gridDim.x - tuple_blocks;
@@ -1192,33 +1263,22 @@ __global__ __launch_bounds__(256) void unpack_kernel(const char* __restrict__ re
             unsigned long long acc = 0;
             for (uint32_t sidx = 0; sidx < world; ++sidx)
                 acc += reinterpret_cast<const unsigned long long*>(recv + (size_t)sidx * region_bytes + rider_offset)[i];
+            if (spec && i + 8 >= rider_words) acc += (unsigned long long)s_delta[i + 8 - rider_words];   // the counter words
             rider_sum[i] = acc;
         }
         return;
     }
-    if (threadIdx.x == 0) {
-        uint32_t run = 0, gb = 0, over = 0;
-        for (uint32_t sidx = 0; sidx < world; ++sidx) {
-            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(recv + (size_t)sidx * region_bytes);
-            s_off[sidx] = run;
-            s_base[sidx] = gb;
-            run += hdr[0];
-            gb += hdr[2];
-            over |= hdr[1] > hdr[0] ? 1u : 0u;
-        }
-        s_off[world] = run;
-        if (blockIdx.x == 0 && blockIdx.y == 0) { *n_out = run; if (over) *overflow = 1u; }
-    }
-    __syncthreads();
     const uint32_t sidx = blockIdx.y;
-    const uint32_t cnt = s_off[sidx + 1] - s_off[sidx];
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= cnt) return;
+    if (p >= s_cnt[sidx]) return;
+    const int32_t dl = s_drop_local[sidx], ds = s_drop_src[sidx];
+    if ((int32_t)p == dl) return;
     const char* region = recv + (size_t)sidx * region_bytes + 64;
-    const uint32_t dst = s_off[sidx] + p;
+    const uint32_t dst = s_off[sidx] + p - (dl >= 0 && (int32_t)p > dl ? 1u : 0u);
+    const uint32_t idx = reinterpret_cast<const uint32_t*>(region + (size_t)pair_cap * 16)[p];
     keys[dst] = reinterpret_cast<const uint64_t*>(region)[p];
     payload[dst] = reinterpret_cast<const uint64_t*>(region + (size_t)pair_cap * 8)[p];
-    gidx[dst] = s_base[sidx] + reinterpret_cast<const uint32_t*>(region + (size_t)pair_cap * 16)[p];
+    gidx[dst] = s_base[sidx] + idx - (ds >= 0 && (int32_t)idx > ds ? 1u : 0u);
 }
 
 }  // namespace
@@ -1231,7 +1291,7 @@ size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes) {
 
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,
                      const uint64_t* keys, const uint64_t* payload, int64_t pair_cap, void* send, void* ws,
-                     size_t ws_bytes, const void* rider, int64_t rider_bytes) {
+                     size_t ws_bytes, const void* rider, int64_t rider_bytes, const int32_t* slice_info) {
     BESST_REQUIRE(rider_bytes >= 0 && (rider_bytes & 7) == 0 && rider_bytes < ((int64_t)1 << 31) &&
                       (rider_bytes == 0 || rider), "partition: bad rider");
     BESST_REQUIRE(world >= 1 && world <= 256, "partition: world size must be in [1, 256]");
@@ -1264,7 +1324,7 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
         hipLaunchKernelGGL((partition_scatter_kernel<kItems>), dim3(nb_launch + rider_blocks), dim3(kSortThreads), 0, s,
                            keys, payload, n_tuples, (uint32_t)cap, ds, w.table, stride, w.row_total, scanned,
                            (uint32_t)world, (uint32_t)pair_cap, static_cast<char*>(send), region, nb_launch,
-                           static_cast<const uint64_t*>(rider), rider_words, rider_offset);
+                           static_cast<const uint64_t*>(rider), rider_words, rider_offset, slice_info);
     };
     if (nb_sort <= (uint32_t)kMsdMaxBlocks) run(std::integral_constant<int, 4>{});
     else run(std::integral_constant<int, kSortItems>{});
@@ -1273,8 +1333,11 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
 }
 
 int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, uint64_t* keys, uint64_t* payload,
-                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes) {
+                  uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum, int64_t rider_bytes,
+                  int speculative, int rank, int detect_dup, int32_t* all_info, besst_counters* counters) {
     BESST_REQUIRE(world >= 1 && world <= 256, "unpack: world size must be in [1, 256]");
+    BESST_REQUIRE(!speculative || (rank >= 0 && rank < world && counters), "unpack: bad speculative-head arguments");
+    BESST_REQUIRE(!speculative || rider_bytes == 0 || rider_bytes >= 64, "unpack: the rider must end with the counters");
     BESST_REQUIRE(pair_cap > 0, "unpack: pair capacity must be positive");
     BESST_REQUIRE(rider_bytes >= 0 && (rider_bytes & 7) == 0 && rider_bytes < ((int64_t)1 << 31) &&
                       (rider_bytes == 0 || rider_sum), "unpack: bad rider");
@@ -1285,7 +1348,8 @@ int launch_unpack(hipStream_t s, int world, int64_t pair_cap, const void* recv, 
     hipLaunchKernelGGL(unpack_kernel, dim3(tuple_blocks + rider_blocks, (uint32_t)world), dim3(256), 0, s,
                        static_cast<const char*>(recv), (uint32_t)world, (uint32_t)pair_cap, region, keys, payload,
                        gidx, n_out, overflow, tuple_blocks, static_cast<unsigned long long*>(rider_sum), rider_words,
-                       align_up(exchange_region_bytes(pair_cap), 8));
+                       align_up(exchange_region_bytes(pair_cap), 8), speculative ? 1 : 0, (uint32_t)rank, detect_dup,
+                       all_info, reinterpret_cast<unsigned long long*>(counters));
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

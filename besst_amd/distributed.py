@@ -167,14 +167,14 @@ class HipBackend(object):
             self._args['tails_ptr'] = tails.data_ptr()
         self._call('classify_emit', self.lib.besst_dev_classify_emit, lambda: (
             self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
-            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned), p(tails), self.rank))
+            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned), p(tails), self.rank, None))
 
     def partition(self):
         g, p = self.gb, self.pipeline._p
         self._call('partition', self.lib.besst_dev_partition, lambda: (
             self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
             p(self.send), p(self.ws_part), self.ws_part.numel(),
-            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes))
+            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes, None))
         return self.send
 
     def unpack(self, recv):
@@ -185,7 +185,7 @@ class HipBackend(object):
         self._call('unpack', self.lib.besst_dev_unpack, lambda: (
             self.world, self.pair_cap, p(recv), p(self.rkeys), p(self.rpayload), p(self.gidx),
             C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4),
-            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes))
+            p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes, 0, self.rank, 0, None, None))
 
     def reduce(self):
         g, p = self.gb, self.pipeline._p

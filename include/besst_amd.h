@@ -297,7 +297,7 @@ int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, in
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table,
-                            int64_t* aligned, const int32_t* tails, int32_t rank);
+                            int64_t* aligned, const int32_t* tails, int32_t rank, int32_t* slice_info);
 /* Per-edge scoring on caller-owned device buffers (the device-pointer form of besst_ctx_score_edges;
  * CreateGraph.py:498-614): ML gap by bisection, expected sigma, KS numerator h = max|#{l1 <= x} - #{l2 <= x}| on the
  * centred per-end observations.  In the sharded build every rank scores the rows it owns.
@@ -343,10 +343,11 @@ uint32_t besst_owner_of_scaffold(uint32_t scaffold_id, uint32_t world);
 int besst_dev_partition(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t node_bits,
                         int32_t world, const uint64_t* keys, const uint64_t* payload, int64_t pair_capacity,
                         void* send_buffer, void* workspace, size_t workspace_bytes, const void* rider,
-                        int64_t rider_bytes);
+                        int64_t rider_bytes, const int32_t* slice_info);
 int besst_dev_unpack(void* stream, int32_t world, int64_t pair_capacity, const void* recv_buffer, uint64_t* keys,
                      uint64_t* payload, uint32_t* gidx, uint32_t* n_out, uint32_t* overflow, void* rider_sum,
-                     int64_t rider_bytes);
+                     int64_t rider_bytes, int32_t speculative_heads, int32_t rank, int32_t detect_duplicate,
+                     int32_t* all_slice_info, besst_counters* counters);
 
 /* ---- Scaffold-graph linearisation on the scored edge table -----------------------------------
  * Steps 1-4 of MakeScaffolds.Algorithm (MakeScaffolds.py:75-82) in one call:
