@@ -107,6 +107,10 @@ class HipBackend(object):
         self.part_cap = min(int(tuple_capacity), self.rec.n) if tuple_capacity else self.rec.n
         self.ws_part = torch.empty(self.lib.besst_dev_reduce_workspace_bytes(self.part_cap), **u8)
         self.tail = torch.zeros(4, dtype=torch.int32, device=device)
+        # tail mode 'exchange': the slice head travels in the exchange headers (see ShardedGraphBuild.step)
+        self.slice_info = torch.zeros(8, dtype=torch.int32, device=device)
+        self.all_slice_info = torch.zeros(world * 8, dtype=torch.int32, device=device)
+        self.heads_ride_exchange = False
         self.tail_scratch = torch.zeros(2, dtype=torch.int64, device=device)
         self._args = {}
         self.rkeys = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
@@ -128,6 +132,7 @@ class HipBackend(object):
 
     def reset(self):
         self.gb.reset()
+        self.heads_ride_exchange = False
 
     # The argument lists of the stage calls never change (all buffers are allocated once), so they are marshalled
     # once: at ~230 us per step the Python side of a ctypes call with 20 pointer arguments is not free.
@@ -169,8 +174,25 @@ class HipBackend(object):
             self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
             g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned), p(tails), self.rank, None))
 
+    def classify_emit_speculative(self):
+        """Emit without knowing the slices before this one: the slice's first reaching record stays unresolved and
+        is described in ``slice_info``; partition() puts that into the exchange headers and unpack() - on every
+        owner - resolves the heads of all slices in stream order."""
+        g, p = self.gb, self.pipeline._p
+        self.heads_ride_exchange = True
+        self._call('classify_emit_spec', self.lib.besst_dev_classify_emit, lambda: (
+            self.rec.n, g.params.detect_duplicate, g._carry, p(g.keys), p(g.payload), g._n_out,
+            g._small(0), p(g.ws1), g.ws1.numel(), g.n_contigs, p(g.table), p(g.aligned), None, self.rank,
+            p(self.slice_info)))
+
     def partition(self):
         g, p = self.gb, self.pipeline._p
+        if self.heads_ride_exchange:
+            self._call('partition_spec', self.lib.besst_dev_partition, lambda: (
+                self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
+                p(self.send), p(self.ws_part), self.ws_part.numel(),
+                p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes, p(self.slice_info)))
+            return self.send
         self._call('partition', self.lib.besst_dev_partition, lambda: (
             self.part_cap, g._n_out, g.node_bits, self.world, p(g.keys), p(g.payload), self.pair_cap,
             p(self.send), p(self.ws_part), self.ws_part.numel(),
@@ -181,7 +203,16 @@ class HipBackend(object):
         p = self.pipeline._p
         if self._args.get('recv_ptr') != recv.data_ptr():
             self._args.pop('unpack', None)
+            self._args.pop('unpack_spec', None)
             self._args['recv_ptr'] = recv.data_ptr()
+        if self.heads_ride_exchange:
+            g = self.gb
+            self._call('unpack_spec', self.lib.besst_dev_unpack, lambda: (
+                self.world, self.pair_cap, p(recv), p(self.rkeys), p(self.rpayload), p(self.gidx),
+                C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4),
+                p(self._sum_buf) if self.rider_bytes else None, self.rider_bytes, 1, self.rank,
+                g.params.detect_duplicate, p(self.all_slice_info), g._small(0)))
+            return
         self._call('unpack', self.lib.besst_dev_unpack, lambda: (
             self.world, self.pair_cap, p(recv), p(self.rkeys), p(self.rpayload), p(self.gidx),
             C.c_void_p(self.flags.data_ptr()), C.c_void_p(self.flags.data_ptr() + 4),
@@ -239,7 +270,7 @@ class ShardedGraphBuild(object):
         # variants are within 4 % of each other because the step is bound by the host's launch rate there; 'side'
         # hides the gather behind the per-record pass and should win once the gather crosses xGMI, but that could
         # not be measured on the single-GPU development box.
-        self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'late')      # 'late' | 'side' | 'inline'
+        self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'exchange')   # 'exchange' | 'late' | 'side' | 'inline'
         self._recv = None
         # BESST_ALLREDUCE_ASYNC=1: the coverage/counter all-reduce overlaps the tuple exchange and the sort on its own
         # communicator (so that it is not serialised behind the all-to-all); BESST_SIDE_GROUP=0 keeps even that on
@@ -269,7 +300,15 @@ class ShardedGraphBuild(object):
         b = self.backend
         b.reset()
         mode = self.tail_mode if hasattr(b, 'classify_tail_early') else 'late'
-        if mode == 'side':
+        if mode == 'exchange':
+            # No tail exchange at all: every slice emits with its first reaching record unresolved and describes it
+            # in the headers of the all-to-all regions; the owners replay the chain over the slices, resolve the heads,
+            # drop a head's tuple where it was a duplicate and correct the summed counters (unpack_kernel).  The step
+            # is then one collective (plus the all-reduce of large assemblies).
+            b.classify_scan()
+            b.classify_emit_speculative()
+            tails = None
+        elif mode == 'side':
             # The tail of a slice is its last record that reaches CreateEdge - found by a backward search that is
             # independent of the per-record pass - so the search and the tail all-gather run on a side stream while
             # stream_kernel / ordered_kernel occupy the main one: the gather's latency is hidden.
@@ -309,7 +348,8 @@ class ShardedGraphBuild(object):
             gathered = [torch.empty_like(tail) for _ in range(self.world)]
             dist.all_gather(gathered, tail, group=self.group)
             self._tails = tails = torch.cat(gathered)
-        b.classify_emit(tails)
+        if mode != 'exchange':
+            b.classify_emit(tails)
         # Coverage numerators and counters are final here.  Default: a plain all-reduce in stream order on the main
         # communicator.  BESST_ALLREDUCE_ASYNC=1 issues it asynchronously on a second communicator instead, so that
         # it overlaps the tuple exchange and the sort; with one rank over RCCL that was 17 us SLOWER per step (192
@@ -374,7 +414,10 @@ class ShardedGraphBuild(object):
 
     def final_prev_obs(self):
         """counter.prev_obs1/2 after the last record of the global stream."""
-        tails = self._tails.cpu().numpy().reshape(self.world, 4)
+        if getattr(self.backend, 'heads_ride_exchange', False):
+            tails = self.backend.all_slice_info.cpu().numpy().reshape(self.world, 8)[:, :3]
+        else:
+            tails = self._tails.cpu().numpy().reshape(self.world, 4)
         prev = (-1, -1)
         for j in range(self.world):
             if tails[j, 0]:

@@ -11,10 +11,15 @@ from tests import dist_util as DU
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world,orientation,coverage', [(2, 'fr', 'rider'), (3, 'rf', 'allreduce'), (8, 'fr', 'auto'),
-                                                        (2, 'fr', 'allreduce')])
-def test_simulated_ranks_match_oracle(world, orientation, coverage, monkeypatch):
-    """coverage: how the coverage numerators and counters are summed - as a rider of the exchange regions (the
+@pytest.mark.parametrize('world,orientation,coverage,heads', [
+    (2, 'fr', 'rider', 'gather'), (3, 'rf', 'allreduce', 'gather'), (8, 'fr', 'auto', 'gather'),
+    (2, 'fr', 'allreduce', 'gather'), (2, 'fr', 'rider', 'exchange'), (3, 'rf', 'allreduce', 'exchange'),
+    (8, 'fr', 'auto', 'exchange'), (5, 'rf', 'rider', 'exchange')])
+def test_simulated_ranks_match_oracle(world, orientation, coverage, heads, monkeypatch):
+    """heads: how the duplicate chain crosses slices - 'gather': the 16-byte tails are exchanged before the emit stage;
+    'exchange': every slice emits with its first reaching record unresolved, the owners resolve the heads from the
+    exchange headers (no tail exchange).
+    coverage: how the coverage numerators and counters are summed - as a rider of the exchange regions (the
     receivers sum their sources' copies; 'auto' picks it for these small assemblies) or by the all-reduce."""
     import torch
     from besst_amd import distributed, workload
@@ -41,8 +46,19 @@ def test_simulated_ranks_match_oracle(world, orientation, coverage, monkeypatch)
         tails = torch.cat(tails)
         sends = []
         for b in backends:
-            b.classify_emit(tails)
+            if heads == 'exchange':
+                b.classify_emit_speculative()
+                assert b.slice_info[:3].tolist() == tails[4 * b.rank:4 * b.rank + 3].tolist()
+            else:
+                b.classify_emit(tails)
             sends.append(b.partition().clone())
+        if not backends[0].sums_ride_exchange:              # what the step's all-reduce does at this point
+            assert coverage == 'allreduce'
+            total = sum(b.pack_for_allreduce().clone() for b in backends)
+            for b in backends:
+                b.pack_for_allreduce().copy_(total)
+        else:
+            assert coverage != 'allreduce'
         region = backends[0].region
         for r, b in enumerate(backends):
             recv = torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)])
@@ -52,18 +68,15 @@ def test_simulated_ranks_match_oracle(world, orientation, coverage, monkeypatch)
     assert not any(b.overflowed() for b in backends)
     want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
     assert want.nr_of_duplicates > 0 and want.fishy_reads > 0
-    if backends[0].sums_ride_exchange:
-        assert coverage != 'allreduce'
-        # the riders were summed by every receiver: each rank already holds the global values
-        for b in backends[1:]:
-            assert torch.equal(b.aligned, backends[0].aligned)
-            assert torch.equal(b.counter_words[:8], backends[0].counter_words[:8])
-        aligned = backends[0].aligned.cpu()
-        counters = backends[0].counter_words.cpu()
-    else:
-        assert coverage == 'allreduce'
-        aligned = sum(b.aligned.cpu() for b in backends)          # what the all-reduce computes
-        counters = sum(b.counter_words.cpu() for b in backends)
+    if heads == 'exchange':
+        for b in backends:                                   # every owner saw every slice's description
+            assert b.all_slice_info.view(world, 8)[:, :3].tolist() == tails.view(world, 4)[:, :3].tolist()
+    # riders summed by every receiver, or all-reduced: each rank holds the global values
+    for b in backends[1:]:
+        assert torch.equal(b.aligned, backends[0].aligned)
+        assert torch.equal(b.counter_words[:8], backends[0].counter_words[:8])
+    aligned = backends[0].aligned.cpu()
+    counters = backends[0].counter_words.cpu()
     assert aligned.tolist() == want.aligned
     assert counters.tolist() == [want.count, want.non_unique, want.non_unique_for_scaf, want.nr_of_duplicates,
                                  want.too_long, want.fishy_reads, len(want.tuples), want.n_reach]
@@ -320,3 +333,80 @@ def test_large_slices_take_the_sort_tile_partition():
     total = backends[0].aligned.cpu().numpy() if backends[0].sums_ride_exchange else \
         sum(b.aligned.cpu().numpy() for b in backends)
     assert total.tolist() == aligned.tolist()
+
+
+@pytest.mark.parametrize('which,world', [(0, 2), (1, 2), (2, 3), (5, 2)])
+def test_slice_boundary_right_before_a_duplicate(which, world):
+    """The `which`-th duplicate record of the stream becomes the FIRST record of a slice: its slice emits the record
+    provisionally, the owner of its key has to drop the tuple again and every rank has to correct the counters and
+    the global emit indexes behind it.  Both the gathered-tails path and the header path must agree with the
+    single-process oracle."""
+    import numpy as np
+    import torch
+    from besst_amd import distributed, workload
+    from oracle import c_oracle as CO
+    wl = workload.make('C2', 0, pairs=100000, nc=500)
+    batch = wl['batch']
+    n = len(batch)
+
+    def dups_in_prefix(k):
+        return int(CO.record_loop(batch.take(slice(0, k)), wl['table'], wl['lib'], wl['node_bits'])[3][3])
+    total = dups_in_prefix(n)
+    assert total > which
+    lo, hi = 0, n                                            # smallest prefix holding which + 1 duplicates
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if dups_in_prefix(mid) >= which + 1:
+            hi = mid
+        else:
+            lo = mid
+    cut = hi - 1                                             # record `cut` is the duplicate
+    bounds = [0, cut, n] if world == 2 else [0, cut // 2, cut, n]
+    parts = [batch.take(slice(bounds[r], bounds[r + 1])) for r in range(world)]
+    want_rows, want = DU.expected_rows(batch, wl['table'], wl['lib'], wl['node_bits'])
+    dev = torch.device('cuda', 0)
+    for heads in ('gather', 'exchange'):
+        backends = []
+        for r in range(world):
+            sub = dict(wl)
+            sub['batch'] = parts[r]
+            backends.append(distributed.HipBackend(dev, sub, r, world, 16384))
+        tails = []
+        for b in backends:
+            b.reset()
+            b.classify_scan()
+            tails.append(b.classify_tail().clone())
+        tails = torch.cat(tails)
+        sends = []
+        for b in backends:
+            if heads == 'exchange':
+                b.classify_emit_speculative()
+            else:
+                b.classify_emit(tails)
+            sends.append(b.partition().clone())
+        if heads == 'exchange':
+            info = backends[-1].slice_info.tolist()
+            assert info[3] == 1 and info[7] >= 0            # the last slice's head was emitted provisionally
+        region = backends[0].region
+        for r, b in enumerate(backends):
+            b.unpack(torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)]))
+            b.reduce()
+        torch.cuda.synchronize()
+        assert backends[0].sums_ride_exchange
+        for b in backends:
+            assert b.counter_words.cpu().tolist() == [want.count, want.non_unique, want.non_unique_for_scaf,
+                                                      want.nr_of_duplicates, want.too_long, want.fishy_reads,
+                                                      len(want.tuples), want.n_reach], heads
+        merged = {}
+        for b in backends:
+            rows = DU.rows_from_table(b.local_table())
+            for k in rows:
+                if k & 1:
+                    rows[k]['lo'] = [0] * rows[k]['n']
+                    rows[k]['hi'] = [0] * rows[k]['n']
+            merged.update(rows)
+        for k, r in want_rows.items():
+            if k & 1:
+                r['s'] = r['s2'] = 0
+        assert merged == want_rows, heads
+        assert sum(int(b.flags.cpu()[0]) for b in backends) == len(want.tuples)
