@@ -4,8 +4,11 @@ Partitioning
   phase 1 (stream order)  rank r owns the r-th contiguous slice of the (tid,pos)-sorted record stream and
                           runs the per-record kernel on it.  CreateEdge's duplicate rule compares a record
                           with the previous record that reached CreateEdge *anywhere earlier in the stream*
-                          (CreateGraph.py:835-838,869-870), so every rank publishes the last such observation
-                          of its slice (16 bytes) and picks its incoming prev_obs from the gathered tails.
+                          (CreateGraph.py:835-838,869-870).  Default ('exchange'): a slice leaves its first
+                          reaching record unresolved and describes it in the headers of the phase-2 regions;
+                          the owners resolve those heads, so nothing is exchanged before the emit stage.
+                          Other modes: every rank publishes the last such observation of its slice (16
+                          bytes) and picks its incoming prev_obs from the all-gathered tails.
   phase 2 (key owners)    every link/fishy tuple is routed to owner = hash(min scaffold of the key) mod W with
                           ONE equal-split all-to-all of fixed-capacity regions (count in the region header, so
                           no size exchange and no host round trip).  A stable partition on the sender plus

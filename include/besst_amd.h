@@ -331,7 +331,16 @@ int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const 
                              int32_t min_mapq, double read_len, int32_t count_only, int32_t* isize_out,
                              int32_t* contam_out, int64_t* state, void* workspace, size_t workspace_bytes);
 size_t besst_dev_exchange_region_bytes(int64_t pair_capacity);
-/* A region may be followed by a RIDER: `rider_bytes` (multiple of 8) of 64-bit words that every source copies behind
+/* Speculative slice heads (the sharded build's default, no tail exchange): besst_dev_classify_emit with
+ * `slice_info` (8 x int32, device) instead of `tails` leaves the slice's first record that reaches CreateEdge
+ * unresolved and fills slice_info = { any reaching record, tail obs1, tail obs2, head present, head obs1, head obs2,
+ * head flags (1 accept, 2 double call, 4 mapq 0, 8 tuple emitted), position of the head's tuple or -1 };
+ * besst_dev_partition(..., slice_info) copies it into words 4..11 of every region header and records where the head's
+ * tuple went (words 12, 13); besst_dev_unpack(..., speculative_heads = 1, rank, detect_duplicate, all_slice_info,
+ * counters) replays the chain over the sources (CreateGraph.py:835-870), corrects the summed counters, drops a
+ * duplicate head's tuple at its owner and shifts the global emit indexes; all_slice_info (world x 8, device, may be
+ * null) receives every source's description.
+ * A region may be followed by a RIDER: `rider_bytes` (multiple of 8) of 64-bit words that every source copies behind
  * the tuples of each of its regions (besst_dev_partition) and every receiver sums over its sources
  * (besst_dev_unpack, written to `rider_sum`).  The sharded build sends the coverage numerators and counters of
  * small assemblies this way instead of all-reducing them: one collective less per step.  The exchange
