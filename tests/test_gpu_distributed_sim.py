@@ -410,3 +410,67 @@ def test_slice_boundary_right_before_a_duplicate(which, world):
                 r['s'] = r['s2'] = 0
         assert merged == want_rows, heads
         assert sum(int(b.flags.cpu()[0]) for b in backends) == len(want.tuples)
+
+
+@pytest.mark.parametrize('heads', ['gather', 'exchange'])
+def test_empty_and_linkless_slices_in_the_middle(heads):
+    """Rank 1 holds no records at all, rank 2 only records of one contig (nothing reaches CreateEdge): the chain has
+    to pass through both to rank 3."""
+    import numpy as np
+    import torch
+    from besst_amd import distributed, workload
+    wl = workload.make('C2', 0, pairs=80000, nc=400)
+    batch = wl['batch']
+    n = len(batch)
+    same = np.nonzero((batch.tid == batch.mtid) & (batch.tid == batch.tid[n // 2]))[0]
+    same = same[(same > n // 3)][:300]
+    assert same.shape[0] > 10
+    a = int(same[0])
+    # slices: [0, a) | empty | the linkless records | everything behind them
+    rest = np.setdiff1d(np.arange(a, n), same)
+    parts = [batch.take(slice(0, a)), batch.take(slice(0, 0)), batch.take(same), batch.take(rest)]
+    world = 4
+    whole = batch.take(np.concatenate([np.arange(0, a), same, rest]))
+    want_rows, want = DU.expected_rows(whole, wl['table'], wl['lib'], wl['node_bits'])
+    dev = torch.device('cuda', 0)
+    backends = []
+    for r in range(world):
+        sub = dict(wl)
+        sub['batch'] = parts[r]
+        backends.append(distributed.HipBackend(dev, sub, r, world, 16384))
+    tails = []
+    for b in backends:
+        b.reset()
+        b.classify_scan()
+        tails.append(b.classify_tail().clone())
+    tails = torch.cat(tails)
+    assert tails.view(world, 4)[1:3, 0].tolist() == [0, 0]
+    sends = []
+    for b in backends:
+        if heads == 'exchange':
+            b.classify_emit_speculative()
+        else:
+            b.classify_emit(tails)
+        sends.append(b.partition().clone())
+    region = backends[0].region
+    for r, b in enumerate(backends):
+        b.unpack(torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)]))
+        b.reduce()
+    torch.cuda.synchronize()
+    for b in backends:
+        assert b.counter_words.cpu().tolist() == [want.count, want.non_unique, want.non_unique_for_scaf,
+                                                  want.nr_of_duplicates, want.too_long, want.fishy_reads,
+                                                  len(want.tuples), want.n_reach]
+        assert b.aligned.cpu().tolist() == want.aligned
+    merged = {}
+    for b in backends:
+        rows = DU.rows_from_table(b.local_table())
+        for k in rows:
+            if k & 1:
+                rows[k]['lo'] = [0] * rows[k]['n']
+                rows[k]['hi'] = [0] * rows[k]['n']
+        merged.update(rows)
+    for k, r in want_rows.items():
+        if k & 1:
+            r['s'] = r['s2'] = 0
+    assert merged == want_rows
