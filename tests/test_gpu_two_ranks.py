@@ -84,7 +84,8 @@ def _worker(rank, port, config, tail_mode, pair_cap, coverage, out):
                                                                 ('C2', 'inline', 512, 'allreduce'),
                                                                 ('C2', 'late', 512, 'rider'),
                                                                 ('C2', 'exchange', 16384, 'auto'),
-                                                                ('C3', 'exchange', 65536, 'allreduce')])
+                                                                ('C3', 'exchange', 65536, 'allreduce'),
+                                                                ('C2', 'exchange', 512, 'auto')])
 def test_two_processes_one_gpu(config, tail_mode, pair_cap, coverage):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
