@@ -231,7 +231,8 @@ def test_simulated_ranks_score_their_own_edges():
 
 @pytest.mark.parametrize('flags', [dict(detect_duplicate=False), dict(extend_paths=False), dict(no_score=True),
                                    dict(detect_duplicate=False, extend_paths=False)])
-def test_simulated_ranks_library_flags(flags):
+@pytest.mark.parametrize('heads', ['gather', 'exchange'])
+def test_simulated_ranks_library_flags(flags, heads):
     """The slice-boundary carry with the other CreateEdge regimes: duplicates kept (-d off), no G' (second CreateEdge
     call absent), no_score (G' only)."""
     import torch
@@ -255,7 +256,10 @@ def test_simulated_ranks_library_flags(flags):
     tails = torch.cat(tails)
     sends = []
     for b in backends:
-        b.classify_emit(tails)
+        if heads == 'exchange':
+            b.classify_emit_speculative()
+        else:
+            b.classify_emit(tails)
         sends.append(b.partition().clone())
     region = backends[0].region
     for r, b in enumerate(backends):
@@ -335,8 +339,10 @@ def test_large_slices_take_the_sort_tile_partition():
     assert total.tolist() == aligned.tolist()
 
 
-@pytest.mark.parametrize('which,world', [(0, 2), (1, 2), (2, 3), (5, 2)])
-def test_slice_boundary_right_before_a_duplicate(which, world):
+@pytest.mark.parametrize('which,world,flags', [(0, 2, {}), (1, 2, {}), (2, 3, {}), (5, 2, {}),
+                                               (3, 2, dict(detect_duplicate=False)), (4, 3, dict(extend_paths=False)),
+                                               (6, 2, dict(no_score=True))])
+def test_slice_boundary_right_before_a_duplicate(which, world, flags):
     """The `which`-th duplicate record of the stream becomes the FIRST record of a slice: its slice emits the record
     provisionally, the owner of its key has to drop the tuple again and every rank has to correct the counters and
     the global emit indexes behind it.  Both the gathered-tails path and the header path must agree with the
@@ -346,6 +352,7 @@ def test_slice_boundary_right_before_a_duplicate(which, world):
     from besst_amd import distributed, workload
     from oracle import c_oracle as CO
     wl = workload.make('C2', 0, pairs=100000, nc=500)
+    wl['lib'] = dict(wl['lib'], **flags)
     batch = wl['batch']
     n = len(batch)
 
