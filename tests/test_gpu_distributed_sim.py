@@ -286,7 +286,8 @@ def test_simulated_ranks_library_flags(flags, heads):
     assert merged == want_rows
 
 
-def test_large_slices_take_the_sort_tile_partition():
+@pytest.mark.parametrize('heads', ['gather', 'exchange'])
+def test_large_slices_take_the_sort_tile_partition(heads):
     """Slices of more than 4 M records: the owner partition keeps the sort's 4096-tuple tiles and the row-scanned
     table (smaller slices use 1024-tuple tiles).  Two simulated ranks, union of the owned rows against the C oracle
     on the whole stream."""
@@ -312,7 +313,10 @@ def test_large_slices_take_the_sort_tile_partition():
     tails = torch.cat(tails)
     sends = []
     for b in backends:
-        b.classify_emit(tails)
+        if heads == 'exchange':
+            b.classify_emit_speculative()
+        else:
+            b.classify_emit(tails)
         sends.append(b.partition().clone())
     region = backends[0].region
     for r, b in enumerate(backends):
@@ -337,6 +341,8 @@ def test_large_slices_take_the_sort_tile_partition():
     total = backends[0].aligned.cpu().numpy() if backends[0].sums_ride_exchange else \
         sum(b.aligned.cpu().numpy() for b in backends)
     assert total.tolist() == aligned.tolist()
+    if backends[0].sums_ride_exchange:
+        assert backends[1].counter_words.cpu().numpy().tolist() == c_ctr[:8].tolist()
 
 
 @pytest.mark.parametrize('which,world,flags', [(0, 2, {}), (1, 2, {}), (2, 3, {}), (5, 2, {}),
