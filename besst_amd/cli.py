@@ -15,6 +15,7 @@ import sys
 from time import time
 
 from . import CreateGraph as CG
+from . import MakeScaffolds as MS
 from . import Parameter, bamio, libmetrics, session
 
 
@@ -53,6 +54,9 @@ def build_parser():
     ap.add_argument('-y', dest='extendpaths', action='store_false', help='switch path extension off')
     ap.add_argument('--no_score', dest='no_score', action='store_true')
     ap.add_argument('--threads', type=int, default=None, help='BAM inflate threads')
+    ap.add_argument('--linearize', action='store_true',
+                    help="also run steps 1-4 of MakeScaffolds.Algorithm on a copy of G (isolated scaffolds, "
+                         "score-based ambiguity removal, cycles) and write the surviving link edges")
     return ap
 
 
@@ -122,6 +126,14 @@ def main(argv=None):
         os.makedirs(pass_dir, exist_ok=True)
         write_edges(os.path.join(pass_dir, 'edges_G.tsv'), G)
         write_edges(os.path.join(pass_dir, 'edges_Gprime.tsv'), G_prime)
+        if args.linearize and not param.no_score:
+            # on copies: the graphs CreateGraph.PE returned stay as BESST's own MakeScaffolds expects them
+            t0 = time()
+            L, L_prime = G.copy(), G_prime.copy()
+            L, _, _ = MS.LinearizeGraph(L, L_prime, Contigs, Scaffolds, Information, param)
+            print('Time elapsed for the graph linearisation (steps 1-4), iteration ' + str(i) + ': ' + str(time() - t0)
+                  + '\n', file=Information)
+            write_edges(os.path.join(pass_dir, 'edges_G_linear.tsv'), L)
         print('pass %d: %d records, G %d link edges, G_prime %d link edges' % (
             i + 1, len(records), sum(1 for u, v in G.edges() if G[u][v]['nr_links'] is not None),
             sum(1 for u, v in G_prime.edges() if G_prime[u][v]['nr_links'] is not None)))

@@ -158,12 +158,19 @@ def test_cli_end_to_end(tmp_path):
     with open(fasta, 'w') as fh:
         for n in doc['fasta_names']:
             fh.write('>%s\n%s\n' % (n, 'A' * lens[n]))
-    assert cli.main(['-c', fasta, '-f', bam, '-orientation', 'fr', '-o', str(tmp_path)]) == 0
+    assert cli.main(['-c', fasta, '-f', bam, '-orientation', 'fr', '-o', str(tmp_path), '--linearize']) == 0
     rows = [l.rstrip('\n').split('\t') for l in open(str(tmp_path / 'BESST_output' / 'pass1' / 'edges_G.tsv'))][1:]
     got = [(int(r[0]), r[1], int(r[2]), r[3], int(r[4]), int(r[5]), int(r[6])) for r in rows]
     want = [(e['u'][0], e['u'][1], e['v'][0], e['v'][1], e['nr_links'], e['obs'], e['obs_sq']) for e in doc['final']['G']]
     assert got == want
     assert (tmp_path / 'BESST_output' / 'Statistics.txt').exists()
+    # --linearize: a subset of G's link edges, at most one per scaffold end
+    lin = [l.rstrip('\n').split('\t') for l in open(str(tmp_path / 'BESST_output' / 'pass1' / 'edges_G_linear.tsv'))][1:]
+    assert 0 < len(lin) < len(rows)
+    assert set(tuple(r[:4]) for r in lin) <= set(tuple(r[:4]) for r in rows)
+    ends = [(r[0], r[1]) for r in lin] + [(r[2], r[3]) for r in lin]
+    assert len(ends) == len(set(ends))
+    assert 'cycles removed from graph' in open(str(tmp_path / 'BESST_output' / 'Statistics.txt')).read()
 
 
 @pytest.mark.parametrize('name', ['fr_infer', 'rf_contam', 'rf_second_lib'])
