@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
     if (t == 0) row_total[blockIdx.x] = s_carry;
 }
 
-template <int BITS, bool kFirst>
+template <int BITS, bool kFirst, int ITEMS = kSortItems>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
     const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds, const uint32_t* __restrict__ table,
@@ -166,18 +166,18 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __shared__ uint32_t s_w[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t wbase = b * kSortTile + wave * (kSortItems * 64);
-    uint64_t key[kSortItems];
-    uint32_t idx[kSortItems];
+    const uint32_t wbase = b * (kSortThreads * ITEMS) + wave * (ITEMS * 64);
+    uint64_t key[ITEMS];
+    uint32_t idx[ITEMS];
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         key[r] = i < cap ? keys_in[i] : ~0ull;
         idx[r] = kFirst ? i : ((i < cap && !packed_bits) ? idx_in[i] : 0u);
     }
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
-    const uint32_t nb = nblocks_of(n, kSortTile);
+    const uint32_t nb = nblocks_of(n, (kSortThreads * ITEMS));
     if (b >= nb) return;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const bool unstable = packed_bits != 0 && bucket_start != nullptr;
     if (unstable) {
         const uint64_t low_mask = ds.shift > 0 ? ((1ull << ds.shift) - 1ull) : 0ull;
-        uint32_t dig_rank[kSortItems];
+        uint32_t dig_rank[ITEMS];
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = wbase + r * 64 + lane;
             dig_rank[r] = 0;
             if (i < n) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             }
         }
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = wbase + r * 64 + lane;
             if (i < n) {
                 const uint32_t dst = s_base[dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         return;
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t dig_rank[kSortItems];   // digit | rank << BITS
+    uint32_t dig_rank[ITEMS];   // digit | rank << BITS
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t d = valid ? digit_of(key[r], ds) : (uint32_t)(RADIX - 1);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
+    for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         if (i < n) {
             const uint32_t dst = s_whist[wave][dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
@@ -879,6 +879,17 @@ constexpr int kMaxRadix = 1 << 11;
 #define BESST_MSD_MAX_BLOCKS 1024
 #endif
 constexpr int kMsdMaxBlocks = BESST_MSD_MAX_BLOCKS;
+// Streams of up to this many sort tiles take the MSD pass with kMsdSmallItems keys per thread (build knob, 0 =
+// never).  Measured on C2 (34 sort tiles) with 64 / 8: the scatter drops from 15 to 10 us, the row scan the 68 small
+// tiles need adds 6.5: step 112.6 vs 113.8 - 115.1 us.  Inside the noise of a default, so it stays off.
+#ifndef BESST_MSD_SMALL_MAX_BLOCKS
+#define BESST_MSD_SMALL_MAX_BLOCKS 0
+#endif
+#ifndef BESST_MSD_SMALL_ITEMS
+#define BESST_MSD_SMALL_ITEMS 8
+#endif
+constexpr int kMsdSmallMaxBlocks = BESST_MSD_SMALL_MAX_BLOCKS;
+constexpr int kMsdSmallItems = BESST_MSD_SMALL_ITEMS;
 // Digit width of the LSD passes large streams take (build knob).  C3 slice of 8.5 M tuples (37-bit keys): 10 bits
 // = 4 passes instead of 5, but the per-tile table of 1024 counters is written as scattered 4-byte words and the
 // histogram launches go from 0.127 to 0.174 ms in total, the scatter stays at 0.22: step 1.24 -> 1.29 ms (11 bits:
@@ -900,7 +911,8 @@ RedWorkspace carve(void* ws, int64_t cap) {
     // the wide-digit path is only taken for small streams, the 8-bit path for any size
     const size_t wide_max = (size_t)(kWideDigitMaxBlocks > kMsdMaxBlocks ? kWideDigitMaxBlocks : kMsdMaxBlocks);
     const size_t table_entries = nb_sort <= wide_max
-                                     ? (nb_sort > (size_t)kScanFreeMaxBlocks ? nb_sort : (size_t)kScanFreeMaxBlocks) * kMaxRadix
+                                     ? (nb_sort * (kSortItems / kMsdSmallItems) > (size_t)kScanFreeMaxBlocks
+                                            ? nb_sort * (kSortItems / kMsdSmallItems) : (size_t)kScanFreeMaxBlocks) * kMaxRadix
                                      : nb_sort * (size_t)(1 << kLsdBits);
     w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
     w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
@@ -917,30 +929,32 @@ RedWorkspace carve(void* ws, int64_t cap) {
 }
 
 // one LSD pass over `bits`-bit digits selected by ds; zero_* != nullptr on the last pass
-template <int BITS>
+template <int BITS, int ITEMS = kSortItems>
 void launch_pass(hipStream_t s, const RedWorkspace& w, uint32_t nb_sort, uint32_t cap, const uint32_t* n_tuples,
                  DigitSel ds, bool first, const uint64_t* kin, const uint32_t* iin, uint64_t* kout, uint32_t* iout,
                  uint32_t* zero_n, unsigned long long* zero_sum, unsigned long long* zero_sum_sq,
                  uint32_t* bucket_start = nullptr, int packed_bits = 0) {
+    // nb_sort counts tiles of kSortThreads * ITEMS keys; the scanned table's rows are that long
     const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
+    const uint32_t stride = ITEMS == kSortItems ? w.stride : nb_sort;
     {
         ProfScope ps(s, kProfSortHist);
-        hipLaunchKernelGGL((radix_hist_kernel<BITS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples, cap, ds,
-                           w.table, w.stride, scanned, zero_n, zero_sum, zero_sum_sq);
+        hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples, cap, ds,
+                           w.table, stride, scanned, zero_n, zero_sum, zero_sum_sq);
     }
     if (scanned) {
         ProfScope ps(s, kProfSortScan);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << BITS), dim3(256), 0, s, n_tuples, cap, w.table, w.stride,
-                           w.row_total);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << BITS), dim3(256), 0, s, n_tuples, cap, w.table, stride,
+                           w.row_total, (uint32_t)(kSortThreads * ITEMS));
     }
     ProfScope ps(s, kProfSortScatter);
     if (first)
-        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
-                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout, bucket_start,
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, ITEMS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
+                           n_tuples, cap, ds, w.table, stride, w.row_total, scanned, kout, iout, bucket_start,
                            packed_bits);
     else
-        hipLaunchKernelGGL((radix_scatter_kernel<BITS, false>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
-                           n_tuples, cap, ds, w.table, w.stride, w.row_total, scanned, kout, iout, bucket_start,
+        hipLaunchKernelGGL((radix_scatter_kernel<BITS, false, ITEMS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
+                           n_tuples, cap, ds, w.table, stride, w.row_total, scanned, kout, iout, bucket_start,
                            packed_bits);
 }
 
@@ -983,8 +997,15 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
         const DigitSel ds{0, shift, 0, 1u, kMsdBits};
         packed_bits = packable ? cap_idx_bits : 0;    // key and stream index in one word (always, in practice)
-        launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
-                              row_n, zsum, zsq, w.bucket_start, packed_bits);
+        if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
+            // few sort tiles leave most of the chip idle: half-size tiles (and the row scan they then need)
+            const uint32_t nb_small = (uint32_t)((cap + kSortThreads * kMsdSmallItems - 1) / (kSortThreads * kMsdSmallItems));
+            launch_pass<kMsdBits, kMsdSmallItems>(s, w, nb_small, (uint32_t)cap, n_tuples, ds, true, keys, nullptr,
+                                                  w.keys[0], w.idx[0], row_n, zsum, zsq, w.bucket_start, packed_bits);
+        } else {
+            launch_pass<kMsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, true, keys, nullptr, w.keys[0], w.idx[0],
+                                  row_n, zsum, zsq, w.bucket_start, packed_bits);
+        }
         if (shift > 0 || packed_bits) {   // the packed partition is unstable: buckets always need their sort
             ProfScope ps(s, kProfBucketSort);
             const dim3 grid(1u << kMsdBits), block(kBucketThreads);
