@@ -8,11 +8,17 @@ inside a step.  At N > 1 every rank owns a contiguous slice of the (tid,pos)-sor
 (weak scaling: one C2-sized slice per GPU, all of one assembly) and the result is checked against the
 single-GPU build of the whole stream (sharded_equals_single_gpu); see besst_amd/distributed.py.
 
+N = 1 (the default): the workload is BASELINE.json configs[2] (C3: 100 k contigs / 200 M mate pairs with PE
+contamination) at FULL size - the largest single-GPU config - generated on the GPU; configs[1] (C2) is measured
+afterwards and rides along as the "c2" object of the same line.
+
 Prints ONE JSON line on rank 0 (see the repo prompt for the contract) with two extra objects:
-  roofline     - dominant kernel (stream_kernel): algorithmic bytes per launch / mean launch
-                 duration from HIP events recorded on the launch stream inside the timed region
+  roofline     - the WHOLE step priced at SURVEY 8(d)'s (38 + 32 f) bytes per read pair over the step time and
+                 the 8 TB/s peak; the streaming kernel's own bytes over its HIP-event duration as an extra;
+                 traffic = HBM bytes per step from the committed rocprofv3 PMC passes of this very build
   cpu_baseline - the pure-Python oracle (port of the reference's record loop) timed on this box's
-                 host cores over a bounded sample of the same stream
+                 host cores over a bounded sample of the same stream, with the port's measured speed
+                 relative to the real reference (oracle/cpu_port_calibration.json)
 """
 import argparse
 import json
@@ -28,21 +34,6 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 CLASSIFY_SLOT = 0
-PMC_SUMMARY = os.path.join(REPO, 'profiles', 'r01_c2_pmc_traffic.json')
-
-
-def pmc_traffic(config, n_rec):
-    """HBM bytes per stream_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
-    separately, gfx950 x2 correction on FETCH_SIZE; see profiles/README.md).  Only valid for the workload it was
-    collected on, otherwise None."""
-    try:
-        with open(PMC_SUMMARY) as fh:
-            doc = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    if config != 'C2' or n_rec * 11 != doc.get('stream_kernel_algorithmic_bytes_per_launch'):
-        return None
-    return doc.get('stream_kernel_traffic_bytes_per_launch')
 
 
 def parse_args():
@@ -50,16 +41,20 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='C2')
+    ap.add_argument('--config', default=None,
+                    help='BASELINE.json config of the workload; default C3 (configs[2], the largest single-GPU config) '
+                         'at N = 1, a C2-sized slice per rank at N > 1')
+    ap.add_argument('--also', default='C2', help='second config measured after the headline one at N = 1 ("" = none)')
     ap.add_argument('--pairs', type=int, default=None, help='override pairs per GPU (smoke runs)')
     ap.add_argument('--contigs', type=int, default=None)
     ap.add_argument('--cpu-sample-records', type=int, default=20_000_000,
                     help='records of the stream the Python port is timed on; 0 skips it (C port + check only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown-steps', type=int, default=3)
-    ap.add_argument('--copies', type=int, default=3,
+    ap.add_argument('--copies', type=int, default=None,
                     help='resident copies of the record columns cycled through by consecutive steps, so that a step '
-                         'cannot be served from the 256 MiB Infinity Cache left warm by the previous one')
+                         'cannot be served from the 256 MiB Infinity Cache left warm by the previous one '
+                         '(default: 3 for C2, 1 for C3 whose 9.2 GB of records cannot stay cached)')
     ap.add_argument('--no-verify', action='store_true', help='skip the full-size check against the C oracle')
     ap.add_argument('--no-stages', action='store_true', help='skip the separate metrics / scoring stage timings')
     ap.add_argument('--in-flight', type=int, default=3,
@@ -121,9 +116,13 @@ def verify_full(runner, wl):
     C_PORT_TIMING['seconds'] = time.perf_counter() - t0
     C_PORT_TIMING['records'] = len(wl['batch'])
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    mt = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'], threads=cores)
-    C_PORT_TIMING['mt_seconds'] = time.perf_counter() - t0
+    best = None
+    for _ in range(2):                                   # the first call pays thread start-up and page faults
+        t0 = time.perf_counter()
+        mt = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'], threads=cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    C_PORT_TIMING['mt_seconds'] = best
     C_PORT_TIMING['mt_cores'] = cores
     C_PORT_TIMING['mt_equal'] = bool(np.array_equal(mt[0], keys) and np.array_equal(mt[3], c_ctr))
     rows = CO.edge_rows(keys, payload)
@@ -427,6 +426,195 @@ def linearize_cpu_baseline(n_scaf=200_000, n_edges=300_000):
                       % (n_scaf, len(la), dt)}
 
 
+def source_hash():
+    """sha256 over the kernel sources: ties a committed PMC summary to the build it was collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, 'besst_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(REPO, 'besst_amd', 'csrc', '*.h'))):
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_step_traffic(config, n_rec):
+    """HBM bytes per graph-build step (all kernels of one step) from the committed rocprofv3 PMC passes of THIS build
+    on THIS workload (profiles/r02_<config>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
+    passes, gfx950 x2 correction on FETCH_SIZE, tools/pmc_summary.py), else None - a summary collected on other
+    kernel sources or another record count says nothing about this run."""
+    path = os.path.join(REPO, 'profiles', 'r02_%s_pmc_traffic.json' % config.lower())
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if doc.get('source_hash') != source_hash() or doc.get('records') != n_rec:
+        return None
+    return doc.get('step_traffic_bytes')
+
+
+def reference_calibration():
+    try:
+        with open(os.path.join(REPO, 'oracle', 'cpu_port_calibration.json')) as fh:
+            doc = json.load(fh)
+        return {'port_over_reference': round(doc['port_over_reference'], 3),
+                'reference_pairs_per_s_there': round(doc['reference_pairs_per_s'], 1),
+                'port_pairs_per_s_there': round(doc['port_pairs_per_s'], 1),
+                'measured': 'build container, one core, %s; tools/calibrate_cpu_port.py (real BESST/CreateGraph.py '
+                            'record loop vs oracle/py_oracle.record_loop on one stream)' % doc['workload']}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def measure_single(args, device, config, steps, warmup, copies, pairs=None, contigs=None, verify=True):
+    """One GPU, one library pass at a time, records resident: timed steps, per-kernel breakdown, full-size check.
+    Returns (result dict, workload, runner)."""
+    import torch
+    from besst_amd import _lib, pipeline, workload
+    lib_h = _lib.load()
+    t0 = time.perf_counter()
+    wl = workload.make_device(device, config, 0, pairs=pairs, nc=contigs)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    lib = wl['lib']
+    runner = SingleGpu(device, wl, copies)
+    n_rec = runner.rec.n
+    n_pairs = n_rec // 2
+    for _ in range(warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    runner.check_capacity()
+    # the streaming kernel is timed with HIP events inside the timed region, on every 4th launch: an event pair costs
+    # the stream ~3 us, i.e. ~5 % of a C2 step when every launch carries one
+    lib_h.besst_prof_sample_every(4 if steps >= 8 else 1)
+    lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = pipeline.prof_collect()
+    lib_h.besst_prof_enable(0)
+    lib_h.besst_prof_sample_every(1)
+    lib_h.besst_prof_enable(0xffffffff)
+    for _ in range(args.breakdown_steps):
+        runner.step()
+    torch.cuda.synchronize()
+    breakdown = {k: round(v[0] / max(1, args.breakdown_steps), 4) for k, v in pipeline.prof_collect().items()}
+    lib_h.besst_prof_enable(0)
+    n_tuples, n_rows = runner.sizes()
+    f = n_tuples / float(n_pairs)
+    step_s = elapsed / steps
+    alg_step = n_pairs * (38.0 + 32.0 * f)               # SURVEY 8(d): 2 x 19 B of records + 16 B per tuple written and read
+    cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
+    cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
+    own = n_rec * 11.0                                   # tid, mtid, mapq, qlen of every record
+    dominant = max(breakdown.items(), key=lambda kv: kv[1])[0] if breakdown else None
+    verified = None
+    if verify and not args.no_verify and not args.no_cpu_baseline:
+        verified = verify_full(runner, wl)
+    res = {
+        'value': n_pairs / step_s,
+        'ms_per_step': step_s * 1e3,
+        'workload': '%s: %d contigs / %d read-pairs, one %s library%s, %d records resident in HBM (%d cop%s cycled)'
+                    % (config, wl['asm'].nc, n_pairs, lib['orientation'],
+                       ' with %.0f %% PE contamination' % (100 * wl['spec'].contam_frac) if wl['spec'].contam_frac else '',
+                       n_rec, copies, 'y' if copies == 1 else 'ies'),
+        'records': n_rec, 'link_tuples_per_pair': round(f, 5), 'link_tuples': n_tuples, 'edge_rows': n_rows,
+        'roofline': {
+            'bound': 'hbm', 'scope': 'whole graph-build step, SURVEY 8(d): (38 + 32 f) bytes per read pair',
+            'achieved': round(alg_step / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            'traffic': pmc_step_traffic(config, n_rec),
+            'algorithmic_bytes_per_step': alg_step, 'bytes_per_pair': round(38.0 + 32.0 * f, 3),
+            'dominant_kernel': dominant,
+            'stream_kernel': {'own_bytes_per_launch': own, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
+                              'launches_timed': int(cls_launches),
+                              'GBps': round(own / cls_avg_s / 1e9, 1) if cls_avg_s > 0 else None,
+                              'frac': round(own / cls_avg_s / 1e9 / HBM_PEAK_GBS, 4) if cls_avg_s > 0 else None}},
+        'kernel_ms': breakdown,
+        'verified_vs_c_oracle': verified,
+        'generate_s': round(gen_s, 2),
+    }
+    return res, wl, runner
+
+
+def cpu_legs(args, wl, with_stage_ports):
+    """cpu_baseline object: the Python port on a bounded sample, the C port timings verify_full left behind."""
+    if args.cpu_sample_records > 0:
+        base, _ = cpu_baseline(wl['batch'], wl['table'], wl['lib'], args.cpu_sample_records)
+    else:                    # --cpu-sample-records 0: skip the Python port, keep the C port + full-size check
+        base = dict(value=None, unit='read-pairs/s', cores=1, kind='port', sample='python port skipped')
+    cal = reference_calibration()
+    if cal:
+        base['reference_calibration'] = cal
+        if base['value']:
+            base['reference_equivalent_value'] = base['value'] / cal['port_over_reference']
+    if C_PORT_TIMING:      # the C restatement (oracle/besst_oracle.c), whole stream: record loop only
+        base['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'],
+                          'unit': 'read-pairs/s', 'cores': 1,
+                          'sample': 'whole stream (%d records), oracle/besst_oracle.c record loop, %.2f s'
+                                    % (C_PORT_TIMING['records'], C_PORT_TIMING['seconds'])}
+        base['c_port_all_cores'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['mt_seconds'],
+                                    'unit': 'read-pairs/s', 'cores': C_PORT_TIMING['mt_cores'],
+                                    'equals_sequential': C_PORT_TIMING['mt_equal'],
+                                    'sample': 'whole stream, contiguous slices, best of two calls, %.3f s'
+                                              % C_PORT_TIMING['mt_seconds']}
+    if with_stage_ports:
+        base['linearize_port'] = linearize_cpu_baseline()
+        base['scorepaths_port'] = scorepaths_cpu_baseline()
+    return base
+
+
+METRIC = 'read-pairs/sec into scaffold graph; edge-set match + gap MAE vs CPU ref'
+DTYPE = 'int32/int64 (fp64 for read_len truncation)'
+
+
+def main_single(args, device, result_fd):
+    """N = 1: the headline is BASELINE.json configs[2] (C3, the largest single-GPU config) at full size; configs[1]
+    (C2) rides along as a second object of the same line."""
+    import torch
+    copies = args.copies if args.copies is not None else (1 if args.config == 'C3' else 3)
+    res, wl, runner = measure_single(args, device, args.config, args.steps, args.warmup, copies, args.pairs, args.contigs)
+    out = {
+        'metric': METRIC, 'value': res['value'], 'unit': 'read-pairs/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+        'config': {'workload': res['workload'], 'records_per_gpu': res['records'],
+                   'link_tuples_per_pair': res['link_tuples_per_pair'], 'edge_rows': res['edge_rows'],
+                   'parallelism': 'single GPU', 'generator': 'besst_amd.synth.simulate_library_device (torch ops on the '
+                   'GPU, seeded), %.1f s' % res['generate_s']},
+        'roofline': res['roofline'], 'kernel_ms': res['kernel_ms'], 'verified_vs_c_oracle': res['verified_vs_c_oracle'],
+    }
+    out['roofline']['measured_d2d_copy_GBps'] = round(measured_copy_bandwidth(device), 1)
+    if args.in_flight > 1:
+        out['overlapped'] = overlapped_throughput(runner, wl, device, args.in_flight, max(args.steps, 30))
+    if not args.no_stages:
+        del runner
+        torch.cuda.empty_cache()
+        out['stages'] = stage_timings(wl)
+    else:
+        del runner
+    out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_legs(args, wl, not args.no_stages)
+    del wl
+    torch.cuda.empty_cache()
+    if args.also and args.also != args.config and args.pairs is None:
+        C_PORT_TIMING.clear()
+        res2, wl2, runner2 = measure_single(args, device, args.also, 20, 3, 3)
+        del runner2
+        second = {k: res2[k] for k in ('value', 'ms_per_step', 'workload', 'records', 'link_tuples_per_pair',
+                                        'edge_rows', 'roofline', 'kernel_ms', 'verified_vs_c_oracle')}
+        second['unit'] = 'read-pairs/s'
+        second['steps'], second['warmup'] = 20, 3
+        if not args.no_cpu_baseline and C_PORT_TIMING:
+            second['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'], 'cores': 1}
+        out[args.also.lower()] = second
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+
 def main():
     args = parse_args()
     # Only the final JSON line may reach stdout: RCCL prints a version banner to fd 1 when the process group is
@@ -451,6 +639,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     force_dist = os.environ.get('BESST_FORCE_DISTRIBUTED') == '1'   # exercise the RCCL path with one rank
+    if world == 1 and not force_dist:
+        if args.config is None:
+            args.config = 'C3'
+        return main_single(args, device, result_fd)
+    if args.config is None:
+        args.config = 'C2'
+    if args.copies is None:
+        args.copies = 1
     if world > 1 or force_dist:
         if 'MASTER_ADDR' not in os.environ:
             os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -469,13 +665,10 @@ def main():
     n_rec = len(batch)
     pairs = n_rec // 2
 
-    if world > 1 or force_dist:
-        from besst_amd import distributed
-        # BESST_PAIR_CAPACITY: start from a given (too small) exchange-region capacity to exercise the grow-and-retry path
-        cap_env = os.environ.get('BESST_PAIR_CAPACITY')
-        runner = distributed.ShardedGraphBuild(device, wl, rank, world, pair_capacity=int(cap_env) if cap_env else None)
-    else:
-        runner = SingleGpu(device, wl, args.copies)
+    from besst_amd import distributed
+    # BESST_PAIR_CAPACITY: start from a given (too small) exchange-region capacity to exercise the grow-and-retry path
+    cap_env = os.environ.get('BESST_PAIR_CAPACITY')
+    runner = distributed.ShardedGraphBuild(device, wl, rank, world, pair_capacity=int(cap_env) if cap_env else None)
 
     lib_h = _lib.load()
     for _ in range(args.warmup):
@@ -483,8 +676,6 @@ def main():
     torch.cuda.synchronize()
     runner.check_capacity()
 
-    # the roofline kernel is timed with HIP events inside the timed region, on every 4th launch: an event pair costs
-    # the stream ~3 us, i.e. ~5 % of a C2 step when every launch carries one
     lib_h.besst_prof_sample_every(4 if args.steps >= 8 else 1)
     lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
     if world > 1:
@@ -510,19 +701,17 @@ def main():
     for _ in range(args.breakdown_steps):
         runner.step()
     torch.cuda.synchronize()
-    breakdown = {k: round(v[0] / args.breakdown_steps, 4) for k, v in pipeline.prof_collect().items()}
+    breakdown = {k: round(v[0] / max(1, args.breakdown_steps), 4) for k, v in pipeline.prof_collect().items()}
     lib_h.besst_prof_enable(0)
 
     n_tuples, n_rows = runner.sizes()
     verified = None
-    exchange_ok = None
     sharded_ok = None
-    if world > 1 or force_dist:
-        # size-independent check of the exchange at any N: the tuples the owners received are the tuples the slices
-        # emitted (the emitted count is one of the summed counter words), and no region overflowed
-        b = runner.backend
-        emitted = int(b.counter_words.cpu()[6].item())
-        exchange_ok = bool(emitted == n_tuples and not b.overflowed())
+    # size-independent check of the exchange at any N: the tuples the owners received are the tuples the slices
+    # emitted (the emitted count is one of the summed counter words), and no region overflowed
+    b = runner.backend
+    emitted = int(b.counter_words.cpu()[6].item())
+    exchange_ok = bool(emitted == n_tuples and not b.overflowed())
     if world > 1 and not args.no_verify:
         try:
             sharded_ok = verify_sharded_vs_single_gpu(runner, wl, args, rank, world, device)
@@ -530,85 +719,41 @@ def main():
             sharded_ok = 'error: %s' % (str(e).splitlines()[0][:200] if str(e) else type(e).__name__)
     # the oracle is touched only in the cpu_baseline leg (--no-cpu-baseline: no oracle at all in this process)
     if world == 1 and not args.no_verify and not args.no_cpu_baseline:
-        verified = verify_sharded_single_rank(runner, wl) if force_dist else verify_full(runner, wl)
+        verified = verify_sharded_single_rank(runner, wl)
     f = n_tuples / float(pairs * world)                  # sizes() of the sharded runner are global sums
     cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
-    # algorithmic bytes of one stream_kernel launch: tid, mtid (4 B each), mapq (1 B), qlen (2 B) per record;
-    # pos / mpos / flag are needed only for the ~1.5 % candidate records and belong to ordered_kernel
-    alg_bytes = n_rec * 11.0
-    achieved = alg_bytes / cls_avg_s / 1e9 if cls_avg_s > 0 else 0.0
+    own = n_rec * 11.0
 
-    copy_gbs = measured_copy_bandwidth(device) if rank == 0 else None
     if rank == 0:
         total_pairs = pairs * world
+        step_s = elapsed / args.steps
+        alg_step = total_pairs * (38.0 + 32.0 * f)
         out = {
-            'metric': 'read-pairs/sec into scaffold graph; edge-set match + gap MAE vs CPU ref',
-            'value': total_pairs / (elapsed / args.steps),
-            'unit': 'read-pairs/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'int32/int64 (fp64 for read_len truncation)',
-            'data': 'synthetic',
-            'config': {'workload': '%s: %d contigs / %d read-pairs per GPU, one %s library, records resident in HBM '
-                                   '(%d copies cycled to defeat the Infinity Cache)'
-                                   % (args.config, wl['asm'].nc, pairs, lib['orientation'], args.copies if world == 1 else 1),
+            'metric': METRIC, 'value': total_pairs / step_s, 'unit': 'read-pairs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
+            'config': {'workload': '%s: %d contigs / %d read-pairs per GPU, one %s library, records resident in HBM'
+                                   % (args.config, wl['asm'].nc, pairs, lib['orientation']),
                        'records_per_gpu': n_rec, 'link_tuples_per_pair': round(f, 5), 'edge_rows': n_rows,
-                       'parallelism': 'stream-slice x%d + key-owner all-to-all' % world if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'kernel': 'stream_kernel', 'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': pmc_traffic(args.config, n_rec) if world == 1 else None,
-                         'avg_launch_ms': round(cls_avg_s * 1e3, 4), 'launches_timed': int(cls_launches),
-                         'measured_d2d_copy_GBps': round(copy_gbs, 1),
-                         'frac_of_measured_copy': round(achieved / copy_gbs, 4),
-                         'algorithmic_bytes_per_launch': alg_bytes},
-            # whole graph-build pass = 38 B/pair of records + each tuple written and read once
-            'graph_pass': {'algorithmic_bytes_per_step': total_pairs * (38.0 + 32.0 * f),
-                           'effective_GBps': round(total_pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9, 1),
-                           'frac_of_hbm_peak': round(total_pairs * (38.0 + 32.0 * f) / (elapsed / args.steps) / 1e9
-                                                     / (HBM_PEAK_GBS * world), 4)},
+                       'parallelism': 'stream-slice x%d + key-owner all-to-all' % world},
+            'roofline': {'bound': 'hbm', 'scope': 'whole graph-build step, SURVEY 8(d): (38 + 32 f) bytes per read pair, '
+                                                  'over the aggregate peak of all GPUs',
+                         'achieved': round(alg_step / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s',
+                         'frac': round(alg_step / step_s / 1e9 / (HBM_PEAK_GBS * world), 4), 'traffic': None,
+                         'algorithmic_bytes_per_step': alg_step,
+                         'stream_kernel': {'own_bytes_per_launch': own, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
+                                           'GBps': round(own / cls_avg_s / 1e9, 1) if cls_avg_s > 0 else None}},
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': verified,
             'exchange_consistent': exchange_ok,
             'sharded_equals_single_gpu': sharded_ok,
+            'cpu_baseline': None,
         }
-        if world == 1 and args.in_flight > 1 and not force_dist:
-            out['overlapped'] = overlapped_throughput(runner, wl, device, args.in_flight, max(args.steps, 30))
-        if world == 1 and not args.no_stages and not force_dist:
-            del runner
-            torch.cuda.empty_cache()
-            out['stages'] = stage_timings(wl)
-        if not args.no_cpu_baseline and world == 1:          # the CPU legs run on rank 0 at N = 1 only
-            if args.cpu_sample_records > 0:
-                base, _ = cpu_baseline(batch, table, lib, args.cpu_sample_records)
-            else:                    # --cpu-sample-records 0: skip the Python port, keep the C port + full-size check
-                base = dict(value=None, unit='read-pairs/s', cores=1, kind='port', sample='python port skipped')
-            if C_PORT_TIMING:      # the C restatement (oracle/besst_oracle.c), one thread, whole stream: record loop only
-                base['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'],
-                                  'unit': 'read-pairs/s', 'cores': 1,
-                                  'sample': 'whole stream (%d records), oracle/besst_oracle.c record loop, %.2f s'
-                                            % (C_PORT_TIMING['records'], C_PORT_TIMING['seconds'])}
-                base['c_port_all_cores'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['mt_seconds'],
-                                            'unit': 'read-pairs/s', 'cores': C_PORT_TIMING['mt_cores'],
-                                            'equals_sequential': C_PORT_TIMING['mt_equal'],
-                                            'sample': 'whole stream, contiguous slices, %.3f s (includes numpy column '
-                                                      'setup and thread start)' % C_PORT_TIMING['mt_seconds']}
-            if not args.no_stages:
-                base['linearize_port'] = linearize_cpu_baseline()
-                base['scorepaths_port'] = scorepaths_cpu_baseline()
-            out['cpu_baseline'] = base
-        else:
-            out['cpu_baseline'] = None
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
-    if world > 1 or force_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def overlapped_throughput(runner, wl, device, in_flight, steps):
@@ -643,7 +788,10 @@ def overlapped_throughput(runner, wl, device, in_flight, steps):
 class SingleGpu(object):
     def __init__(self, device, wl, copies=1):
         from besst_amd import pipeline
-        self.recs = [pipeline.DeviceRecords(wl['batch'], device) for _ in range(max(1, copies))]
+        if 'cols' in wl:
+            self.recs = [pipeline.DeviceRecords.from_columns(wl['cols'], copy=(k > 0)) for k in range(max(1, copies))]
+        else:
+            self.recs = [pipeline.DeviceRecords(wl['batch'], device) for _ in range(max(1, copies))]
         self.rec = self.recs[0]
         self.i = 0
         # tuple capacity: every record may emit one tuple; sized down after the first measured pass

@@ -212,6 +212,15 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr);
+// chained-scan sort + atomic-free reduction for large streams (onesweep.hip); buf_* = the ping-pong buffers of the
+// sort/reduce workspace
+size_t onesweep_workspace_bytes(int64_t cap);
+int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
+                                const uint64_t* keys, const uint64_t* payload, uint64_t* buf_keys[2],
+                                uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
+                                int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
+                                int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
+                                const uint32_t* first_map);
 size_t exchange_region_bytes(int64_t pair_cap);
 size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes);
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,

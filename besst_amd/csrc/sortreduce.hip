@@ -864,6 +864,8 @@ struct RedWorkspace {
     uint64_t* big_keys;
     uint32_t* big_idx;
     uint32_t stride;
+    char* os_ws;          // chained-scan path (onesweep.hip)
+    size_t os_bytes;
     size_t total;
 };
 
@@ -924,6 +926,9 @@ RedWorkspace carve(void* ws, int64_t cap) {
     const size_t big = nb_sort <= (size_t)kMsdMaxBlocks ? 2 * (size_t)cap + 8 : 8;
     w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
     w.big_idx = reinterpret_cast<uint32_t*>(p + off); off += align_up(big * 4, 256);
+    w.os_ws = p + off;
+    w.os_bytes = nb_sort > (size_t)kScanFreeMaxBlocks ? onesweep_workspace_bytes(cap) : 0;
+    off += align_up(w.os_bytes, 256);
     w.total = off;
     return w;
 }
@@ -980,9 +985,6 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: workspace too small");
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
-    // wide digits (fewer dependent launches) while the stage is latency bound, 8-bit digits for large streams
-    const int bits = nb_sort <= (uint32_t)kWideDigitMaxBlocks ? 11 : kLsdBits;
-    const int passes = (key_bits + bits - 1) / bits;
     auto* zsum = reinterpret_cast<unsigned long long*>(row_sum);
     auto* zsq = reinterpret_cast<unsigned long long*>(row_sum_sq);
     const uint64_t* kin = keys;
@@ -1028,25 +1030,12 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         kin = w.keys[0];
         iin = w.idx[0];
     } else {
-        // key and stream index share one 64-bit word when they fit: the index arrays drop out of every pass
-        int idx_bits = 1;
-        while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
-        packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;
-        for (int p = 0; p < passes; ++p) {
-            // pass 0 reads the raw keys (and packs while scattering); later passes see the packed words
-            const DigitSel ds{0, p * bits + (p > 0 ? packed_bits : 0), 0, 1u, bits};
-            uint64_t* kout = w.keys[p & 1];
-            uint32_t* iout = w.idx[p & 1];
-            const bool last = p == passes - 1;
-            if (bits == 11)
-                launch_pass<11>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
-                                last ? row_n : nullptr, zsum, zsq, nullptr, packed_bits);
-            else
-                launch_pass<kLsdBits>(s, w, nb_sort, (uint32_t)cap, n_tuples, ds, p == 0, kin, iin, kout, iout,
-                                      last ? row_n : nullptr, zsum, zsq, nullptr, packed_bits);
-            kin = kout;
-            iin = iout;
-        }
+        // large streams: one histogram read, chained-scan partition passes, atomic-free row reduction (onesweep.hip)
+        uint64_t* bk[2] = {w.keys[0], w.keys[1]};
+        uint32_t* bi[2] = {w.idx[0], w.idx[1]};
+        return launch_onesweep_sort_reduce(s, cap, n_tuples, key_bits, keys, payload, bk, bi, row_key, row_mask, row_n,
+                                           row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows, w.os_ws,
+                                           w.os_bytes, first_map);
     }
     const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {

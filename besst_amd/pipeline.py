@@ -41,6 +41,15 @@ class DeviceRecords(object):
         self.mapq = _from_np(batch.mapq, device)
         self.qlen = _from_np(batch.qlen, device)
 
+    @classmethod
+    def from_columns(cls, cols, copy=False):
+        """Columns that already live on the device (synth.simulate_library_device)."""
+        self = cls.__new__(cls)
+        self.n = int(cols['tid'].shape[0])
+        for k in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen'):
+            setattr(self, k, cols[k].clone() if copy else cols[k])
+        return self
+
     @property
     def graph_bytes(self):
         return self.n * 19

@@ -42,3 +42,33 @@ def make(config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, tid_offse
     table = first_library_table(asm.lengths, spec.mean + 4 * spec.sd)
     return dict(config=config, asm=asm, batch=batch, table=table, lib=lib, node_bits=node_bits_for(table),
                 pairs=n_pairs, spec=spec)
+
+
+class DeviceWorkload(dict):
+    """A workload whose record columns were drawn on the GPU (synth.simulate_library_device); the host RecordBatch
+    (wl['batch'], what the oracles read) is only materialised when somebody asks for it."""
+
+    def __missing__(self, key):
+        if key == 'batch':
+            self['batch'] = synth.device_columns_to_batch(self['asm'], self['cols'], int(self['spec'].read_len))
+            return self['batch']
+        raise KeyError(key)
+
+
+def make_device(device, config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, reads_seed_offset=0):
+    """``make`` with the records generated on ``device`` (a torch device): the full-size mate-pair configs take
+    seconds instead of minutes.  Same assembly, table and library constants as ``make``; the read pairs come from
+    torch's generator instead of numpy's, so the two streams are different samples of the same model."""
+    cfg = synth.CONFIGS[config]
+    spec = cfg['libs'][lib_index]
+    n_pairs = int(pairs if pairs is not None else cfg['pairs'] // len(cfg['libs']))
+    n_ctg = int(nc if nc is not None else cfg['nc'])
+    seed = synth.config_seed(config) + 1000 * seed_offset
+    asm = synth.make_assembly(n_ctg, cfg['median'], seed)
+    cols = synth.simulate_library_device(asm, spec, n_pairs, seed + 100 + lib_index + 7919 * reads_seed_offset, device)
+    lib = dict(read_len=float(spec.read_len), ins_size_threshold=spec.mean + 6 * spec.sd, min_mapq=11,
+               orientation=spec.orientation, detect_duplicate=True, extend_paths=True, no_score=False,
+               mean=spec.mean, sd=spec.sd)
+    table = first_library_table(asm.lengths, spec.mean + 4 * spec.sd)
+    return DeviceWorkload(config=config, asm=asm, cols=cols, table=table, lib=lib, node_bits=node_bits_for(table),
+                          pairs=n_pairs, spec=spec)

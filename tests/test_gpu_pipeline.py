@@ -33,14 +33,16 @@ def test_dev_layer_matches_oracle():
                                             (600_000, 33, 100_000), (700_000, 41, 0), (1_000_000, 41, 3_000),
                                             (1_000_000, 45, 0), (1_500_000, 41, 0), (200_000, 57, 500),
                                             (700_000, 55, 0), (1_000_000, 59, 0), (5_000_000, 41, 0),
-                                            (6_000_000, 37, 150_000)])
+                                            (6_000_000, 37, 150_000), (5_000_000, 45, 0), (4_300_000, 3, 0),
+                                            (8192 * 600 + 1, 37, 0), (4096 * 1100, 5, 0)])
 def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     """The sort/reduce stage alone, on skewed keys: a hub bucket larger than the LDS sort capacity, fewer key bits
     than one digit, the small-stream MSD path (scan-free table, rank sort), the mid-size MSD path (row-scanned table,
     rank sort / LDS bitonic / global bitonic buckets), 57- and 55-bit keys that only pack because the MSD digit is implied by the bucket, a
     stream whose words do not fit 64 bits even so (59-bit keys: LSD passes with index arrays), and streams beyond 4 M
-    tuples (wide partition + per-bucket two-level sort; the hub case puts 150 000 tuples in ONE group of one bucket,
-    which takes the global bitonic fallback) and a large one (packed LSD passes)."""
+    tuples (chained-scan radix passes + atomic-free row reduction, csrc/onesweep.hip): packed words, a hub row of
+    150 000 tuples, 45-bit keys that travel with a separate index array, 3- and 5-bit keys whose few rows run
+    across hundreds of reduce tiles, and streams that end one tuple into / exactly at a tile."""
     import ctypes as C
     import numpy as np
     import torch
