@@ -30,14 +30,37 @@ namespace {
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define BESST_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr int kOsThreads = 512;
+// Tile geometry of the partition passes (build knobs).  Measured on full C3 (42.7 M tuples, 5 passes): larger tiles
+// win - 256 x 16 keys 1.55 ms, 512 x 12 1.38, 512 x 16 1.12, 1024 x 16 1.02 for the five passes - as long as the
+// keys per thread stay at 16 (24 / 32 keys per thread: 1.41 / 1.69 ms, the ranking rounds of a wave are serial).
+#ifndef BESST_OS_THREADS
+#define BESST_OS_THREADS 512
+#endif
+#ifndef BESST_OS_ITEMS
+#define BESST_OS_ITEMS 16
+#endif
+constexpr int kOsThreads = BESST_OS_THREADS;
 constexpr int kOsWaves = kOsThreads / 64;
-constexpr int kOsItems = 16;
+constexpr int kOsItems = BESST_OS_ITEMS;
 constexpr int kOsTile = kOsThreads * kOsItems;          // 8192 keys per scatter tile
-constexpr int kOsHistThreads = 256;
+#ifndef BESST_OS_HIST_THREADS
+#define BESST_OS_HIST_THREADS 1024
+#endif
+#ifndef BESST_OS_HIST_BLOCKS
+#define BESST_OS_HIST_BLOCKS 512
+#endif
+#ifndef BESST_OS_HIST_COPIES
+#define BESST_OS_HIST_COPIES 8
+#endif
+constexpr int kOsHistThreads = BESST_OS_HIST_THREADS;
 constexpr int kOsHistTile = kOsHistThreads * 16;
-constexpr int kOsHistBlocks = 512;
-constexpr int kOsMaxPasses = 8;
+constexpr int kOsHistBlocks = BESST_OS_HIST_BLOCKS;
+constexpr int kOsHistCopies = BESST_OS_HIST_COPIES;
+#ifndef BESST_OS_BITS
+#define BESST_OS_BITS 8
+#endif
+constexpr int kOsBits = BESST_OS_BITS;
+constexpr int kOsMaxPasses = (64 + kOsBits - 1) / kOsBits;
 constexpr int kOsRedThreads = 256;
 constexpr int kOsRedItems = 16;
 constexpr int kOsRedTile = kOsRedThreads * kOsRedItems; // 4096 tuples per reduce tile
@@ -62,9 +85,14 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
                                                                  unsigned long long* __restrict__ granules,
                                                                  size_t granule_words) {
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_hist[kOsMaxPasses * RADIX];
+    // 64 consecutive tuples of a (tid,pos)-ordered stream touch one or two contigs, so every digit takes a handful of
+    // values inside a wave and per-lane LDS atomics pile up on a few counters.  kOsHistCopies copies of the counters,
+    // picked by lane and shifted by one bank each, spread those lanes over different banks (C3: 0.21 -> 0.12 ms;
+    // peeling off the distinct values with ballots instead cost the same 0.2 ms in scalar-chain latency).
+    __shared__ uint32_t s_hist[kOsHistCopies * (kOsMaxPasses * RADIX + 1)];
     const int t = threadIdx.x, lane = t & 63;
-    for (int d = t; d < passes * RADIX; d += kOsHistThreads) s_hist[d] = 0;
+    const int stride = passes * RADIX + 1;
+    for (int d = t; d < kOsHistCopies * stride; d += kOsHistThreads) s_hist[d] = 0;
     // every granule of this call starts as "nothing published" (plain stores: first polled after a kernel boundary)
     {
         const size_t gsz = (size_t)gridDim.x * kOsHistThreads;
@@ -72,6 +100,7 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
     }
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
+    uint32_t* mine = s_hist + (lane & (kOsHistCopies - 1)) * stride;
     __syncthreads();
     for (uint32_t base = blockIdx.x * (uint32_t)kOsHistTile; base < n; base += gridDim.x * (uint32_t)kOsHistTile) {
         if (base + kOsHistTile <= n) {
@@ -82,13 +111,11 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
             for (int r = 0; r < 16; ++r) {
                 for (int p = 0; p < passes; ++p) {
                     const uint32_t d = (uint32_t)(k[r] >> (p * BITS)) & (uint32_t)(RADIX - 1);
-                    // high digits of a (tid,pos)-ordered stream: the whole wave shares one digit, which as 64 LDS
-                    // atomics on one counter would serialise
                     const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-                    if (__all(d == f)) {
-                        if (lane == 0) atomicAdd(&s_hist[p * RADIX + f], 64u);
+                    if (__all(d == f)) {                    // the whole wave on one value (high digits): one add
+                        if (lane == 0) atomicAdd(&mine[p * RADIX + f], 64u);
                     } else {
-                        atomicAdd(&s_hist[p * RADIX + d], 1u);
+                        atomicAdd(&mine[p * RADIX + d], 1u);
                     }
                 }
             }
@@ -98,14 +125,19 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
                 if (i < n) {
                     const uint64_t k = keys[i];
                     for (int p = 0; p < passes; ++p)
-                        atomicAdd(&s_hist[p * RADIX + ((uint32_t)(k >> (p * BITS)) & (uint32_t)(RADIX - 1))], 1u);
+                        atomicAdd(&mine[p * RADIX + ((uint32_t)(k >> (p * BITS)) & (uint32_t)(RADIX - 1))], 1u);
                 }
             }
         }
     }
     __syncthreads();
     uint32_t* row = table + (size_t)blockIdx.x * passes * RADIX;
-    for (int d = t; d < passes * RADIX; d += kOsHistThreads) row[d] = s_hist[d];
+    for (int d = t; d < passes * RADIX; d += kOsHistThreads) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < kOsHistCopies; ++c) v += s_hist[c * stride + d];
+        row[d] = v;
+    }
 }
 
 // 2. block p: start of every digit of pass p; clears the arrival tickets
@@ -121,10 +153,19 @@ __global__ __launch_bounds__(256) void os_offsets_kernel(const uint32_t* __restr
     uint32_t tot[DPT];
 #pragma unroll
     for (int q = 0; q < DPT; ++q) tot[q] = 0;
-    for (int g = 0; g < hist_blocks; ++g) {
-        const uint32_t* row = table + ((size_t)g * passes + p) * RADIX + (size_t)t * DPT;
+    for (int g0 = 0; g0 < hist_blocks; g0 += 16) {          // 16 rows in flight per round trip
+        uint32_t v[16][DPT];
 #pragma unroll
-        for (int q = 0; q < DPT; ++q) tot[q] += row[q];
+        for (int u = 0; u < 16; ++u) {
+            const int g = g0 + u < hist_blocks ? g0 + u : hist_blocks - 1;
+            const uint32_t* row = table + ((size_t)g * passes + p) * RADIX + (size_t)t * DPT;
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) v[u][q] = row[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) tot[q] += g0 + u < hist_blocks ? v[u][q] : 0u;
     }
     uint32_t run = 0;
 #pragma unroll
@@ -151,16 +192,33 @@ __global__ __launch_bounds__(256) void os_offsets_kernel(const uint32_t* __restr
 // ---------------------------------------------------------------------------------------------------
 // 3. one radix pass: stable partition by chained scan
 // ---------------------------------------------------------------------------------------------------
-// kFirst: the input is the raw key stream (the stream index is the position); packed_bits > 0: the words written
-// (and read by later passes) are key << packed_bits | stream index; packed_bits == 0: keys and indexes travel as
-// two arrays (keys wider than 64 - index bits).
-template <int BITS, bool kFirst>
-__global__ __launch_bounds__(kOsThreads) void os_scatter_kernel(
+// kFirst: the input is the raw key stream (the stream index is the position); kPacked: the words written (and read
+// by later passes) are key << packed_bits | stream index; otherwise keys and indexes travel as two arrays (keys
+// wider than 64 - index bits).
+//
+// Ranking (a key's position among the keys of its wave with the same digit, in lane order: the partition is stable)
+// is where the instructions of this kernel go - with a plain BITS-ballot match-any per key the passes were bound by
+// VALU issue, not by memory (~190 instructions per key round, 160 of the 223 us of a C3 pass).  The digits of 64
+// consecutive tuples of a (tid,pos)-ordered stream take a handful of values, so the distinct values are peeled off
+// one at a time - lowest lane still unranked -> its digit (readlane) -> one compare = the group's lane mask (a
+// scalar) -> rank inside the group (mbcnt) and group size (scalar popcount) - at ~6 vector + ~6 scalar instructions
+// per distinct value; only what is left after kPeel values (digits of an unordered stream) takes the match-any.
+#ifndef BESST_OS_MIN_WAVES
+#define BESST_OS_MIN_WAVES 4
+#endif
+#ifndef BESST_OS_PEEL
+#define BESST_OS_PEEL 8
+#endif
+constexpr int kPeel = BESST_OS_PEEL;
+
+template <int BITS, bool kFirst, bool kPacked>
+__global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ n_ptr,
     uint32_t cap, int shift, int pass, int packed_bits, const uint32_t* __restrict__ digit_base,
     unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err) {
     constexpr int RADIX = 1 << BITS;
+    constexpr int kIdxRegs = kPacked ? 1 : kOsItems;
     __shared__ uint32_t s_whist[kOsWaves][RADIX];
     __shared__ uint32_t s_base[RADIX];
     __shared__ uint32_t s_tile;
@@ -176,36 +234,55 @@ __global__ __launch_bounds__(kOsThreads) void os_scatter_kernel(
     if (tile >= os_nblocks(n, kOsTile)) return;             // uniform
     const uint32_t wbase = tile * (uint32_t)kOsTile + (uint32_t)wave * (kOsItems * 64);
     uint64_t key[kOsItems];
-    uint32_t idx[kOsItems];
+    uint32_t idx[kIdxRegs];
 #pragma unroll
     for (int r = 0; r < kOsItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         key[r] = i < n ? keys_in[i] : ~0ull;
-        idx[r] = kFirst ? i : ((i < n && !packed_bits) ? idx_in[i] : 0u);
+        if (!kPacked) idx[r] = kFirst ? i : (i < n ? idx_in[i] : 0u);
     }
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* my_hist = &s_whist[wave][0];
     uint32_t dig_rank[kOsItems];                            // digit | rank inside the wave's share << BITS
 #pragma unroll
     for (int r = 0; r < kOsItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t d = valid ? ((uint32_t)(key[r] >> shift) & (uint32_t)(RADIX - 1)) : (uint32_t)(RADIX - 1);
-        unsigned long long peers = __ballot(valid);
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(RADIX - 1);
+        uint32_t info = 0;                                   // rank inside my group | group size << 8
+        bool todo = valid;
+        unsigned long long rest = __ballot(todo);
+        for (int it = 0; it < kPeel && rest; ++it) {         // uniform loop
+            const int src = __ffsll((long long)rest) - 1;
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)d, src);
+            const bool hit = todo && d == f;
+            const unsigned long long m = __ballot(hit);
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t c8 = (uint32_t)__popcll(m) << 8;
+            if (hit) { info = rk | c8; todo = false; }
+            rest &= ~m;
+        }
+        if (rest) {                                          // uniform: many distinct digits in this wave
+            unsigned long long pm = rest;
 #pragma unroll
-        for (int bit = 0; bit < BITS; ++bit) {
-            const bool one = (d >> bit) & 1u;
-            const unsigned long long bal = __ballot(one);
-            peers &= one ? bal : ~bal;
+            for (int bit = 0; bit < BITS; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                pm &= one ? bal : ~bal;
+            }
+            if (todo) {
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                info = rk | ((uint32_t)__popcll(pm) << 8);
+            }
         }
+        // every lane reads its digit's running count, then the first lane of each group adds the group's size: LDS
+        // operations of a wave execute in order, so the reads see the counts of the earlier rounds only
         uint32_t pre = 0;
-        const int leader = __ffsll((long long)peers) - 1;
-        if (valid && lane == leader) {
-            volatile uint32_t* slot = &s_whist[wave][d];     // an earlier round of this wave may have updated it
+        if (valid) {
+            volatile uint32_t* slot = my_hist + d;
             pre = *slot;
-            *slot = pre + (uint32_t)__popcll(peers);
+            if ((info & 0xffu) == 0u) *slot = pre + (info >> 8);
         }
-        pre = __shfl(pre, leader < 0 ? 0 : leader, 64);
-        dig_rank[r] = d | ((pre + (uint32_t)__popcll(peers & lt_mask)) << BITS);
+        dig_rank[r] = d | ((pre + (info & 0xffu)) << BITS);
     }
     __syncthreads();
     // per digit: the tile's count, published; the count of all earlier tiles, looked back; the waves' shares
@@ -244,8 +321,8 @@ __global__ __launch_bounds__(kOsThreads) void os_scatter_kernel(
         if (i < n) {
             const uint32_t d = dig_rank[r] & (uint32_t)(RADIX - 1);
             const uint32_t dst = s_base[d] + s_whist[wave][d] + (dig_rank[r] >> BITS);
-            if (packed_bits) {
-                keys_out[dst] = kFirst ? ((key[r] << packed_bits) | idx[r]) : key[r];
+            if (kPacked) {
+                keys_out[dst] = kFirst ? ((key[r] << packed_bits) | i) : key[r];
             } else {
                 keys_out[dst] = key[r];
                 idx_out[dst] = idx[r];
@@ -270,13 +347,15 @@ __device__ __forceinline__ Part part_shfl_up(const Part& a, int d) {
     o.s2 = __shfl_up(a.s2, d, 64);
     return o;
 }
-__device__ __forceinline__ Part part_shfl(const Part& a, int src) {
-    Part o;
-    o.n = __shfl(a.n, src, 64);
-    o.s = __shfl(a.s, src, 64);
-    o.s2 = __shfl(a.s2, src, 64);
-    return o;
-}
+
+// Two phases per 4096-tuple tile.  Phase 1 is a streaming pass in lane-contiguous layout: sorted words in (coalesced),
+// observations gathered through the stream index and written out (coalesced), per tuple only obs1 + obs2 and a head
+// flag are kept, in LDS.  Phase 2 re-reads them thread-contiguous (16 consecutive tuples per thread, padded rows:
+// conflict free), so that the row sums are sequential adds plus ONE segmented scan over the tile's threads; the few
+// tuples that start a row fetch their word again for the row's key / first index / graph mask.
+// (Loading the words thread-contiguous straight from memory - 128 bytes per lane - thrashed the 32 KB L1 and ran the
+// stage at 0.71 ms on C3; this form takes 0.40.)
+__device__ __forceinline__ int os_pad(int i) { return i + (i >> 4); }
 
 __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     const uint64_t* __restrict__ words, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ payload,
@@ -287,6 +366,8 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
     uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo,
     int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map, uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_o[kOsRedTile + kOsRedTile / 16];          // obs1 + obs2 per tuple, padded rows of 16
+    __shared__ unsigned long long s_heads[kOsRedTile / 64];         // head flags, one bit per tuple
     __shared__ uint32_t s_tile, s_base;
     __shared__ int s_wcnt[4];
     __shared__ uint32_t s_pn[4], s_pf[4];
@@ -303,50 +384,47 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
         return;
     }
     if (tile >= ntiles) return;
-    const uint32_t i0 = tile * (uint32_t)kOsRedTile + (uint32_t)t * kOsRedItems;
+    const uint32_t tbase = tile * (uint32_t)kOsRedTile;
     const uint64_t idx_mask = packed_bits ? ((1ull << packed_bits) - 1ull) : 0ull;
-    uint64_t key[kOsRedItems];
-    uint32_t src[kOsRedItems];
-    uint64_t prev = (i0 > 0 && i0 - 1 < n) ? (words[i0 - 1] >> packed_bits) : 0ull;
-    if (i0 + kOsRedItems <= n) {
+    // ---- phase 1, two halves of 8 rounds (all loads of a half in flight together)
 #pragma unroll
-        for (int k = 0; k < kOsRedItems; k += 2) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(words + i0 + k);
-            key[k] = v.x >> packed_bits;
-            key[k + 1] = v.y >> packed_bits;
-            src[k] = (uint32_t)(v.x & idx_mask);
-            src[k + 1] = (uint32_t)(v.y & idx_mask);
+    for (int h = 0; h < 2; ++h) {
+        uint64_t w[8];
+        uint32_t src[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = tbase + (uint32_t)(h * 8 + q) * kOsRedThreads + t;
+            w[q] = i < n ? words[i] : 0ull;
+            src[q] = packed_bits ? (uint32_t)(w[q] & idx_mask) : (i < n ? idx[i] : 0u);
         }
-        if (!packed_bits) {
+        uint64_t pl[8];
 #pragma unroll
-            for (int k = 0; k < kOsRedItems; k += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(idx + i0 + k);
-                src[k] = v.x; src[k + 1] = v.y; src[k + 2] = v.z; src[k + 3] = v.w;
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = tbase + (uint32_t)(h * 8 + q) * kOsRedThreads + t;
+            pl[q] = i < n ? payload[src[q]] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            const uint32_t i = tbase + (uint32_t)r * kOsRedThreads + t;
+            uint64_t wp = __shfl_up(w[q], 1, 64);
+            if (lane == 0) wp = (i > 0 && i < n) ? words[i - 1] : ~w[q];
+            const bool head = i < n && (i == 0 || (w[q] >> packed_bits) != (wp >> packed_bits));
+            const unsigned long long hm = __ballot(head);
+            if (lane == 0) s_heads[r * 4 + wave] = hm;
+            const uint32_t lo = (uint32_t)pl[q], hi = (uint32_t)(pl[q] >> 32) & 0x3fffffffu;
+            if (i < n) {
+                obs_lo[i] = (int32_t)lo;
+                obs_hi[i] = (int32_t)hi;
             }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kOsRedItems; ++k) {
-            const uint32_t i = i0 + k;
-            const uint64_t v = i < n ? words[i] : 0ull;
-            key[k] = v >> packed_bits;
-            src[k] = packed_bits ? (uint32_t)(v & idx_mask) : (i < n ? idx[i] : 0u);
+            s_o[os_pad(r * kOsRedThreads + t)] = i < n ? lo + hi : 0u;
         }
     }
-    // the observations are gathered through the stream index; nothing below depends on the look-back yet
-    uint64_t pl[kOsRedItems];
-#pragma unroll
-    for (int k = 0; k < kOsRedItems; ++k) pl[k] = (i0 + k) < n ? payload[src[k]] : 0ull;
-    uint32_t headbits = 0;
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kOsRedItems; ++k) {
-        const uint32_t i = i0 + k;
-        const bool h = i < n && (i == 0 || key[k] != prev);
-        headbits |= h ? (1u << k) : 0u;
-        cnt += h ? 1 : 0;
-        prev = key[k];
-    }
+    __syncthreads();
+    // ---- phase 2: thread t owns tuples [16 t, 16 t + 16) of the tile
+    const uint32_t i0 = tbase + (uint32_t)t * kOsRedItems;
+    const uint32_t headbits = (uint32_t)(s_heads[t >> 2] >> ((t & 3) * 16)) & 0xffffu;
+    const int cnt = __popc(headbits);
     int x = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -358,7 +436,7 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     int pre = x - cnt;
     for (int w = 0; w < wave; ++w) pre += s_wcnt[w];
     const uint32_t tile_heads = (uint32_t)(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
-    // ---- rows before this tile: chained scan of the head counts, wave 0, 64 predecessors per round
+    // rows before this tile: chained scan of the head counts, wave 0, 64 predecessors per round
     if (wave == 0) {
         const uint32_t tag_agg = (1u << 2) | kStAgg, tag_pre = (1u << 2) | kStPrefix;
         uint32_t excl = 0;
@@ -407,8 +485,6 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     for (int k = 0; k < kOsRedItems; ++k) {
         const uint32_t i = i0 + k;
         if (i < n) {
-            const uint32_t lo = (uint32_t)pl[k], hi = (uint32_t)(pl[k] >> 32);
-            const int32_t o_lo = (int32_t)lo, o_hi = (int32_t)(hi & 0x3fffffffu);
             if ((headbits >> k) & 1u) {
                 if (!seen) {
                     lead = run;                              // closes the row that was open at the thread's start
@@ -420,14 +496,14 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
                 seen = true;
                 run = part_zero();
                 ++row;
-                row_key[row] = key[k];
-                row_mask[row] = hi >> 30;
-                row_first[row] = first_map ? first_map[src[k]] : src[k];
+                const uint64_t w = words[i];
+                const uint32_t src = packed_bits ? (uint32_t)(w & idx_mask) : idx[i];
+                row_key[row] = w >> packed_bits;
+                row_mask[row] = (uint32_t)(payload[src] >> 62);
+                row_first[row] = first_map ? first_map[src] : src;
                 row_offset[row] = i;
             }
-            obs_lo[i] = o_lo;
-            obs_hi[i] = o_hi;
-            const unsigned long long o = (unsigned long long)((long long)o_lo + o_hi);
+            const unsigned long long o = (unsigned long long)s_o[os_pad(t * kOsRedItems + k)];
             run.n += 1;
             run.s += o;
             run.s2 += o * o;
@@ -487,7 +563,6 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
             lead_s2[tile] = incl.s2;
         }
     }
-    (void)part_shfl;
 }
 
 // 5. a tile that begins inside a row adds its leading share to that row (the last row before the tile)
@@ -548,11 +623,6 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     return w;
 }
 
-#ifndef BESST_OS_BITS
-#define BESST_OS_BITS 8
-#endif
-constexpr int kOsBits = BESST_OS_BITS;
-
 }  // namespace
 
 size_t onesweep_workspace_bytes(int64_t cap) {
@@ -596,14 +666,16 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         uint64_t* kout = buf_keys[p & 1];
         uint32_t* iout = buf_idx[p & 1];
         const int shift = p * kOsBits + (p > 0 ? packed_bits : 0);
-        if (p == 0)
-            hipLaunchKernelGGL((os_scatter_kernel<kOsBits, true>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin, n_tuples,
-                               (uint32_t)cap, shift, p, packed_bits, w.digit_base + (size_t)p * RADIX, w.granules,
-                               w.tickets + p, kout, iout, w.err);
-        else
-            hipLaunchKernelGGL((os_scatter_kernel<kOsBits, false>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin, n_tuples,
-                               (uint32_t)cap, shift, p, packed_bits, w.digit_base + (size_t)p * RADIX, w.granules,
-                               w.tickets + p, kout, iout, w.err);
+#define BESST_OS_LAUNCH(FIRST, PACKED)                                                                                   \
+    hipLaunchKernelGGL((os_scatter_kernel<kOsBits, FIRST, PACKED>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,      \
+                       n_tuples, (uint32_t)cap, shift, p, packed_bits, w.digit_base + (size_t)p * RADIX, w.granules,      \
+                       w.tickets + p, kout, iout, w.err)
+        if (packed_bits) {
+            if (p == 0) BESST_OS_LAUNCH(true, true); else BESST_OS_LAUNCH(false, true);
+        } else {
+            if (p == 0) BESST_OS_LAUNCH(true, false); else BESST_OS_LAUNCH(false, false);
+        }
+#undef BESST_OS_LAUNCH
         kin = kout;
         iin = iout;
     }
