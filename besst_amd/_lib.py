@@ -21,7 +21,7 @@ class BesstDeviceError(RuntimeError):
 class LibParams(C.Structure):
     _fields_ = [('read_len', C.c_double), ('ins_size_threshold', C.c_double), ('min_mapq', C.c_int32),
                 ('orientation', C.c_int32), ('detect_duplicate', C.c_int32), ('extend_paths', C.c_int32),
-                ('no_score', C.c_int32), ('reserved', C.c_int32)]
+                ('no_score', C.c_int32), ('record_path', C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -78,6 +78,8 @@ _SIGNATURES = {
     'besst_dev_pack_contigs': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_classify': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                      C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t]),
+    'besst_dev_candidate_density': (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int32)]),
     'besst_dev_reduce': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, C.c_size_t, _P]),
     'besst_dev_classify_scan': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,

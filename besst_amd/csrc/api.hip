@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -382,6 +383,8 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     a.detect_dup = p->detect_duplicate;
     a.extend_paths = p->extend_paths;
     a.no_score = p->no_score;
+    a.record_path = p->record_path;
+    BESST_REQUIRE(p->record_path == 0 || p->record_path == 1, "classify: record_path must be 0 or 1");
     return BESST_OK;
 }
 
@@ -396,6 +399,25 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
     BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
     return launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
                            workspace, workspace_bytes);
+}
+
+int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                                int64_t sample_records, void* counts_scratch, double* h_share,
+                                int32_t* h_record_path) {
+    BESST_REQUIRE(n >= 0 && (n == 0 || (tid && mtid)) && counts_scratch && h_share && h_record_path,
+                  "candidate_density: bad argument");
+    unsigned long long host[2] = {0ull, 0ull};
+    if (n > 0) {
+        int rc = launch_candidate_density(static_cast<hipStream_t>(stream), n, tid, mtid, sample_records,
+                                          static_cast<unsigned long long*>(counts_scratch));
+        if (rc) return rc;
+        BESST_HIP_TRY(hipMemcpyAsync(host, counts_scratch, sizeof(host), hipMemcpyDeviceToHost,
+                                     static_cast<hipStream_t>(stream)));
+        BESST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    }
+    *h_share = host[1] ? (double)host[0] / (double)host[1] : 0.0;
+    *h_record_path = *h_share >= BESST_DENSE_CANDIDATE_SHARE ? 1 : 0;
+    return BESST_OK;
 }
 
 int besst_dev_classify_scan(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
@@ -540,6 +562,14 @@ int besst_ctx_build_graph(besst_ctx* c) {
     if ((rc = c->payload.ensure(cap1))) return rc;
     if ((rc = c->ws.ensure(classify_workspace_bytes(n)))) return rc;
     besst_lib_params lp = c->lib;
+    {   // which form of the record loop: one fused pass for candidate-dense (mate-pair) libraries
+        double share = 0.0;
+        if ((rc = c->aux.ensure(64))) return rc;
+        rc = besst_dev_candidate_density(c->stream, n, c->tid.p, c->mtid.p, 4 << 20, c->aux.p, &share, &lp.record_path);
+        if (rc) return rc;
+        const char* forced = getenv("BESST_RECORD_PATH");   // tests and experiments: "0" / "1"
+        if (forced && (forced[0] == '0' || forced[0] == '1') && forced[1] == 0) lp.record_path = forced[0] - '0';
+    }
     rc = besst_dev_classify(c->stream, n, c->tid.p, c->mtid.p, c->pos.p, c->mpos.p, c->flag.p, c->mapq.p, c->qlen.p,
                             c->n_contigs, c->table.p, &lp, c->node_bits, sb->carry, c->aligned.p, c->keys.p,
                             c->payload.p, &sb->n_out, &sb->counters, c->ws.p, c->ws.cap);

@@ -542,6 +542,186 @@ __global__ __launch_bounds__(kOrdThreads, BESST_ORD_MIN_BLOCKS) void ordered_ker
     chain.publish(summ, blockIdx.x, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fused_kernel: the record loop of a candidate-DENSE library (mate pairs: a fifth of the records have their mate
+// on another contig) in ONE pass over the seven columns.  stream_kernel + ordered_kernel read such a library twice
+// (the candidates' seven scattered column reads touch every sector again: 12.4 GB instead of 8.4 GB on C3) and
+// ordered_kernel is bound by vector instructions there - 600 per candidate, most of them spent finding the r-th set
+// bit of a group mask.  Here a 256-thread workgroup walks its 16 384 records in 16 sub-tiles of 1024:
+//   all waves  coalesced loads of the seven columns; tid == mtid records only add coverage (a running (contig, sum)
+//              per wave, flushed with one atomic when the contig changes);
+//              candidates are compacted, in stream order, into LDS (ballot prefix; five words per record)
+//   all waves  thread j evaluates candidate j: two contig rows (L2), PosDirCalculator, link dispatch -> the same
+//              16-byte entry ordered_kernel builds, written over the candidate's record
+//   wave 0     Chain::step over the entries, 64 at a time (duplicate chain, acceptance, counters, ordered
+//              emission into the block's segment) - the very code of the two-pass path
+// and publishes the same block summary, so stitch_kernel / compact_kernel and the sharded build's head / tail logic
+// are shared by both paths.  besst_lib_params.record_path selects the path (the host samples the candidate density).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFusedThreads = 256;
+constexpr int kFusedSub = kFusedThreads * 4;              // records per sub-tile
+#ifndef BESST_FUSED_MIN_WAVES
+#define BESST_FUSED_MIN_WAVES 4
+#endif
+
+__global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_kernel(
+    ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
+    uint64_t* __restrict__ seg_payload, SummView summ) {
+    // SoA over the sub-tile's candidates: words 0..4 = tid, mtid, pos, mpos, flag | mapq << 16 (qlen in word 5's
+    // place would make six; it travels in the top half of the flag word: flag bits above 0x100 are not read)
+    __shared__ uint32_t s_buf[5][kFusedSub];
+    __shared__ uint32_t s_qlen[kFusedSub / 2];            // 16 bits per candidate
+    __shared__ int s_wcnt[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    Chain chain;                                            // wave 0 only
+    int32_t run_tid = -1;                                   // the wave's running coverage (uniform)
+    int run_sum = 0;
+    for (int st = 0; st < kClsTile / kFusedSub; ++st) {
+        const int64_t sub_base = block_base + (int64_t)st * kFusedSub;
+        if (sub_base >= a.n) break;                         // uniform
+        const int64_t i0 = sub_base + (int64_t)t * 4;
+        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
+        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
+        if (sub_base + kFusedSub <= a.n) {
+            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
+            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
+            const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
+            const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
+            const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
+            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
+            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
+            r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
+            r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
+            r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
+            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
+            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                r_tid[k] = in ? a.tid[i] : -1;
+                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
+                r_pos[k] = in ? a.pos[i] : 0;
+                r_mpos[k] = in ? a.mpos[i] : 0;
+                r_flag[k] = in ? a.flag[i] : 0;
+                r_mapq[k] = in ? a.mapq[i] : 0;
+                r_qlen[k] = in ? a.qlen[i] : 0;
+            }
+        }
+        // ---- coverage of the tid == mtid records [:138-139]
+        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
+        bool uni = true;
+        int mine = 0;
+        bool cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cand[k] = r_tid[k] != r_mtid[k];
+            uni = uni && (r_tid[k] == ref);
+            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+            if (!cand[k] && cov) mine += (int)r_qlen[k];
+        }
+        if (__all(uni)) {
+            const int s = wave_sum(mine);
+            if (ref != run_tid) {
+                if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
+                    atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+                run_tid = ref;
+                run_sum = 0;
+            }
+            run_sum += s;
+        } else {
+            // a contig boundary (or unsorted input) inside the wave: run-segmented reduction over the lanes, a lane
+            // that itself straddles a boundary adds its records directly (see stream_kernel)
+            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
+            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);
+            int val = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
+                if (!act) continue;
+                if (lane_uni) val += (int)r_qlen[k];
+                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
+            }
+            if (lane_uni) key = r_tid[0];
+            wave_add_runs(aligned, key, val, lane);
+        }
+        // ---- candidates -> LDS, in record order (record = 4 * lane + k inside the wave's 256)
+        const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
+        const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
+        const int wcount = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        if (lane == 0) s_wcnt[wave] = wcount;
+        __syncthreads();                                    // also: wave 0 is done with the previous sub-tile's entries
+        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) slot += s_wcnt[w];
+            total += s_wcnt[w];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (cand[k]) {
+                s_buf[0][slot] = (uint32_t)r_tid[k];
+                s_buf[1][slot] = (uint32_t)r_mtid[k];
+                s_buf[2][slot] = (uint32_t)r_pos[k];
+                s_buf[3][slot] = (uint32_t)r_mpos[k];
+                s_buf[4][slot] = (r_flag[k] & 0xffffu) | (r_mapq[k] << 16);
+                reinterpret_cast<unsigned short*>(s_qlen)[slot] = (unsigned short)r_qlen[k];
+                ++slot;
+            }
+        }
+        __syncthreads();
+        // ---- evaluation: thread j takes candidate j (one round unless more than a quarter of the records are candidates)
+        for (int c0 = 0; c0 < total; c0 += kFusedThreads) {
+            const int j = c0 + t;
+            const bool live = j < total;
+            int32_t tid = -1, mtid = -1, pos = 0, mpos = 0;
+            uint32_t fm = 0, qlen = 0;
+            if (live) {
+                tid = (int32_t)s_buf[0][j]; mtid = (int32_t)s_buf[1][j];
+                pos = (int32_t)s_buf[2][j]; mpos = (int32_t)s_buf[3][j];
+                fm = s_buf[4][j];
+                qlen = reinterpret_cast<const unsigned short*>(s_qlen)[j];
+            }
+            const bool in_range = live && (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs;
+            ContigRow c1, c2;
+            c1.w0 = c2.w0 = 0; c1.scaf_len = c2.scaf_len = 0; c1.ctg_pos = c2.ctg_pos = 0; c1.ctg_len = c2.ctg_len = 0;
+            if (in_range) {
+                c1 = a.table[tid];
+                c2 = a.table[mtid];
+            }
+            const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
+            const uint4 ent = pack_entry(e);
+            if (live) {                                      // the entry replaces the record it was made from
+                s_buf[0][j] = ent.x; s_buf[1][j] = ent.y; s_buf[2][j] = ent.z; s_buf[3][j] = ent.w;
+            }
+            if (c0 + wave * 64 < total)                      // uniform per wave: the candidates' own coverage
+                wave_add_runs(aligned, live ? tid : -1, (live && (e.bits & EV_COV)) ? (int)qlen : 0, lane);
+        }
+        __syncthreads();
+        // ---- the order-dependent part, wave 0 over the sub-tile's entries in stream order
+        if (wave == 0) {
+            for (int q0 = 0; q0 < total; q0 += 64) {
+                const int j = q0 + lane;
+                uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+                if (j < total) ent = make_uint4(s_buf[0][j], s_buf[1][j], s_buf[2][j], s_buf[3][j]);
+                chain.step(a, ent, j < total, lane, seg_keys, seg_payload, block_base);
+            }
+        }
+        // (the barrier at the top of the next sub-tile keeps the other waves off the entries until wave 0 is done)
+    }
+    if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
+        atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+    if (wave != 0) return;
+    chain.publish(summ, blockIdx.x, lane);
+}
+
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------
 // One workgroup, one lane per block and round, kStitchRounds rounds (4096 blocks) per iteration.  The summaries of
 // all rounds are fetched up front (one memory round trip); both scans - "nearest earlier block that reached
@@ -881,6 +1061,25 @@ __global__ void zero_tail_kernel(int32_t* tail) {
     if (threadIdx.x < 4) tail[threadIdx.x] = 0;
 }
 
+// counts[0] += records with tid != mtid, counts[1] += records looked at, over `tiles` evenly spaced 1024-record tiles
+__global__ __launch_bounds__(256) void density_kernel(const int32_t* __restrict__ tid, const int32_t* __restrict__ mtid,
+                                                      int64_t n, int64_t n_tiles, int64_t step,
+                                                      unsigned long long* __restrict__ counts) {
+    const int64_t tile = (int64_t)blockIdx.x * step;
+    if (tile >= n_tiles) return;
+    const int64_t i0 = tile * 1024 + (int64_t)threadIdx.x * 4;
+    int c = 0, m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) { ++m; c += tid[i0 + k] != mtid[i0 + k] ? 1 : 0; }
+    c = wave_sum(c);
+    m = wave_sum(m);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)c);
+        atomicAdd(&counts[1], (unsigned long long)m);
+    }
+}
+
 // prev_obs entering rank `rank`: the tail of the nearest earlier rank that has one, else what is in carry
 __global__ void resolve_carry_kernel(const int32_t* __restrict__ tails, int rank, int32_t* __restrict__ carry) {
     if (threadIdx.x != 0) return;
@@ -902,6 +1101,13 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     // compacted and evaluated in LDS, chain by wave 0 - was built and measured on a C3 slice: correct, but 0.70 ms
     // against 0.16 + 0.42 ms for the two passes; at 135 VGPRs and a barrier-separated chain per 1024 records it is
     // latency bound at 3 waves per SIMD.  The split design below serves every library.)
+    if (a.record_path == 1) {
+        ProfScope ps(s, kProfClassify);
+        hipLaunchKernelGGL(fused_kernel, dim3(nblocks), dim3(kFusedThreads), 0, s, a,
+                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
+        BESST_HIP_TRY(hipGetLastError());
+        return BESST_OK;
+    }
     {
         ProfScope ps(s, kProfClassify);
         hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
@@ -913,6 +1119,21 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
                            reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
     }
     (void)counters;
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+int launch_candidate_density(hipStream_t s, int64_t n, const int32_t* tid, const int32_t* mtid, int64_t sample_records,
+                             unsigned long long* counts) {
+    BESST_HIP_TRY(hipMemsetAsync(counts, 0, 16, s));
+    if (n <= 0) return BESST_OK;
+    const int64_t n_tiles = (n + 1023) / 1024;
+    int64_t want = sample_records > 0 ? (sample_records + 1023) / 1024 : n_tiles;
+    if (want < 1) want = 1;
+    if (want > n_tiles) want = n_tiles;
+    const int64_t step = n_tiles / want;                    // every step-th tile
+    const int64_t blocks = (n_tiles + step - 1) / step;
+    hipLaunchKernelGGL(density_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, tid, mtid, n, n_tiles, step, counts);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

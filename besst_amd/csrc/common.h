@@ -121,6 +121,7 @@ struct ClassifyArgs {
     int32_t detect_dup;
     int32_t extend_paths;
     int32_t no_score;
+    int32_t record_path;   // 0: stream_kernel + ordered_kernel (sparse candidates), 1: fused_kernel (dense)
 };
 
 // ---- sort / reduce geometry -------------------------------------------------------------------------
@@ -198,6 +199,8 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
 // the same split in three phases for the multi-GPU path (the duplicate chain crosses rank boundaries)
 int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
                          void* ws, size_t ws_bytes);
+int launch_candidate_density(hipStream_t s, int64_t n, const int32_t* tid, const int32_t* mtid, int64_t sample_records,
+                             unsigned long long* counts);
 int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes);
 int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry);
 int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* tail, unsigned long long* scratch);

@@ -6,6 +6,7 @@ only lend their ``data_ptr()``.  Used by bench.py, the multi-GPU path and the GP
 ctypes drop-in (CreateGraph.PE) uses the host-buffer layer in device.py instead.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -99,6 +100,9 @@ class DeviceGraphBuilder(object):
         init_small[COUNTER_BYTES:COUNTER_BYTES + 8] = torch.from_numpy(np.array([-1, -1], dtype=np.int32).view(np.uint8))
         self._init = init.to(device)
         self._args = {}
+        self._paths = {}
+        self._density = torch.zeros(2, dtype=torch.int64, device=device)
+        self.candidate_share = None
 
     # device addresses inside the small block
     def _small(self, off):
@@ -127,7 +131,27 @@ class DeviceGraphBuilder(object):
         """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
         self.state.copy_(self._init)
 
+    def record_path(self, rec):
+        """Which form of the record loop serves this record set (include/besst_amd.h, besst_lib_params.record_path):
+        sampled once per record set with besst_dev_candidate_density (synchronises), BESST_RECORD_PATH overrides."""
+        path = self._paths.get(id(rec))
+        if path is None:
+            forced = os.environ.get('BESST_RECORD_PATH')
+            if forced in ('0', '1'):
+                path = int(forced)
+            else:
+                share, out = C.c_double(0.0), C.c_int32(0)
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                _lib.check(self.lib.besst_dev_candidate_density(C.c_void_p(stream), rec.n, _p(rec.tid), _p(rec.mtid),
+                                                                4 << 20, C.c_void_p(self._density.data_ptr()),
+                                                                C.byref(share), C.byref(out)), 'candidate_density')
+                path = int(out.value)
+                self.candidate_share = float(share.value)
+            self._paths[id(rec)] = path
+        return path
+
     def classify(self, rec):
+        self.params.record_path = self.record_path(rec)
         # argument lists are marshalled once per record set (every buffer is allocated once)
         args = self._args.get(id(rec))
         if args is None:

@@ -62,7 +62,10 @@ typedef struct besst_lib_params {
     int32_t detect_duplicate;  /* param.detect_duplicate (-d, default on)                            */
     int32_t extend_paths;      /* param.extend_paths (-y, default on)                                */
     int32_t no_score;          /* param.no_score (--no_score)                                        */
-    int32_t reserved;
+    int32_t record_path;       /* which form of the record loop runs (results are identical): 0 = two passes, the
+                                * second over the tid != mtid records only (paired-end libraries: ~1 % of the
+                                * records); 1 = one fused pass (mate-pair libraries: ~20 %); pick it from
+                                * besst_dev_candidate_density() - the besst_ctx_* layer does that itself          */
 } besst_lib_params;
 
 /* Tallies of the record loop: Parameter.counters (Parameter.py:113-124) plus the fishy-read count
@@ -252,9 +255,18 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                        uint32_t* n_out, besst_counters* counters, void* workspace,
                        size_t workspace_bytes);
 
+/* Share of the records whose mate lies on another contig (tid != mtid) - the only records the record loop does more
+ * than add coverage for (CreateGraph.py:141-206) - counted over evenly spaced 1024-record tiles covering about
+ * `sample_records` records; SYNCHRONISES the stream.  *record_path = the besst_lib_params.record_path to use
+ * (1 from BESST_DENSE_CANDIDATE_SHARE on).  counts_scratch: 16 bytes of device memory. */
+#define BESST_DENSE_CANDIDATE_SHARE 0.05
+int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                                int64_t sample_records, void* counts_scratch, double* h_share,
+                                int32_t* h_record_path);
+
 /* Stage 2: sort of the tuples by (key, position in the stream) - observably a stable sort by key - and segmented
- * reduction into edge rows (up to 4 M tuples: one MSD partition + per-bucket sort and reduction; beyond: LSD radix
- * passes + tile-based reduction).
+ * reduction into edge rows (up to 4 M tuples: one MSD partition + per-bucket sort and reduction; beyond, up to 2^30:
+ * chained-scan radix passes + atomic-free tile reduction).
  *   n_tuples  uint32 device: number of valid tuples in keys/payload (<= capacity)
  *   key_bits  number of significant key bits (2 * node_bits + 1)
  * Outputs (capacity entries each): row_* arrays, obs_lo/obs_hi grouped by row, n_rows (uint32). */

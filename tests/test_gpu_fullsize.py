@@ -10,6 +10,13 @@ from besst_amd import workload
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['two_pass', 'fused'])
+def record_path(request, monkeypatch):
+    """Every scenario runs through both forms of the record loop (besst_lib_params.record_path): stream_kernel +
+    ordered_kernel, and fused_kernel."""
+    monkeypatch.setenv('BESST_RECORD_PATH', '0' if request.param == 'two_pass' else '1')
+
+
 def assert_table_equals_c_oracle(table, aligned, ctr, batch, wl):
     keys, payload, c_aligned, c_ctr = CO.record_loop(batch, wl['table'], wl['lib'], wl['node_bits'])
     rows = CO.edge_rows(keys, payload)

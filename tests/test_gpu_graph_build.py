@@ -11,6 +11,13 @@ from tests.test_oracle_golden import oracle_state_from_layout
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['two_pass', 'fused'])
+def record_path(request, monkeypatch):
+    """Every scenario runs through both forms of the record loop (besst_lib_params.record_path): stream_kernel +
+    ordered_kernel, and fused_kernel."""
+    monkeypatch.setenv('BESST_RECORD_PATH', '0' if request.param == 'two_pass' else '1')
+
+
 def _oracle_inputs(doc, batch):
     p = O.LibParams(**doc['overrides'])
     rec = GU.rec_lists(batch)

@@ -8,8 +8,13 @@ from tests import gpu_util as DU
 pytestmark = pytest.mark.gpu
 
 
-def test_dev_layer_matches_oracle():
+@pytest.mark.parametrize('path', ['0', '1', None])
+def test_dev_layer_matches_oracle(path, monkeypatch):
     import torch
+    if path is None:
+        monkeypatch.delenv('BESST_RECORD_PATH', raising=False)
+    else:
+        monkeypatch.setenv('BESST_RECORD_PATH', path)
     from besst_amd import pipeline, workload
     wl = workload.make('C2', 0, pairs=300000, nc=1500)
     batch, table, lib = wl['batch'], wl['table'], wl['lib']
@@ -27,6 +32,24 @@ def test_dev_layer_matches_oracle():
     torch.cuda.synchronize()
     edges = gb.fetch_table()
     DU.assert_matches_oracle(edges, gb.aligned.cpu().numpy(), gb.read_counters(), loop, wl['asm'].nc)
+    if path is None:
+        assert gb.params.record_path == (1 if gb.candidate_share >= 0.05 else 0)
+
+
+def test_record_path_follows_candidate_density(monkeypatch):
+    """Sampled share of tid != mtid records: a paired-end library on long contigs stays on the two-pass form, a
+    mate-pair library goes to the fused pass."""
+    import torch
+    from besst_amd import pipeline, workload
+    monkeypatch.delenv('BESST_RECORD_PATH', raising=False)
+    dev = torch.device('cuda', 0)
+    for config, want in (('C2', 0), ('C3', 1)):
+        wl = workload.make(config, 0, pairs=200000, nc=400 if config == 'C2' else 300)
+        rec = pipeline.DeviceRecords(wl['batch'], dev)
+        gb = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, rec.n)
+        assert gb.record_path(rec) == want, (config, gb.candidate_share)
+        share = float((wl['batch'].tid != wl['batch'].mtid).mean())
+        assert abs(gb.candidate_share - share) < 0.02
 
 
 @pytest.mark.parametrize('n,key_bits,hub', [(50_000, 31, 20_000), (3_000, 9, 0), (200_000, 41, 700), (1, 31, 0),
