@@ -377,6 +377,7 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     a.n_contigs = (int32_t)n_contigs;
     a.node_bits = node_bits;
     a.read_len = p->read_len;
+    a.read_len_int = (p->read_len >= 0.0 && p->read_len < 2147483648.0 && p->read_len == floor(p->read_len)) ? (int64_t)p->read_len : -1;
     a.ins_size_threshold = p->ins_size_threshold;
     a.min_mapq = p->min_mapq;
     a.rf = p->orientation;

@@ -551,17 +551,18 @@ __global__ __launch_bounds__(kOrdThreads, BESST_ORD_MIN_BLOCKS) void ordered_ker
 //   all waves  coalesced loads of the seven columns; tid == mtid records only add coverage (a running (contig, sum)
 //              per wave, flushed with one atomic when the contig changes);
 //              candidates are compacted, in stream order, into LDS (ballot prefix; five words per record)
-//   all waves  thread j evaluates candidate j: two contig rows (L2), PosDirCalculator, link dispatch -> the same
-//              16-byte entry ordered_kernel builds, written over the candidate's record
-//   wave 0     Chain::step over the entries, 64 at a time (duplicate chain, acceptance, counters, ordered
-//              emission into the block's segment) - the very code of the two-pass path
+//   all waves  thread j evaluates candidate j: two contig rows (L2), PosDirCalculator, link dispatch, then the
+//              order-dependent part (duplicate chain, acceptance, counters, ordered emission into the block's
+//              segment) for all 256 candidates of the round at once - ballots inside a wave, the waves' tails and
+//              counts through LDS; a single wave walking the entries 64 at a time, as ordered_kernel does, was the
+//              critical path of every sub-tile here
 // and publishes the same block summary, so stitch_kernel / compact_kernel and the sharded build's head / tail logic
 // are shared by both paths.  besst_lib_params.record_path selects the path (the host samples the candidate density).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFusedThreads = 256;
 constexpr int kFusedSub = kFusedThreads * 4;              // records per sub-tile
 #ifndef BESST_FUSED_MIN_WAVES
-#define BESST_FUSED_MIN_WAVES 4
+#define BESST_FUSED_MIN_WAVES 5
 #endif
 
 __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_kernel(
@@ -572,10 +573,18 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     __shared__ uint32_t s_buf[5][kFusedSub];
     __shared__ uint32_t s_qlen[kFusedSub / 2];            // 16 bits per candidate
     __shared__ int s_wcnt[4];
+    __shared__ int32_t s_tail[4][4];                      // per wave: {has, obs1, obs2} of its last reaching record
+    __shared__ int s_ecnt[4];                             // per wave: tuples emitted this round
+    // running state of the block, double buffered by round: {prev known, prev obs1, prev obs2, emit base, any reach}
+    __shared__ int32_t s_state[2][8];
+    __shared__ int32_t s_head[8];                         // the block's first reaching record {present, obs1, obs2, info, slot}
+    __shared__ int s_red[4][7];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    Chain chain;                                            // wave 0 only
+    if (t < 8) { s_state[0][t] = 0; s_state[1][t] = 0; s_head[t] = 0; }   // visible after the first sub-tile's barriers
+    int round = 0;
+    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
     int32_t run_tid = -1;                                   // the wave's running coverage (uniform)
     int run_sum = 0;
     for (int st = 0; st < kClsTile / kFusedSub; ++st) {
@@ -677,7 +686,11 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
             }
         }
         __syncthreads();
-        // ---- evaluation: thread j takes candidate j (one round unless more than a quarter of the records are candidates)
+        // ---- evaluation + the order-dependent part, thread j on candidate j (one round unless more than a quarter
+        // of the records are candidates).  The chain (Chain::step's semantics, CreateGraph.py:835-870) runs over all
+        // four waves at once: "previous record that reached CreateEdge" = nearest reaching lane below (ballot), else
+        // the tail of the nearest earlier wave that has one, else the block's running state; emission slots by
+        // ballot prefix + the waves' counts.  Two barriers per round, no serial wave.
         for (int c0 = 0; c0 < total; c0 += kFusedThreads) {
             const int j = c0 + t;
             const bool live = j < total;
@@ -697,29 +710,115 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
                 c2 = a.table[mtid];
             }
             const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
-            const uint4 ent = pack_entry(e);
-            if (live) {                                      // the entry replaces the record it was made from
-                s_buf[0][j] = ent.x; s_buf[1][j] = ent.y; s_buf[2][j] = ent.z; s_buf[3][j] = ent.w;
-            }
             if (c0 + wave * 64 < total)                      // uniform per wave: the candidates' own coverage
                 wave_add_runs(aligned, live ? tid : -1, (live && (e.bits & EV_COV)) ? (int)qlen : 0, lane);
-        }
-        __syncthreads();
-        // ---- the order-dependent part, wave 0 over the sub-tile's entries in stream order
-        if (wave == 0) {
-            for (int q0 = 0; q0 < total; q0 += 64) {
-                const int j = q0 + lane;
-                uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-                if (j < total) ent = make_uint4(s_buf[0][j], s_buf[1][j], s_buf[2][j], s_buf[3][j]);
-                chain.step(a, ent, j < total, lane, seg_keys, seg_payload, block_base);
+            const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
+            const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
+            const bool dbl = (e.bits & EV_DOUBLE) != 0;
+            c_nonuniq += (live && (e.bits & EV_NONUNIQ)) ? 1 : 0;
+            c_fishy += fishy ? 1 : 0;
+            c_reach += reach ? 1 : 0;
+            const int32_t o1 = e.o1, o2 = e.o2;
+            const unsigned long long has_mask = __ballot(reach);
+            const unsigned long long below = has_mask & lt_mask;
+            bool pk = below != 0ull;
+            int32_t p1, p2;
+            {
+                const int src = below ? 63 - __clzll((long long)below) : 0;
+                p1 = __shfl(o1, src, 64);
+                p2 = __shfl(o2, src, 64);
             }
+            if (has_mask) {
+                if (lane == 63 - __clzll((long long)has_mask)) { s_tail[wave][0] = 1; s_tail[wave][1] = o1; s_tail[wave][2] = o2; }
+            } else if (lane == 0) {
+                s_tail[wave][0] = 0;
+            }
+            const int par = round & 1;
+            __syncthreads();                                 // A: the waves' tails; the state left by the round before
+            if (reach && !pk) {
+                pk = s_state[par][0] != 0; p1 = s_state[par][1]; p2 = s_state[par][2];
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    if (w < wave && s_tail[w][0]) { pk = true; p1 = s_tail[w][1]; p2 = s_tail[w][2]; }
+            }
+            // thread 0 also works out what the next round starts from; the tails must be read on this side of barrier B
+            // (a fast wave may already write the next round's tail behind it)
+            int nx_known = 0, nx_q1 = 0, nx_q2 = 0, nx_has = 0;
+            if (t == 0) {
+                nx_known = s_state[par][0]; nx_q1 = s_state[par][1]; nx_q2 = s_state[par][2]; nx_has = s_state[par][4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (s_tail[w][0]) { nx_known = 1; nx_has = 1; nx_q1 = s_tail[w][1]; nx_q2 = s_tail[w][2]; }
+            }
+            const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+            bool emit = fishy, is_head = false;
+            if (reach) {
+                if (!pk) {
+                    is_head = true;                          // first reaching record of the workgroup: stitch_kernel's
+                    emit = accept;
+                } else {
+                    const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
+                    c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                    emit = d.keep;
+                }
+            }
+            const unsigned long long emit_mask = __ballot(emit);
+            if (lane == 0) s_ecnt[wave] = __popcll(emit_mask);
+            __syncthreads();                                 // B: the waves' emission counts
+            int slot = s_state[par][3] + __popcll(emit_mask & lt_mask);
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+                if (w < wave) slot += s_ecnt[w];
+            if (emit) {
+                const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
+                const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+                const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
+                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+                seg_keys[block_base + slot] = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+                seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+            }
+            if (is_head) {                                   // at most one thread of the whole block, once
+                s_head[0] = 1; s_head[1] = o1; s_head[2] = o2;
+                s_head[3] = (int32_t)((accept ? 9u : 0u) | (dbl ? 2u : 0u) | (mapq0 ? 4u : 0u));
+                s_head[4] = accept ? slot : (int32_t)kNoSlot;
+            }
+            if (t == 0) {                                    // the state the next round starts from (other buffer)
+                int eb = s_state[par][3];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) eb += s_ecnt[w];
+                s_state[par ^ 1][0] = nx_known; s_state[par ^ 1][1] = nx_q1; s_state[par ^ 1][2] = nx_q2;
+                s_state[par ^ 1][3] = eb; s_state[par ^ 1][4] = nx_has;
+            }
+            ++round;
         }
-        // (the barrier at the top of the next sub-tile keeps the other waves off the entries until wave 0 is done)
     }
     if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
         atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+    // ---- block summary (same planes as ordered_kernel's Chain::publish)
+    {
+        const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
+#pragma unroll
+        for (int f = 0; f < 7; ++f) {
+            const int v = wave_sum(vals[f]);
+            if (lane == 0) s_red[wave][f] = v;
+        }
+    }
+    __syncthreads();
     if (wave != 0) return;
-    chain.publish(summ, blockIdx.x, lane);
+    const int par = round & 1;
+    uint32_t v = 0;
+    if (lane == kSumEmit) v = (uint32_t)s_state[par][3];
+    if (lane == kSumHas) v = s_state[par][4] ? 1u : 0u;
+    if (lane == kSumFirst1) v = s_head[0] ? (uint32_t)s_head[1] : 0u;
+    if (lane == kSumFirst2) v = s_head[0] ? (uint32_t)s_head[2] : 0u;
+    if (lane == kSumLast1) v = (uint32_t)s_state[par][1];
+    if (lane == kSumLast2) v = (uint32_t)s_state[par][2];
+    if (lane == kSumHeadInfo) v = s_head[0] ? (uint32_t)s_head[3] : 0u;
+    if (lane == kSumHeadSlot) v = s_head[0] ? (uint32_t)s_head[4] : kNoSlot;
+    if (lane >= kSumCtr0 && lane < kSumCtr0 + 7)
+        v = (uint32_t)(s_red[0][lane - kSumCtr0] + s_red[1][lane - kSumCtr0] + s_red[2][lane - kSumCtr0] + s_red[3][lane - kSumCtr0]);
+    if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
 }
 
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------

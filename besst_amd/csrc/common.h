@@ -116,6 +116,7 @@ struct ClassifyArgs {
     int32_t node_bits;
     double read_len;
     double ins_size_threshold;
+    int64_t read_len_int;  // read_len when it is a whole number in [0, 2^31), else -1 (integer form of PosDirCalculator)
     int32_t min_mapq;
     int32_t rf;            // orientation == 'rf'
     int32_t detect_dup;
