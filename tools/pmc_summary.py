@@ -1,9 +1,30 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection CSVs) into profiles/*.json.
 
-usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <records_per_launch> <out.json>
+usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <config> <records> <steps_in_run> <out.json>   (steps_in_run: informative)
+
+Per kernel: mean KB per dispatch of each counter and dispatches per step; step_traffic_bytes = sum over the kernels of a
+graph-build step of (2 * FETCH_SIZE + WRITE_SIZE) * 1024 * dispatches per step.  The factor 2 is the gfx950 correction
+of MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of the bytes of a wide coalesced streaming read; narrow /
+gathered reads and WRITE_SIZE are uncalibrated there, so the figure is an upper estimate for the gather-heavy kernels.
+bench.py attaches it to roofline.traffic only when source_hash and records match the run.
 """
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel', 'radix_hist_kernel',
+                'radix_rowscan_kernel', 'radix_scatter_kernel', 'bucket_sort_kernel', 'bucket_reduce_kernel',
+                'row_heads_kernel', 'row_scan_kernel', 'row_reduce_kernel', 'os_hist_kernel', 'os_offsets_kernel',
+                'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel')
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, 'besst_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(REPO, 'besst_amd', 'csrc', '*.h'))):
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def collect(d, counter):
@@ -15,33 +36,36 @@ def collect(d, counter):
                     continue
                 name = row['Kernel_Name'].replace('besst::(anonymous namespace)::', '')
                 name = re.sub(r'^void ', '', name)
-                name = re.sub(r'\(.*$', '', name).strip()
+                name = re.sub(r'[<(].*$', '', name).strip()
                 acc[name].append(float(row['Counter_Value']))
     return acc
 
 
 def main():
-    fetch_dir, write_dir, n_rec, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fetch_dir, write_dir, config, n_rec, steps, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     f, w = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
-    kernels = {}
+    kernels, total = {}, 0.0
     for k in sorted(set(f) | set(w)):
-        if not any(t in k for t in ('_kernel',)):
+        if k not in STEP_KERNELS:
             continue
-        kernels[k] = {'FETCH_SIZE_KB_mean': round(sum(f[k]) / max(1, len(f[k])), 1), 'FETCH_SIZE_launches': len(f[k]),
-                      'WRITE_SIZE_KB_mean': round(sum(w[k]) / max(1, len(w[k])), 1), 'WRITE_SIZE_launches': len(w[k])}
-    doc = {'_about': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py '
-                     '--steps 5 --warmup 1 --no-stages --no-cpu-baseline --no-verify --breakdown-steps 0 --in-flight 0` on C2; '
-                     'counter units are KB per dispatch. MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of '
-                     'the bytes of a wide coalesced streaming read, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 for '
-                     'stream_kernel; WRITE_SIZE and narrow/gather reads are uncalibrated. Summarised by tools/pmc_summary.py.',
-           'kernels': kernels}
-    sk = kernels.get('stream_kernel')
-    if sk:
-        doc['stream_kernel_traffic_bytes_per_launch'] = int((2 * sk['FETCH_SIZE_KB_mean'] + sk['WRITE_SIZE_KB_mean']) * 1024)
-        doc['stream_kernel_algorithmic_bytes_per_launch'] = n_rec * 11
+        fm = sum(f[k]) / max(1, len(f[k]))
+        wm = sum(w[k]) / max(1, len(w[k]))
+        # dispatches per step: relative to a kernel that runs exactly once per record loop / once per sort
+        classify = k in ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel')
+        anchor = 'stitch_kernel' if classify else ('os_hist_kernel' if 'os_hist_kernel' in f else 'radix_hist_kernel')
+        per_step = len(f[k]) / float(max(1, len(f.get(anchor, []))))
+        kernels[k] = {'FETCH_SIZE_KB_mean': round(fm, 1), 'WRITE_SIZE_KB_mean': round(wm, 1),
+                      'dispatches_per_step': round(per_step, 2),
+                      'traffic_bytes_per_step': int((2 * fm + wm) * 1024 * per_step)}
+        total += (2 * fm + wm) * 1024 * per_step
+    doc = {'_about': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of bench.py on %s; '
+                     'KB per dispatch; traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction on FETCH_SIZE, '
+                     'MI355X_MICROARCH.md HBM section; gathered reads and WRITE_SIZE uncalibrated). tools/pmc_summary.py.' % config,
+           'config': config, 'records': n_rec, 'steps_in_run': steps, 'source_hash': source_hash(),
+           'step_traffic_bytes': int(total), 'kernels': kernels}
     with open(out, 'w') as fh:
         json.dump(doc, fh, indent=1)
-    print(json.dumps(doc.get('kernels', {}).get('stream_kernel')), doc.get('stream_kernel_traffic_bytes_per_launch'))
+    print(json.dumps({k: v['traffic_bytes_per_step'] for k, v in kernels.items()}), int(total))
 
 
 if __name__ == '__main__':
