@@ -92,11 +92,15 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
         print('Number of duplicated reads indicated and removed: ', counter.nr_of_duplicates, file=Information)
 
     # ---- coverage (CreateGraph.py:237-246) -----------------------------------------------------------------
+    # a contig that is not in THIS library's BAM header has no aligned bases: the reference starts every contig's
+    # counter at 0 (CreateGraph.py:89-95), so its coverage is 0 there too
     aligned = aligned.tolist()
     for name, cont in Contigs.items():
-        cont.coverage = aligned[tid_of[name]] / float(cont.length)
+        tid = tid_of.get(name)
+        cont.coverage = (aligned[tid] if tid is not None else 0) / float(cont.length)
     for name, cont in small_contigs.items():
-        cont.coverage = aligned[tid_of[name]] / float(cont.length)
+        tid = tid_of.get(name)
+        cont.coverage = (aligned[tid] if tid is not None else 0) / float(cont.length)
 
     if param.first_lib and param.lower_cov_cutoff:
         filter_low_coverage_contigs(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information)

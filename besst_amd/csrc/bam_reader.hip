@@ -411,7 +411,7 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
         const auto tw1 = std::chrono::steady_clock::now();
         const size_t m = b->rec_off.size();
         const size_t n_tasks = m < 4096 ? 1 : (size_t)b->pool->size() * 4;
-        std::atomic<bool> corrupt(false);
+        std::atomic<bool> corrupt(false), too_long(false);
         const uint8_t* base = b->inflated.data();
         const size_t* offs = b->rec_off.data();
         b->pool->parallel_for(n_tasks, [&](size_t task, int) {
@@ -432,20 +432,47 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
                 tlen[o] = (int32_t)le32(r + 28);
                 if (32 + l_read_name + 4ull * n_cigar > block_size) { corrupt = true; return; }
                 const uint8_t* cg = r + 32 + l_read_name;
-                int64_t q_aln = 0, ref_len = 0;
+                // pysam 0.8.4's AlignedRead properties, which is what the reference reads (CreateGraph.py:138 qlen;
+                // libmetrics.py:258-262 rlen / alen):
+                //   qlen = query_alignment_length = qend - qstart, qstart = the leading soft clips (hard clips in front
+                //          of them skipped), qend = l_seq - or, for a record without sequence, the M/I/S/=/X total of
+                //          the CIGAR - minus the trailing soft clips.  A record WITHOUT a CIGAR (BWA's unmapped read
+                //          placed at its mate) therefore has qlen = l_seq, and the reference does add it to the
+                //          coverage of the contig it is placed on (mapq 0 passes the test of CreateGraph.py:138-139).
+                //   alen = reference_length = the M/D/N/=/X total (None -> 0 without a CIGAR)
+                // The CG:B,I long-CIGAR convention postdates that pysam: the placeholder <l_seq>S<n>N is read as it stands.
+                int64_t q_total = 0, ref_len = 0, lead = 0, trail = 0;
+                bool in_lead = true;
                 for (uint32_t c = 0; c < n_cigar; ++c) {
                     const uint32_t v = le32(cg + 4 * c);
                     const uint32_t op = v & 15u, len = v >> 4;
                     // M=0 I=1 D=2 N=3 S=4 H=5 P=6 '='=7 X=8
-                    if (op == 0 || op == 1 || op == 7 || op == 8) q_aln += len;
+                    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q_total += len;
                     if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += len;
+                    if (in_lead) {
+                        if (op == 4) lead += len;
+                        else if (op != 5) in_lead = false;
+                    }
                 }
-                qlen[o] = (uint16_t)(q_aln > 65535 ? 65535 : q_aln);
+                for (uint32_t c = n_cigar; c-- > 0;) {
+                    const uint32_t v = le32(cg + 4 * c);
+                    const uint32_t op = v & 15u, len = v >> 4;
+                    if (op == 4) trail += len;
+                    else if (op != 5) break;
+                }
+                int64_t q_aln = (l_seq ? (int64_t)l_seq : q_total) - lead - trail;
+                if (q_aln < 0) q_aln = 0;                    // a CIGAR of clips only: pysam gives a negative length
+                if (q_aln > 65535) { too_long = true; return; }   // the qlen column is 16 bits wide, like RecordBatch's
+                qlen[o] = (uint16_t)q_aln;
                 rlen[o] = (int32_t)l_seq;
                 alen[o] = (int32_t)ref_len;
             }
         });
         if (corrupt.load()) { besst::set_error("bam_read_records: corrupt record"); return -BESST_ERR_ARG; }
+        if (too_long.load()) {
+            besst::set_error("bam_read_records: an aligned query longer than 65535 bases does not fit the 16-bit qlen column");
+            return -BESST_ERR_ARG;
+        }
         b->cursor = cur;
         n += (int64_t)m;
         const auto tw2 = std::chrono::steady_clock::now();

@@ -11,6 +11,9 @@ from . import device
 from .records import RecordBatch
 
 _sessions = weakref.WeakKeyDictionary()
+# bam_file objects that cannot be weakly referenced or hashed (some pysam handles): keyed by id(); such a session lives
+# until close_session(bam_file) is called (the CLI does so after CreateGraph.PE)
+_sessions_by_id = {}
 
 
 class Session(object):
@@ -36,6 +39,10 @@ def open_session(bam_file, device_index=0):
         sess = _sessions.get(bam_file)
     except TypeError:
         sess = None
+    if sess is None:
+        entry = _sessions_by_id.get(id(bam_file))
+        if entry is not None and entry[0] is bam_file:
+            sess = entry[1]
     if sess is not None:
         return sess
     batch = RecordBatch.from_pysam_like(bam_file)
@@ -43,11 +50,17 @@ def open_session(bam_file, device_index=0):
     try:
         _sessions[bam_file] = sess
     except TypeError:
-        pass
+        _sessions_by_id[id(bam_file)] = (bam_file, sess)      # the strong reference keeps id() from being reused
     return sess
 
 
 def close_session(bam_file):
-    sess = _sessions.pop(bam_file, None)
+    try:
+        sess = _sessions.pop(bam_file, None)
+    except TypeError:
+        sess = None
+    if sess is None:
+        entry = _sessions_by_id.pop(id(bam_file), None)
+        sess = entry[1] if entry is not None and entry[0] is bam_file else None
     if sess is not None:
         sess.close()

@@ -73,3 +73,34 @@ def test_device_equals_c_oracle(config, pairs, nc):
         hist, overflow = ctx.value_histogram(c_isize, 2048)
         want = np.bincount(np.minimum(c_isize, 2048), minlength=2049)
         assert hist.tolist() == want[:2048].tolist() and overflow == int(want[2048])
+
+
+def test_split_distribution_from_device_histogram():
+    """Row a7 end to end on the device side: the count-per-value histogram of every reference-captured sample
+    (tests/golden/unit_golden.json 'split', produced by BESST/find_bimodality.py:39-205 itself) is built by
+    value_hist_kernel, fed to split_from_histogram, and must give the reference's clusters and moments exactly."""
+    import json
+    import os
+    from besst_amd import device, find_bimodality
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unit_golden.json')) as fh:
+        gold = json.load(fh)['split']
+    assert len(gold) >= 5
+    with device.GraphContext(0) as ctx:
+        for g in gold:
+            vals = np.asarray(g['values'], dtype=np.int64)
+            assert np.all(vals >= 0)
+            n_bins = int(vals.max()) + 1
+            hist, overflow = ctx.value_histogram(vals.astype(np.int32), n_bins)
+            assert int(overflow) == 0 and int(hist.sum()) == len(vals)
+            values = np.nonzero(hist)[0]
+            counts = hist[values]
+            split, m1, s1, m2, s2 = find_bimodality.split_from_histogram(values.tolist(), [int(c) for c in counts])
+            if split < 0:
+                got = ([], [], 0, 0, 0, 0)
+            else:
+                c1 = [int(v) for v, c in zip(values[:split], counts[:split]) for _ in range(int(c))]
+                c2 = [int(v) for v, c in zip(values[split:], counts[split:]) for _ in range(int(c))]
+                got = (c1, c2, m1, s1, m2, s2)
+            assert got[0] == g['cluster1'] and got[1] == g['cluster2']
+            assert (float(got[2]), float(got[3]), float(got[4]), float(got[5])) == \
+                (g['mean1'], g['stddev1'], g['mean2'], g['stddev2'])
