@@ -20,7 +20,7 @@ Two files with the same records:
   handmade_a.bam  header in its own block, a few records per block, a record cut in two by a block boundary, an empty
                   block in the middle, the standard EOF marker
   handmade_b.bam  97 payload bytes per block (the header and nearly every record straddle blocks), NO EOF marker
-Run:  python tests/golden/make_bam_fixture.py   (writes the .bam files and handmade_bam.json next to this script)
+Run:  python tests/golden/bam/make_bam_fixture.py   (writes the .bam files and handmade_bam.json next to this script)
 """
 import json
 import os

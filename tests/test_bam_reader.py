@@ -45,13 +45,13 @@ def test_rejects_non_bam():
 @pytest.mark.parametrize('name', ['handmade_a.bam', 'handmade_b.bam'])
 @pytest.mark.parametrize('threads,chunk', [(1, 8_000_000), (4, 3), (2, 1)])
 def test_hand_assembled_bam(name, threads, chunk):
-    """BAM bytes the reader's author did not write with the reader's own writer: tests/golden/make_bam_fixture.py packs
+    """BAM bytes the reader's author did not write with the reader's own writer: tests/golden/bam/make_bam_fixture.py packs
     header, records and BGZF blocks field by field from the SAM/BAM specification.  Covered: CIGAR I/D/N/S/H/P/=/X, a
     record without CIGAR (qlen = l_seq, as pysam 0.8.4 reports it), records without sequence, the CG:B,I placeholder,
     254-character and 1-character read names, auxiliary fields of several types, a record (and in _b nearly every record
     and the header) straddling BGZF blocks, an empty block in the middle of the file, a missing EOF marker."""
     import json
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bam')
     with open(os.path.join(here, 'handmade_bam.json')) as fh:
         want = json.load(fh)
     got = bamio.read_bam(os.path.join(here, name), threads=threads, chunk_records=chunk)
