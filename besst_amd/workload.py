@@ -72,3 +72,37 @@ def make_device(device, config='C2', lib_index=0, pairs=None, nc=None, seed_offs
     table = first_library_table(asm.lengths, spec.mean + 4 * spec.sd)
     return DeviceWorkload(config=config, asm=asm, cols=cols, table=table, lib=lib, node_bits=node_bits_for(table),
                           pairs=n_pairs, spec=spec)
+
+
+def later_library_table(asm, seed, contig_threshold, max_run=5, first_scaffold_id=1):
+    """Contig table of a library >= 2: the state a previous pass leaves behind (MakeScaffolds.py:362-414) - random runs
+    of 1..max_run adjacent contigs chained into scaffolds with random per-contig direction, cumulative position (+ true
+    gap) and scaffold length - classified by CleanObjects' rule for the new library (CreateGraph.py:788-810:
+    scaffolds shorter than the new contig_threshold become small).  Vectorised form of synth.chain_scaffolds (same
+    model, its own random stream), for the 500 k - 2 M contig configs."""
+    rng = np.random.default_rng(seed)
+    nc = asm.nc
+    runs = rng.integers(1, max_run + 1, nc)                       # more than enough runs
+    ends = np.cumsum(runs)
+    k = int(np.searchsorted(ends, nc, side='left')) + 1
+    runs = runs[:k].copy()
+    runs[-1] -= int(ends[k - 1] - nc)
+    scaf_index = np.repeat(np.arange(k), runs)
+    first = np.concatenate(([0], np.cumsum(runs)[:-1]))           # first contig of every scaffold
+    step = asm.lengths + asm.gaps                                 # contig + the gap behind it
+    excl = np.concatenate(([0], np.cumsum(step)[:-1]))
+    position = excl - excl[first][scaf_index]
+    last = first + runs - 1
+    scaf_len = (position[last] + asm.lengths[last])[scaf_index]
+    direction = rng.random(nc) < 0.5
+    cls = np.where(scaf_len >= contig_threshold, 1, 2)
+    table = dict(scaf_id=(first_scaffold_id + scaf_index).astype(np.int32), scaf_len=scaf_len.astype(np.int32),
+                 ctg_pos=position.astype(np.int32), ctg_len=asm.lengths.astype(np.int32),
+                 direction=direction.astype(np.uint8), cls=cls.astype(np.uint8))
+    return table
+
+
+def library_constants(spec):
+    return dict(read_len=float(spec.read_len), ins_size_threshold=spec.mean + 6 * spec.sd, min_mapq=11,
+                orientation=spec.orientation, detect_duplicate=True, extend_paths=True, no_score=False,
+                mean=spec.mean, sd=spec.sd)
