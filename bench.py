@@ -5,8 +5,8 @@ A step = one pass of the hot path over one resident batch: record loop (classify
 chain, ordered tuple emission, radix sort and edge-table reduction, all enqueued on one HIP stream
 through the besst_dev_* C ABI with the record columns already in HBM.  No host round trip happens
 inside a step.  At N > 1 every rank owns a contiguous slice of the (tid,pos)-sorted stream
-(weak scaling: one C2-sized slice per GPU, all of one assembly) and the result is checked against the
-single-GPU build of the whole stream (sharded_equals_single_gpu); see besst_amd/distributed.py.
+(weak scaling on the C4 shape - 500 k contigs, two libraries, one eighth of each library's pairs per GPU) and every
+rank checks its share against the C oracle (verify_sharded_vs_oracle); see besst_amd/distributed.py.
 
 N = 1 (the default): the workload is BASELINE.json configs[2] (C3: 100 k contigs / 200 M mate pairs with PE
 contamination) at FULL size - the largest single-GPU config - generated on the GPU; configs[1] (C2) is measured
@@ -137,96 +137,6 @@ def verify_full(runner, wl):
           and [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates,
                ctr.reads_with_too_long_insert, ctr.fishy_reads, ctr.n_tuples, ctr.n_reach, ctr.prev_obs1,
                ctr.prev_obs2] == c_ctr.tolist())
-    return bool(ok)
-
-
-def verify_sharded_single_rank(job, wl):
-    """The sharded orchestration over RCCL with ONE rank owns every key: its table must equal the C oracle's."""
-    import numpy as np
-    from oracle import c_oracle as CO
-    b = job.backend
-    table = b.local_table()
-    keys, payload, aligned, c_ctr = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
-    rows = CO.edge_rows(keys, payload)
-    link = ~table.is_fishy
-    return bool(np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
-                and np.array_equal(table.sum_obs[link], rows['sum_obs'][link])
-                and np.array_equal(table.first_idx.astype(np.int64), rows['first_idx'])
-                and np.array_equal(table.obs_lo.astype(np.int64), rows['obs_lo'])
-                and b.aligned.cpu().numpy().tolist() == aligned.tolist()
-                and b.counter_words.cpu().numpy().tolist() == c_ctr[:8].tolist()
-                and job.final_prev_obs() == (int(c_ctr[8]), int(c_ctr[9])))
-
-
-def _make_slice(job):
-    from besst_amd import workload
-    config, pairs, contigs, r = job
-    return workload.make(config, 0, pairs=pairs, nc=contigs, reads_seed_offset=r)['batch']
-
-
-def _other_slices(args, world):
-    """The record slices of ranks 1 .. world-1, regenerated on rank 0 (same seeds): in worker processes when that
-    works (numpy only, spawned so that they never see this process' HIP state), one after the other otherwise."""
-    jobs = [(args.config, args.pairs, args.contigs, r) for r in range(1, world)]
-    try:
-        import multiprocessing as mp
-        from concurrent.futures import ProcessPoolExecutor
-        with ProcessPoolExecutor(max_workers=min(len(jobs), 8), mp_context=mp.get_context('spawn')) as pool:
-            return list(pool.map(_make_slice, jobs))
-    except Exception:                                     # noqa: BLE001 - any pool problem: do it serially
-        return [_make_slice(j) for j in jobs]
-
-
-def verify_sharded_vs_single_gpu(runner, wl, args, rank, world, device):
-    """N > 1: the union of the owners' edge rows must equal what the single-GPU path builds from the whole stream
-    (all slices one after the other) - the product checked against itself, no oracle involved; the single-GPU path
-    is what the N = 1 run of the same bench checks against the C oracle.  Every rank takes part in the gather,
-    rank 0 rebuilds the other slices (same seeds) and runs the single-GPU pass."""
-    import torch
-    import torch.distributed as dist
-    from besst_amd import distributed, workload
-    from besst_amd.records import RecordBatch
-    b = runner.backend
-    t = b.local_table()
-    n_rows = torch.tensor([len(t)], dtype=torch.int64, device=device)
-    distributed._all_reduce(n_rows, None, op=dist.ReduceOp.MAX)
-    cap = int(n_rows.item()) + 1
-    # fixed-size block per rank: [rows, key..., n..., first_idx..., sum_obs...] as int64
-    block = np.zeros(1 + 4 * cap, np.int64)
-    block[0] = len(t)
-    block[1:1 + len(t)] = t.key.view(np.int64)
-    block[1 + cap:1 + cap + len(t)] = t.n
-    block[1 + 2 * cap:1 + 2 * cap + len(t)] = t.first_idx
-    block[1 + 3 * cap:1 + 3 * cap + len(t)] = t.sum_obs
-    mine = torch.from_numpy(block).to(device)
-    everything = torch.empty(world * block.shape[0], dtype=torch.int64, device=device)
-    distributed._all_gather_into(everything, mine, None)
-    if rank != 0:
-        return None
-    got = everything.cpu().numpy().reshape(world, -1)
-    parts = []
-    for r in range(world):
-        k = int(got[r, 0])
-        parts.append((got[r, 1:1 + k].view(np.uint64), got[r, 1 + cap:1 + cap + k], got[r, 1 + 2 * cap:1 + 2 * cap + k],
-                      got[r, 1 + 3 * cap:1 + 3 * cap + k]))
-    key = np.concatenate([p[0] for p in parts])
-    order = np.argsort(key, kind='stable')
-    batches = [wl['batch']] + _other_slices(args, world)
-    whole = dict(wl)
-    whole['batch'] = RecordBatch.concatenate(batches)
-    single = SingleGpu(device, whole, 1)
-    single.step()
-    ref = single.gb.fetch_table()
-    link = ~ref.is_fishy
-    ok = (np.array_equal(key[order], ref.key)
-          and np.array_equal(np.concatenate([p[1] for p in parts])[order], ref.n.astype(np.int64))
-          and np.array_equal(np.concatenate([p[2] for p in parts])[order], ref.first_idx.astype(np.int64))
-          and np.array_equal(np.concatenate([p[3] for p in parts])[order][link], ref.sum_obs[link])
-          and b.aligned.cpu().numpy().tolist() == single.gb.aligned.cpu().numpy().tolist())
-    ctr = single.gb.read_counters()
-    ok = ok and b.counter_words.cpu().numpy().tolist() == [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf,
-                                                            ctr.nr_of_duplicates, ctr.reads_with_too_long_insert,
-                                                            ctr.fishy_reads, ctr.n_tuples, ctr.n_reach]
     return bool(ok)
 
 
@@ -643,111 +553,201 @@ def main():
         if args.config is None:
             args.config = 'C3'
         return main_single(args, device, result_fd)
-    if args.config is None:
-        args.config = 'C2'
-    if args.copies is None:
-        args.copies = 1
-    if world > 1 or force_dist:
-        if 'MASTER_ADDR' not in os.environ:
-            os.environ['MASTER_ADDR'] = '127.0.0.1'
-            os.environ.setdefault('MASTER_PORT', '29531')
-        if backend == 'gloo':
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    return main_sharded(args, device, rank, world, backend, force_dist, result_fd)
+
+
+def owner_checksums(keys, payload, owners, world):
+    """[world, 4] order-independent summaries (count, sum key, sum payload, sum of a mix) of a tuple multiset per owner,
+    in wrapping 64-bit arithmetic - numpy or torch tensors alike."""
+    import torch
+    k = torch.as_tensor(keys.view(np.int64) if isinstance(keys, np.ndarray) else keys)
+    p = torch.as_tensor(payload.view(np.int64) if isinstance(payload, np.ndarray) else payload)
+    o = torch.as_tensor(owners).to(torch.int64)
+    mix = k ^ (p * -7046029254386353131)                     # 0x9E3779B97F4A7C15 as a signed 64-bit constant
+    out = torch.zeros(world, 4, dtype=torch.int64, device=k.device)
+    out[:, 0].index_add_(0, o, torch.ones_like(k))
+    out[:, 1].index_add_(0, o, k)
+    out[:, 2].index_add_(0, o, p)
+    out[:, 3].index_add_(0, o, mix)
+    return out
+
+
+def verify_sharded_vs_oracle(job, wl, rank, world, device, backend_name):
+    """N >= 1, any size: every rank checks ITS share against the C oracle, nothing is rebuilt on one rank.
+      * the oracle's record loop runs on the rank's own slice (host), with the duplicate chain's carry-in taken from
+        the tails of the slices before it (all-gather of three words);
+      * its tuples are split by key owner and summarised per owner (count + three wrapping sums); the summaries are
+        summed over the ranks, and each owner compares its line with the same summary of the tuples it RECEIVED;
+      * the owner's edge table must equal the oracle's aggregation of those received tuples (keys, link counts, sums,
+        per-link observations in arrival order, first-occurrence index);
+      * coverage and counters: sums of the oracles' per-slice values against the all-reduced device values."""
+    import torch
+    import torch.distributed as dist
+    from besst_amd import distributed
+    from oracle import c_oracle as CO
+    b = job.backend
+    cpu = torch.device('cpu')
+    coll_dev = cpu if backend_name == 'gloo' else device
+    threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    batch, table, lib, nb = wl['batch'], wl['table'], wl['lib'], wl['node_bits']
+    keys, payload, aligned, ctr = CO.record_loop(batch, table, lib, nb, threads=threads)
+    tails = torch.zeros(world, 3, dtype=torch.int64, device=coll_dev)
+    tails[rank] = torch.tensor([1 if ctr[7] > 0 else 0, int(ctr[8]), int(ctr[9])], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(tails)
+    prev = (-1, -1)
+    for j in range(rank):
+        if int(tails[j, 0]):
+            prev = (int(tails[j, 1]), int(tails[j, 2]))
+    if prev != (-1, -1):
+        keys, payload, aligned, ctr = CO.record_loop(batch, table, lib, nb, prev=prev, threads=threads)
+    scaf = (keys >> np.uint64(2 + nb)).astype(np.uint64)
+    owners = ((((scaf * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(15)) % np.uint64(world)).astype(np.int64)
+    want = owner_checksums(keys, payload, owners, world).to(coll_dev)
+    sums = torch.cat([torch.from_numpy(aligned.astype(np.int64)), torch.from_numpy(ctr[:8].astype(np.int64))]).to(coll_dev)
+    if world > 1:
+        dist.all_reduce(want)
+        dist.all_reduce(sums)
+    n_recv, n_rows = b.sizes()
+    rk, rp = b.rkeys[:n_recv], b.rpayload[:n_recv]
+    got = owner_checksums(rk, rp, torch.full((n_recv,), rank, dtype=torch.int64, device=device), world)[rank].cpu()
+    ok_exchange = bool(torch.equal(got, want[rank].cpu()))
+    table_d = b.local_table()
+    hk, hp = rk.cpu().numpy().view(np.uint64), rp.cpu().numpy().view(np.uint64)
+    rows = CO.edge_rows(hk, hp)
+    gidx = b.gidx[:n_recv].cpu().numpy().view(np.uint32).astype(np.int64)
+    link = ~table_d.is_fishy
+    ok_rows = bool(np.array_equal(table_d.key, rows['key']) and np.array_equal(table_d.n.astype(np.int64), rows['n'])
+                   and np.array_equal(table_d.sum_obs[link], rows['sum_obs'][link])
+                   and np.array_equal(table_d.sum_obs_sq[link], rows['sum_obs_sq'][link])
+                   and np.array_equal(table_d.obs_lo.astype(np.int64), rows['obs_lo'])
+                   and np.array_equal(table_d.obs_hi.astype(np.int64), rows['obs_hi'])
+                   and np.array_equal(table_d.first_idx.astype(np.int64), gidx[rows['first_idx']] if n_recv else rows['first_idx']))
+    dev_sums = torch.cat([b.aligned.cpu(), b.counter_words.cpu()[:8]])
+    ok_sums = bool(torch.equal(dev_sums, sums.cpu()))
+    last = (-1, -1)
+    for j in range(world):
+        if int(tails[j, 0]):
+            last = (int(tails[j, 1]), int(tails[j, 2]))
+    ok_prev = job.final_prev_obs() == last
+    flags = torch.tensor([int(ok_exchange), int(ok_rows), int(ok_sums), int(ok_prev)], dtype=torch.int64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    return {'tuples_received_match_oracle_per_owner': bool(flags[0]), 'owner_edge_tables_match_oracle': bool(flags[1]),
+            'coverage_and_counters_match_oracle': bool(flags[2]), 'final_prev_obs_matches': bool(flags[3])}
+
+
+def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd):
+    """N > 1 (or one rank forced through the sharded orchestration): BASELINE.json configs[3] (C4) shaped weak scaling -
+    ONE assembly of 500 k contigs, TWO libraries (PE 500 bp on the first-library contig table, then MP 5 kb with PE
+    contamination on the table a previous pass leaves behind); every rank holds one eighth of each library's pairs
+    (62.5 M pairs per library and GPU: the full config on eight GPUs), as a contiguous slice of the rank-ordered stream.
+    A step = both library passes, each: per-record pass on the slice -> one all-to-all by key owner -> per-owner sort and
+    reduction."""
+    import torch
+    import torch.distributed as dist
+    from besst_amd import _lib, distributed, pipeline, synth, workload
+    if 'MASTER_ADDR' not in os.environ:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ.setdefault('MASTER_PORT', '29531')
+    if backend_name == 'gloo':
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
-
-    # ---- workload: one C2-sized slice per rank (weak scaling) -------------------------------------------
-    # one assembly, one library; rank r holds the r-th slice of its stream (independent reads per slice)
-    wl = workload.make(args.config, 0, pairs=args.pairs, nc=args.contigs, reads_seed_offset=rank)
-    batch, table, lib = wl['batch'], wl['table'], wl['lib']
-    n_rec = len(batch)
-    pairs = n_rec // 2
-
-    from besst_amd import distributed
-    # BESST_PAIR_CAPACITY: start from a given (too small) exchange-region capacity to exercise the grow-and-retry path
-    cap_env = os.environ.get('BESST_PAIR_CAPACITY')
-    runner = distributed.ShardedGraphBuild(device, wl, rank, world, pair_capacity=int(cap_env) if cap_env else None)
-
+    config = args.config or 'C4'
+    cfg = synth.CONFIGS[config]
+    seed = synth.config_seed(config)
+    n_ctg = int(args.contigs if args.contigs is not None else cfg['nc'])
+    asm = synth.make_assembly(n_ctg, cfg['median'], seed)
+    per_lib = int(args.pairs if args.pairs is not None else cfg['pairs'] // len(cfg['libs']) // 8)
+    cap_env = os.environ.get('BESST_PAIR_CAPACITY')     # start from a (too small) region capacity: grow-and-retry path
+    jobs, wls = [], []
+    for li, spec in enumerate(cfg['libs']):
+        cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device)
+        thr = spec.mean + 4 * spec.sd
+        table = (workload.first_library_table(asm.lengths, thr) if li == 0 else
+                 workload.later_library_table(asm, seed + 50 + li, thr, first_scaffold_id=asm.nc * li + 1))
+        wl = workload.DeviceWorkload(config=config, asm=asm, cols=cols, table=table, lib=workload.library_constants(spec),
+                                     node_bits=workload.node_bits_for(table), pairs=per_lib, spec=spec)
+        wls.append(wl)
+        jobs.append(distributed.ShardedGraphBuild(device, wl, rank, world, pair_capacity=int(cap_env) if cap_env else None))
     lib_h = _lib.load()
-    for _ in range(args.warmup):
-        runner.step()
-    torch.cuda.synchronize()
-    runner.check_capacity()
 
-    lib_h.besst_prof_sample_every(4 if args.steps >= 8 else 1)
+    def step():
+        for job in jobs:
+            job.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    for job in jobs:
+        job.check_capacity()
+    lib_h.besst_prof_sample_every(1)
     lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = pipeline.prof_collect()
+    pipeline.prof_collect()
     lib_h.besst_prof_enable(0)
-    lib_h.besst_prof_sample_every(1)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if backend_name == 'gloo' else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    # ---- per-kernel breakdown (untimed extra steps, every slot) ------------------------------------------
     lib_h.besst_prof_enable(0xffffffff)
     for _ in range(args.breakdown_steps):
-        runner.step()
+        step()
     torch.cuda.synchronize()
     breakdown = {k: round(v[0] / max(1, args.breakdown_steps), 4) for k, v in pipeline.prof_collect().items()}
     lib_h.besst_prof_enable(0)
-
-    n_tuples, n_rows = runner.sizes()
-    verified = None
-    sharded_ok = None
-    # size-independent check of the exchange at any N: the tuples the owners received are the tuples the slices
-    # emitted (the emitted count is one of the summed counter words), and no region overflowed
-    b = runner.backend
-    emitted = int(b.counter_words.cpu()[6].item())
-    exchange_ok = bool(emitted == n_tuples and not b.overflowed())
-    if world > 1 and not args.no_verify:
-        try:
-            sharded_ok = verify_sharded_vs_single_gpu(runner, wl, args, rank, world, device)
-        except Exception as e:                           # noqa: BLE001 - the bench line must still be printed
-            sharded_ok = 'error: %s' % (str(e).splitlines()[0][:200] if str(e) else type(e).__name__)
-    # the oracle is touched only in the cpu_baseline leg (--no-cpu-baseline: no oracle at all in this process)
-    if world == 1 and not args.no_verify and not args.no_cpu_baseline:
-        verified = verify_sharded_single_rank(runner, wl)
-    f = n_tuples / float(pairs * world)                  # sizes() of the sharded runner are global sums
-    cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
-    cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
-    own = n_rec * 11.0
-
+    libs_out, n_tuples_total, checks = [], 0, []
+    for li, (job, wl) in enumerate(zip(jobs, wls)):
+        n_tuples, n_rows = job.sizes()
+        n_tuples_total += n_tuples
+        b = job.backend
+        emitted = int(b.counter_words.cpu()[6].item())
+        entry = {'library': '%s N(%g, %g)%s' % (wl['spec'].orientation, wl['spec'].mean, wl['spec'].sd,
+                                                 ' + %.0f %% PE contamination' % (100 * wl['spec'].contam_frac)
+                                                 if wl['spec'].contam_frac else ''),
+                 'record_path': 'fused' if b.gb.params.record_path else 'two-pass', 'node_bits': wl['node_bits'],
+                 'link_tuples': n_tuples, 'edge_rows': n_rows,
+                 'exchange_consistent': bool(emitted == n_tuples and not b.overflowed())}
+        if not args.no_verify and not args.no_cpu_baseline:
+            try:
+                entry['verified_vs_c_oracle'] = verify_sharded_vs_oracle(job, wl, rank, world, device, backend_name)
+            except Exception as e:                       # noqa: BLE001 - the bench line must still be printed
+                entry['verified_vs_c_oracle'] = 'error: %s' % (str(e).splitlines()[0][:200] if str(e) else type(e).__name__)
+        libs_out.append(entry)
     if rank == 0:
-        total_pairs = pairs * world
+        total_pairs = per_lib * len(jobs) * world
         step_s = elapsed / args.steps
+        f = n_tuples_total / float(total_pairs)
         alg_step = total_pairs * (38.0 + 32.0 * f)
+        ok = all(isinstance(e.get('verified_vs_c_oracle'), dict) and all(e['verified_vs_c_oracle'].values()) for e in libs_out)
         out = {
             'metric': METRIC, 'value': total_pairs / step_s, 'unit': 'read-pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': step_s * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
-            'config': {'workload': '%s: %d contigs / %d read-pairs per GPU, one %s library, records resident in HBM'
-                                   % (args.config, wl['asm'].nc, pairs, lib['orientation']),
-                       'records_per_gpu': n_rec, 'link_tuples_per_pair': round(f, 5), 'edge_rows': n_rows,
-                       'parallelism': 'stream-slice x%d + key-owner all-to-all' % world},
-            'roofline': {'bound': 'hbm', 'scope': 'whole graph-build step, SURVEY 8(d): (38 + 32 f) bytes per read pair, '
-                                                  'over the aggregate peak of all GPUs',
+            'config': {'workload': '%s-shaped: %d contigs, %d libraries, %d read-pairs per library and GPU (%d in all), '
+                                   'records resident in HBM; a step = every library\'s pass'
+                                   % (config, asm.nc, len(jobs), per_lib, total_pairs),
+                       'records_per_gpu': 2 * per_lib * len(jobs), 'link_tuples_per_pair': round(f, 5),
+                       'parallelism': 'stream-slice x%d + key-owner all-to-all (RCCL)' % world, 'libraries': libs_out},
+            'roofline': {'bound': 'hbm', 'scope': 'whole step, SURVEY 8(d): (38 + 32 f) bytes per read pair, over the '
+                                                  'aggregate peak of all GPUs',
                          'achieved': round(alg_step / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s',
                          'frac': round(alg_step / step_s / 1e9 / (HBM_PEAK_GBS * world), 4), 'traffic': None,
-                         'algorithmic_bytes_per_step': alg_step,
-                         'stream_kernel': {'own_bytes_per_launch': own, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
-                                           'GBps': round(own / cls_avg_s / 1e9, 1) if cls_avg_s > 0 else None}},
+                         'algorithmic_bytes_per_step': alg_step},
             'kernel_ms': breakdown,
-            'verified_vs_c_oracle': verified,
-            'exchange_consistent': exchange_ok,
-            'sharded_equals_single_gpu': sharded_ok,
+            'verified_vs_c_oracle': ok if not (args.no_verify or args.no_cpu_baseline) else None,
             'cpu_baseline': None,
         }
         sys.stdout.flush()

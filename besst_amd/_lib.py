@@ -81,7 +81,7 @@ _SIGNATURES = {
     'besst_dev_candidate_density': (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, C.POINTER(C.c_double),
                                               C.POINTER(C.c_int32)]),
     'besst_dev_reduce': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                   _P, _P, C.c_size_t, _P]),
+                                   _P, _P, C.c_size_t, _P, C.c_uint64]),
     'besst_dev_classify_scan': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                           C.POINTER(LibParams), C.c_int32, _P, _P, _P, C.c_size_t]),
     'besst_dev_classify_tail': (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t]),

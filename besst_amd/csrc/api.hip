@@ -92,6 +92,8 @@ struct besst_ctx {
     // contig table
     int64_t n_contigs = 0;
     int32_t node_bits = 1;
+    uint64_t key_base = 0;
+    int32_t key_bits = 3;
     DevBuf<ContigRow> table;
     DevBuf<int64_t> aligned;
     // library
@@ -280,10 +282,17 @@ int besst_ctx_set_contigs(besst_ctx* c, int64_t n, const int32_t* scaf_id, const
     if ((rc = c->aligned.ensure((size_t)n + 1))) return rc;
     if ((rc = besst_dev_pack_contigs(c->stream, n, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls, c->table.p)))
         return rc;
-    uint32_t max_id = 1;
+    uint32_t max_id = 1, min_id = 0xffffffffu;
     for (int64_t i = 0; i < n; ++i)
-        if (cls[i] != BESST_CLS_ABSENT && (uint32_t)scaf_id[i] > max_id) max_id = (uint32_t)scaf_id[i];
+        if (cls[i] != BESST_CLS_ABSENT) {
+            if ((uint32_t)scaf_id[i] > max_id) max_id = (uint32_t)scaf_id[i];
+            if ((uint32_t)scaf_id[i] < min_id) min_id = (uint32_t)scaf_id[i];
+        }
+    if (min_id > max_id) min_id = max_id;
     c->node_bits = bits_for((uint64_t)max_id * 2 + 1);
+    // every key is >= the one of (lowest node, lowest node): later libraries' scaffold ids start far above 1
+    c->key_base = (((uint64_t)min_id * 2) << c->node_bits) << 1;
+    c->key_bits = bits_for((((((uint64_t)max_id * 2 + 1) << c->node_bits) | ((uint64_t)max_id * 2 + 1)) << 1 | 1ull) - c->key_base);
     c->n_contigs = n;
     c->built = false;
     return BESST_OK;
@@ -345,14 +354,15 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
 int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
                      const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
                      int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map) {
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
+                     uint64_t key_base) {
     BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
     BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
                                     row_first && row_offset && obs_lo && obs_hi),
                   "reduce: null buffer");
     return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
                               row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
-                              workspace, workspace_bytes, first_map);
+                              workspace, workspace_bytes, first_map, key_base);
 }
 
 static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
@@ -591,9 +601,9 @@ int besst_ctx_build_graph(besst_ctx* c) {
     if ((rc = c->obs_lo.ensure(cap2))) return rc;
     if ((rc = c->obs_hi.ensure(cap2))) return rc;
     if ((rc = c->ws.ensure(reduce_workspace_bytes(L)))) return rc;
-    rc = besst_dev_reduce(c->stream, L, &sb->n_out, 2 * c->node_bits + 1, c->keys.p, c->payload.p, c->row_key.p,
+    rc = besst_dev_reduce(c->stream, L, &sb->n_out, c->key_bits, c->keys.p, c->payload.p, c->row_key.p,
                           c->row_mask.p, c->row_n.p, c->row_sum.p, c->row_sum_sq.p, c->row_first.p, c->row_offset.p,
-                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap, nullptr);
+                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap, nullptr, c->key_base);
     if (rc) return rc;
     BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
     BESST_HIP_TRY(hipStreamSynchronize(c->stream));

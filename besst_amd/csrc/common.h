@@ -185,6 +185,7 @@ struct DigitSel {
     int node_bits;
     uint32_t world;
     int bits;      // digit width in mode 0
+    uint64_t base; // mode 0: the digit is taken from key - base (scaffold ids of a later library start far above 1)
 };
 
 // Owner rank of a scaffold's edges (multi-GPU key partition): multiplicative hash, then mod world.
@@ -215,7 +216,8 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr);
+                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr,
+                       uint64_t key_base = 0);
 // chained-scan sort + atomic-free reduction for large streams (onesweep.hip); buf_* = the ping-pong buffers of the
 // sort/reduce workspace
 size_t onesweep_workspace_bytes(int64_t cap);
@@ -224,7 +226,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
                                 int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
                                 int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
-                                const uint32_t* first_map);
+                                const uint32_t* first_map, uint64_t key_base);
 size_t exchange_region_bytes(int64_t pair_cap);
 size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes);
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,

@@ -81,7 +81,8 @@ __device__ __forceinline__ uint32_t os_nblocks(uint32_t n, uint32_t tile) { retu
 template <int BITS>
 __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t* __restrict__ keys,
                                                                  const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                                 int passes, uint32_t* __restrict__ table,
+                                                                 int passes, uint64_t key_base,
+                                                                 uint32_t* __restrict__ table,
                                                                  unsigned long long* __restrict__ granules,
                                                                  size_t granule_words) {
     constexpr int RADIX = 1 << BITS;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
         if (base + kOsHistTile <= n) {
             uint64_t k[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) k[r] = keys[base + r * kOsHistThreads + t];
+            for (int r = 0; r < 16; ++r) k[r] = keys[base + r * kOsHistThreads + t] - key_base;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 for (int p = 0; p < passes; ++p) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
             for (int r = 0; r < 16; ++r) {
                 const uint32_t i = base + r * kOsHistThreads + t;
                 if (i < n) {
-                    const uint64_t k = keys[i];
+                    const uint64_t k = keys[i] - key_base;
                     for (int p = 0; p < passes; ++p)
                         atomicAdd(&mine[p * RADIX + ((uint32_t)(k >> (p * BITS)) & (uint32_t)(RADIX - 1))], 1u);
                 }
@@ -214,10 +215,12 @@ constexpr int kPeel = BESST_OS_PEEL;
 template <int BITS, bool kFirst, bool kPacked>
 __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ n_ptr,
-    uint32_t cap, int shift, int pass, int packed_bits, const uint32_t* __restrict__ digit_base,
+    uint32_t cap, int shift, int pass, int packed_bits, uint64_t key_base, const uint32_t* __restrict__ digit_base,
     unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err) {
     constexpr int RADIX = 1 << BITS;
+    // the raw key stream (first pass) and unpacked keys carry key_base; packed words hold key - key_base already
+    const uint64_t sub = (kFirst || !kPacked) ? key_base : 0ull;
     constexpr int kIdxRegs = kPacked ? 1 : kOsItems;
     __shared__ uint32_t s_whist[kOsWaves][RADIX];
     __shared__ uint32_t s_base[RADIX];
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
     for (int r = 0; r < kOsItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & (uint32_t)(RADIX - 1);
+        const uint32_t d = (uint32_t)((key[r] - sub) >> shift) & (uint32_t)(RADIX - 1);
         uint32_t info = 0;                                   // rank inside my group | group size << 8
         bool todo = valid;
         unsigned long long rest = __ballot(todo);
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
             const uint32_t d = dig_rank[r] & (uint32_t)(RADIX - 1);
             const uint32_t dst = s_base[d] + s_whist[wave][d] + (dig_rank[r] >> BITS);
             if (kPacked) {
-                keys_out[dst] = kFirst ? ((key[r] << packed_bits) | i) : key[r];
+                keys_out[dst] = kFirst ? (((key[r] - key_base) << packed_bits) | i) : key[r];
             } else {
                 keys_out[dst] = key[r];
                 idx_out[dst] = idx[r];
@@ -359,8 +362,8 @@ __device__ __forceinline__ int os_pad(int i) { return i + (i >> 4); }
 
 __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     const uint64_t* __restrict__ words, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ payload,
-    const uint32_t* __restrict__ n_ptr, uint32_t cap, int packed_bits, unsigned long long* __restrict__ rdesc,
-    uint32_t* __restrict__ ticket, uint32_t* __restrict__ tile_base, uint32_t* __restrict__ lead_n,
+    const uint32_t* __restrict__ n_ptr, uint32_t cap, int packed_bits, uint64_t key_base,
+    unsigned long long* __restrict__ rdesc, uint32_t* __restrict__ ticket, uint32_t* __restrict__ tile_base, uint32_t* __restrict__ lead_n,
     unsigned long long* __restrict__ lead_s, unsigned long long* __restrict__ lead_s2, uint32_t* __restrict__ n_rows,
     uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask, uint32_t* __restrict__ row_n,
     unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
                 ++row;
                 const uint64_t w = words[i];
                 const uint32_t src = packed_bits ? (uint32_t)(w & idx_mask) : idx[i];
-                row_key[row] = w >> packed_bits;
+                row_key[row] = packed_bits ? (w >> packed_bits) + key_base : w;
                 row_mask[row] = (uint32_t)(payload[src] >> 62);
                 row_first[row] = first_map ? first_map[src] : src;
                 row_offset[row] = i;
@@ -635,7 +638,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
                                 int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
                                 int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
-                                const uint32_t* first_map) {
+                                const uint32_t* first_map, uint64_t key_base) {
     const OsWorkspace w = os_carve(ws, cap, kOsBits);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: chained-scan workspace too small");
     const int passes = (key_bits + kOsBits - 1) / kOsBits;
@@ -652,7 +655,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         const uint32_t hist_tiles = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
         (void)hist_tiles;
         hipLaunchKernelGGL((os_hist_kernel<kOsBits>), dim3(kOsHistBlocks), dim3(kOsHistThreads), 0, s, keys, n_tuples,
-                           (uint32_t)cap, passes, w.table, w.granules, w.granule_words);
+                           (uint32_t)cap, passes, key_base, w.table, w.granules, w.granule_words);
     }
     {
         ProfScope ps(s, kProfSortScan);
@@ -668,7 +671,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         const int shift = p * kOsBits + (p > 0 ? packed_bits : 0);
 #define BESST_OS_LAUNCH(FIRST, PACKED)                                                                                   \
     hipLaunchKernelGGL((os_scatter_kernel<kOsBits, FIRST, PACKED>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,      \
-                       n_tuples, (uint32_t)cap, shift, p, packed_bits, w.digit_base + (size_t)p * RADIX, w.granules,      \
+                       n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX, w.granules, \
                        w.tickets + p, kout, iout, w.err)
         if (packed_bits) {
             if (p == 0) BESST_OS_LAUNCH(true, true); else BESST_OS_LAUNCH(false, true);
@@ -682,7 +685,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     {
         ProfScope ps(s, kProfRowReduce);
         hipLaunchKernelGGL(os_reduce_kernel, dim3(nt_red), dim3(kOsRedThreads), 0, s, kin, iin, payload, n_tuples,
-                           (uint32_t)cap, packed_bits, w.granules + w.desc_words, w.tickets + kOsMaxPasses, w.tile_base,
+                           (uint32_t)cap, packed_bits, key_base, w.granules + w.desc_words, w.tickets + kOsMaxPasses, w.tile_base,
                            w.lead_n, w.lead_s, w.lead_s2, n_rows, row_key, row_mask, row_n,
                            reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),
                            row_first, row_offset, obs_lo, obs_hi, first_map, w.err);

@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t nblocks_of(uint32_t n, uint32_t tile) { retu
 
 // digit of a key: a radix digit (mode 0) or the owning rank of the key's min scaffold (mode 1)
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, const DigitSel& ds) {
-    if (ds.mode == 0) return (uint32_t)(key >> ds.shift) & ((1u << ds.bits) - 1u);
+    if (ds.mode == 0) return (uint32_t)((key - ds.base) >> ds.shift) & ((1u << ds.bits) - 1u);
     const uint32_t scaf = (uint32_t)(key >> (2 + ds.node_bits));   // key = ((min_node << nb) | max_node) << 1 | f
     return owner_of_scaffold(scaf, ds.world);
 }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
                 const uint32_t dst = s_base[dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
                 // the bucket number IS the digit: only the key bits below it travel in the word, so that keys of
                 // up to 64 - index bits + 11 bits still pack (bucket_reduce_kernel puts the digit back)
-                keys_out[dst] = ((key[r] & low_mask) << packed_bits) | idx[r];
+                keys_out[dst] = (((key[r] - ds.base) & low_mask) << packed_bits) | idx[r];
             }
         }
         return;
@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void bucket_reduce_kernel(
     uint32_t* __restrict__ n_rows, uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
     uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
     unsigned long long* __restrict__ row_sum_sq, uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset,
-    int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map) {
+    int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map,
+    uint64_t key_base) {
     __shared__ uint32_t s_part[4];
     __shared__ int s_wheads[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(256) void bucket_reduce_kernel(
             obs_lo[i] = o_lo;
             obs_hi[i] = o_hi;
             if (head) {
-                row_key[row] = key;
+                row_key[row] = key + key_base;
                 row_mask[row] = hi >> 30;
                 row_first[row] = first_map ? first_map[src] : src;
                 row_offset[row] = i;
@@ -974,7 +975,9 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map) {
+                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base) {
+    // key_bits counts the significant bits of key - key_base: every path below sorts that difference (the order is
+    // the same) and puts key_base back when it writes a row's key
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
     BESST_REQUIRE(key_bits >= 1 && key_bits <= 64, "reduce: key_bits out of range");
     if (cap == 0) {
@@ -997,7 +1000,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     if (nb_sort <= (uint32_t)kScanFreeMaxBlocks || (packable && nb_sort <= (uint32_t)kMsdMaxBlocks)) {
         // one MSD pass on the top 11 significant bits, then every bucket sorts and reduces itself
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
-        const DigitSel ds{0, shift, 0, 1u, kMsdBits};
+        const DigitSel ds{0, shift, 0, 1u, kMsdBits, key_base};
         packed_bits = packable ? cap_idx_bits : 0;    // key and stream index in one word (always, in practice)
         if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
             // few sort tiles leave most of the chip idle: half-size tiles (and the row scan they then need)
@@ -1023,7 +1026,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             ProfScope ps(s, kProfRowReduce);
             hipLaunchKernelGGL(bucket_reduce_kernel, dim3(1u << kMsdBits), dim3(256), 0, s, w.keys[0], payload, n_tuples,
                                w.bucket_start, w.bucket_rows, packed_bits, shift, n_rows, row_key, row_mask, row_n, zsum, zsq,
-                               row_first, row_offset, obs_lo, obs_hi, first_map);
+                               row_first, row_offset, obs_lo, obs_hi, first_map, key_base);
             BESST_HIP_TRY(hipGetLastError());
             return BESST_OK;
         }
@@ -1035,7 +1038,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         uint32_t* bi[2] = {w.idx[0], w.idx[1]};
         return launch_onesweep_sort_reduce(s, cap, n_tuples, key_bits, keys, payload, bk, bi, row_key, row_mask, row_n,
                                            row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows, w.os_ws,
-                                           w.os_bytes, first_map);
+                                           w.os_bytes, first_map, key_base);
     }
     const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {
@@ -1318,7 +1321,7 @@ int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int n
     // (one rank over RCCL, whole step 190 -> 173 us).  Their [owner][tile] table (256 x 4 x sort tiles) fits the
     // MSD table of the same workspace; larger streams keep the sort's tile.
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
-    const DigitSel ds{1, 0, node_bits, (uint32_t)world, kRadixBits};
+    const DigitSel ds{1, 0, node_bits, (uint32_t)world, kRadixBits, 0ull};
     auto run = [&](auto items_tag) {
         constexpr int kItems = decltype(items_tag)::value;
         constexpr uint32_t kTile = kSortThreads * kItems;

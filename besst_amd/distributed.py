@@ -76,6 +76,19 @@ def _all_reduce(x, group, op=dist.ReduceOp.SUM, async_op=False):
 RIDER_MAX_BYTES = 256 * 1024
 
 
+def device_records(wl, device):
+    """The workload's record columns in HBM, uploaded (or adopted, when they were generated on the GPU) once."""
+    from . import pipeline
+    rec = wl.get('_rec') if isinstance(wl, dict) else None
+    if rec is None:
+        rec = pipeline.DeviceRecords.from_columns(wl['cols']) if 'cols' in wl else pipeline.DeviceRecords(wl['batch'], device)
+        try:
+            wl['_rec'] = rec
+        except TypeError:
+            pass
+    return rec
+
+
 class HipBackend(object):
     """Kernel stages of one rank on its GPU."""
 
@@ -86,7 +99,7 @@ class HipBackend(object):
         self.device = device
         self.rank, self.world = rank, world
         self.wl = wl
-        self.rec = pipeline.DeviceRecords(wl['batch'], device)
+        self.rec = device_records(wl, device)
         self.pair_cap = int(pair_capacity + (pair_capacity & 1))
         self.recv_cap = self.pair_cap * world
         self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n,
@@ -226,9 +239,9 @@ class HipBackend(object):
     def reduce(self):
         g, p = self.gb, self.pipeline._p
         self._call('dev_reduce', self.lib.besst_dev_reduce, lambda: (
-            self.recv_cap, C.c_void_p(self.flags.data_ptr()), 2 * g.node_bits + 1, p(self.rkeys), p(self.rpayload),
+            self.recv_cap, C.c_void_p(self.flags.data_ptr()), g.key_bits, p(self.rkeys), p(self.rpayload),
             p(g.row_key), p(g.row_mask), p(g.row_n), p(g.row_sum), p(g.row_sum_sq), p(g.row_first), p(g.row_offset),
-            p(g.obs_lo), p(g.obs_hi), g._n_rows, p(g.ws2), g.ws2.numel(), p(self.gidx)))
+            p(g.obs_lo), p(g.obs_hi), g._n_rows, p(g.ws2), g.ws2.numel(), p(self.gidx), g.key_base))
 
     def pack_for_allreduce(self):
         return self._sum_buf
@@ -290,7 +303,7 @@ class ShardedGraphBuild(object):
     def _probe_pair_capacity(device, wl, world):
         """One untimed local pass to size the exchange regions (tuples per (src,dst) pair, 1.5x slack)."""
         from . import pipeline
-        rec = pipeline.DeviceRecords(wl['batch'], device)
+        rec = device_records(wl, device)
         probe = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, 1)
         probe.set_contigs(**wl['table'])
         probe.reset()

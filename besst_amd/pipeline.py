@@ -101,6 +101,7 @@ class DeviceGraphBuilder(object):
         self._init = init.to(device)
         self._args = {}
         self._paths = {}
+        self.key_base, self.key_bits = 0, 2 * self.node_bits + 1
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
         self.candidate_share = None
 
@@ -126,6 +127,15 @@ class DeviceGraphBuilder(object):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self.lib.besst_dev_pack_contigs(C.c_void_p(stream), self.n_contigs, *[_lib.ptr(c) for c in cols],
                                                    _p(self.table)), 'pack_contigs')
+        # key range of this table (include/besst_amd.h, besst_dev_reduce): scaffold ids of a later library start far
+        # above 1, so the sort works on key - key_base
+        present = cols[5] != 0
+        if present.any():
+            lo, hi = int(cols[0][present].min()), int(cols[0][present].max())
+            top = hi * 2 + 1
+            self.key_base = ((lo * 2) << self.node_bits) << 1
+            self.key_bits = max(1, int(((((top << self.node_bits) | top) << 1) | 1) - self.key_base).bit_length())
+            self._args.pop('reduce', None)
 
     def reset(self):
         """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
@@ -168,20 +178,20 @@ class DeviceGraphBuilder(object):
             args = self._args.get('reduce')
             if args is None:
                 args = self._args['reduce'] = (
-                    self.tup_cap, self._n_out, 2 * self.node_bits + 1, _p(self.keys), _p(self.payload),
+                    self.tup_cap, self._n_out, self.key_bits, _p(self.keys), _p(self.payload),
                     _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
                     _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
-                    _p(self.ws2), self.ws2.numel(), None)
+                    _p(self.ws2), self.ws2.numel(), None, self.key_base)
             _lib.check(self.lib.besst_dev_reduce(C.c_void_p(stream), *args), 'dev_reduce')
             return
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
         cap = self.tup_cap if capacity is None else int(capacity)
         _lib.check(self.lib.besst_dev_reduce(
-            C.c_void_p(stream), cap, n_tuples_ptr or self._n_out, 2 * self.node_bits + 1, _p(keys), _p(payload),
+            C.c_void_p(stream), cap, n_tuples_ptr or self._n_out, self.key_bits, _p(keys), _p(payload),
             _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
             _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
-            _p(self.ws2), self.ws2.numel(), _p(first_map)), 'dev_reduce')
+            _p(self.ws2), self.ws2.numel(), _p(first_map), self.key_base), 'dev_reduce')
 
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
         """Score rows of the table this builder holds (besst_dev_score_edges) -> (gap, sd0, ks_h, flags) numpy arrays.

@@ -268,13 +268,17 @@ int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, con
  * reduction into edge rows (up to 4 M tuples: one MSD partition + per-bucket sort and reduction; beyond, up to 2^30:
  * chained-scan radix passes + atomic-free tile reduction).
  *   n_tuples  uint32 device: number of valid tuples in keys/payload (<= capacity)
- *   key_bits  number of significant key bits (2 * node_bits + 1)
+ *   key_base  a lower bound of every key (0 is always valid).  Scaffold ids keep growing across passes
+ *             (param.scaffold_indexer, MakeScaffolds.py:276), so from the second library on all keys share a long
+ *             common prefix; with key_base = ((2 * min scaffold id) << node_bits) << 1 the sort works on key - key_base
+ *   key_bits  number of significant bits of key - key_base (2 * node_bits + 1 with key_base 0)
  * Outputs (capacity entries each): row_* arrays, obs_lo/obs_hi grouped by row, n_rows (uint32). */
 int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
                      const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                      uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                      uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map);
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
+                     uint64_t key_base);
 
 /* ---- multi-GPU path ----------------------------------------------------
  * Ranks own contiguous slices of the (tid,pos)-sorted stream.  The duplicate chain of CreateEdge

@@ -30,6 +30,7 @@ def test_single_gpu_line_has_the_contract_fields():
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['higher_is_better'] is True
     assert d['verified_vs_c_oracle'] is True
+    assert d['config']['workload'].startswith('C3')
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline'])
     assert d['stages']['linearize_calls_agree'] is True
@@ -48,7 +49,11 @@ def test_two_ranks_over_gloo_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json_line(out.stdout)
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
-    assert d['exchange_consistent'] is True
-    assert d['sharded_equals_single_gpu'] is True
+    libs = d['config']['libraries']
+    assert len(libs) == 2                                 # C4 shape: two libraries per step
+    for lib in libs:
+        assert lib['exchange_consistent'] is True
+        assert all(lib['verified_vs_c_oracle'].values()), lib
+    assert d['verified_vs_c_oracle'] is True
     assert d['cpu_baseline'] is None                      # the CPU legs run at N = 1 only
-    assert abs(d['value'] - 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert abs(d['value'] - 2 * 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']

@@ -136,3 +136,52 @@ def test_pass_pool_overlapped_passes_are_independent():
         assert np.array_equal(table.key, rows['key']) and np.array_equal(table.n.astype(np.int64), rows['n'])
         assert np.array_equal(table.obs_lo.astype(np.int64), rows['obs_lo'])
         assert gb.aligned.cpu().numpy().tolist() == aligned.tolist()
+
+
+@pytest.mark.parametrize('n', [300_000, 2_000_000, 6_000_000])
+def test_sort_reduce_with_offset_scaffold_ids(n):
+    """Scaffold ids of a later library start far above 1 (param.scaffold_indexer keeps growing, MakeScaffolds.py:276):
+    all keys share a long prefix.  With key_base / key_bits describing the occupied range the MSD buckets stay balanced
+    (without it 2 M such tuples fell into ~160 of 2048 buckets and took the global-memory fallback); results must be
+    the same as ever on every sort path."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from besst_amd import pipeline
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(n)
+    node_bits, lo_id, hi_id = 21, 600_001, 760_000
+    rows = max(1000, n // 12)
+    a = rng.integers(lo_id * 2, hi_id * 2 + 2, rows, dtype=np.int64)
+    b = rng.integers(lo_id * 2, hi_id * 2 + 2, rows, dtype=np.int64)
+    pair = ((np.minimum(a, b) << node_bits) | np.maximum(a, b))[rng.integers(0, rows, n)]
+    fishy = (rng.random(n) < 0.01).astype(np.int64)
+    keys = ((pair << 1) | fishy).astype(np.uint64)
+    lo = rng.integers(26, 5000, n).astype(np.uint64)
+    hi = rng.integers(26, 5000, n).astype(np.uint64) | (np.uint64(3) << np.uint64(30))
+    lo[fishy == 1] = 0
+    hi[fishy == 1] = 0
+    payload = lo | (hi << np.uint64(32))
+    dev = torch.device('cuda', 0)
+    lib = dict(read_len=100.0, ins_size_threshold=800.0, min_mapq=11, orientation='fr', detect_duplicate=True,
+               extend_paths=True, no_score=False)
+    gb = pipeline.DeviceGraphBuilder(dev, 4, node_bits, lib, n, n)
+    top = hi_id * 2 + 1
+    gb.key_base = ((lo_id * 2) << node_bits) << 1
+    gb.key_bits = int(((((top << node_bits) | top) << 1) | 1) - gb.key_base).bit_length()
+    assert gb.key_bits < 2 * node_bits + 1
+    dk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    dp = torch.from_numpy(payload.view(np.int64)).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    gb.reduce(keys=dk, payload=dp, n_tuples_ptr=C.c_void_p(cnt.data_ptr()), capacity=n)
+    torch.cuda.synchronize()
+    want = CO.edge_rows(keys, payload)
+    r = len(want['key'])
+    raw = gb.small.cpu().numpy()
+    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
+    assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
+    assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
+    assert np.array_equal(get(gb.row_sum, r, np.int64), want['sum_obs'])
+    assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
+    assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
