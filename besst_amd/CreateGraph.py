@@ -17,6 +17,7 @@ Split of work:
 """
 from __future__ import print_function
 
+import math
 import os
 import sys
 from collections import Counter
@@ -24,7 +25,7 @@ from time import time
 
 import numpy as np
 
-from . import Contig, Scaffold, e_nr_links, session
+from . import Contig, Scaffold, e_nr_links, mathstats_compat, session
 from . import GenerateOutput as GO
 from .Parameter import counters
 from .device import CLS_LARGE, CLS_SMALL, MASK_G, MASK_GPRIME
@@ -463,15 +464,52 @@ def remove_edges_below_threshold(graph, param):
         counter_low_support), file=param.information_file)
 
 
+def get_conditional_stddevs(steps, empirical_isize_distr, max_isize):
+    """Expected std-dev of the spanning insert size given the gap, from the empirical distribution
+    (CreateGraph.py:436-469): for every gap of `steps` the density f(x) * max(0, x - gap + 1), its mean and sigma (sums
+    in index order, as the reference's sum() over the list), repeated for the gaps up to the next step."""
+    expected = []
+    previous_gap = 0
+    items = list(empirical_isize_distr.items())
+    for gap in steps:
+        density = [0] * (max_isize + 1)
+        for x, f_x in items:
+            w_x = max(0, x - gap + 1)
+            if w_x > 0:
+                density[x] = f_x * w_x
+        tot = 0
+        for v in density:
+            tot = tot + v
+        tot = float(tot)
+        acc = 0
+        for i, v in enumerate(density):
+            acc = acc + i * v
+        mu = acc / tot
+        acc = 0
+        for i, v in enumerate(density):
+            acc = acc + (i - mu) ** 2 * v
+        sigma = math.sqrt(acc / tot)
+        expected.extend([sigma] if gap == 0 else [sigma] * (gap - previous_gap))
+        previous_gap = gap
+    return expected
+
+
 def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, plot, ctx):
     """Score every link edge of G (normal-distribution branch of CreateGraph.py:498-614).
 
     The device returns per edge the ML gap, the expected std-dev and the integer KS numerator h; the
     remaining scalar arithmetic below is evaluated with the reference's expressions so the floats agree.
     """
+    cond_sd = None
     if param.lognormal:
-        raise NotImplementedError('log-normal scoring branch (CreateGraph.py:485-531) is not provided: the reference '
-                                  'itself fails there on Python 3 (float range step, :490)')
+        # skewed library (libmetrics: skew_adj > 0.5): gaps from the log-normal estimator over the raw observations,
+        # expected sigma from the empirical distribution conditioned on the gap (CreateGraph.py:485-494).  The
+        # reference's `range(0, int(max_isize*0.8), max_isize/50)` is Python 2 integer division.
+        emp_distr = param.empirical_distribution
+        max_isize = sorted(emp_distr.keys())[-1]
+        steps = list(range(0, int(max_isize * 0.8), max_isize // 50))
+        cond_sd = get_conditional_stddevs(steps, emp_distr, max_isize)
+        log_norm_max_gap = len(cond_sd) - 1
     score_file = None
     if param.print_scores:
         score_file = open(os.path.join(param.output_directory, 'score_file_pass_{0}.tsv'.format(param.pass_number)), 'w')
@@ -503,13 +541,28 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
         data.pop('device_min_node')
         n = data['nr_links']
         mean_ = data['obs'] / float(n)
-        # integer-valued when the ML estimator was used (int in the reference), float otherwise
-        gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
-        data['gap'] = int(gap)
-        if flags[j] & 2:                      # -gap > len1 or -gap > len2
-            data['score'] = 0
-            continue
-        std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
+        if cond_sd is not None:               # log-normal branch (:522-531, :549-553): host, per edge
+            long_enough = 2 * param.std_dev_ins_size < len1[j] and 2 * param.std_dev_ins_size < len2[j]
+            if long_enough:
+                gap = mathstats_compat.lognormal_GapEstimator(param.lognormal_mean, param.lognormal_sigma, param.read_len,
+                                                              data['observations'], len1[j], c2_len=len2[j])
+                if gap > log_norm_max_gap:
+                    gap = log_norm_max_gap
+            else:
+                gap = (n * param.mean_ins_size - data['obs']) / float(n)
+            data['gap'] = int(gap)
+            if -gap > len1[j] or -gap > len2[j]:
+                data['score'] = 0
+                continue
+            std_dev_d_eq_0 = (cond_sd[int(gap)] if gap > 0 else cond_sd[0]) if long_enough else 2 ** 32
+        else:
+            # integer-valued when the ML estimator was used (int in the reference), float otherwise
+            gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
+            data['gap'] = int(gap)
+            if flags[j] & 2:                      # -gap > len1 or -gap > len2
+                data['score'] = 0
+                continue
+            std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
         try:
             std_dev = ((data['obs_sq'] - n * mean_ ** 2) / (n - 1)) ** 0.5
         except ZeroDivisionError:

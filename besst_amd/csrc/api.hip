@@ -764,6 +764,26 @@ int besst_ctx_value_histogram(besst_ctx* c, const int32_t* values, int64_t n, in
     return BESST_OK;
 }
 
+int besst_dev_gap_condition_table(void* stream, double mean, double sigma, double read_len, double contig_len,
+                                  int32_t d_lower, int32_t n, double* out) {
+    BESST_REQUIRE(n >= 0 && (n == 0 || out) && sigma > 0.0, "gap_condition_table: bad argument");
+    return launch_gap_table(static_cast<hipStream_t>(stream), mean, sigma, read_len, contig_len, d_lower, n, out);
+}
+
+int besst_ctx_gap_condition_table(besst_ctx* c, double mean, double sigma, double read_len, double contig_len,
+                                  int32_t d_lower, int32_t n, double* h_out) {
+    BESST_REQUIRE(c && n >= 0 && (n == 0 || h_out) && sigma > 0.0, "gap_condition_table: bad argument");
+    if (n == 0) return BESST_OK;
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = c->aux.ensure((size_t)n * sizeof(double)))) return rc;
+    auto* d_out = reinterpret_cast<double*>(c->aux.p);
+    if ((rc = launch_gap_table(c->stream, mean, sigma, read_len, contig_len, d_lower, n, d_out))) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(h_out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
+}
+
 int besst_ctx_score_edges(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
                           const int32_t* len2, double mean, double sigma, double read_len, double* gap, double* sd0,
                           int32_t* ks_h, uint8_t* flags) {

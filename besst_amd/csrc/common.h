@@ -270,6 +270,7 @@ struct ScoreArgs {
     int64_t n_edges;
 };
 size_t score_workspace_bytes(int64_t n_edges, int64_t n_tuples);
+int launch_gap_table(hipStream_t s, double mean, double sigma, double r, double c_len, int32_t d_lower, int32_t n, double* out);
 int launch_score(hipStream_t s, const ScoreArgs& a, double* gap, double* sd0, int32_t* ks_h,
                  uint8_t* flags, void* ws, size_t ws_bytes);
 

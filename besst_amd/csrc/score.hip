@@ -259,7 +259,26 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, doubl
     if (t == 0) ks_out[e] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 }
 
+// d + sigma^2 g'(d) / g(d) for a run of consecutive gaps d = d_lower, d_lower + 1, ... between two contigs of the same
+// length: the table mathstats' PreCalcMLvaluesOfdLongContigs is built from (MakeScaffolds.py:68,447 look gaps of long
+// scaffold pairs up instead of bisecting per edge).  One thread per d.
+__global__ __launch_bounds__(256) void gap_table_kernel(double mean, double sigma, double r, double c_len, int32_t d_lower,
+                                                        int32_t n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = (double)(d_lower + i);
+    const Moments M = gap_moments(d, mean, sigma, c_len, c_len, r);
+    out[i] = M.m0 > 0.0 ? d + sigma * sigma * M.gprime / M.m0 : d;
+}
+
 }  // namespace
+
+int launch_gap_table(hipStream_t s, double mean, double sigma, double r, double c_len, int32_t d_lower, int32_t n, double* out) {
+    if (n <= 0) return BESST_OK;
+    hipLaunchKernelGGL(gap_table_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, mean, sigma, r, c_len, d_lower, n, out);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
 
 size_t score_workspace_bytes(int64_t n_edges, int64_t n_tuples) {
     // worst case every big edge needs 2 * next_pow2(n) <= 4 n ints of scratch

@@ -105,6 +105,13 @@ class GraphContext(object):
             int(bool(want_isize)), _lib.ptr(isize), _lib.ptr(contam), C.byref(counts)), 'metrics_sample')
         return isize[:counts.n_isize], contam[:counts.n_contam], counts
 
+    def gap_condition_table(self, mean, sigma, read_len, contig_len, d_lower, n):
+        out = np.zeros(int(n), dtype=np.float64)
+        _lib.check(self._lib.besst_ctx_gap_condition_table(self._ctx, float(mean), float(sigma), float(read_len),
+                                                           float(contig_len), int(d_lower), int(n), _lib.ptr(out)),
+                   'gap_condition_table')
+        return out
+
     def value_histogram(self, values, n_bins):
         vals = _lib.as_col(values, np.int32)
         hist = np.zeros(int(n_bins), dtype=np.int64)

@@ -173,22 +173,107 @@ def tr_sk_std_dev(mean, sigma, read_length, c1_len, c2_len, d):
     return math.sqrt(var)
 
 
-def PreCalcMLvaluesOfdLongContigs(mean, sigma, read_length):
-    """Table {round(naive_gap) -> ML gap} for two long contigs.
+def PreCalcMLvaluesOfdLongContigs(mean, sigma, read_length, ctx=None):
+    """Table {round(naive_gap) -> ML gap} for two long contigs (MakeScaffolds.py:68,447).
 
-    Consumed only downstream of the hot path (MakeScaffolds.py:68,447); provided so
-    the unchanged reference stages keep working against this package.
+    ctx: a besst_amd.device.GraphContext - the ML condition of every gap of the range is then evaluated by the
+    device (besst_ctx_gap_condition_table, one thread per gap) and only the rounding and the inversion of the map
+    stay on the host; without it everything runs here.  Both give the same table up to the last-bit differences of
+    the device's erf / exp at a rounding boundary (tests/test_gpu_score_numeric.py).
     """
     big = 10.0 * (mean + 4 * sigma) + 10.0 * read_length
     d_upper = int(mean + 2 * sigma - 2 * read_length)
     d_lower = int(-2 * sigma)
+    values = None
+    if ctx is not None and d_upper >= d_lower:
+        values = ctx.gap_condition_table(mean, sigma, read_length, big, d_lower, d_upper - d_lower + 1).tolist()
     table = {}
     prev = None
     for d in range(d_lower, d_upper + 1):
-        f = int(math.floor(ml_condition(float(d), mean, sigma, big, big, read_length) + 0.5))
+        v = values[d - d_lower] if values is not None else ml_condition(float(d), mean, sigma, big, big, read_length)
+        f = int(math.floor(v + 0.5))
         if prev is None:
             prev = f
         for k in range(prev, f + 1):
             table.setdefault(k, d)
         prev = f
     return table
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# mathstats.log_normal_param_est.GapEstimator (CreateGraph.py:37,526; MakeScaffolds.py:421) - also un-vendored.
+# Restated from the same model as the normal case with the log-normal density: parity with 0.2.6.5 UNPINNED.
+#   x ~ LogNormal(mu, sigma) on the integers, w(x; d) placements as in the normal case, g(d) = sum_x w(x; d) f(x),
+#   log-likelihood of the observations o_i = x_i - d:   L(d) = sum_i log f(o_i + d) - n log g(d)
+# (the placement weight of an observation does not depend on d).  Unlike the normal case L depends on every
+# observation, not only on their mean.  The estimate is the integer d maximising L over all gaps that keep every
+# x_i inside the support [1, exp(mu + 6 sigma)], found by a coarse scan (stride 64) and an exhaustive scan of the
+# 129 gaps around the coarse optimum.
+# ---------------------------------------------------------------------------------------------------------------
+def _lognormal_tables(mu, sigma):
+    import numpy as np
+    x_max = int(min(math.exp(mu + 6.0 * sigma), 4.0e6))
+    x = np.arange(1, x_max + 1, dtype=np.float64)
+    lx = np.log(x)
+    f = np.exp(-((lx - mu) ** 2) / (2.0 * sigma * sigma)) / (x * sigma * math.sqrt(2.0 * math.pi))
+    F0 = np.concatenate(([0.0], np.cumsum(f)))              # F0[k] = sum_{x <= k} f(x)
+    F1 = np.concatenate(([0.0], np.cumsum(f * x)))
+    return x_max, F0, F1
+
+
+def _lognormal_log_g(d, x_max, F0, F1, c_min, c_max, r):
+    """log g(d) for an array of integer gaps d (three linear pieces of w, prefix sums of f and x f)."""
+    import numpy as np
+    d = np.asarray(d, dtype=np.int64)
+
+    def seg(a, b):                                           # sums over integer x in [a, b] clipped to [1, x_max]
+        a = np.clip(a, 1, x_max + 1)
+        b = np.clip(b, 0, x_max)
+        ok = b >= a
+        a0 = np.where(ok, a, 1)
+        b0 = np.where(ok, b, 0)
+        return np.where(ok, F0[b0] - F0[a0 - 1], 0.0), np.where(ok, F1[b0] - F1[a0 - 1], 0.0)
+    s0, s1 = seg(d + 2 * r, d + c_min + r - 1)               # w = x - d - 2r + 1
+    g = s1 - (d + 2 * r - 1) * s0
+    s0, s1 = seg(d + c_min + r, d + c_max + r)               # w = c_min - r + 1
+    g = g + (c_min - r + 1) * s0
+    s0, s1 = seg(d + c_max + r + 1, d + c_min + c_max)       # w = c_min + c_max + d - x + 1
+    g = g + (c_min + c_max + d + 1) * s0 - s1
+    with np.errstate(divide='ignore'):
+        return np.where(g > 0.0, np.log(np.where(g > 0.0, g, 1.0)), -np.inf)
+
+
+_LN_CACHE = {}
+
+
+def lognormal_GapEstimator(mu, sigma, read_length, samples, c1_len, c2_len=None):
+    import numpy as np
+    obs = np.asarray(samples, dtype=np.int64)
+    n = obs.shape[0]
+    if n == 0:
+        return 0
+    key = (float(mu), float(sigma))
+    if key not in _LN_CACHE:
+        _LN_CACHE.clear()
+        _LN_CACHE[key] = _lognormal_tables(mu, sigma)
+    x_max, F0, F1 = _LN_CACHE[key]
+    if c2_len is None:
+        c2_len = 10 * x_max
+    r = int(round(read_length))
+    c_min, c_max = int(min(c1_len, c2_len)), int(max(c1_len, c2_len))
+    d_lo, d_hi = 1 - int(obs.min()), x_max - int(obs.max())
+    if d_hi < d_lo:
+        return int(round(math.exp(mu) - float(obs.mean())))
+
+    def loglik(ds):
+        ds = np.asarray(ds, dtype=np.int64)
+        out = np.empty(ds.shape[0], dtype=np.float64)
+        for a in range(0, ds.shape[0], 4096):                # bounded (gaps x observations) blocks
+            blk = ds[a:a + 4096]
+            lx = np.log((obs[None, :] + blk[:, None]).astype(np.float64))
+            out[a:a + 4096] = (-lx - ((lx - mu) ** 2) / (2.0 * sigma * sigma)).sum(axis=1)
+        return out - n * _lognormal_log_g(ds, x_max, F0, F1, c_min, c_max, r)
+    coarse = np.arange(d_lo, d_hi + 1, 64, dtype=np.int64)
+    best = int(coarse[int(np.argmax(loglik(coarse)))])
+    fine = np.arange(max(d_lo, best - 64), min(d_hi, best + 64) + 1, dtype=np.int64)
+    return int(fine[int(np.argmax(loglik(fine)))])

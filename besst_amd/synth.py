@@ -48,7 +48,7 @@ def make_assembly(nc, median_len, seed, sigma_log=1.0, min_len=500, max_len=2000
 
 class LibrarySpec(object):
     def __init__(self, orientation='fr', mean=500.0, sd=50.0, contam_frac=0.0, contam_mean=350.0,
-                 contam_sd=60.0, read_len=100, dup_frac=0.01, fishy_frac=0.001, softclip_frac=0.05):
+                 contam_sd=60.0, read_len=100, dup_frac=0.01, fishy_frac=0.001, softclip_frac=0.05, lognormal_sigma=None):
         self.orientation = orientation
         self.mean = mean
         self.sd = sd
@@ -59,6 +59,7 @@ class LibrarySpec(object):
         self.dup_frac = dup_frac
         self.fishy_frac = fishy_frac
         self.softclip_frac = softclip_frac
+        self.lognormal_sigma = lognormal_sigma      # insert sizes exp(N(ln mean, .)) instead of N(mean, sd): a skewed library
 
 
 def simulate_library(asm, spec, n_pairs, seed, chunk=4_000_000):
@@ -75,8 +76,10 @@ def simulate_library(asm, spec, n_pairs, seed, chunk=4_000_000):
         m = min(chunk, max(1024, int((n_pairs - done) * 1.3)))
         start = rng.integers(0, asm.total, m)
         contam = rng.random(m) < spec.contam_frac
-        x = np.where(contam, rng.normal(spec.contam_mean, spec.contam_sd, m),
-                     rng.normal(spec.mean, spec.sd, m))
+        main = rng.normal(spec.mean, spec.sd, m)
+        if getattr(spec, 'lognormal_sigma', None):
+            main = np.exp(np.log(spec.mean) + spec.lognormal_sigma * (main - spec.mean) / spec.sd)
+        x = np.where(contam, rng.normal(spec.contam_mean, spec.contam_sd, m), main)
         x = np.maximum(np.rint(x).astype(np.int64), 2 * r)
         lpos = start                       # left read  [lpos, lpos + r)
         rpos = start + x - r               # right read [rpos, rpos + r)

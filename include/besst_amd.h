@@ -314,6 +314,15 @@ int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, i
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table,
                             int64_t* aligned, const int32_t* tails, int32_t rank, int32_t* slice_info);
+/* out[i] = d + sigma^2 g'(d) / g(d) at d = d_lower + i, i < n, for two contigs of length contig_len: the left-hand side of
+ * the GapEst ML condition over a run of gaps.  mathstats' PreCalcMLvaluesOfdLongContigs (MakeScaffolds.py:68) rounds
+ * these values and inverts the map into its {observation -> gap} table; besst_amd/mathstats_compat.py does that on the
+ * host from this array.  _dev: device pointer out, nothing synchronised; _ctx: host pointer out. */
+int besst_dev_gap_condition_table(void* stream, double mean, double sigma, double read_len, double contig_len,
+                                  int32_t d_lower, int32_t n, double* out);
+int besst_ctx_gap_condition_table(besst_ctx* ctx, double mean, double sigma, double read_len, double contig_len,
+                                  int32_t d_lower, int32_t n, double* h_out);
+
 /* Per-edge scoring on caller-owned device buffers (the device-pointer form of besst_ctx_score_edges;
  * CreateGraph.py:498-614): ML gap by bisection, expected sigma, KS numerator h = max|#{l1 <= x} - #{l2 <= x}| on the
  * centred per-end observations.  In the sharded build every rank scores the rows it owns.

@@ -104,8 +104,28 @@ def edgecase_stream(asm, spec, seed):
     return RecordBatch(refs, lens, **cat)
 
 
+def lognormal_scenario(mods):
+    """A skewed library (insert sizes exp(N(ln 1500, 0.35))): libmetrics sets param.lognormal and GiveScoreOnEdges takes
+    its log-normal branch (CreateGraph.py:485-531).  That branch is Python 2 code - `range(0, ..., max_isize/50)` raises
+    TypeError on Python 3 (:490) - so the reference module gets ONE patch for this scenario: a `range` that truncates
+    its arguments to int, i.e. Python 2's integer division.  lnpe.GapEstimator is the shim's restatement
+    (tests/refharness/stubs/mathstats/log_normal_param_est.py): like the normal gap it pins plumbing only."""
+    import builtins
+    cg = mods['CreateGraph']
+    cg.range = lambda *a: builtins.range(*[int(v) for v in a])
+    try:
+        asm = synth.make_assembly(300, 6000, 501)
+        ln = synth.simulate_library(asm, synth.LibrarySpec('fr', 1500.0, 150.0, lognormal_sigma=0.35), 30000, 502)
+        save_batch('stream_ln', ln)
+        scenario(mods, 'fr_lognormal', 'stream_ln', ln, {})
+    finally:
+        del cg.range
+
+
 def main():
     mods = loader.load()
+    if len(sys.argv) > 1 and sys.argv[1] == 'lognormal':     # only the scenario added in round 2
+        return lognormal_scenario(mods)
 
     # ---- PE library, short contigs: many contig-spanning pairs --------------------------------
     asm = synth.make_assembly(300, 1500, 101)
@@ -142,6 +162,8 @@ def main():
     save_batch('stream_edge', ec)
     fasta = [n for i, n in enumerate(ec.references) if i % 37 != 5]
     scenario(mods, 'fr_edgecases', 'stream_edge', ec, {}, fasta_names=fasta)
+
+    lognormal_scenario(mods)
 
 
 if __name__ == '__main__':

@@ -60,3 +60,26 @@ def test_score_kernel_gap_and_sigma_vs_brute_force(mu, sigma, r):
         want_sd = GN.span_sd(int(gap[i]), mu, sigma, c1, c2, ri)
         if want_sd is not None and sd0[i] < 2 ** 31:
             assert abs(sd0[i] - want_sd) <= 0.005 * want_sd + 0.05, (edges[i], sd0[i], want_sd)
+
+
+@pytest.mark.parametrize('mu,sigma,r', [(500.0, 50.0, 100), (5199.56, 499.55, 100), (2500.0, 250.0, 100.38)])
+def test_gap_table_of_long_contigs(mu, sigma, r):
+    """PreCalcMLvaluesOfdLongContigs (MakeScaffolds.py:68,447): the table built from the device's evaluation of the ML
+    condition equals the host restatement's (an entry may move by one where the device's erf/exp land on the other side of
+    a rounding boundary), and reading a gap off it agrees with the brute-force likelihood to +-1 bp."""
+    from besst_amd import device, mathstats_compat as MC
+    host = MC.PreCalcMLvaluesOfdLongContigs(mu, sigma, r)
+    with device.GraphContext(0) as ctx:
+        dev = MC.PreCalcMLvaluesOfdLongContigs(mu, sigma, r, ctx=ctx)
+    assert set(dev) == set(host) or len(set(dev) ^ set(host)) <= 2
+    common = sorted(set(dev) & set(host))
+    assert len(common) > 100
+    diff = [k for k in common if dev[k] != host[k]]
+    assert all(abs(dev[k] - host[k]) <= 1 for k in diff) and len(diff) <= len(common) // 100 + 1
+    big = int(10.0 * (mu + 4 * sigma) + 10.0 * r)
+    ri = int(round(r))
+    for k in common[5:-5:max(1, len(common) // 12)]:
+        want, fs = GN.ml_gap(mu, sigma, ri, mu - k, big, big)      # naive gap k  <=>  mean observation mu - k
+        if want in (min(fs), max(fs)):
+            continue
+        assert abs(dev[k] - want) <= 1, (k, dev[k], want)
