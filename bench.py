@@ -183,10 +183,54 @@ def stage_timings(wl):
             out['score_edges_per_s'] = rows.shape[0] / dt
         lib_h.besst_prof_enable(0)
         out.update(linearize_timing())
+        out.update(chain_timing())
         out.update(scorepaths_timing())
         pairs = len(batch) // 2
         out['pcie_inclusive_pairs_per_s'] = pairs / ((out['h2d_push_ms'] + out['ctx_build_graph_ms']) * 1e-3)
     return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in out.items()}
+
+
+def dropin_timing(device, config, pairs=None, contigs=None):
+    """Wall time of the drop-in as BESST calls it (runBESST:168,182): libmetrics.get_metrics + CreateGraph.PE on a host
+    RecordBatch (what besst_amd.bamio.read_bam returns), everything included - upload, device passes, download of the
+    edge table, and the Python side that fills Contig/Scaffold objects and the networkx-compatible graphs.  `library_s`
+    is the share spent inside the C ABI (transfers + kernels), the rest is interpreter time."""
+    import io
+    import tempfile
+    from besst_amd import CreateGraph, Parameter, device as dev_mod, libmetrics, session, workload
+    wl = workload.make_device(device, config, 0, pairs=pairs, nc=contigs)
+    batch = wl['batch']
+    del wl['cols']
+    p = Parameter.parameter()
+    p.scaffold_indexer = 1; p.min_mapq = 11; p.lower_cov_cutoff = 0.001; p.cov_cutoff = None; p.first_lib = True
+    p.orientation = wl['lib']['orientation']; p.detect_duplicate = True; p.extend_paths = True; p.no_score = False
+    p.detect_haplotype = False; p.print_scores = False; p.max_contig_overlap = 200; p.pass_number = 1
+    p.information_file = io.StringIO(); p.output_directory = tempfile.mkdtemp(prefix='besst_amd_')
+    p.contig_index = dict(enumerate(batch.references))
+
+    class SeqLen(object):                                # PE only takes len() of a contig's sequence and stores it
+        __slots__ = ('n',)
+
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+    C_dict = {name: SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
+    dev_mod.CALL_SECONDS = {}
+    t0 = time.perf_counter()
+    libmetrics.get_metrics(batch, p, p.information_file)
+    t1 = time.perf_counter()
+    G, Gp = CreateGraph.PE({}, {}, p.information_file, C_dict, p, {}, {}, batch)
+    t2 = time.perf_counter()
+    lib_s = dict(dev_mod.CALL_SECONDS)
+    dev_mod.CALL_SECONDS = None
+    session.close_session(batch)
+    total = t2 - t0
+    return {'records': len(batch), 'get_metrics_s': round(t1 - t0, 3), 'PE_s': round(t2 - t1, 3), 'total_s': round(total, 3),
+            'library_s': round(sum(lib_s.values()), 3), 'library_calls_s': {k: round(v, 3) for k, v in lib_s.items()},
+            'host_share': round(1.0 - sum(lib_s.values()) / total, 3), 'edges_G': G.number_of_edges(),
+            'edges_G_prime': Gp.number_of_edges(), 'pairs_per_s': (len(batch) // 2) / total}
 
 
 def linearize_workload(n_scaf, n_edges, seed=20240929):
@@ -245,6 +289,37 @@ def linearize_timing(n_scaf=2_000_000, n_edges=3_000_000):
     return {'linearize_scaffolds': n_scaf, 'linearize_edges': m, 'linearize_rounds': int(counters[4]),
             'linearize_host_call_ms': host_ms, 'linearize_resident_ms': dev_ms,
             'linearize_edges_per_s': m / (dev_ms * 1e-3), 'linearize_calls_agree': same}
+
+
+def chain_timing(n_scaf=2_000_000, seed=7):
+    """Chain extraction (NewContigsScaffolds' list ranking) on a C5-sized linearised graph: paths of 1..40 scaffolds,
+    wall time through the host-pointer call (copies and the per-pass synchronisation included)."""
+    from besst_amd import MakeScaffolds as MS
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n_scaf)
+    runs = rng.integers(1, 41, n_scaf)
+    ends = np.cumsum(runs)
+    k = int(np.searchsorted(ends, n_scaf)) + 1
+    first = np.concatenate(([0], ends[:k - 1]))
+    is_first = np.zeros(n_scaf, bool)
+    is_first[first[first < n_scaf]] = True
+    sides = rng.integers(0, 2, n_scaf)
+    a = np.arange(n_scaf - 1)
+    joined = ~is_first[a + 1]                               # perm[a] -- perm[a + 1] are neighbours on a path
+    u = 2 * perm[a[joined]] + (1 - sides[a[joined]])
+    v = 2 * perm[a[joined] + 1] + sides[a[joined] + 1]
+    link = np.full(2 * n_scaf, -1, np.int32)
+    link[u], link[v] = v, u
+    gap = np.zeros(2 * n_scaf, np.int32)
+    gap[u] = gap[v] = rng.integers(1, 500, u.shape[0])
+    slen = rng.integers(200, 20000, n_scaf)
+    order = rng.permutation(2 * n_scaf).astype(np.int32)
+    MS.chain_arrays(n_scaf, link, gap, slen, order)
+    t0 = time.perf_counter()
+    _, _, _, passes = MS.chain_arrays(n_scaf, link, gap, slen, order)
+    ms = (time.perf_counter() - t0) * 1e3
+    return {'chain_scaffolds': n_scaf, 'chain_paths': int(is_first.sum()), 'chain_passes': passes,
+            'chain_host_call_ms': ms, 'chain_scaffolds_per_s': n_scaf / (ms * 1e-3)}
 
 
 def scorepaths_workload(n_scaf=50_000, n_links=150_000, n_paths=200_000, seed=11):
@@ -510,6 +585,11 @@ def main_single(args, device, result_fd):
     out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_legs(args, wl, not args.no_stages)
     del wl
     torch.cuda.empty_cache()
+    if not args.no_stages:
+        # end to end through the reference's two entry points, from host records to the scored graphs
+        out['stages']['dropin_' + args.config.lower()] = dropin_timing(device, args.config, args.pairs, args.contigs)
+        if args.also and args.also != args.config and args.pairs is None:
+            out['stages']['dropin_' + args.also.lower()] = dropin_timing(device, args.also)
     if args.also and args.also != args.config and args.pairs is None:
         C_PORT_TIMING.clear()
         res2, wl2, runner2 = measure_single(args, device, args.also, 20, 3, 3)

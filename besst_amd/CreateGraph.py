@@ -208,10 +208,18 @@ def add_link_edges(table, G, G_prime):
         observations = obs_all[lo:hi].tolist()
         if mask[i] & MASK_G:
             # device_row lets GiveScoreOnEdges find the per-end observation lists without copying them
-            G.add_edge(u, v, nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=list(observations), device_row=i,
-                       device_min_node=u)
+            data = dict(nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=list(observations), device_row=i,
+                        device_min_node=u)
+            if u in G._adj and v in G._adj and v not in G._adj[u]:
+                G.add_link(u, v, data)
+            else:
+                G.add_edge(u, v, **data)
         if mask[i] & MASK_GPRIME:
-            G_prime.add_edge(u, v, nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=observations)
+            data = dict(nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=observations)
+            if u in G_prime._adj and v in G_prime._adj and v not in G_prime._adj[u]:
+                G_prime.add_link(u, v, data)
+            else:
+                G_prime.add_edge(u, v, **data)
     return fishy
 
 

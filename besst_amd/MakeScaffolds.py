@@ -6,6 +6,8 @@ Mirror of the reference's functions of the same names (BESST/MakeScaffolds.py):
     RemoveAmbiguousRegionsUsingScore(G, G_prime, Information, param, plot)      :206-241   step 2 (+ remove_edges :156-204)
     RemoveLoops(G, G_prime, Scaffolds, Contigs, Information, param)             :248-274   step 4
     LinearizeGraph(...)   steps 1, 2, 3, 4 in the order of Algorithm (:75-82) with ONE device call
+    NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, Information,
+                        dValuesTable, param, already_visited)                   :270-341   step 5 (+ UpdateInfo :344-482)
 
 They take and mutate the same ``networkx``-1.x style graphs CreateGraph.PE returns (``besst_amd.nxcompat.Graph``),
 print the same lines to ``Information`` and leave the same graphs behind; the work itself runs in
@@ -209,3 +211,161 @@ def LinearizeGraph(G, G_prime, Contigs, Scaffolds, Information, param, device=0)
     print('Remove remaining cycles...', file=Information)
     _apply_step4(G, G_prime, Information, param, arr, alive, after3, res)
     return (G, Contigs, Scaffolds)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# step 5: the linear paths become the new scaffolds
+# -----------------------------------------------------------------------------------------------------------------
+def chain_arrays(n_scaffolds, link, gap, scaffold_length, node_order, device=0):
+    """besst_chain_scaffolds on host arrays (include/besst_amd.h) -> (terminal, beyond, lowest_order, passes)."""
+    lib = _lib.load()
+    n = int(n_scaffolds)
+    link = np.ascontiguousarray(link, np.int32)
+    gap = np.ascontiguousarray(gap, np.int32)
+    slen = np.ascontiguousarray(scaffold_length, np.int32)
+    order = np.ascontiguousarray(node_order, np.int32)
+    if link.shape[0] != 2 * n or gap.shape[0] != 2 * n or slen.shape[0] != n or order.shape[0] != 2 * n:
+        raise ValueError('chain_arrays: array sizes do not match the scaffold count')
+    terminal = np.zeros(max(2 * n, 1), np.int32)
+    beyond = np.zeros(max(2 * n, 1), np.int64)
+    lowest = np.zeros(max(2 * n, 1), np.int32)
+    import ctypes as C
+    passes = C.c_int32(0)
+    _lib.check(lib.besst_chain_scaffolds(device, n, _lib.ptr(link), _lib.ptr(gap), _lib.ptr(slen), _lib.ptr(order),
+                                         _lib.ptr(terminal), _lib.ptr(beyond), _lib.ptr(lowest), C.byref(passes)),
+               'besst_chain_scaffolds')
+    return terminal[:2 * n], beyond[:2 * n], lowest[:2 * n], int(passes.value)
+
+
+def _edge_gap(data, c1_len, c2_len, dValuesTable, param):
+    """The gap UpdateInfo adds when it crosses a link edge (:413-471) -> (avg_gap, value appended to
+    param.gap_estimations or None).  Symmetric in the two scaffolds."""
+    from . import mathstats_compat as GC
+    if 'avg_gap' in data:
+        return data['avg_gap'], data['avg_gap']
+    if param.lognormal:
+        return GC.lognormal_GapEstimator(param.lognormal_mean, param.lognormal_sigma, param.read_len,
+                                         data['observations'], c1_len, c2_len=c2_len), None
+    sum_obs, nr_links = data['obs'], data['nr_links']
+    data_observation = (nr_links * param.mean_ins_size - sum_obs) / float(nr_links)
+    mean_obs = sum_obs / float(nr_links)
+    if param.std_dev_ins_size and nr_links >= 5:
+        far = param.mean_ins_size + 4 * param.std_dev_ins_size
+        near = param.std_dev_ins_size + param.read_len
+        if c1_len > far and c2_len > far:
+            try:
+                return dValuesTable[int(round(data_observation, 0))], None
+            except (KeyError, TypeError):                # TypeError: no table was built (dValuesTable is None)
+                return GC.GapEstimator(param.mean_ins_size, param.std_dev_ins_size, param.read_len, mean_obs, c1_len,
+                                       c2_len), None
+        if c1_len > near and c2_len > near:
+            return GC.GapEstimator(param.mean_ins_size, param.std_dev_ins_size, param.read_len, mean_obs, c1_len,
+                                   c2_len), None
+    return int(data_observation), int(data_observation)
+
+
+def NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, Information, dValuesTable, param,
+                        already_visited, device=0):
+    """Mirror of MakeScaffolds.NewContigsScaffolds (:270-341) with UpdateInfo (:344-482): every connected component of
+    the linearised G - a path of scaffolds - becomes one new scaffold.  Same arguments, same mutations: contigs get the
+    new scaffold id, their position along the path and (for scaffolds the walk enters through 'R') the flipped
+    direction; the old scaffold objects are deleted, the new ones appended; G loses the nodes of every component; with
+    param.extend_paths G_prime gets the new scaffold's two nodes with the link edges of the path's ends.  The walk
+    itself - which end a path starts from, every scaffold's position and orientation - comes from the device
+    (besst_chain_scaffolds, list ranking); the per-edge gap values follow the reference's rules on the host.
+
+    Not provided: PROWithinScaf (:283-285), the path search the reference runs per component when param.extend_paths
+    (ExtendLargeScaffolds' search is sequential and stays with BESST); components are taken as they are."""
+    import networkx as nx
+    from . import Scaffold
+    nodes = G.nodes()
+    order_of = {n: i for i, n in enumerate(nodes)}
+    index = {}
+    for s, _ in nodes:
+        index.setdefault(s, len(index))
+    scaffolds = list(index)
+    n = len(scaffolds)
+    if n == 0:
+        print('Nr of new scaffolds created in this step: 0', file=Information)
+        return (Contigs, Scaffolds, param)
+
+    def code(node):
+        return 2 * index[node[0]] + (node[1] == 'R')
+    link = np.full(2 * n, -1, np.int32)
+    gap = np.zeros(2 * n, np.int32)
+    appended = {}
+    slen = np.array([Scaffolds[s].s_length for s in scaffolds], np.int64)
+    order = np.zeros(2 * n, np.int32)
+    for node, i in order_of.items():
+        order[code(node)] = i
+    for u, v, data in G.edges(data=True):
+        if data['nr_links'] is None:
+            continue
+        avg_gap, app = _edge_gap(data, Scaffolds[u[0]].s_length, Scaffolds[v[0]].s_length, dValuesTable, param)
+        if avg_gap <= 1:
+            avg_gap = 1
+        cu, cv = code(u), code(v)
+        link[cu], link[cv] = cv, cu
+        gap[cu] = gap[cv] = int(avg_gap)
+        appended[cu] = appended[cv] = app
+    terminal, beyond, lowest, _ = chain_arrays(n, link, gap, slen, order, device)
+    k = np.arange(n)
+    ord_l, ord_r = order[terminal[2 * k]], order[terminal[2 * k + 1]]
+    from_l = ord_l < ord_r                                   # the path's start lies beyond this scaffold's 'L' end
+    pos = np.where(from_l, beyond[2 * k], beyond[2 * k + 1])
+    comp = np.minimum(np.minimum(lowest[2 * k], lowest[2 * k + 1]), np.minimum(order[2 * k], order[2 * k + 1]))
+    comp_ids, comp_of = np.unique(comp, return_inverse=True)     # ascending first node = nx.connected_components order
+    print('Nr of new scaffolds created in this step: ' + str(len(comp_ids)), file=Information)
+    members = [[] for _ in comp_ids]
+    for j in np.lexsort((pos, comp_of)).tolist():
+        members[comp_of[j]].append(j)
+    node_of = {}
+    for node in nodes:
+        node_of[code(node)] = node
+    for path in members:
+        param.scaffold_indexer += 1
+        contig_list = []
+        first, last = path[0], path[-1]
+        start = node_of[2 * first + (0 if from_l[first] else 1)]       # the terminal the walk starts from
+        end = node_of[2 * last + (1 if from_l[last] else 0)]
+        for a, j in enumerate(path):
+            s = scaffolds[j]
+            obj = Scaffolds[s]
+            p0 = int(pos[j])
+            if from_l[j]:                                    # entered through 'L': same orientation (:363-378)
+                for contig in obj.contigs:
+                    contig.scaffold = param.scaffold_indexer
+                    contig.position += p0
+                    contig_list.append(contig)
+            else:                                            # entered through 'R': flipped (:384-404)
+                for contig in obj.contigs:
+                    contig.scaffold = param.scaffold_indexer
+                    contig.position = p0 + (obj.s_length - contig.position) - contig.length
+                    contig.direction = bool(True - contig.direction)
+                    contig_list.append(contig)
+            if a + 1 < len(path):                            # the edge the walk crosses next
+                app = appended[2 * j + (1 if from_l[j] else 0)]
+                if app is not None:
+                    param.gap_estimations.append(app)
+            del Scaffolds[s]
+        longest = max(contig_list, key=lambda c: c.position + c.length)
+        S = Scaffold.scaffold(param.scaffold_indexer, contig_list, longest.position + longest.length)
+        Scaffolds[S.name] = S
+        old_nodes = [node_of[2 * j + side] for j in path for side in (0, 1)]
+        old_nodes.sort(key=lambda nd: order_of[nd])
+        G.remove_nodes_from(old_nodes)
+        if param.extend_paths:
+            G_prime.add_node((S.name, 'L'))
+            G_prime.add_node((S.name, 'R'))
+            G_prime.add_edge((S.name, 'L'), (S.name, 'R'), nr_links=None)
+            try:
+                for new_side, old in (('L', start), ('R', end)):
+                    for nbr in G_prime.neighbors(old):
+                        d = G_prime[old][nbr]
+                        if d['nr_links']:
+                            G_prime.add_edge((S.name, new_side), nbr, nr_links=d['nr_links'], obs=d['obs'],
+                                             obs_sq=d['obs_sq'], observations=d['observations'])
+                G_prime.remove_nodes_from(old_nodes)
+            except (nx.exception.NetworkXError, KeyError):
+                pass
+    return (Contigs, Scaffolds, param)

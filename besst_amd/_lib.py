@@ -92,6 +92,9 @@ _SIGNATURES = {
                                           _P, _P, _P, C.c_int32, _P]),
     'besst_dev_gap_condition_table': (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _P]),
     'besst_ctx_gap_condition_table': (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _P]),
+    'besst_dev_chain_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_chain_scaffolds': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    'besst_chain_scaffolds': (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                         C.c_double, _P, _P, _P, _P, _P, C.c_size_t]),
     'besst_dev_metrics_workspace_bytes': (C.c_size_t, [C.c_int64]),

@@ -39,6 +39,28 @@ class EdgeTable(object):
         return int(self.key.shape[0])
 
 
+# Wall time spent inside the C-ABI calls of GraphContext (seconds per method), filled only while `CALL_SECONDS` is a dict:
+# bench.py uses it to split the drop-in's wall time into library (device + transfers) and Python host time.
+CALL_SECONDS = None
+
+
+def _timed(fn):
+    import functools
+    import time
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        acc = CALL_SECONDS
+        if acc is None:
+            return fn(self, *args, **kwargs)
+        t0 = time.perf_counter()
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            acc[fn.__name__] = acc.get(fn.__name__, 0.0) + time.perf_counter() - t0
+    return wrapper
+
+
 class GraphContext(object):
     def __init__(self, device=0):
         self._lib = _lib.load()
@@ -66,6 +88,7 @@ class GraphContext(object):
         return False
 
     # ---- inputs ----------------------------------------------------------------------------------
+    @_timed
     def set_contigs(self, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls):
         cols = [_lib.as_col(scaf_id, np.int32), _lib.as_col(scaf_len, np.int32), _lib.as_col(ctg_pos, np.int32),
                 _lib.as_col(ctg_len, np.int32), _lib.as_col(direction, np.uint8), _lib.as_col(cls, np.uint8)]
@@ -85,6 +108,7 @@ class GraphContext(object):
     def clear_records(self):
         _lib.check(self._lib.besst_ctx_clear_records(self._ctx), 'clear_records')
 
+    @_timed
     def push_records(self, batch):
         """``batch``: a RecordBatch (or anything with the eight SoA columns)."""
         cols = [_lib.as_col(batch.tid, np.int32), _lib.as_col(batch.mtid, np.int32),
@@ -95,6 +119,7 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
 
     # ---- library statistics ----------------------------------------------------------------------
+    @_timed
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):
         top = _lib.as_col(top_mask, np.uint8)
         isize = np.empty(SAMPLE_CAP, dtype=np.int32)
@@ -105,6 +130,7 @@ class GraphContext(object):
             int(bool(want_isize)), _lib.ptr(isize), _lib.ptr(contam), C.byref(counts)), 'metrics_sample')
         return isize[:counts.n_isize], contam[:counts.n_contam], counts
 
+    @_timed
     def gap_condition_table(self, mean, sigma, read_len, contig_len, d_lower, n):
         out = np.zeros(int(n), dtype=np.float64)
         _lib.check(self._lib.besst_ctx_gap_condition_table(self._ctx, float(mean), float(sigma), float(read_len),
@@ -112,6 +138,7 @@ class GraphContext(object):
                    'gap_condition_table')
         return out
 
+    @_timed
     def value_histogram(self, values, n_bins):
         vals = _lib.as_col(values, np.int32)
         hist = np.zeros(int(n_bins), dtype=np.int64)
@@ -121,6 +148,7 @@ class GraphContext(object):
         return hist, int(overflow[0])
 
     # ---- graph build -----------------------------------------------------------------------------
+    @_timed
     def build_graph(self):
         _lib.check(self._lib.besst_ctx_build_graph(self._ctx), 'build_graph')
         rows, tuples = C.c_int64(), C.c_int64()
@@ -147,6 +175,7 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_fetch_counters(self._ctx, C.byref(ctr)), 'fetch_counters')
         return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, lo, hi), aligned, ctr
 
+    @_timed
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
         rows = _lib.as_col(rows, np.uint32)
         swap = _lib.as_col(swap, np.uint8)

@@ -413,6 +413,29 @@ int besst_dev_linearize(void* stream, int32_t steps, int64_t n_scaffolds, int64_
                         uint8_t* scaffold_removed_by, uint8_t* node_ambivalent, double* node_top,
                         double* node_second, uint32_t* node_best_edge, int64_t* counters);
 
+/* ---- chain extraction of the linearised scaffold graph (the rest of SURVEY 8(f) rank 3) ----------------------------
+ * The data-parallel part of MakeScaffolds.NewContigsScaffolds / UpdateInfo (MakeScaffolds.py:270-341, 344-482): after
+ * steps 1-4 every scaffold end has at most one link edge, i.e. the graph is a set of paths, and the reference walks each
+ * path from one end.  Nodes: 2 * scaffold + (side == 'R'), scaffolds numbered in node order.
+ *   link[2n]             the node at the other end of a node's link edge, -1 without one
+ *   gap[2n]              the gap the walk adds when it crosses that edge (max(1, int(avg_gap)), MakeScaffolds.py:468-471)
+ *   scaffold_length[n]   s_length of every scaffold;  node_order[2n]  position of every node in G.nodes()
+ * Out, per node h (walking OUT of the scaffold through end h):
+ *   terminal[2n]         the end of the path on that side (h itself when h has no link)
+ *   beyond[2n]           lengths of the scaffolds beyond h on that side + the gaps in between (int64)
+ *   lowest_order[2n]     smallest node_order among the nodes beyond h (INT32_MAX when there are none)
+ * The host mirror (besst_amd/MakeScaffolds.py) turns these into the reference's Scaffolds / Contigs state.
+ * besst_chain_scaffolds takes host pointers; besst_dev_chain_scaffolds device pointers (it synchronises the stream
+ * between its doubling passes to find out when nothing moves any more); *passes = doubling passes run. */
+size_t besst_dev_chain_workspace_bytes(int64_t n_scaffolds);
+int besst_dev_chain_scaffolds(void* stream, int64_t n_scaffolds, const int32_t* link, const int32_t* gap,
+                              const int32_t* scaffold_length, const int32_t* node_order, void* workspace,
+                              size_t workspace_bytes, int32_t* terminal, int64_t* beyond, int32_t* lowest_order,
+                              int32_t* h_passes);
+int besst_chain_scaffolds(int device, int64_t n_scaffolds, const int32_t* link, const int32_t* gap,
+                          const int32_t* scaffold_length, const int32_t* node_order, int32_t* terminal, int64_t* beyond,
+                          int32_t* lowest_order, int32_t* passes);
+
 /* ---- ScorePaths on the link graph -------------------------------------------------------------
  * Connectivity weights of a batch of candidate paths: calculate_connectivity / calculate_connectivity_contamination
  * of ScorePaths (ExtendLargeScaffolds.py:29-130); the path search itself stays on the host.

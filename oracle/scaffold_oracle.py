@@ -126,3 +126,57 @@ def linearize(n_scaf, a, b, score):
     for k in on_cycle:
         present[k] = False
     return dict(alive2=alive, present=present, isolated=[iso1, iso3], cycles=cycles, ambivalent=amb)
+
+
+def new_contigs_scaffolds(node_order, link, gap, appended, slen, contigs, scaffold_indexer):
+    """NewContigsScaffolds + UpdateInfo (MakeScaffolds.py:270-341, 344-482) on arrays, walked sequentially like the
+    reference (TEST INFRASTRUCTURE; the device path ranks the lists in parallel, besst_amd/csrc/chain.hip).
+
+      node_order  nodes (2k / 2k+1 of scaffold k) in G.nodes() order
+      link        per node: the node at the other end of its link edge, -1 without one (after steps 1-4: a set of paths)
+      gap         per node: what crossing that edge adds to the position (max(1, int(avg_gap)), :468-471)
+      appended    per node: the value that branch appends to param.gap_estimations, or None (:413-467)
+      slen        per scaffold: s_length
+      contigs     per scaffold: list of [name, position, direction, length]  (Scaffold.contigs order)
+    Returns (new_scaffolds [(id, [[name, position, direction, length], ...], s_length)] in creation order,
+             gap_estimations, scaffold_indexer afterwards)."""
+    n_nodes = len(link)
+    seen = [False] * n_nodes
+    out, estimations = [], []
+    for first in node_order:                                 # nx.connected_components: components by first node
+        if seen[first]:
+            continue
+        comp, stack = [], [first]                            # the component's nodes
+        seen[first] = True
+        while stack:
+            x = stack.pop()
+            comp.append(x)
+            for y in (x ^ 1, link[x]):
+                if y >= 0 and not seen[y]:
+                    seen[y] = True
+                    stack.append(y)
+        members = set(comp)
+        in_order = [x for x in node_order if x in members]
+        start = next(x for x in in_order if link[x] < 0)     # first node with one neighbour (:287-290)
+        scaffold_indexer += 1
+        pos = 0
+        contig_list = []
+        node = start
+        while True:
+            k, side = node >> 1, node & 1
+            for name, cpos, cdir, clen in contigs[k]:
+                if side == 0:                                # entered through 'L' (:363-378)
+                    contig_list.append([name, cpos + pos, cdir, clen])
+                else:                                        # entered through 'R' (:384-404)
+                    contig_list.append([name, pos + (slen[k] - cpos) - clen, bool(True - cdir), clen])
+            pos += slen[k]
+            leave = node ^ 1
+            if link[leave] < 0:                              # reached the end of the path (:348-357)
+                break
+            if appended[leave] is not None:
+                estimations.append(appended[leave])
+            pos += gap[leave]
+            node = link[leave]
+        length = max(c[1] + c[3] for c in contig_list)
+        out.append((scaffold_indexer, contig_list, length))
+    return out, estimations, scaffold_indexer
