@@ -129,8 +129,8 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
         print('User has set -e to be {0} for this library.'.format(param.edgesupport), file=Information)
 
     counter_low_support = 0
-    for u, v in G.edges():
-        nr = G[u][v]['nr_links']
+    for u, v, d in G.edges(data=True):
+        nr = d['nr_links']
         if nr is not None and nr < param.edgesupport:
             G.remove_edge(u, v)
             counter_low_support += 1
@@ -227,10 +227,8 @@ def add_link_edges(table, G, G_prime):
 # host-side stages, same names as the reference
 # -----------------------------------------------------------------------------------------------------------
 def InitializeGraph(dict_with_scaffolds, graph, Information):
-    for scaffold_ in dict_with_scaffolds:
-        graph.add_edge((scaffold_, 'L'), (scaffold_, 'R'), nr_links=None)
-        graph.node[(scaffold_, 'L')]['length'] = dict_with_scaffolds[scaffold_].s_length
-        graph.node[(scaffold_, 'R')]['length'] = dict_with_scaffolds[scaffold_].s_length
+    for scaffold_, obj in dict_with_scaffolds.items():
+        graph.add_scaffold(scaffold_, obj.s_length)
     return ()
 
 
@@ -437,8 +435,7 @@ def infer_spurious_link_count_threshold(G_prime, param):
     link_params = e_nr_links.Param(param.mean_ins_size, param.std_dev_ins_size, cov, param.read_len, 0)
     gap = param.mean_ins_size + param.std_dev_ins_size - 2 * param.read_len
     expected = e_nr_links.ExpectedLinks(100000, 100000, gap, link_params)
-    link_counter = Counter(G_prime[u][v]['nr_links'] for u, v in G_prime.edges()
-                           if G_prime[u][v]['nr_links'] is not None)
+    link_counter = Counter(d['nr_links'] for _, _, d in G_prime.edges(data=True) if d['nr_links'] is not None)
     total_included_edges = 0
     for link_number in sorted(link_counter, reverse=True):
         total_included_edges += link_counter[link_number]
@@ -454,17 +451,17 @@ def remove_edges_below_threshold(graph, param):
     """Dense-region pruning; order dependent, so it runs on the host in graph iteration order (:355-404)."""
     print('Remove edges in high complexity areas.', file=param.information_file)
     limit = param.expected_links_over_mean_plus_stddev
-    thin = [(u, v) for u, v in graph.edges()
-            if graph[u][v]['nr_links'] is not None and graph[u][v]['nr_links'] < limit]
+    thin = [(u, v) for u, v, d in graph.edges(data=True) if d['nr_links'] is not None and d['nr_links'] < limit]
     removed = 0
+    adj = graph.edge                                     # degrees change as edges go: read them at visiting time
     for u, v in thin:
-        if len(graph.neighbors(u)) > 4 and len(graph.neighbors(v)) > 4:
+        if len(adj[u]) > 4 and len(adj[v]) > 4:
             graph.remove_edge(u, v)
             removed += 1
     print('Removed total of {0} edges in high density areas.'.format(removed), file=param.information_file)
     counter_low_support = 0
-    for u, v in graph.edges():
-        nr = graph[u][v]['nr_links']
+    for u, v, d in graph.edges(data=True):
+        nr = d['nr_links']
         if nr is not None and nr < param.edgesupport:
             graph.remove_edge(u, v)
             counter_low_support += 1
@@ -531,8 +528,7 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
             return small_scaffolds[sid].s_length
 
     edges, rows, swap, len1, len2 = [], [], [], [], []
-    for u, v in G.edges():
-        data = G[u][v]
+    for u, v, data in G.edges(data=True):
         if data['nr_links'] is None:
             continue
         edges.append((u, v))

@@ -61,6 +61,21 @@ class Graph(_BaseGraph):
                     H._adj[u][v] = d
         return H
 
+    def add_scaffold(self, scaffold, length):
+        """The two end nodes of a scaffold with their 'length' attribute and the intra-scaffold edge (nr_links=None):
+        what InitializeGraph does per scaffold (CreateGraph.py:710-722) with three networkx calls."""
+        left, right = (scaffold, 'L'), (scaffold, 'R')
+        if left in self._node or right in self._node:
+            self.add_edge(left, right, nr_links=None)
+            self._node[left]['length'] = length
+            self._node[right]['length'] = length
+            return
+        data = {'nr_links': None}
+        self._node[left] = {'length': length}
+        self._node[right] = {'length': length}
+        self._adj[left] = {right: data}
+        self._adj[right] = {left: data}
+
     def add_link(self, u, v, data):
         """add_edge(u, v, **data) for two nodes that are already in the graph and not yet adjacent (what
         CreateGraph.PE's bulk insertion of the device's edge rows guarantees): the attribute dict is stored as it is,
