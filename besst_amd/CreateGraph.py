@@ -579,8 +579,15 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
             sys.stderr.write(str(std_dev) + ' ' + str(std_dev_d_eq_0) + ' ' + str(span_score) + '\n')
         data['score'] = std_dev_score + span_score if std_dev_score > 0.5 and span_score > 0.5 else 0
         if score_file is not None:
-            print('{0}\t{1}\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}'.format(u[0], u[1], v[0], v[1], gap, std_dev_score,
-                                                                   span_score, n), file=score_file)
+            # --print_scores rows as the reference writes them (:622-651): the contig names of each scaffold, listed
+            # from the far end towards the link, and one sign per contig - '+' throughout for an 'R' end on the left
+            # and an 'L' end on the right, '-' throughout otherwise (the reference's `'+' if True else '-'`)
+            objs1 = Scaffolds[u[0]].contigs if u[1] == 'R' else Scaffolds[u[0]].contigs[::-1]
+            objs2 = Scaffolds[v[0]].contigs if v[1] == 'L' else Scaffolds[v[0]].contigs[::-1]
+            print('{0}\t{1}\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}'.format(
+                ';'.join(c.name for c in objs1), ';'.join(('+' if u[1] == 'R' else '-') for _ in objs1),
+                ';'.join(c.name for c in objs2), ';'.join(('+' if v[1] == 'L' else '-') for _ in objs2),
+                gap, std_dev_score, span_score, n), file=score_file)
     if score_file is not None:
         score_file.close()
     print('Number of significantly spurious edges:', 0, file=Information)

@@ -253,6 +253,8 @@ def get_metrics(bam_file, param, Information):
         param.mean_ins_size = mu_adj
         param.std_dev_ins_size = sigma_adj
         if param.skew_adj > 0.5 and math.log(median_adj) > math.log(mode_adj):
+            print('Mode on getdistr adjusted: ', mode_adj, file=Information)
+            print('Median on getdistr adjusted:', median_adj, file=Information)
             param.lognormal_mean = math.log(median_adj)
             param.lognormal_sigma = math.sqrt(param.lognormal_mean - math.log(mode_adj))
             print('Lognormal mean getdistr adjusted: ', param.lognormal_mean, file=Information)
