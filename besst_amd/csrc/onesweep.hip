@@ -8,6 +8,11 @@
 //                          look-back): a tile publishes its per-digit counts, then the running totals, as 8-byte
 //                          {tag, value} granules; tiles are numbered by an arrival ticket, so every predecessor of a
 //                          tile is running or done and the look-back cannot wait on a workgroup that is not resident
+//   3b. packed keys of four digits or more: only the TOP 16 bits take stream-wide passes (two); that leaves up to
+//                          65 536 buckets in stream order, each finished on chip - os_bucket_start_kernel (binary
+//                          search of the bucket borders), os_bucket_wave_kernel (one wave per bucket, a handful of
+//                          distinct keys: C3 0.12 ms for what three more stream passes did in 0.69),
+//                          os_bucket_sort_kernel (the listed rest: LDS digit passes, global-memory passes for a hub)
 //   4. os_reduce_kernel    segmented reduction of the sorted stream into edge rows: head counts chained the same way,
 //                          every row's nr_links / sum obs / sum obs^2 WRITTEN once by the tile that holds its head
 //                          (segmented scan over the tile's threads, no atomics, no zero-initialised accumulators);
@@ -81,7 +86,7 @@ __device__ __forceinline__ uint32_t os_nblocks(uint32_t n, uint32_t tile) { retu
 template <int BITS>
 __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t* __restrict__ keys,
                                                                  const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                                 int passes, uint64_t key_base,
+                                                                 int passes, int shift0, uint64_t key_base,
                                                                  uint32_t* __restrict__ table,
                                                                  unsigned long long* __restrict__ granules,
                                                                  size_t granule_words) {
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 for (int p = 0; p < passes; ++p) {
-                    const uint32_t d = (uint32_t)(k[r] >> (p * BITS)) & (uint32_t)(RADIX - 1);
+                    const uint32_t d = (uint32_t)(k[r] >> (shift0 + p * BITS)) & (uint32_t)(RADIX - 1);
                     const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
                     if (__all(d == f)) {                    // the whole wave on one value (high digits): one add
                         if (lane == 0) atomicAdd(&mine[p * RADIX + f], 64u);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(kOsHistThreads) void os_hist_kernel(const uint64_t*
                 if (i < n) {
                     const uint64_t k = keys[i] - key_base;
                     for (int p = 0; p < passes; ++p)
-                        atomicAdd(&mine[p * RADIX + ((uint32_t)(k >> (p * BITS)) & (uint32_t)(RADIX - 1))], 1u);
+                        atomicAdd(&mine[p * RADIX + ((uint32_t)(k >> (shift0 + p * BITS)) & (uint32_t)(RADIX - 1))], 1u);
                 }
             }
         }
@@ -331,6 +336,402 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
                 idx_out[dst] = idx[r];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3b. the low key bits, bucket by bucket in LDS
+// ---------------------------------------------------------------------------------------------------
+// Keys of four or more digits: only the TOP two digits are sorted with stream-wide passes (LSD order on those two
+// digits).  That leaves the stream partitioned into up to 65 536 buckets of equal top-16 bits - a few hundred to a
+// few thousand tuples, each bucket still in stream order - and every bucket is finished by one workgroup: stable
+// 7-bit LSD passes over the remaining low bits with the words in registers and ONE LDS buffer in between (the same
+// peel-off ranking as the stream-wide passes), no look-back, no HBM traffic between the passes.  On C3 this replaces
+// three stream-wide passes (16 B/tuple each plus their chained scans) by one read and one write of the words.
+// A bucket that does not fit the LDS buffer (a hub scaffold end with thousands of links) is sorted by its workgroup
+// in global memory, tile after tile, with the other ping-pong buffer as scratch: exact, not fast.
+#ifndef BESST_BK_BITS
+#define BESST_BK_BITS 7
+#endif
+#ifndef BESST_BK_PEEL
+#define BESST_BK_PEEL 2
+#endif
+constexpr int kBkThreads = 256;
+constexpr int kBkWaves = 4;
+constexpr int kBkItems = 16;
+constexpr int kBkCap = kBkThreads * kBkItems;          // 4096 words in LDS
+constexpr int kBkBits = BESST_BK_BITS;
+constexpr int kBkRadix = 1 << kBkBits;
+constexpr int kBkPeel = BESST_BK_PEEL;
+constexpr int kTopBuckets = 1 << 16;
+static_assert(kBkBits >= 6 && kBkBits <= 10, "bucket digit width");
+
+// start[b] = first position of the sorted-by-top-digits stream whose bucket number is >= b (binary search)
+__global__ __launch_bounds__(256) void os_bucket_start_kernel(const uint64_t* __restrict__ words,
+                                                              const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                              int bucket_shift, uint32_t* __restrict__ start,
+                                                              uint32_t* __restrict__ big_count) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *big_count = 0;
+    if (b > (uint32_t)kTopBuckets) return;
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    uint32_t lo = 0, hi = n;                                 // first index with (word >> shift) >= b
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((words[mid] >> bucket_shift) < (uint64_t)b) lo = mid + 1; else hi = mid;
+    }
+    start[b] = lo;
+}
+
+// rank of a word among the words of equal digit in its round of 64 (see os_scatter_kernel): rank | group size << 8
+__device__ __forceinline__ uint32_t bk_wave_rank(uint32_t d, bool valid) {
+    uint32_t info = 0;
+    bool todo = valid;
+    unsigned long long rest = __ballot(todo);
+    for (int it = 0; it < kBkPeel && rest; ++it) {
+        const int src = __ffsll((long long)rest) - 1;
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)d, src);
+        const bool hit = todo && d == f;
+        const unsigned long long m = __ballot(hit);
+        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (hit) { info = rk | ((uint32_t)__popcll(m) << 8); todo = false; }
+        rest &= ~m;
+    }
+    if (rest) {
+        unsigned long long pm = rest;
+#pragma unroll
+        for (int bit = 0; bit < kBkBits; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const unsigned long long bal = __ballot(one);
+            pm &= one ? bal : ~bal;
+        }
+        if (todo) {
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            info = rk | ((uint32_t)__popcll(pm) << 8);
+        }
+    }
+    return info;
+}
+
+// vals[0 .. kBkRadix): totals in, exclusive prefix sums out (whole workgroup; ends with a barrier)
+__device__ __forceinline__ void bk_excl_scan(uint32_t* vals, uint32_t* s_wtot, int t) {
+    constexpr int per = kBkRadix > kBkThreads ? kBkRadix / kBkThreads : 1;
+    constexpr int active = kBkRadix / per;
+    const int lane = t & 63, wave = t >> 6;
+    uint32_t loc[per];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        loc[j] = t < active ? vals[t * per + j] : 0u;
+        tot += loc[j];
+    }
+    uint32_t x = tot;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t o = __shfl_up(x, dd, 64);
+        if (lane >= dd) x += o;
+    }
+    if (lane == 63) s_wtot[wave] = x;
+    __syncthreads();
+    uint32_t off = x - tot;
+    for (int q = 0; q < wave; ++q) off += s_wtot[q];
+    if (t < active) {
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            vals[t * per + j] = off;
+            off += loc[j];
+        }
+    }
+    __syncthreads();
+}
+
+// The usual bucket holds a handful of distinct keys (a few scaffold ends, each with a few partners and MANY links per
+// partner: C3 has a median of 815 tuples and 4 keys per bucket, at most 15).  ONE WAVE per bucket, no LDS: find the
+// smallest key not yet placed (a min over the lane's words, then over the wave), match it against every word of the
+// bucket (one compare + mbcnt per round of 64) - the words of that key go, in stream order, right behind the ones
+// placed so far - and repeat.  A bucket of more than kBwCap words or more than kBwKeys distinct keys, or whose eight
+// smallest keys cover less than a sixth of it, is put on the list of os_bucket_sort_kernel (digit passes in LDS).
+#ifndef BESST_BW_ITEMS
+#define BESST_BW_ITEMS 24
+#endif
+#ifndef BESST_BW_DPP
+#define BESST_BW_DPP 1
+#endif
+constexpr int kBwItems = BESST_BW_ITEMS;
+constexpr int kBwCap = 64 * kBwItems;
+constexpr int kBwKeys = 48;
+static_assert(kBwItems % 4 == 0 && kBwItems <= 32, "rounds are dispatched in steps of four");
+
+__device__ __forceinline__ uint32_t bw_wave_min(uint32_t v) {
+#if BESST_BW_DPP
+    // row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 and 31: lane 63 holds the minimum
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#else
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+// one bucket of at most 64 R words; false: not placed (too many distinct keys), nothing written
+template <int R>
+__device__ __forceinline__ bool bw_bucket(uint64_t* __restrict__ words, uint32_t s0, uint32_t n, int low_shift,
+                                          int low_bits, int lane) {
+    const uint32_t lowmask = (1u << low_bits) - 1u;          // low_bits <= 31 (launcher): a key is below 2^31
+    const uint64_t idx_mask = (1ull << low_shift) - 1ull;
+    uint32_t kk[R], idx[R], pos[R];
+    uint64_t top = 0;                                        // the bits above the low key bits: the same for the whole bucket
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t p = r * 64 + lane;
+        const bool valid = p < n;
+        const uint64_t w = valid ? words[s0 + p] : ~0ull;
+        kk[r] = valid ? ((uint32_t)(w >> low_shift) & lowmask) : 0xffffffffu;
+        idx[r] = (uint32_t)(w & idx_mask);
+        if (r == 0) top = w >> (low_shift + low_bits);       // lane 0 of round 0 is always valid
+        pos[r] = 0;
+    }
+    top = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(top >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
+    uint32_t lo = 0, covered = 0;                            // keys below lo are placed; covered: how many words that is
+    for (int K = 0;; ++K) {
+        // smallest key >= lo: kk - lo wraps around for the placed ones and is >= 2^31 for the padding
+        uint32_t acc = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc = min(acc, kk[r] - lo);
+        const uint32_t dmin = bw_wave_min(acc);
+        if (dmin >= 0x80000000u) break;                      // nothing left to place
+        if (K == kBwKeys || (K == 8 && covered * 6u < n)) return false;
+        const uint32_t f = lo + dmin;
+        uint32_t run = covered;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool hit = kk[r] == f;
+            const unsigned long long m = __ballot(hit);
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
+            if (hit) pos[r] = rk;
+            run += (uint32_t)__popcll(m);
+        }
+        covered = run;
+        lo = f + 1u;
+        if (covered == n) break;
+    }
+    // (the stores come after the loop: a bucket that is handed on must be left as it was)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t p = r * 64 + lane;
+        if (p < n) {
+            const uint64_t key = (top << low_bits) | (uint64_t)kk[r];
+            words[s0 + pos[r]] = (key << low_shift) | (uint64_t)idx[r];
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(uint64_t* __restrict__ words,
+                                                                    const uint32_t* __restrict__ start,
+                                                                    int low_shift, int low_bits,
+                                                                    uint32_t* __restrict__ big_list,
+                                                                    uint32_t* __restrict__ big_count) {
+    const int lane = threadIdx.x & 63;
+    // wave-uniform values, and the compiler is told so: the round and key loops are scalar control flow
+    const uint32_t bucket = blockIdx.x * kBkWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket]);
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket + 1]) - s0;
+    if (n <= 1) return;
+    bool placed = false;
+    if (n <= (uint32_t)kBwCap) {
+        switch ((n + 255u) >> 8) {                           // rounds of 64, in steps of four
+            case 1: placed = bw_bucket<4>(words, s0, n, low_shift, low_bits, lane); break;
+            case 2: placed = bw_bucket<8>(words, s0, n, low_shift, low_bits, lane); break;
+            case 3: placed = bw_bucket<12>(words, s0, n, low_shift, low_bits, lane); break;
+            case 4: placed = bw_bucket<16>(words, s0, n, low_shift, low_bits, lane); break;
+#if BESST_BW_ITEMS >= 20
+            case 5: placed = bw_bucket<20>(words, s0, n, low_shift, low_bits, lane); break;
+#endif
+#if BESST_BW_ITEMS >= 24
+            case 6: placed = bw_bucket<24>(words, s0, n, low_shift, low_bits, lane); break;
+#endif
+#if BESST_BW_ITEMS >= 28
+            case 7: placed = bw_bucket<28>(words, s0, n, low_shift, low_bits, lane); break;
+#endif
+#if BESST_BW_ITEMS >= 32
+            case 8: placed = bw_bucket<32>(words, s0, n, low_shift, low_bits, lane); break;
+#endif
+            default: break;
+        }
+    }
+    if (!placed && lane == 0) big_list[atomicAdd(big_count, 1u)] = bucket;
+}
+
+__device__ void bk_sort_bucket(uint64_t* words, uint64_t* scratch, uint32_t s0, uint32_t n, int low_shift, int low_bits) {
+    __shared__ uint64_t s_words[kBkCap];
+    __shared__ uint32_t s_whist[kBkWaves][kBkRadix];
+    __shared__ uint32_t s_base[kBkRadix];
+    __shared__ uint32_t s_wtot[kBkWaves];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_pass = (low_bits + kBkBits - 1) / kBkBits;
+    if (n <= (uint32_t)kBkCap) {
+        // ---- the whole bucket in registers: word p = wave * (rounds * 64) + r * 64 + lane (stream order = position)
+        const int rounds = (int)((n + kBkThreads - 1) / kBkThreads);
+        const uint32_t wbase = (uint32_t)wave * (uint32_t)(rounds * 64);
+        uint64_t w[kBkItems];
+#pragma unroll
+        for (int r = 0; r < kBkItems; ++r) {
+            const uint32_t p = wbase + r * 64 + lane;
+            w[r] = (r < rounds && p < n) ? words[s0 + p] : ~0ull;
+        }
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int shift = low_shift + pass * kBkBits;
+            const int bits = low_bits - pass * kBkBits < kBkBits ? low_bits - pass * kBkBits : kBkBits;
+            const uint32_t dmask = (1u << bits) - 1u;
+            for (int d = t; d < kBkWaves * kBkRadix; d += kBkThreads) (&s_whist[0][0])[d] = 0;
+            __syncthreads();
+            uint32_t dig_rank[kBkItems];
+#pragma unroll
+            for (int r = 0; r < kBkItems; ++r) {
+                dig_rank[r] = 0;
+                if (r < rounds) {                            // uniform
+                    const uint32_t p = wbase + r * 64 + lane;
+                    const bool valid = p < n;
+                    const uint32_t d = (uint32_t)(w[r] >> shift) & dmask;
+                    const uint32_t info = bk_wave_rank(d, valid);
+                    uint32_t pre = 0;
+                    if (valid) {
+                        volatile uint32_t* slot = &s_whist[wave][d];
+                        pre = *slot;
+                        if ((info & 0xffu) == 0u) *slot = pre + (info >> 8);
+                    }
+                    dig_rank[r] = d | ((pre + (info & 0xffu)) << kBkBits);
+                }
+            }
+            __syncthreads();
+            for (int d = t; d < kBkRadix; d += kBkThreads) {
+                uint32_t tot = 0;
+#pragma unroll
+                for (int q = 0; q < kBkWaves; ++q) tot += s_whist[q][d];
+                s_base[d] = tot;
+            }
+            __syncthreads();
+            bk_excl_scan(s_base, s_wtot, t);
+            for (int d = t; d < kBkRadix; d += kBkThreads) {     // every wave's share of a digit, waves in order
+                uint32_t run = s_base[d];
+#pragma unroll
+                for (int q = 0; q < kBkWaves; ++q) {
+                    const uint32_t c = s_whist[q][d];
+                    s_whist[q][d] = run;
+                    run += c;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kBkItems; ++r) {
+                if (r < rounds) {
+                    const uint32_t p = wbase + r * 64 + lane;
+                    if (p < n) s_words[s_whist[wave][dig_rank[r] & (kBkRadix - 1)] + (dig_rank[r] >> kBkBits)] = w[r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kBkItems; ++r) {
+                if (r < rounds) {
+                    const uint32_t p = wbase + r * 64 + lane;
+                    w[r] = p < n ? s_words[p] : ~0ull;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < kBkItems; ++r) {
+            if (r < rounds) {
+                const uint32_t p = wbase + r * 64 + lane;
+                if (p < n) words[s0 + p] = w[r];
+            }
+        }
+        return;
+    }
+    // ---- a bucket larger than the LDS buffer: the same passes over tiles of 4096 words in global memory
+    uint64_t* src = words + s0;
+    uint64_t* dst = scratch + s0;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int shift = low_shift + pass * kBkBits;
+        const int bits = low_bits - pass * kBkBits < kBkBits ? low_bits - pass * kBkBits : kBkBits;
+        const uint32_t dmask = (1u << bits) - 1u;
+        for (int d = t; d < kBkRadix; d += kBkThreads) s_base[d] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += kBkThreads)
+            atomicAdd(&s_base[(uint32_t)(__hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> shift) & dmask], 1u);
+        __syncthreads();
+        bk_excl_scan(s_base, s_wtot, t);
+        for (uint32_t t0 = 0; t0 < n; t0 += kBkCap) {
+            const uint32_t tn = n - t0 < (uint32_t)kBkCap ? n - t0 : (uint32_t)kBkCap;
+            for (int d = t; d < kBkWaves * kBkRadix; d += kBkThreads) (&s_whist[0][0])[d] = 0;
+            __syncthreads();
+            const uint32_t wbase = (uint32_t)wave * (kBkItems * 64);
+            uint64_t w[kBkItems];
+            uint32_t dig_rank[kBkItems];
+#pragma unroll
+            for (int r = 0; r < kBkItems; ++r) {
+                const uint32_t p = wbase + r * 64 + lane;
+                const bool valid = p < tn;
+                w[r] = valid ? __hip_atomic_load(&src[t0 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0ull;
+                const uint32_t d = (uint32_t)(w[r] >> shift) & dmask;
+                const uint32_t info = bk_wave_rank(d, valid);
+                uint32_t pre = 0;
+                if (valid) {
+                    volatile uint32_t* slot = &s_whist[wave][d];
+                    pre = *slot;
+                    if ((info & 0xffu) == 0u) *slot = pre + (info >> 8);
+                }
+                dig_rank[r] = d | ((pre + (info & 0xffu)) << kBkBits);
+            }
+            __syncthreads();
+            for (int d = t; d < kBkRadix; d += kBkThreads) {     // this tile's shares: digit base, then the waves in order
+                uint32_t run = s_base[d];
+#pragma unroll
+                for (int q = 0; q < kBkWaves; ++q) {
+                    const uint32_t c = s_whist[q][d];
+                    s_whist[q][d] = run;
+                    run += c;
+                }
+                s_base[d] = run;                             // where the next tile continues
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kBkItems; ++r) {
+                const uint32_t p = wbase + r * 64 + lane;
+                if (p < tn) dst[s_whist[wave][dig_rank[r] & (kBkRadix - 1)] + (dig_rank[r] >> kBkBits)] = w[r];
+            }
+            __syncthreads();
+        }
+        // the next pass of THIS workgroup reads what it has just written
+        __threadfence();
+        __syncthreads();
+        uint64_t* tmp = src; src = dst; dst = tmp;
+    }
+    if (src != words + s0) {                                 // an odd number of passes left the result in the scratch
+        for (uint32_t i = t; i < n; i += kBkThreads) words[s0 + i] = src[i];
+    }
+}
+
+// the buckets os_bucket_wave_kernel has put on the list, one workgroup each
+__global__ __launch_bounds__(kBkThreads) void os_bucket_sort_kernel(uint64_t* words, uint64_t* scratch,
+                                                                    const uint32_t* __restrict__ start,
+                                                                    int low_shift, int low_bits,
+                                                                    const uint32_t* __restrict__ big_list,
+                                                                    const uint32_t* __restrict__ big_count) {
+    const uint32_t count = *big_count;
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        const uint32_t b = big_list[li];
+        const uint32_t s0 = start[b];
+        bk_sort_bucket(words, scratch, s0, start[b + 1] - s0, low_shift, low_bits);
+        __syncthreads();
     }
 }
 
@@ -601,6 +1002,8 @@ struct OsWorkspace {
     uint32_t* lead_n;
     unsigned long long* lead_s;
     unsigned long long* lead_s2;
+    uint32_t* bucket_start;     // kTopBuckets + 1
+    uint32_t* big_list;         // kTopBuckets, then the counter
     size_t total;
 };
 
@@ -622,6 +1025,8 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     w.lead_n = reinterpret_cast<uint32_t*>(p + off); off += align_up(nt_red * 4, 256);
     w.lead_s = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
     w.lead_s2 = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
+    w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
+    w.big_list = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
     w.total = off;
     return w;
 }
@@ -641,11 +1046,16 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 const uint32_t* first_map, uint64_t key_base) {
     const OsWorkspace w = os_carve(ws, cap, kOsBits);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: chained-scan workspace too small");
-    const int passes = (key_bits + kOsBits - 1) / kOsBits;
+    int passes = (key_bits + kOsBits - 1) / kOsBits;
     BESST_REQUIRE(passes >= 1 && passes <= kOsMaxPasses, "reduce: too many radix passes");
     int idx_bits = 1;
     while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
     const int packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;
+    // keys of four digits or more: two stream-wide passes on the top 16 bits, the rest bucket by bucket in LDS (3b)
+    static const int hybrid_knob = [] { const char* e = getenv("BESST_SORT_HYBRID"); return e ? atoi(e) : 1; }();
+    const bool hybrid = hybrid_knob && packed_bits && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31;
+    const int shift0 = hybrid ? key_bits - 16 : 0;
+    if (hybrid) passes = 2;
     const uint32_t nt_sort = (uint32_t)((cap + kOsTile - 1) / kOsTile);
     const uint32_t nt_red = (uint32_t)((cap + kOsRedTile - 1) / kOsRedTile);
     constexpr int RADIX = 1 << kOsBits;
@@ -655,7 +1065,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         const uint32_t hist_tiles = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
         (void)hist_tiles;
         hipLaunchKernelGGL((os_hist_kernel<kOsBits>), dim3(kOsHistBlocks), dim3(kOsHistThreads), 0, s, keys, n_tuples,
-                           (uint32_t)cap, passes, key_base, w.table, w.granules, w.granule_words);
+                           (uint32_t)cap, passes, shift0, key_base, w.table, w.granules, w.granule_words);
     }
     {
         ProfScope ps(s, kProfSortScan);
@@ -668,7 +1078,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         ProfScope ps(s, kProfSortScatter);
         uint64_t* kout = buf_keys[p & 1];
         uint32_t* iout = buf_idx[p & 1];
-        const int shift = p * kOsBits + (p > 0 ? packed_bits : 0);
+        const int shift = shift0 + p * kOsBits + (p > 0 ? packed_bits : 0);
 #define BESST_OS_LAUNCH(FIRST, PACKED)                                                                                   \
     hipLaunchKernelGGL((os_scatter_kernel<kOsBits, FIRST, PACKED>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,      \
                        n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX, w.granules, \
@@ -681,6 +1091,15 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
 #undef BESST_OS_LAUNCH
         kin = kout;
         iin = iout;
+    }
+    if (hybrid) {
+        ProfScope ps(s, kProfBucketSort);
+        hipLaunchKernelGGL(os_bucket_start_kernel, dim3((kTopBuckets + 1 + 255) / 256), dim3(256), 0, s, kin, n_tuples,
+                           (uint32_t)cap, shift0 + packed_bits, w.bucket_start, w.big_list + kTopBuckets);
+        hipLaunchKernelGGL(os_bucket_wave_kernel, dim3(kTopBuckets / kBkWaves), dim3(kBkThreads), 0, s, buf_keys[1],
+                           w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets);
+        hipLaunchKernelGGL(os_bucket_sort_kernel, dim3(1024), dim3(kBkThreads), 0, s, buf_keys[1], buf_keys[0],
+                           w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets);
     }
     {
         ProfScope ps(s, kProfRowReduce);

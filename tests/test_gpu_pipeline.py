@@ -57,7 +57,8 @@ def test_record_path_follows_candidate_density(monkeypatch):
                                             (1_000_000, 45, 0), (1_500_000, 41, 0), (200_000, 57, 500),
                                             (700_000, 55, 0), (1_000_000, 59, 0), (5_000_000, 41, 0),
                                             (6_000_000, 37, 150_000), (5_000_000, 45, 0), (4_300_000, 3, 0),
-                                            (8192 * 600 + 1, 37, 0), (4096 * 1100, 5, 0)])
+                                            (8192 * 600 + 1, 37, 0), (4096 * 1100, 5, 0), (4_500_000, 39, 3_000),
+                                            (4_400_000, 33, 1_800)])
 def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     """The sort/reduce stage alone, on skewed keys: a hub bucket larger than the LDS sort capacity, fewer key bits
     than one digit, the small-stream MSD path (scan-free table, rank sort), the mid-size MSD path (row-scanned table,
@@ -65,7 +66,11 @@ def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     stream whose words do not fit 64 bits even so (59-bit keys: LSD passes with index arrays), and streams beyond 4 M
     tuples (chained-scan radix passes + atomic-free row reduction, csrc/onesweep.hip): packed words, a hub row of
     150 000 tuples, 45-bit keys that travel with a separate index array, 3- and 5-bit keys whose few rows run
-    across hundreds of reduce tiles, and streams that end one tuple into / exactly at a tile."""
+    across hundreds of reduce tiles, and streams that end one tuple into / exactly at a tile.  Packed keys of four digits
+    or more take two chained-scan passes on the top 16 bits and finish bucket by bucket: random keys overflow the
+    distinct-key limit of the wave-per-bucket kernel and go through the LDS digit passes, the 3 000- and 1 800-tuple
+    hubs of 40 keys through the LDS passes / the wave kernel's largest size class, the 150 000-tuple hub through the
+    global-memory passes."""
     import ctypes as C
     import numpy as np
     import torch
@@ -138,12 +143,13 @@ def test_pass_pool_overlapped_passes_are_independent():
         assert gb.aligned.cpu().numpy().tolist() == aligned.tolist()
 
 
-@pytest.mark.parametrize('n', [300_000, 2_000_000, 6_000_000])
+@pytest.mark.parametrize('n', [300_000, 2_000_000, 6_000_000, 24_000_000])
 def test_sort_reduce_with_offset_scaffold_ids(n):
     """Scaffold ids of a later library start far above 1 (param.scaffold_indexer keeps growing, MakeScaffolds.py:276):
     all keys share a long prefix.  With key_base / key_bits describing the occupied range the MSD buckets stay balanced
     (without it 2 M such tuples fell into ~160 of 2048 buckets and took the global-memory fallback); results must be
-    the same as ever on every sort path."""
+    the same as ever on every sort path.  (The two largest sizes are the wave-per-bucket kernel's own case: a dozen
+    links per edge, a few to a few dozen distinct keys per top-16-bit bucket.)"""
     import ctypes as C
     import numpy as np
     import torch
