@@ -561,8 +561,9 @@ __global__ __launch_bounds__(kOrdThreads, BESST_ORD_MIN_BLOCKS) void ordered_ker
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFusedThreads = 256;
 constexpr int kFusedSub = kFusedThreads * 4;              // records per sub-tile
+constexpr int kFusedRing = kFusedSub + kFusedThreads;     // candidates in LDS: a sub-tile's worth + an unfinished round
 #ifndef BESST_FUSED_MIN_WAVES
-#define BESST_FUSED_MIN_WAVES 5
+#define BESST_FUSED_MIN_WAVES 4
 #endif
 
 __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_kernel(
@@ -570,8 +571,11 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     uint64_t* __restrict__ seg_payload, SummView summ) {
     // SoA over the sub-tile's candidates: words 0..4 = tid, mtid, pos, mpos, flag | mapq << 16 (qlen in word 5's
     // place would make six; it travels in the top half of the flag word: flag bits above 0x100 are not read)
-    __shared__ uint32_t s_buf[5][kFusedSub];
-    __shared__ uint32_t s_qlen[kFusedSub / 2];            // 16 bits per candidate
+    // ... a RING of kFusedRing entries: candidates queue up across sub-tiles and are evaluated 256 at a time, so the
+    // evaluation rounds run with every lane busy (C3: a median of 207 candidates per sub-tile but 621 at the ninth
+    // decile - one round per started 256 of a sub-tile left a quarter of the lanes idle)
+    __shared__ uint32_t s_buf[5][kFusedRing];
+    __shared__ uint32_t s_qlen[kFusedRing / 2];           // 16 bits per candidate
     __shared__ int s_wcnt[4];
     __shared__ int32_t s_tail[4][4];                      // per wave: {has, obs1, obs2} of its last reaching record
     __shared__ int s_ecnt[4];                             // per wave: tuples emitted this round
@@ -587,116 +591,20 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
     int32_t run_tid = -1;                                   // the wave's running coverage (uniform)
     int run_sum = 0;
-    for (int st = 0; st < kClsTile / kFusedSub; ++st) {
-        const int64_t sub_base = block_base + (int64_t)st * kFusedSub;
-        if (sub_base >= a.n) break;                         // uniform
-        const int64_t i0 = sub_base + (int64_t)t * 4;
-        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
-        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
-        if (sub_base + kFusedSub <= a.n) {
-            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
-            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
-            const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
-            const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
-            const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
-            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
-            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
-            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
-            r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
-            r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
-            r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
-            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
-            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t i = i0 + k;
-                const bool in = i < a.n;
-                r_tid[k] = in ? a.tid[i] : -1;
-                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
-                r_pos[k] = in ? a.pos[i] : 0;
-                r_mpos[k] = in ? a.mpos[i] : 0;
-                r_flag[k] = in ? a.flag[i] : 0;
-                r_mapq[k] = in ? a.mapq[i] : 0;
-                r_qlen[k] = in ? a.qlen[i] : 0;
-            }
-        }
-        // ---- coverage of the tid == mtid records [:138-139]
-        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
-        bool uni = true;
-        int mine = 0;
-        bool cand[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cand[k] = r_tid[k] != r_mtid[k];
-            uni = uni && (r_tid[k] == ref);
-            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-            if (!cand[k] && cov) mine += (int)r_qlen[k];
-        }
-        if (__all(uni)) {
-            const int s = wave_sum(mine);
-            if (ref != run_tid) {
-                if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
-                    atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
-                run_tid = ref;
-                run_sum = 0;
-            }
-            run_sum += s;
-        } else {
-            // a contig boundary (or unsorted input) inside the wave: run-segmented reduction over the lanes, a lane
-            // that itself straddles a boundary adds its records directly (see stream_kernel)
-            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
-            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);
-            int val = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
-                if (!act) continue;
-                if (lane_uni) val += (int)r_qlen[k];
-                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
-            }
-            if (lane_uni) key = r_tid[0];
-            wave_add_runs(aligned, key, val, lane);
-        }
-        // ---- candidates -> LDS, in record order (record = 4 * lane + k inside the wave's 256)
-        const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
-        const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
-        const int wcount = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        if (lane == 0) s_wcnt[wave] = wcount;
-        __syncthreads();                                    // also: wave 0 is done with the previous sub-tile's entries
-        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
-        int total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) slot += s_wcnt[w];
-            total += s_wcnt[w];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (cand[k]) {
-                s_buf[0][slot] = (uint32_t)r_tid[k];
-                s_buf[1][slot] = (uint32_t)r_mtid[k];
-                s_buf[2][slot] = (uint32_t)r_pos[k];
-                s_buf[3][slot] = (uint32_t)r_mpos[k];
-                s_buf[4][slot] = (r_flag[k] & 0xffffu) | (r_mapq[k] << 16);
-                reinterpret_cast<unsigned short*>(s_qlen)[slot] = (unsigned short)r_qlen[k];
-                ++slot;
-            }
-        }
-        __syncthreads();
-        // ---- evaluation + the order-dependent part, thread j on candidate j (one round unless more than a quarter
-        // of the records are candidates).  The chain (Chain::step's semantics, CreateGraph.py:835-870) runs over all
-        // four waves at once: "previous record that reached CreateEdge" = nearest reaching lane below (ballot), else
-        // the tail of the nearest earlier wave that has one, else the block's running state; emission slots by
-        // ballot prefix + the waves' counts.  Two barriers per round, no serial wave.
-        for (int c0 = 0; c0 < total; c0 += kFusedThreads) {
-            const int j = c0 + t;
-            const bool live = j < total;
+    int q_head = 0, q_count = 0;                            // the queue of candidates not yet evaluated (uniform)
+    // ---- evaluation + the order-dependent part of up to 256 queued candidates, thread j on candidate j.  The chain
+    // (Chain::step's semantics, CreateGraph.py:835-870) runs over all four waves at once: "previous record that
+    // reached CreateEdge" = nearest reaching lane below (ballot), else the tail of the nearest earlier wave that has
+    // one, else the block's running state; emission slots by ballot prefix + the waves' counts.  Two barriers per
+    // round, no serial wave.
+    auto run_round = [&](const int cnt) {
+        {
+            const bool live = t < cnt;
             int32_t tid = -1, mtid = -1, pos = 0, mpos = 0;
             uint32_t fm = 0, qlen = 0;
             if (live) {
+                int j = q_head + t;
+                j = j >= kFusedRing ? j - kFusedRing : j;
                 tid = (int32_t)s_buf[0][j]; mtid = (int32_t)s_buf[1][j];
                 pos = (int32_t)s_buf[2][j]; mpos = (int32_t)s_buf[3][j];
                 fm = s_buf[4][j];
@@ -710,7 +618,7 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
                 c2 = a.table[mtid];
             }
             const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
-            if (c0 + wave * 64 < total)                      // uniform per wave: the candidates' own coverage
+            if (wave * 64 < cnt)                             // uniform per wave: the candidates' own coverage
                 wave_add_runs(aligned, live ? tid : -1, (live && (e.bits & EV_COV)) ? (int)qlen : 0, lane);
             const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
             const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
@@ -792,7 +700,118 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
             }
             ++round;
         }
+        q_head += kFusedThreads;
+        q_head = q_head >= kFusedRing ? q_head - kFusedRing : q_head;
+        q_count -= cnt;
+    };
+    for (int st = 0; st < kClsTile / kFusedSub; ++st) {
+        const int64_t sub_base = block_base + (int64_t)st * kFusedSub;
+        if (sub_base >= a.n) break;                         // uniform
+        const int64_t i0 = sub_base + (int64_t)t * 4;
+        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
+        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
+        if (sub_base + kFusedSub <= a.n) {
+            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
+            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
+            const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
+            const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
+            const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
+            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
+            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
+            r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
+            r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
+            r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
+            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
+            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                r_tid[k] = in ? a.tid[i] : -1;
+                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
+                r_pos[k] = in ? a.pos[i] : 0;
+                r_mpos[k] = in ? a.mpos[i] : 0;
+                r_flag[k] = in ? a.flag[i] : 0;
+                r_mapq[k] = in ? a.mapq[i] : 0;
+                r_qlen[k] = in ? a.qlen[i] : 0;
+            }
+        }
+        // ---- coverage of the tid == mtid records [:138-139]
+        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
+        bool uni = true;
+        int mine = 0;
+        bool cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cand[k] = r_tid[k] != r_mtid[k];
+            uni = uni && (r_tid[k] == ref);
+            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+            if (!cand[k] && cov) mine += (int)r_qlen[k];
+        }
+        if (__all(uni)) {
+            const int s = wave_sum(mine);
+            if (ref != run_tid) {
+                if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
+                    atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+                run_tid = ref;
+                run_sum = 0;
+            }
+            run_sum += s;
+        } else {
+            // a contig boundary (or unsorted input) inside the wave: run-segmented reduction over the lanes, a lane
+            // that itself straddles a boundary adds its records directly (see stream_kernel)
+            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
+            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);
+            int val = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
+                if (!act) continue;
+                if (lane_uni) val += (int)r_qlen[k];
+                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
+            }
+            if (lane_uni) key = r_tid[0];
+            wave_add_runs(aligned, key, val, lane);
+        }
+        // ---- candidates -> LDS, in record order (record = 4 * lane + k inside the wave's 256)
+        const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
+        const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
+        const int wcount = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        if (lane == 0) s_wcnt[wave] = wcount;
+        __syncthreads();
+        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) slot += s_wcnt[w];
+            total += s_wcnt[w];
+        }
+        total = __builtin_amdgcn_readfirstlane(total);
+        slot += q_head + q_count;                           // behind the queued ones (at most 255 + 1024 entries in all)
+        slot = slot >= kFusedRing ? slot - kFusedRing : slot;
+        slot = slot >= kFusedRing ? slot - kFusedRing : slot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (cand[k]) {
+                s_buf[0][slot] = (uint32_t)r_tid[k];
+                s_buf[1][slot] = (uint32_t)r_mtid[k];
+                s_buf[2][slot] = (uint32_t)r_pos[k];
+                s_buf[3][slot] = (uint32_t)r_mpos[k];
+                s_buf[4][slot] = (r_flag[k] & 0xffffu) | (r_mapq[k] << 16);
+                reinterpret_cast<unsigned short*>(s_qlen)[slot] = (unsigned short)r_qlen[k];
+                ++slot;
+                slot = slot == kFusedRing ? 0 : slot;
+            }
+        }
+        __syncthreads();
+        q_count += total;
+        while (q_count >= kFusedThreads) run_round(kFusedThreads);
     }
+    if (q_count > 0) run_round(q_count);                    // the unfinished round (uniform)
     if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
         atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
     // ---- block summary (same planes as ordered_kernel's Chain::publish)
