@@ -11,8 +11,12 @@
 //   3b. packed keys of four digits or more: only the TOP 16 bits take stream-wide passes (two); that leaves up to
 //                          65 536 buckets in stream order, each finished on chip - os_bucket_start_kernel (binary
 //                          search of the bucket borders), os_bucket_wave_kernel (one wave per bucket, a handful of
-//                          distinct keys: C3 0.12 ms for what three more stream passes did in 0.69),
-//                          os_bucket_sort_kernel (the listed rest: LDS digit passes, global-memory passes for a hub)
+//                          distinct keys: sorts the bucket in registers AND reduces it - observations to their
+//                          sorted places, the bucket's edge rows staged; C3 0.23 ms for what three more stream
+//                          passes and os_reduce_kernel did in 1.1), os_bucket_sort_kernel (the listed rest: LDS
+//                          digit passes, global-memory passes for a hub, then the same outputs),
+//                          os_bucket_rows_scan_kernel + os_bucket_rows_kernel (rows numbered and moved to the table);
+//                          steps 4 and 5 are not run on this path
 //   4. os_reduce_kernel    segmented reduction of the sorted stream into edge rows: head counts chained the same way,
 //                          every row's nr_links / sum obs / sum obs^2 WRITTEN once by the tile that holds its head
 //                          (segmented scan over the tile's threads, no atomics, no zero-initialised accumulators);
@@ -480,10 +484,36 @@ __device__ __forceinline__ uint32_t bw_wave_min(uint32_t v) {
 #endif
 }
 
-// one bucket of at most 64 R words; false: not placed (too many distinct keys), nothing written
+// What the bucket kernels leave behind: every tuple's observations at its sorted place, and the bucket's edge rows
+// STAGED at [bucket start + k] - a row's number needs the row counts of all buckets before it, so
+// os_bucket_rows_scan_kernel / os_bucket_rows_kernel number and move them afterwards.  (The sorted words themselves are
+// nobody's input any more: the wave kernel does not write them.)
+struct BwOut {
+    const uint64_t* payload;
+    const uint32_t* first_map;
+    uint64_t key_base;
+    int32_t* obs_lo;
+    int32_t* obs_hi;
+    uint64_t* st_key;
+    unsigned long long* st_sum;
+    unsigned long long* st_sq;
+    uint32_t* st_n;
+    uint32_t* st_first;
+    uint32_t* st_off;
+    uint32_t* st_mask;
+    uint32_t* bucket_rows;
+};
+
+__device__ __forceinline__ unsigned long long bw_wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// one bucket of at most 64 R words: sorted AND reduced; false: too many distinct keys, nothing written
 template <int R>
-__device__ __forceinline__ bool bw_bucket(uint64_t* __restrict__ words, uint32_t s0, uint32_t n, int low_shift,
-                                          int low_bits, int lane) {
+__device__ __forceinline__ bool bw_bucket(const uint64_t* __restrict__ words, uint32_t s0, uint32_t n, int low_shift,
+                                          int low_bits, int lane, const BwOut& o) {
     const uint32_t lowmask = (1u << low_bits) - 1u;          // low_bits <= 31 (launcher): a key is below 2^31
     const uint64_t idx_mask = (1ull << low_shift) - 1ull;
     uint32_t kk[R], idx[R], pos[R];
@@ -500,7 +530,9 @@ __device__ __forceinline__ bool bw_bucket(uint64_t* __restrict__ words, uint32_t
     }
     top = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(top >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
     uint32_t lo = 0, covered = 0;                            // keys below lo are placed; covered: how many words that is
-    for (int K = 0;; ++K) {
+    uint32_t my_key = 0, my_start = 0, my_cnt = 0, my_first = 0;   // lane k: the k-th smallest key and its row
+    int K = 0;
+    for (;; ++K) {
         // smallest key >= lo: kk - lo wraps around for the placed ones and is >= 2^31 for the padding
         uint32_t acc = 0xffffffffu;
 #pragma unroll
@@ -509,60 +541,105 @@ __device__ __forceinline__ bool bw_bucket(uint64_t* __restrict__ words, uint32_t
         if (dmin >= 0x80000000u) break;                      // nothing left to place
         if (K == kBwKeys || (K == 8 && covered * 6u < n)) return false;
         const uint32_t f = lo + dmin;
-        uint32_t run = covered;
+        uint32_t run = covered, first = 0;
+        bool found = false;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool hit = kk[r] == f;
             const unsigned long long m = __ballot(hit);
             const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
             if (hit) pos[r] = rk;
+            if (!found && m) {                               // the row's first tuple in stream order
+                found = true;
+                first = (uint32_t)__builtin_amdgcn_readlane((int)idx[r], __ffsll((long long)m) - 1);
+            }
             run += (uint32_t)__popcll(m);
         }
+        if (lane == K) { my_key = f; my_start = covered; my_cnt = run - covered; my_first = first; }
         covered = run;
         lo = f + 1u;
-        if (covered == n) break;
+        if (covered == n) { ++K; break; }
     }
-    // (the stores come after the loop: a bucket that is handed on must be left as it was)
+    // ---- observations to their sorted places; obs1 + obs2 per word stays in registers for the row sums
+    uint32_t ov[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t p = r * 64 + lane;
-        if (p < n) {
-            const uint64_t key = (top << low_bits) | (uint64_t)kk[r];
-            words[s0 + pos[r]] = (key << low_shift) | (uint64_t)idx[r];
+    for (int r0 = 0; r0 < R; r0 += 4) {
+        uint64_t pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pl[q] = (r0 + q) * 64 + lane < n ? o.payload[idx[r0 + q]] : 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            const uint32_t l = (uint32_t)pl[q], h = (uint32_t)(pl[q] >> 32) & 0x3fffffffu;
+            if (r * 64 + lane < n) {
+                o.obs_lo[s0 + pos[r]] = (int32_t)l;
+                o.obs_hi[s0 + pos[r]] = (int32_t)h;
+            }
+            ov[r] = l + h;                                   // 0 for the padding
         }
     }
+    // ---- row sums, key by key
+    unsigned long long my_s = 0, my_s2 = 0;
+    for (int k = 0; k < K; ++k) {
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)my_key, k);
+        unsigned long long sum = 0, sq = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t m = kk[r] == f ? ov[r] : 0u;
+            sum += m;
+            sq += (unsigned long long)m * m;
+        }
+        sum = bw_wave_sum64(sum);
+        sq = bw_wave_sum64(sq);
+        if (lane == k) { my_s = sum; my_s2 = sq; }
+    }
+    if (lane < K) {
+        const uint32_t row = s0 + (uint32_t)lane;
+        o.st_key[row] = ((top << low_bits) | (uint64_t)my_key) + o.key_base;
+        o.st_n[row] = my_cnt;
+        o.st_sum[row] = my_s;
+        o.st_sq[row] = my_s2;
+        o.st_off[row] = s0 + my_start;
+        o.st_first[row] = o.first_map ? o.first_map[my_first] : my_first;
+        o.st_mask[row] = (uint32_t)(o.payload[my_first] >> 62);
+    }
+    if (lane == 0) o.bucket_rows[0] = (uint32_t)K;
     return true;
 }
 
-__global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(uint64_t* __restrict__ words,
+__global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(const uint64_t* __restrict__ words,
                                                                     const uint32_t* __restrict__ start,
                                                                     int low_shift, int low_bits,
                                                                     uint32_t* __restrict__ big_list,
-                                                                    uint32_t* __restrict__ big_count) {
+                                                                    uint32_t* __restrict__ big_count, BwOut o) {
     const int lane = threadIdx.x & 63;
     // wave-uniform values, and the compiler is told so: the round and key loops are scalar control flow
     const uint32_t bucket = blockIdx.x * kBkWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket]);
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket + 1]) - s0;
-    if (n <= 1) return;
+    o.bucket_rows += bucket;
+    if (n == 0) {
+        if (lane == 0) o.bucket_rows[0] = 0;
+        return;
+    }
     bool placed = false;
     if (n <= (uint32_t)kBwCap) {
         switch ((n + 255u) >> 8) {                           // rounds of 64, in steps of four
-            case 1: placed = bw_bucket<4>(words, s0, n, low_shift, low_bits, lane); break;
-            case 2: placed = bw_bucket<8>(words, s0, n, low_shift, low_bits, lane); break;
-            case 3: placed = bw_bucket<12>(words, s0, n, low_shift, low_bits, lane); break;
-            case 4: placed = bw_bucket<16>(words, s0, n, low_shift, low_bits, lane); break;
+            case 1: placed = bw_bucket<4>(words, s0, n, low_shift, low_bits, lane, o); break;
+            case 2: placed = bw_bucket<8>(words, s0, n, low_shift, low_bits, lane, o); break;
+            case 3: placed = bw_bucket<12>(words, s0, n, low_shift, low_bits, lane, o); break;
+            case 4: placed = bw_bucket<16>(words, s0, n, low_shift, low_bits, lane, o); break;
 #if BESST_BW_ITEMS >= 20
-            case 5: placed = bw_bucket<20>(words, s0, n, low_shift, low_bits, lane); break;
+            case 5: placed = bw_bucket<20>(words, s0, n, low_shift, low_bits, lane, o); break;
 #endif
 #if BESST_BW_ITEMS >= 24
-            case 6: placed = bw_bucket<24>(words, s0, n, low_shift, low_bits, lane); break;
+            case 6: placed = bw_bucket<24>(words, s0, n, low_shift, low_bits, lane, o); break;
 #endif
 #if BESST_BW_ITEMS >= 28
-            case 7: placed = bw_bucket<28>(words, s0, n, low_shift, low_bits, lane); break;
+            case 7: placed = bw_bucket<28>(words, s0, n, low_shift, low_bits, lane, o); break;
 #endif
 #if BESST_BW_ITEMS >= 32
-            case 8: placed = bw_bucket<32>(words, s0, n, low_shift, low_bits, lane); break;
+            case 8: placed = bw_bucket<32>(words, s0, n, low_shift, low_bits, lane, o); break;
 #endif
             default: break;
         }
@@ -720,18 +797,169 @@ __device__ void bk_sort_bucket(uint64_t* words, uint64_t* scratch, uint32_t s0, 
     }
 }
 
-// the buckets os_bucket_wave_kernel has put on the list, one workgroup each
+// A sorted bucket of any size -> observations + staged rows, by one workgroup: 256 words at a time, run sums by a
+// segmented scan inside each wave, one atomic triple per (run, wave) into the staged row (zeroed first).
+__device__ void bk_reduce_bucket(const uint64_t* words, uint32_t s0, uint32_t n, int packed_bits, const BwOut& o) {
+    __shared__ uint32_t s_cnt[kBkWaves];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint64_t idx_mask = (1ull << packed_bits) - 1ull;
+    // rows of the bucket
+    uint32_t heads = 0;
+    for (uint32_t i = t; i < n; i += kBkThreads) {
+        const uint64_t key = words[s0 + i] >> packed_bits;
+        heads += (i == 0 || (words[s0 + i - 1] >> packed_bits) != key) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) heads += (uint32_t)__shfl_xor((int)heads, d, 64);
+    if (lane == 0) s_cnt[wave] = heads;
+    __syncthreads();
+    const uint32_t rows = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (uint32_t k = t; k < rows; k += kBkThreads) {
+        o.st_n[s0 + k] = 0;
+        o.st_sum[s0 + k] = 0ull;
+        o.st_sq[s0 + k] = 0ull;
+    }
+    __threadfence();
+    __syncthreads();
+    uint32_t rows_before = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += kBkThreads) {
+        const uint32_t i = c0 + t;
+        const bool valid = i < n;
+        const uint64_t w = valid ? words[s0 + i] : 0ull;
+        const uint64_t key = w >> packed_bits;
+        const bool head = valid && (i == 0 || (words[s0 + i - 1] >> packed_bits) != key);
+        const uint32_t src = (uint32_t)(w & idx_mask);
+        const uint64_t pl = valid ? o.payload[src] : 0ull;
+        const uint32_t l = (uint32_t)pl, h = (uint32_t)(pl >> 32) & 0x3fffffffu;
+        if (valid) {
+            o.obs_lo[s0 + i] = (int32_t)l;
+            o.obs_hi[s0 + i] = (int32_t)h;
+        }
+        const unsigned long long hm = __ballot(head);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(hm);
+        __syncthreads();
+        uint32_t incl = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull));
+        uint32_t chunk_heads = 0;
+#pragma unroll
+        for (int q = 0; q < kBkWaves; ++q) {
+            if (q < wave) incl += s_cnt[q];
+            chunk_heads += s_cnt[q];
+        }
+        const uint32_t row = s0 + rows_before + incl - 1u;   // the bucket's first word is a head: never below s0
+        if (head) {
+            o.st_key[row] = key + o.key_base;
+            o.st_off[row] = s0 + i;
+            o.st_first[row] = o.first_map ? o.first_map[src] : src;
+            o.st_mask[row] = (uint32_t)(pl >> 62);
+        }
+        // run sums inside the wave
+        uint32_t c = valid ? 1u : 0u;
+        unsigned long long sm = (unsigned long long)(l + h), sq = sm * sm;
+        bool fl = head || lane == 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t oc = (uint32_t)__shfl_up((int)c, d, 64);
+            const unsigned long long os = __shfl_up(sm, d, 64), oq = __shfl_up(sq, d, 64);
+            const int of = __shfl_up((int)fl, d, 64);
+            if (lane >= d && !fl) { c += oc; sm += os; sq += oq; fl = of != 0; }
+        }
+        const bool next_head = lane == 63 || ((hm >> (lane + 1)) & 1ull) || i + 1 >= n;
+        if (valid && next_head) {
+            atomicAdd(&o.st_n[row], c);
+            atomicAdd(&o.st_sum[row], sm);
+            atomicAdd(&o.st_sq[row], sq);
+        }
+        rows_before += chunk_heads;
+        __syncthreads();
+    }
+    if (t == 0) o.bucket_rows[0] = rows;
+}
+
+// the buckets os_bucket_wave_kernel has put on the list, one workgroup each: digit passes, then the rows
 __global__ __launch_bounds__(kBkThreads) void os_bucket_sort_kernel(uint64_t* words, uint64_t* scratch,
                                                                     const uint32_t* __restrict__ start,
                                                                     int low_shift, int low_bits,
                                                                     const uint32_t* __restrict__ big_list,
-                                                                    const uint32_t* __restrict__ big_count) {
+                                                                    const uint32_t* __restrict__ big_count, BwOut o) {
     const uint32_t count = *big_count;
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
         const uint32_t b = big_list[li];
         const uint32_t s0 = start[b];
-        bk_sort_bucket(words, scratch, s0, start[b + 1] - s0, low_shift, low_bits);
+        const uint32_t n = start[b + 1] - s0;
+        if (n > 1) bk_sort_bucket(words, scratch, s0, n, low_shift, low_bits);
+        __threadfence();
         __syncthreads();
+        BwOut ob = o;
+        ob.bucket_rows += b;
+        bk_reduce_bucket(words, s0, n, low_shift, ob);
+        __syncthreads();
+    }
+}
+
+// rows before every bucket (one workgroup: 64 buckets per thread) and the table's row count
+__global__ __launch_bounds__(1024) void os_bucket_rows_scan_kernel(const uint32_t* __restrict__ bucket_rows,
+                                                                   uint32_t* __restrict__ row_base,
+                                                                   uint32_t* __restrict__ n_rows) {
+    __shared__ uint32_t s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t c[64];
+    uint32_t tot = 0;
+    const uint4* in = reinterpret_cast<const uint4*>(bucket_rows + (size_t)t * 64);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint4 v = in[j];
+        c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
+        tot += v.x + v.y + v.z + v.w;
+    }
+    uint32_t x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= d) x += o;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t off = x - tot, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (q < wave) off += s_w[q];
+        all += s_w[q];
+    }
+    uint4* out = reinterpret_cast<uint4*>(row_base + (size_t)t * 64);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint4 v;
+        v.x = off; off += c[4 * j];
+        v.y = off; off += c[4 * j + 1];
+        v.z = off; off += c[4 * j + 2];
+        v.w = off; off += c[4 * j + 3];
+        out[j] = v;
+    }
+    if (t == 0) *n_rows = all;
+}
+
+// staged rows -> the edge table, one wave per bucket
+__global__ __launch_bounds__(256) void os_bucket_rows_kernel(const uint32_t* __restrict__ start,
+                                                             const uint32_t* __restrict__ row_base, BwOut o,
+                                                             uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
+                                                             uint32_t* __restrict__ row_n,
+                                                             unsigned long long* __restrict__ row_sum,
+                                                             unsigned long long* __restrict__ row_sum_sq,
+                                                             uint32_t* __restrict__ row_first,
+                                                             uint32_t* __restrict__ row_offset) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t rows = o.bucket_rows[b];
+    if (rows == 0) return;
+    const uint32_t s0 = start[b], base = row_base[b];
+    for (uint32_t k = lane; k < rows; k += 64) {
+        row_key[base + k] = o.st_key[s0 + k];
+        row_mask[base + k] = o.st_mask[s0 + k];
+        row_n[base + k] = o.st_n[s0 + k];
+        row_sum[base + k] = o.st_sum[s0 + k];
+        row_sum_sq[base + k] = o.st_sq[s0 + k];
+        row_first[base + k] = o.st_first[s0 + k];
+        row_offset[base + k] = o.st_off[s0 + k];
     }
 }
 
@@ -1004,6 +1232,9 @@ struct OsWorkspace {
     unsigned long long* lead_s2;
     uint32_t* bucket_start;     // kTopBuckets + 1
     uint32_t* big_list;         // kTopBuckets, then the counter
+    uint32_t* bucket_rows;      // kTopBuckets
+    uint32_t* row_base;         // kTopBuckets
+    char* staged;               // 40 bytes per tuple of capacity: the buckets' rows before they are numbered
     size_t total;
 };
 
@@ -1027,6 +1258,9 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     w.lead_s2 = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
     w.big_list = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
+    w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
+    w.row_base = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
+    w.staged = p + off; off += align_up((size_t)cap * 40, 256);
     w.total = off;
     return w;
 }
@@ -1053,7 +1287,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     const int packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;
     // keys of four digits or more: two stream-wide passes on the top 16 bits, the rest bucket by bucket in LDS (3b)
     static const int hybrid_knob = [] { const char* e = getenv("BESST_SORT_HYBRID"); return e ? atoi(e) : 1; }();
-    const bool hybrid = hybrid_knob && packed_bits && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31;
+    const bool hybrid = hybrid_knob && packed_bits && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31 && cap <= ((int64_t)1 << 30);
     const int shift0 = hybrid ? key_bits - 16 : 0;
     if (hybrid) passes = 2;
     const uint32_t nt_sort = (uint32_t)((cap + kOsTile - 1) / kOsTile);
@@ -1093,13 +1327,35 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         iin = iout;
     }
     if (hybrid) {
-        ProfScope ps(s, kProfBucketSort);
-        hipLaunchKernelGGL(os_bucket_start_kernel, dim3((kTopBuckets + 1 + 255) / 256), dim3(256), 0, s, kin, n_tuples,
-                           (uint32_t)cap, shift0 + packed_bits, w.bucket_start, w.big_list + kTopBuckets);
-        hipLaunchKernelGGL(os_bucket_wave_kernel, dim3(kTopBuckets / kBkWaves), dim3(kBkThreads), 0, s, buf_keys[1],
-                           w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets);
-        hipLaunchKernelGGL(os_bucket_sort_kernel, dim3(1024), dim3(kBkThreads), 0, s, buf_keys[1], buf_keys[0],
-                           w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets);
+        BwOut o;
+        o.payload = payload; o.first_map = first_map; o.key_base = key_base; o.obs_lo = obs_lo; o.obs_hi = obs_hi;
+        char* st = w.staged;
+        o.st_key = reinterpret_cast<uint64_t*>(st); st += (size_t)cap * 8;
+        o.st_sum = reinterpret_cast<unsigned long long*>(st); st += (size_t)cap * 8;
+        o.st_sq = reinterpret_cast<unsigned long long*>(st); st += (size_t)cap * 8;
+        o.st_n = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
+        o.st_first = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
+        o.st_off = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
+        o.st_mask = reinterpret_cast<uint32_t*>(st);
+        o.bucket_rows = w.bucket_rows;
+        {
+            ProfScope ps(s, kProfBucketSort);
+            hipLaunchKernelGGL(os_bucket_start_kernel, dim3((kTopBuckets + 1 + 255) / 256), dim3(256), 0, s, kin, n_tuples,
+                               (uint32_t)cap, shift0 + packed_bits, w.bucket_start, w.big_list + kTopBuckets);
+            hipLaunchKernelGGL(os_bucket_wave_kernel, dim3(kTopBuckets / kBkWaves), dim3(kBkThreads), 0, s, buf_keys[1],
+                               w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets, o);
+            hipLaunchKernelGGL(os_bucket_sort_kernel, dim3(1024), dim3(kBkThreads), 0, s, buf_keys[1], buf_keys[0],
+                               w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets, o);
+        }
+        {
+            ProfScope ps(s, kProfRowReduce);
+            hipLaunchKernelGGL(os_bucket_rows_scan_kernel, dim3(1), dim3(1024), 0, s, w.bucket_rows, w.row_base, n_rows);
+            hipLaunchKernelGGL(os_bucket_rows_kernel, dim3(kTopBuckets / 4), dim3(256), 0, s, w.bucket_start, w.row_base, o,
+                               row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
+                               reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset);
+        }
+        BESST_HIP_TRY(hipGetLastError());
+        return BESST_OK;
     }
     {
         ProfScope ps(s, kProfRowReduce);
