@@ -389,6 +389,7 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     a.read_len = p->read_len;
     a.read_len_int = (p->read_len >= 0.0 && p->read_len < 2147483648.0 && p->read_len == floor(p->read_len)) ? (int64_t)p->read_len : -1;
     a.ins_size_threshold = p->ins_size_threshold;
+    a.ins_thr_int = p->ins_size_threshold <= -4611686018427387904.0 ? INT64_MIN : (int64_t)ceil(p->ins_size_threshold);   // NaN and >= 2^30 were refused above
     a.min_mapq = p->min_mapq;
     a.rf = p->orientation;
     a.detect_dup = p->detect_duplicate;

@@ -34,6 +34,12 @@ constexpr uint32_t kNoSlot = 0xffffffffu;
 constexpr uint32_t EV_COV = 1u, EV_FISHY = 2u, EV_NONUNIQ = 4u, EV_REACH = 8u,
                    EV_DOUBLE = 32u, EV_MAPQ0 = 64u, EV_CASEA = 128u, EV_FIRSTMIN = 256u;
 
+// obs1 + obs2 < ins_size_threshold for two observations above 25 (so their sum is a whole number in (50, 2^32)) as an
+// unsigned compare against ceil(threshold); the threshold is below 2^30 (api.hip), one that is not positive accepts nothing
+__device__ __forceinline__ uint32_t ins_thr_u32(const ClassifyArgs& a) {
+    return a.ins_thr_int <= 0 ? 0u : (uint32_t)a.ins_thr_int;
+}
+
 struct Eval {
     uint32_t bits;
     int32_t o1, o2;
@@ -44,8 +50,11 @@ struct Eval {
 // the PE one with the read strand inverted.  read_len may be fractional: Python evaluates
 // `cpos + rpos + read_len` and `slen - cpos - (clen - rpos - read_len)` left to right in float and
 // truncates with int(); the same two roundings are done here in fp64 (built with -ffp-contract=off).
+// rl_int >= 0: read_len is that whole number - every intermediate is an integer below 2^53, the float evaluation is
+// exact and the same sums are taken in int64 (an fp64 instruction costs the SIMD two to four integer ones, and the
+// record loop of a mate-pair library is bound by instruction issue).
 __device__ __forceinline__ void posdir(bool rf, bool cdir, bool rdir, int32_t cpos, int32_t rpos,
-                                       int32_t slen, int32_t clen, double read_len, int32_t& obs,
+                                       int32_t slen, int32_t clen, double read_len, int64_t rl_int, int32_t& obs,
                                        uint32_t& side) {
     if (rf) rdir = !rdir;
     if (rdir) {
@@ -57,7 +66,14 @@ __device__ __forceinline__ void posdir(bool rf, bool cdir, bool rdir, int32_t cp
             side = 0;
         }
     } else {
-        if (cdir) {
+        if (rl_int >= 0) {                                   // uniform
+            // (wrapping 32-bit sums: the low 32 bits of the int64 result, which is what the cast keeps)
+            const uint32_t rl = (uint32_t)rl_int;
+            const uint32_t v = cdir ? (uint32_t)cpos + (uint32_t)rpos + rl
+                                    : ((uint32_t)slen - (uint32_t)cpos) - (((uint32_t)clen - (uint32_t)rpos) - rl);
+            obs = (int32_t)v;
+            side = cdir ? 0 : 1;
+        } else if (cdir) {
             double v = (double)((int64_t)cpos + rpos) + read_len;
             obs = (int32_t)v;
             side = 0;
@@ -115,8 +131,8 @@ __device__ __forceinline__ Eval eval_record(const ClassifyArgs& a, bool in_range
         return e;
     }
     uint32_t s1, s2;
-    posdir(rf, dir1, rdir, c1.ctg_pos, pos, c1.scaf_len, c1.ctg_len, a.read_len, e.o1, s1);
-    posdir(rf, dir2, mdir, c2.ctg_pos, mpos, c2.scaf_len, c2.ctg_len, a.read_len, e.o2, s2);
+    posdir(rf, dir1, rdir, c1.ctg_pos, pos, c1.scaf_len, c1.ctg_len, a.read_len, a.read_len_int, e.o1, s1);
+    posdir(rf, dir2, mdir, c2.ctg_pos, mpos, c2.scaf_len, c2.ctg_len, a.read_len, a.read_len_int, e.o2, s2);
     const bool dbl = case_a && a.extend_paths && !a.no_score;    // second CreateEdge call for G_prime
     e.bits |= EV_REACH | (case_a ? EV_CASEA : 0u) | (dbl ? EV_DOUBLE : 0u);
     const uint32_t n1 = scaf1 * 2 + s1, n2 = scaf2 * 2 + s2;
@@ -327,6 +343,7 @@ struct Chain {
                                          uint64_t* __restrict__ seg_keys, uint64_t* __restrict__ seg_payload,
                                          const int64_t block_base) {
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        const uint32_t thr_u32 = ins_thr_u32(a);
         const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
         const int32_t o1 = (int32_t)ent.x, o2 = (int32_t)ent.y;
         const bool reach = live && ((ent.z >> 29) & 1u), fishy = live && ((ent.z >> 30) & 1u);
@@ -346,7 +363,7 @@ struct Chain {
             const int32_t q1 = __shfl(o1, src, 64), q2 = __shfl(o2, src, 64);
             if (below) { pk = true; p1 = q1; p2 = q2; }
         }
-        const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+        const bool accept = reach && o1 > 25 && o2 > 25 && ((uint32_t)o1 + (uint32_t)o2 < thr_u32);
         bool emit = fishy;
         bool is_head = false;
         if (reach) {
@@ -586,6 +603,7 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t thr_u32 = ins_thr_u32(a);
     if (t < 8) { s_state[0][t] = 0; s_state[1][t] = 0; s_head[t] = 0; }   // visible after the first sub-tile's barriers
     int round = 0;
     int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
@@ -658,7 +676,7 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
                 for (int w = 0; w < 4; ++w)
                     if (s_tail[w][0]) { nx_known = 1; nx_has = 1; nx_q1 = s_tail[w][1]; nx_q2 = s_tail[w][2]; }
             }
-            const bool accept = reach && ((double)((int64_t)o1 + o2) < a.ins_size_threshold) && o1 > 25 && o2 > 25;
+            const bool accept = reach && o1 > 25 && o2 > 25 && ((uint32_t)o1 + (uint32_t)o2 < thr_u32);
             bool emit = fishy, is_head = false;
             if (reach) {
                 if (!pk) {

@@ -117,6 +117,7 @@ struct ClassifyArgs {
     double read_len;
     double ins_size_threshold;
     int64_t read_len_int;  // read_len when it is a whole number in [0, 2^31), else -1 (integer form of PosDirCalculator)
+    int64_t ins_thr_int;   // ceil(ins_size_threshold): for whole numbers x, x < threshold <=> x < ins_thr_int
     int32_t min_mapq;
     int32_t rf;            // orientation == 'rf'
     int32_t detect_dup;
