@@ -15,7 +15,7 @@
 //                          sorted places, the bucket's edge rows staged; C3 0.23 ms for what three more stream
 //                          passes and os_reduce_kernel did in 1.1), os_bucket_sort_kernel (the listed rest: LDS
 //                          digit passes, global-memory passes for a hub, then the same outputs),
-//                          os_bucket_rows_scan_kernel + os_bucket_rows_kernel (rows numbered and moved to the table);
+//                          os_bucket_rows_kernel (rows numbered and moved to the table);
 //                          steps 4 and 5 are not run on this path
 //   4. os_reduce_kernel    segmented reduction of the sorted stream into edge rows: head counts chained the same way,
 //                          every row's nr_links / sum obs / sum obs^2 WRITTEN once by the tile that holds its head
@@ -486,21 +486,21 @@ __device__ __forceinline__ uint32_t bw_wave_min(uint32_t v) {
 
 // What the bucket kernels leave behind: every tuple's observations at its sorted place, and the bucket's edge rows
 // STAGED at [bucket start + k] - a row's number needs the row counts of all buckets before it, so
-// os_bucket_rows_scan_kernel / os_bucket_rows_kernel number and move them afterwards.  (The sorted words themselves are
+// os_bucket_rows_kernel numbers and moves them afterwards.  (The sorted words themselves are
 // nobody's input any more: the wave kernel does not write them.)
+struct StagedRow {
+    uint64_t key;
+    unsigned long long sum, sq;
+    uint32_t n, first, off, mask;
+};
+
 struct BwOut {
     const uint64_t* payload;
     const uint32_t* first_map;
     uint64_t key_base;
     int32_t* obs_lo;
     int32_t* obs_hi;
-    uint64_t* st_key;
-    unsigned long long* st_sum;
-    unsigned long long* st_sq;
-    uint32_t* st_n;
-    uint32_t* st_first;
-    uint32_t* st_off;
-    uint32_t* st_mask;
+    struct StagedRow* staged;           // one 40-byte record per row: a row is read and written as a whole
     uint32_t* bucket_rows;
 };
 
@@ -595,13 +595,15 @@ __device__ __forceinline__ bool bw_bucket(const uint64_t* __restrict__ words, ui
     }
     if (lane < K) {
         const uint32_t row = s0 + (uint32_t)lane;
-        o.st_key[row] = ((top << low_bits) | (uint64_t)my_key) + o.key_base;
-        o.st_n[row] = my_cnt;
-        o.st_sum[row] = my_s;
-        o.st_sq[row] = my_s2;
-        o.st_off[row] = s0 + my_start;
-        o.st_first[row] = o.first_map ? o.first_map[my_first] : my_first;
-        o.st_mask[row] = (uint32_t)(o.payload[my_first] >> 62);
+        StagedRow sr;
+        sr.key = ((top << low_bits) | (uint64_t)my_key) + o.key_base;
+        sr.sum = my_s;
+        sr.sq = my_s2;
+        sr.n = my_cnt;
+        sr.first = o.first_map ? o.first_map[my_first] : my_first;
+        sr.off = s0 + my_start;
+        sr.mask = (uint32_t)(o.payload[my_first] >> 62);
+        o.staged[row] = sr;
     }
     if (lane == 0) o.bucket_rows[0] = (uint32_t)K;
     return true;
@@ -815,9 +817,9 @@ __device__ void bk_reduce_bucket(const uint64_t* words, uint32_t s0, uint32_t n,
     __syncthreads();
     const uint32_t rows = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     for (uint32_t k = t; k < rows; k += kBkThreads) {
-        o.st_n[s0 + k] = 0;
-        o.st_sum[s0 + k] = 0ull;
-        o.st_sq[s0 + k] = 0ull;
+        o.staged[s0 + k].n = 0;
+        o.staged[s0 + k].sum = 0ull;
+        o.staged[s0 + k].sq = 0ull;
     }
     __threadfence();
     __syncthreads();
@@ -847,10 +849,10 @@ __device__ void bk_reduce_bucket(const uint64_t* words, uint32_t s0, uint32_t n,
         }
         const uint32_t row = s0 + rows_before + incl - 1u;   // the bucket's first word is a head: never below s0
         if (head) {
-            o.st_key[row] = key + o.key_base;
-            o.st_off[row] = s0 + i;
-            o.st_first[row] = o.first_map ? o.first_map[src] : src;
-            o.st_mask[row] = (uint32_t)(pl >> 62);
+            o.staged[row].key = key + o.key_base;
+            o.staged[row].off = s0 + i;
+            o.staged[row].first = o.first_map ? o.first_map[src] : src;
+            o.staged[row].mask = (uint32_t)(pl >> 62);
         }
         // run sums inside the wave
         uint32_t c = valid ? 1u : 0u;
@@ -865,9 +867,9 @@ __device__ void bk_reduce_bucket(const uint64_t* words, uint32_t s0, uint32_t n,
         }
         const bool next_head = lane == 63 || ((hm >> (lane + 1)) & 1ull) || i + 1 >= n;
         if (valid && next_head) {
-            atomicAdd(&o.st_n[row], c);
-            atomicAdd(&o.st_sum[row], sm);
-            atomicAdd(&o.st_sq[row], sq);
+            atomicAdd(&o.staged[row].n, c);
+            atomicAdd(&o.staged[row].sum, sm);
+            atomicAdd(&o.staged[row].sq, sq);
         }
         rows_before += chunk_heads;
         __syncthreads();
@@ -896,70 +898,65 @@ __global__ __launch_bounds__(kBkThreads) void os_bucket_sort_kernel(uint64_t* wo
     }
 }
 
-// rows before every bucket (one workgroup: 64 buckets per thread) and the table's row count
-__global__ __launch_bounds__(1024) void os_bucket_rows_scan_kernel(const uint32_t* __restrict__ bucket_rows,
-                                                                   uint32_t* __restrict__ row_base,
-                                                                   uint32_t* __restrict__ n_rows) {
-    __shared__ uint32_t s_w[16];
+// staged rows -> the edge table.  Workgroup g owns buckets [1024 g, 1024 g + 1024): it sums the row counts of all
+// buckets before them (coalesced, at most 256 KB from L2), scans its own, and moves its rows one thread per row - the
+// row's bucket by binary search in the scanned counts (LDS) - so the table is written in order whatever the buckets'
+// sizes.  The last workgroup writes the table's row count.
+constexpr int kRowsThreads = 1024;
+
+__global__ __launch_bounds__(kRowsThreads) void os_bucket_rows_kernel(const uint32_t* __restrict__ start, BwOut o,
+                                                                      uint32_t* __restrict__ n_rows,
+                                                                      uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
+                                                                      uint32_t* __restrict__ row_n,
+                                                                      unsigned long long* __restrict__ row_sum,
+                                                                      unsigned long long* __restrict__ row_sum_sq,
+                                                                      uint32_t* __restrict__ row_first,
+                                                                      uint32_t* __restrict__ row_offset) {
+    __shared__ uint32_t s_excl[kRowsThreads + 1];
+    __shared__ uint32_t s_w[kRowsThreads / 64], s_b[kRowsThreads / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t c[64];
-    uint32_t tot = 0;
-    const uint4* in = reinterpret_cast<const uint4*>(bucket_rows + (size_t)t * 64);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint4 v = in[j];
-        c[4 * j] = v.x; c[4 * j + 1] = v.y; c[4 * j + 2] = v.z; c[4 * j + 3] = v.w;
-        tot += v.x + v.y + v.z + v.w;
-    }
-    uint32_t x = tot;
+    const uint32_t b0 = blockIdx.x * kRowsThreads;
+    uint32_t before = 0;
+    for (uint32_t i = t; i < b0; i += kRowsThreads) before += o.bucket_rows[i];
+    const uint32_t mine = o.bucket_rows[b0 + t];
+    uint32_t x = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)x, d, 64);
-        if (lane >= d) x += o;
+        const uint32_t v = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= d) x += v;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
     if (lane == 63) s_w[wave] = x;
+    if (lane == 0) s_b[wave] = before;
     __syncthreads();
-    uint32_t off = x - tot, all = 0;
+    uint32_t off = x - mine, base = 0, total = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < kRowsThreads / 64; ++q) {
         if (q < wave) off += s_w[q];
-        all += s_w[q];
+        total += s_w[q];
+        base += s_b[q];
     }
-    uint4* out = reinterpret_cast<uint4*>(row_base + (size_t)t * 64);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        uint4 v;
-        v.x = off; off += c[4 * j];
-        v.y = off; off += c[4 * j + 1];
-        v.z = off; off += c[4 * j + 2];
-        v.w = off; off += c[4 * j + 3];
-        out[j] = v;
-    }
-    if (t == 0) *n_rows = all;
-}
-
-// staged rows -> the edge table, one wave per bucket
-__global__ __launch_bounds__(256) void os_bucket_rows_kernel(const uint32_t* __restrict__ start,
-                                                             const uint32_t* __restrict__ row_base, BwOut o,
-                                                             uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
-                                                             uint32_t* __restrict__ row_n,
-                                                             unsigned long long* __restrict__ row_sum,
-                                                             unsigned long long* __restrict__ row_sum_sq,
-                                                             uint32_t* __restrict__ row_first,
-                                                             uint32_t* __restrict__ row_offset) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t rows = o.bucket_rows[b];
-    if (rows == 0) return;
-    const uint32_t s0 = start[b], base = row_base[b];
-    for (uint32_t k = lane; k < rows; k += 64) {
-        row_key[base + k] = o.st_key[s0 + k];
-        row_mask[base + k] = o.st_mask[s0 + k];
-        row_n[base + k] = o.st_n[s0 + k];
-        row_sum[base + k] = o.st_sum[s0 + k];
-        row_sum_sq[base + k] = o.st_sq[s0 + k];
-        row_first[base + k] = o.st_first[s0 + k];
-        row_offset[base + k] = o.st_off[s0 + k];
+    s_excl[t] = off;
+    if (t == 0) s_excl[kRowsThreads] = total;
+    if (blockIdx.x == gridDim.x - 1 && t == 0) *n_rows = base + total;
+    __syncthreads();
+    for (uint32_t i = t; i < total; i += kRowsThreads) {
+        int lo = 0, hi = kRowsThreads;                       // last bucket whose exclusive count is <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_excl[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t src = start[b0 + lo] + (i - s_excl[lo]);
+        const uint32_t dst = base + i;
+        const StagedRow sr = o.staged[src];
+        row_key[dst] = sr.key;
+        row_mask[dst] = sr.mask;
+        row_n[dst] = sr.n;
+        row_sum[dst] = sr.sum;
+        row_sum_sq[dst] = sr.sq;
+        row_first[dst] = sr.first;
+        row_offset[dst] = sr.off;
     }
 }
 
@@ -1233,7 +1230,6 @@ struct OsWorkspace {
     uint32_t* bucket_start;     // kTopBuckets + 1
     uint32_t* big_list;         // kTopBuckets, then the counter
     uint32_t* bucket_rows;      // kTopBuckets
-    uint32_t* row_base;         // kTopBuckets
     char* staged;               // 40 bytes per tuple of capacity: the buckets' rows before they are numbered
     size_t total;
 };
@@ -1259,7 +1255,6 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
     w.big_list = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
-    w.row_base = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
     w.staged = p + off; off += align_up((size_t)cap * 40, 256);
     w.total = off;
     return w;
@@ -1329,14 +1324,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     if (hybrid) {
         BwOut o;
         o.payload = payload; o.first_map = first_map; o.key_base = key_base; o.obs_lo = obs_lo; o.obs_hi = obs_hi;
-        char* st = w.staged;
-        o.st_key = reinterpret_cast<uint64_t*>(st); st += (size_t)cap * 8;
-        o.st_sum = reinterpret_cast<unsigned long long*>(st); st += (size_t)cap * 8;
-        o.st_sq = reinterpret_cast<unsigned long long*>(st); st += (size_t)cap * 8;
-        o.st_n = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
-        o.st_first = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
-        o.st_off = reinterpret_cast<uint32_t*>(st); st += (size_t)cap * 4;
-        o.st_mask = reinterpret_cast<uint32_t*>(st);
+        o.staged = reinterpret_cast<StagedRow*>(w.staged);
         o.bucket_rows = w.bucket_rows;
         {
             ProfScope ps(s, kProfBucketSort);
@@ -1349,9 +1337,8 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         }
         {
             ProfScope ps(s, kProfRowReduce);
-            hipLaunchKernelGGL(os_bucket_rows_scan_kernel, dim3(1), dim3(1024), 0, s, w.bucket_rows, w.row_base, n_rows);
-            hipLaunchKernelGGL(os_bucket_rows_kernel, dim3(kTopBuckets / 4), dim3(256), 0, s, w.bucket_start, w.row_base, o,
-                               row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
+            hipLaunchKernelGGL(os_bucket_rows_kernel, dim3(kTopBuckets / kRowsThreads), dim3(kRowsThreads), 0, s,
+                               w.bucket_start, o, n_rows, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                                reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset);
         }
         BESST_HIP_TRY(hipGetLastError());

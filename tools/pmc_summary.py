@@ -15,7 +15,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel', 'radix_hist_kernel',
                 'radix_rowscan_kernel', 'radix_scatter_kernel', 'bucket_sort_kernel', 'bucket_reduce_kernel',
                 'row_heads_kernel', 'row_scan_kernel', 'row_reduce_kernel', 'os_hist_kernel', 'os_offsets_kernel',
-                'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel')
+                'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel', 'os_bucket_start_kernel', 'os_bucket_wave_kernel',
+                'os_bucket_sort_kernel', 'os_bucket_rows_kernel')
 
 
 def source_hash():
