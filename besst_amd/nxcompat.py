@@ -35,6 +35,20 @@ class Graph(_BaseGraph):
         return list(_NodeView(self)(data=data))
 
     def edges(self, nbunch=None, data=False):
+        if nbunch is None and (data is True or data is False):
+            # the whole edge list in networkx's own order (every edge reported from its first endpoint in node order),
+            # built straight from the adjacency: list(EdgeDataView) walks the graph twice (its __len__ is a full
+            # iteration) through three layers of views - 3.8 of the drop-in's 9 host seconds on a 100 k-contig assembly
+            out, seen = [], set()
+            if data:
+                for n, nbrs in self._adj.items():
+                    out.extend([(n, nbr, dd) for nbr, dd in nbrs.items() if nbr not in seen])
+                    seen.add(n)
+            else:
+                for n, nbrs in self._adj.items():
+                    out.extend([(n, nbr) for nbr in nbrs if nbr not in seen])
+                    seen.add(n)
+            return out
         return list(_EdgeView(self)(nbunch=nbunch, data=data))
 
     def number_of_edges(self, u=None, v=None):
