@@ -216,6 +216,9 @@ def dropin_timing(device, config, pairs=None, contigs=None):
 
         def __len__(self):
             return self.n
+
+        def __getitem__(self, k):                        # a contig filtered for low coverage is written out as FASTA
+            return 'N' * len(range(*k.indices(self.n))) if isinstance(k, slice) else 'N'
     C_dict = {name: SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
     dev_mod.CALL_SECONDS = {}
     t0 = time.perf_counter()
@@ -759,6 +762,11 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
         for job in jobs:
             job.step()
 
+    # setup, not measurement: RCCL opens its channels and the builders size their exchange regions on the first passes
+    # (a run whose only untimed passes were two warm-up steps once measured 2.8 ms per step instead of 1.36)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
