@@ -24,6 +24,11 @@ class LibParams(C.Structure):
                 ('no_score', C.c_int32), ('record_path', C.c_int32)]
 
 
+class Presort(C.Structure):          # include/besst_amd.h: besst_presort
+    _fields_ = [('table', C.c_void_p), ('rows', C.c_int32), ('shift', C.c_int32), ('key_base', C.c_uint64),
+                ('capacity', C.c_uint32), ('reserved', C.c_uint32)]
+
+
 class Counters(C.Structure):
     _fields_ = [('count', C.c_int64), ('non_unique', C.c_int64), ('non_unique_for_scaf', C.c_int64),
                 ('nr_of_duplicates', C.c_int64), ('reads_with_too_long_insert', C.c_int64),
@@ -82,6 +87,12 @@ _SIGNATURES = {
                                               C.POINTER(C.c_int32)]),
     'besst_dev_reduce': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, C.c_size_t, _P, C.c_uint64]),
+    'besst_dev_reduce_presort': (C.c_int, [C.c_int64, C.c_int32, C.c_uint64, _P, C.c_size_t, C.POINTER(Presort)]),
+    'besst_dev_classify_presort': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
+                                             C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t,
+                                             C.POINTER(Presort)]),
+    'besst_dev_reduce_presorted': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                             _P, _P, C.c_size_t, _P, C.c_uint64]),
     'besst_dev_classify_scan': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                           C.POINTER(LibParams), C.c_int32, _P, _P, _P, C.c_size_t]),
     'besst_dev_classify_tail': (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t]),

@@ -413,6 +413,50 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                            workspace, workspace_bytes);
 }
 
+int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
+                             size_t workspace_bytes, besst_presort* h_out) {
+    BESST_REQUIRE(h_out, "reduce_presort: null output");
+    memset(h_out, 0, sizeof(*h_out));
+    PresortSpec ps{};
+    if (!sort_presort_spec(capacity, key_bits, key_base, workspace, workspace_bytes, &ps)) return 0;
+    h_out->table = ps.table; h_out->rows = ps.rows; h_out->shift = ps.shift; h_out->key_base = ps.key_base;
+    h_out->capacity = ps.cap;
+    return 1;
+}
+
+int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
+                               const int32_t* mpos, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                               int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
+                               int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
+                               besst_counters* counters, void* workspace, size_t workspace_bytes,
+                               const besst_presort* h_presort) {
+    ClassifyArgs a;
+    int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
+    if (rc) return rc;
+    BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
+    PresortSpec ps{};
+    if (h_presort && h_presort->table) {
+        ps.table = h_presort->table; ps.rows = h_presort->rows; ps.shift = h_presort->shift;
+        ps.key_base = h_presort->key_base; ps.cap = h_presort->capacity;
+    }
+    return launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
+                           workspace, workspace_bytes, ps.table ? &ps : nullptr);
+}
+
+int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
+                               const uint64_t* keys, const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask,
+                               uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first,
+                               uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows,
+                               void* workspace, size_t workspace_bytes, const uint32_t* first_map, uint64_t key_base) {
+    BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
+    BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
+                                    row_first && row_offset && obs_lo && obs_hi),
+                  "reduce: null buffer");
+    return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
+                              row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
+                              workspace, workspace_bytes, first_map, key_base, true);
+}
+
 int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
                                 int64_t sample_records, void* counts_scratch, double* h_share,
                                 int32_t* h_record_path) {

@@ -1051,7 +1051,12 @@ __global__ __launch_bounds__(256) void compact_kernel(SummView summ,
                                                       uint64_t* __restrict__ keys,
                                                       uint64_t* __restrict__ payload,
                                                       const uint8_t* __restrict__ cls8, int32_t n_contigs,
-                                                      unsigned long long* __restrict__ aligned) {
+                                                      unsigned long long* __restrict__ aligned, PresortSpec ps) {
+    __shared__ uint32_t s_h[512];                        // the block's share of the sort's two digit histograms
+    if (ps.table) {                                      // uniform
+        s_h[threadIdx.x] = 0;
+        s_h[threadIdx.x + 256] = 0;
+    }
     // coverage of contigs that are not in the table is not part of cont_aligned_len (CreateGraph.py:89-95)
     for (int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); c < n_contigs; c += (int32_t)(gridDim.x * blockDim.x))
         if (!cls8[c]) aligned[c] = 0;
@@ -1063,11 +1068,33 @@ __global__ __launch_bounds__(256) void compact_kernel(SummView summ,
     const uint32_t n = summ.at(kSumEmit, b);
     const uint32_t skip = skip_slot[b], off = offsets[b];
     if (n == 0) return;
+    if (ps.table) __syncthreads();                       // (n is the same in every thread)
     for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
         if (j == skip) continue;
         const uint32_t dst = off + j - (j > skip ? 1u : 0u);
-        keys[dst] = j < blockDim.x ? k0 : seg_keys[base + j];
+        const uint64_t key = j < blockDim.x ? k0 : seg_keys[base + j];
+        keys[dst] = key;
         payload[dst] = j < blockDim.x ? p0 : seg_payload[base + j];
+        if (ps.table && dst < ps.cap) {
+            // tuples of one contig follow each other and half of them have that contig's own end as their smaller node:
+            // the lanes that share the first active lane's digit add once, together (else they pile up on one counter)
+            const uint64_t k = key - ps.key_base;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t d = (uint32_t)(k >> (ps.shift + 8 * q)) & 255u;
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const unsigned long long m = __ballot(d == f);
+                if (d != f) atomicAdd(&s_h[256 * q + d], 1u);
+                else if ((m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&s_h[256 * q + f], (uint32_t)__popcll(m));
+            }
+        }
+    }
+    if (!ps.table) return;
+    __syncthreads();
+    uint32_t* row = ps.table + (size_t)(b & (uint32_t)(ps.rows - 1)) * 512u;
+    for (int d = threadIdx.x; d < 512; d += blockDim.x) {
+        const uint32_t v = s_h[d];
+        if (v) atomicAdd(&row[d], v);
     }
 }
 
@@ -1313,7 +1340,13 @@ int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* t
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,
-                         const int32_t* tails, int rank, int32_t* slice_info) {
+                         const int32_t* tails, int rank, int32_t* slice_info, const PresortSpec* presort) {
+    PresortSpec pre{};
+    if (presort && presort->table) {
+        pre = *presort;
+        BESST_REQUIRE(pre.rows > 0 && (pre.rows & (pre.rows - 1)) == 0 && pre.shift >= 0 && pre.shift <= 47, "classify: bad presort description");
+        BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
+    }
     if (n <= 0) {
         BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
         if (slice_info) BESST_HIP_TRY(hipMemsetAsync(slice_info, 0, 8 * sizeof(int32_t), s));
@@ -1335,18 +1368,19 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     {
         ProfScope ps(s, kProfCompact);
         hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
-                           w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned));
+                           w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned), pre);
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }
 
 int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned, uint64_t* keys,
-                    uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws, size_t ws_bytes) {
+                    uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws, size_t ws_bytes,
+                    const PresortSpec* presort) {
     int rc = launch_classify_scan(s, a, aligned, counters, ws, ws_bytes);
     if (rc) return rc;
     return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
-                                a.n_contigs, aligned, nullptr, 0, nullptr);
+                                a.n_contigs, aligned, nullptr, 0, nullptr, presort);
 }
 
 }  // namespace besst

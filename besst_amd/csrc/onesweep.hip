@@ -1262,6 +1262,32 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
 
 }  // namespace
 
+// rows of the table when the histograms come with the tuples (PresortSpec): every row costs os_offsets_kernel a load per
+// digit, and 24 k compacting workgroups spread over 64 rows do not contend
+constexpr int kOsPresortRows = 64;
+static_assert(kOsPresortRows <= kOsHistBlocks, "the table is sized for kOsHistBlocks rows");
+
+// the two-pass + buckets form (3b) serves packed keys of four digits or more
+static bool os_hybrid(int64_t cap, int key_bits) {
+    static const int hybrid_knob = [] { const char* e = getenv("BESST_SORT_HYBRID"); return e ? atoi(e) : 1; }();
+    const int passes = (key_bits + kOsBits - 1) / kOsBits;
+    int idx_bits = 1;
+    while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
+    const bool packed = key_bits + idx_bits <= 64;
+    return hybrid_knob && packed && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31 && cap <= ((int64_t)1 << 30);
+}
+
+bool onesweep_presort_spec(int64_t cap, int key_bits, uint64_t key_base, void* ws, PresortSpec* out) {
+    if (!os_hybrid(cap, key_bits)) return false;
+    const OsWorkspace w = os_carve(ws, cap, kOsBits);
+    out->table = w.table;
+    out->rows = kOsPresortRows;
+    out->shift = key_bits - 16;
+    out->key_base = key_base;
+    out->cap = (uint32_t)cap;
+    return true;
+}
+
 size_t onesweep_workspace_bytes(int64_t cap) {
     if (cap < 1) cap = 1;
     return os_carve(nullptr, cap, kOsBits).total;
@@ -1272,7 +1298,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
                                 int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
                                 int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
-                                const uint32_t* first_map, uint64_t key_base) {
+                                const uint32_t* first_map, uint64_t key_base, bool hist_ready) {
     const OsWorkspace w = os_carve(ws, cap, kOsBits);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: chained-scan workspace too small");
     int passes = (key_bits + kOsBits - 1) / kOsBits;
@@ -1281,25 +1307,25 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
     const int packed_bits = key_bits + idx_bits <= 64 ? idx_bits : 0;
     // keys of four digits or more: two stream-wide passes on the top 16 bits, the rest bucket by bucket in LDS (3b)
-    static const int hybrid_knob = [] { const char* e = getenv("BESST_SORT_HYBRID"); return e ? atoi(e) : 1; }();
-    const bool hybrid = hybrid_knob && packed_bits && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31 && cap <= ((int64_t)1 << 30);
+    const bool hybrid = os_hybrid(cap, key_bits);
     const int shift0 = hybrid ? key_bits - 16 : 0;
     if (hybrid) passes = 2;
     const uint32_t nt_sort = (uint32_t)((cap + kOsTile - 1) / kOsTile);
     const uint32_t nt_red = (uint32_t)((cap + kOsRedTile - 1) / kOsRedTile);
     constexpr int RADIX = 1 << kOsBits;
     BESST_HIP_TRY(hipMemsetAsync(w.err, 0, 4, s));
-    {
+    if (hist_ready && hybrid) {
+        // the histograms came with the tuples (PresortSpec: compact_kernel); only the descriptors are left to clear
+        BESST_HIP_TRY(hipMemsetAsync(w.granules, 0, w.granule_words * 8, s));
+    } else {
         ProfScope ps(s, kProfSortHist);
-        const uint32_t hist_tiles = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
-        (void)hist_tiles;
         hipLaunchKernelGGL((os_hist_kernel<kOsBits>), dim3(kOsHistBlocks), dim3(kOsHistThreads), 0, s, keys, n_tuples,
                            (uint32_t)cap, passes, shift0, key_base, w.table, w.granules, w.granule_words);
     }
     {
         ProfScope ps(s, kProfSortScan);
-        hipLaunchKernelGGL((os_offsets_kernel<kOsBits>), dim3(passes), dim3(256), 0, s, w.table, kOsHistBlocks, passes,
-                           w.digit_base, w.tickets);
+        hipLaunchKernelGGL((os_offsets_kernel<kOsBits>), dim3(passes), dim3(256), 0, s, w.table,
+                           hist_ready && hybrid ? kOsPresortRows : kOsHistBlocks, passes, w.digit_base, w.tickets);
     }
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;

@@ -971,11 +971,28 @@ size_t reduce_workspace_bytes(int64_t cap) {
     return carve(nullptr, cap).total;
 }
 
+// which streams launch_sort_reduce hands to the chained-scan passes (the test of its large-stream branch)
+static bool takes_large_stream_path(int64_t cap, int key_bits) {
+    const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
+    int cap_idx_bits = 1;
+    while (((int64_t)1 << cap_idx_bits) < cap) ++cap_idx_bits;
+    const bool packable = (key_bits > kMsdBits ? key_bits - kMsdBits : 0) + cap_idx_bits <= 64;
+    return !(nb_sort <= (uint32_t)kScanFreeMaxBlocks || (packable && nb_sort <= (uint32_t)kMsdMaxBlocks));
+}
+
+bool sort_presort_spec(int64_t cap, int key_bits, uint64_t key_base, void* ws, size_t ws_bytes, PresortSpec* out) {
+    if (!out || !ws || cap < 1 || cap >= ((int64_t)1 << 32) || key_bits < 1 || key_bits > 64) return false;
+    const RedWorkspace w = carve(ws, cap);
+    if (ws_bytes < w.total || !takes_large_stream_path(cap, key_bits)) return false;
+    return onesweep_presort_spec(cap, key_bits, key_base, w.os_ws, out);
+}
+
 int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits,
                        const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base) {
+                       uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base,
+                       bool hist_ready) {
     // key_bits counts the significant bits of key - key_base: every path below sorts that difference (the order is
     // the same) and puts key_base back when it writes a row's key
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
@@ -1038,7 +1055,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         uint32_t* bi[2] = {w.idx[0], w.idx[1]};
         return launch_onesweep_sort_reduce(s, cap, n_tuples, key_bits, keys, payload, bk, bi, row_key, row_mask, row_n,
                                            row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows, w.os_ws,
-                                           w.os_bytes, first_map, key_base);
+                                           w.os_bytes, first_map, key_base, hist_ready);
     }
     const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {

@@ -103,6 +103,7 @@ class DeviceGraphBuilder(object):
         self._paths = {}
         self.key_base, self.key_bits = 0, 2 * self.node_bits + 1
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
+        self._presorted = False
         self.candidate_share = None
 
     # device addresses inside the small block
@@ -136,6 +137,7 @@ class DeviceGraphBuilder(object):
             self.key_base = ((lo * 2) << self.node_bits) << 1
             self.key_bits = max(1, int(((((top << self.node_bits) | top) << 1) | 1) - self.key_base).bit_length())
             self._args.pop('reduce', None)
+            self._args.pop('presort', None)
 
     def reset(self):
         """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
@@ -160,7 +162,7 @@ class DeviceGraphBuilder(object):
             self._paths[id(rec)] = path
         return path
 
-    def classify(self, rec):
+    def classify(self, rec, presort=False):
         self.params.record_path = self.record_path(rec)
         # argument lists are marshalled once per record set (every buffer is allocated once)
         args = self._args.get(id(rec))
@@ -170,7 +172,22 @@ class DeviceGraphBuilder(object):
                 self.n_contigs, _p(self.table), C.byref(self.params), self.node_bits, self._carry, _p(self.aligned),
                 _p(self.keys), _p(self.payload), self._n_out, self._small(0), _p(self.ws1), self.ws1.numel())
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.besst_dev_classify(C.c_void_p(stream), *args), 'dev_classify')
+        ref = self._presort_ref(presort)
+        _lib.check(self.lib.besst_dev_classify_presort(C.c_void_p(stream), *args, ref), 'dev_classify')
+        self._presorted = ref is not None               # the next reduce() of the builder's own tuples may trust the table
+
+    def _presort_ref(self, on):
+        """The hand-over of the sort's digit histograms from stage 1 to stage 2 (include/besst_amd.h, besst_presort)
+        for this builder's own tuple buffers, or NULL when stage 2 would not use it."""
+        if not on:
+            return None
+        spec = self._args.get('presort')
+        if spec is None:
+            spec = _lib.Presort()
+            used = self.lib.besst_dev_reduce_presort(self.tup_cap, self.key_bits, self.key_base, _p(self.ws2),
+                                                     self.ws2.numel(), C.byref(spec))
+            spec = self._args['presort'] = (spec, bool(used == 1 and spec.table))
+        return C.byref(spec[0]) if spec[1] else None
 
     def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None, first_map=None):
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -182,8 +199,11 @@ class DeviceGraphBuilder(object):
                     _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
                     _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
                     _p(self.ws2), self.ws2.numel(), None, self.key_base)
-            _lib.check(self.lib.besst_dev_reduce(C.c_void_p(stream), *args), 'dev_reduce')
+            fn = self.lib.besst_dev_reduce_presorted if self._presorted else self.lib.besst_dev_reduce
+            self._presorted = False
+            _lib.check(fn(C.c_void_p(stream), *args), 'dev_reduce')
             return
+        self._presorted = False
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
         cap = self.tup_cap if capacity is None else int(capacity)
@@ -225,7 +245,7 @@ class DeviceGraphBuilder(object):
 
     def step(self, rec):
         self.reset()
-        self.classify(rec)
+        self.classify(rec, presort=True)
         self.reduce()
 
     def read_sizes(self):

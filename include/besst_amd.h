@@ -280,6 +280,39 @@ int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, i
                      uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
                      uint64_t key_base);
 
+/* Stage 1 + 2 on buffers that stay allocated (a resident builder): the large-stream form of stage 2 starts with a
+ * histogram read of the whole key stream, which stage 1 can take on its way out (it has every key in registers when it
+ * writes the ordered stream).  besst_dev_reduce_presort describes that hand-over for a given stage-2 call: it returns
+ * 1 and fills *out when besst_dev_reduce with this capacity / key_bits / key_base / workspace would take its
+ * histograms from `out->table` (a region of that workspace), 0 when it would not (small streams, keys that do not
+ * pack).  besst_dev_classify_presort is besst_dev_classify that also fills the table (presort may be NULL);
+ * besst_dev_reduce_presorted is besst_dev_reduce that trusts it - same workspace, same capacity, same key range, and
+ * the tuples of exactly that classify call.  (Replaces nothing in the reference: it is the seam between
+ * CreateGraph.py:141-206, where links are found, and :842-862, where they are summed per edge.) */
+typedef struct besst_presort {
+    uint32_t* table;      /* device: [rows][2][256] counters inside the stage-2 workspace */
+    int32_t rows;         /* power of two */
+    int32_t shift;        /* digits of key - key_base at shift and shift + 8 */
+    uint64_t key_base;
+    uint32_t capacity;    /* tuples at or beyond it are not counted (stage 2 ignores them too) */
+    uint32_t reserved;
+} besst_presort;
+int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
+                             size_t workspace_bytes, besst_presort* h_out);
+int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
+                               const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
+                               const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
+                               const void* contig_table, const besst_lib_params* h_params, int32_t node_bits,
+                               int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload,
+                               uint32_t* n_out, besst_counters* counters, void* workspace,
+                               size_t workspace_bytes, const besst_presort* h_presort);
+int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
+                               const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
+                               uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                               uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                               uint32_t* n_rows, void* workspace, size_t workspace_bytes,
+                               const uint32_t* first_map, uint64_t key_base);
+
 /* ---- multi-GPU path ----------------------------------------------------
  * Ranks own contiguous slices of the (tid,pos)-sorted stream.  The duplicate chain of CreateEdge
  * (CreateGraph.py:835-838,869-870) crosses slice boundaries, so stage 1 is split in three phases:
