@@ -596,11 +596,14 @@ def main_single(args, device, result_fd):
     if args.also and args.also != args.config and args.pairs is None:
         C_PORT_TIMING.clear()
         res2, wl2, runner2 = measure_single(args, device, args.also, 20, 3, 3)
+        over2 = overlapped_throughput(runner2, wl2, device, args.in_flight, 60) if args.in_flight > 1 else None
         del runner2
         second = {k: res2[k] for k in ('value', 'ms_per_step', 'workload', 'records', 'link_tuples_per_pair',
                                         'edge_rows', 'roofline', 'kernel_ms', 'verified_vs_c_oracle')}
         second['unit'] = 'read-pairs/s'
         second['steps'], second['warmup'] = 20, 3
+        if over2 is not None:
+            second['overlapped'] = over2
         if not args.no_cpu_baseline and C_PORT_TIMING:
             second['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'], 'cores': 1}
         out[args.also.lower()] = second

@@ -104,3 +104,31 @@ def test_split_distribution_from_device_histogram():
             assert got[0] == g['cluster1'] and got[1] == g['cluster2']
             assert (float(got[2]), float(got[3]), float(got[4]), float(got[5])) == \
                 (g['mean1'], g['stddev1'], g['mean2'], g['stddev2'])
+
+
+def test_resident_builder_step_large_stream():
+    """DeviceGraphBuilder.step() - what bench.py times - on a mate-pair library large enough for the large-stream sort
+    (6.4 M link tuples): fused record loop, compact_kernel handing the sort its digit histograms
+    (besst_dev_classify_presort / besst_dev_reduce_presorted), two chained-scan passes, wave-per-bucket sort + reduction.
+    Twice on the same builder (the second pass starts from the first one's leftovers in every workspace), against the
+    C oracle."""
+    import torch
+    from besst_amd import pipeline
+    dev = torch.device('cuda', 0)
+    wl = workload.make_device(dev, 'C3', 0, pairs=30_000_000, nc=20_000)
+    rec = pipeline.DeviceRecords.from_columns(wl['cols'])
+    probe = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, 1)
+    probe.set_contigs(**wl['table'])
+    probe.reset()
+    probe.classify(rec)
+    n_tuples, _ = probe.read_sizes()
+    del probe
+    assert n_tuples > 4_500_000
+    gb = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, int(n_tuples * 1.25) + 4096)
+    gb.set_contigs(**wl['table'])
+    for _ in range(2):
+        gb.step(rec)
+    assert gb._args['presort'][1], 'the large-stream sort should take its histograms from stage 1'
+    table = gb.fetch_table()
+    ctr = gb.read_counters()
+    assert_table_equals_c_oracle(table, gb.aligned.cpu().numpy(), ctr, wl['batch'], wl)

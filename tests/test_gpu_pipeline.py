@@ -191,3 +191,50 @@ def test_sort_reduce_with_offset_scaffold_ids(n):
     assert np.array_equal(get(gb.row_sum, r, np.int64), want['sum_obs'])
     assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
     assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [0, 1, 100, 70_000])
+def test_large_capacity_with_few_tuples(n):
+    """The sort path is chosen by the CAPACITY of the tuple buffers (a resident builder is sized for the largest pass):
+    the chained-scan passes + wave-per-bucket kernels with a stream of 0, 1 and a few tuples (every bucket but a handful
+    empty, n_rows from the last workgroup of the row mover), and 70 000 tuples that still fit one scatter tile each."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from besst_amd import pipeline
+    from oracle import c_oracle as CO
+    cap, key_bits = 5_000_000, 37
+    rng = np.random.default_rng(n + 5)
+    node_bits = (key_bits - 1) // 2
+    rows = max(1, n // 9)
+    pair = rng.integers(0, 1 << (2 * node_bits), rows, dtype=np.int64)[rng.integers(0, rows, n)] if n else np.zeros(0, np.int64)
+    keys = (pair << 1).astype(np.uint64)
+    lo = rng.integers(26, 5000, n).astype(np.uint64)
+    hi = rng.integers(26, 5000, n).astype(np.uint64) | (np.uint64(1) << np.uint64(30))
+    payload = lo | (hi << np.uint64(32))
+    dev = torch.device('cuda', 0)
+    lib = dict(read_len=100.0, ins_size_threshold=800.0, min_mapq=11, orientation='fr', detect_duplicate=True,
+               extend_paths=True, no_score=False)
+    gb = pipeline.DeviceGraphBuilder(dev, 4, node_bits, lib, cap, cap)
+    dk = torch.zeros(cap, dtype=torch.int64, device=dev)
+    dp = torch.zeros(cap, dtype=torch.int64, device=dev)
+    dk[:n] = torch.from_numpy(keys.view(np.int64)).to(dev)
+    dp[:n] = torch.from_numpy(payload.view(np.int64)).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    for _ in range(2):
+        gb.reduce(keys=dk, payload=dp, n_tuples_ptr=C.c_void_p(cnt.data_ptr()), capacity=cap)
+    torch.cuda.synchronize()
+    want = CO.edge_rows(keys, payload)
+    r = len(want['key'])
+    raw = gb.small.cpu().numpy()
+    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
+    assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
+    assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
+    assert np.array_equal(get(gb.row_sum, r, np.int64), want['sum_obs'])
+    assert np.array_equal(get(gb.row_sum_sq, r, np.int64), want['sum_obs_sq'])
+    assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
+    assert np.array_equal(get(gb.row_mask, r, np.uint32).astype(np.int64), np.ones(r, np.int64))
+    assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
+    assert np.array_equal(get(gb.obs_hi, n, np.int32).astype(np.int64), want['obs_hi'])
