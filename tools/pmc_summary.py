@@ -53,7 +53,7 @@ def main():
         wm = sum(w[k]) / max(1, len(w[k]))
         # dispatches per step: relative to a kernel that runs exactly once per record loop / once per sort
         classify = k in ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel')
-        anchor = 'stitch_kernel' if classify else ('os_hist_kernel' if 'os_hist_kernel' in f else 'radix_hist_kernel')
+        anchor = 'stitch_kernel' if classify else ('os_offsets_kernel' if 'os_offsets_kernel' in f else 'radix_hist_kernel')
         per_step = len(f[k]) / float(max(1, len(f.get(anchor, []))))
         kernels[k] = {'FETCH_SIZE_KB_mean': round(fm, 1), 'WRITE_SIZE_KB_mean': round(wm, 1),
                       'dispatches_per_step': round(per_step, 2),
