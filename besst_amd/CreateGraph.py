@@ -233,17 +233,17 @@ def InitializeGraph(dict_with_scaffolds, graph, Information):
 
 
 def CalculateStats(sorted_contig_lengths, sorted_contig_lengths_small, param, Information):
-    cur_length, nr_conts, L50, N50 = 0, 0, 0, 0
-    half = param.tot_assembly_length / 2.0
-    for group in (sorted_contig_lengths, sorted_contig_lengths_small):
-        for contig_length in group:
-            cur_length += contig_length
-            nr_conts += 1
-            if cur_length >= half:
-                N50, L50 = contig_length, nr_conts
-                break
-        if N50 != 0:
-            break
+    """N50 / L50 of the length-sorted large group followed by the small one (CreateGraph.py:727-757): the first position
+    where the running length reaches half the assembly - a cumulative sum and one search (integers: exact)."""
+    lengths = np.concatenate([np.asarray(sorted_contig_lengths, dtype=np.int64).reshape(-1),
+                              np.asarray(sorted_contig_lengths_small, dtype=np.int64).reshape(-1)])
+    N50, L50 = 0, 0
+    if lengths.size:
+        reached = np.flatnonzero(np.cumsum(lengths) >= param.tot_assembly_length / 2.0)
+        # the reference stops at the first group that yields a non-zero N50; zero-length entries cannot occur here
+        if reached.size:
+            L50 = int(reached[0]) + 1
+            N50 = int(lengths[reached[0]])
     print('L50: ', L50, 'N50: ', N50, 'Initial contig assembly length: ', param.tot_assembly_length, file=Information)
     return (N50, L50)
 
@@ -281,85 +281,104 @@ def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime,
     return ()
 
 
+def _column(objects, attribute, dtype):
+    return np.fromiter((getattr(o, attribute) for o in objects), dtype=dtype, count=len(objects))
+
+
 def CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_scaffolds):
-    singeled_out = 0
-    sorted_lengths = sorted((Scaffolds[s].s_length for s in Scaffolds), reverse=True)
-    sorted_lengths_small = sorted((small_scaffolds[s].s_length for s in small_scaffolds), reverse=True)
-    N50, L50 = CalculateStats(sorted_lengths, sorted_lengths_small, param, Information)
+    """Scaffolds below the library's contig threshold move to the small dictionaries (CreateGraph.py:759-784): one
+    length column per dictionary, a mask, and a loop over the scaffolds that actually move."""
+    large_ids = list(Scaffolds)
+    large_len = _column([Scaffolds[i] for i in large_ids], 's_length', np.int64)
+    small_len = _column(list(small_scaffolds.values()), 's_length', np.int64)
+    N50, L50 = CalculateStats(np.sort(large_len)[::-1], np.sort(small_len)[::-1], param, Information)
     param.current_L50 = L50
     param.current_N50 = N50
-    for scaffold_ in list(Scaffolds.keys()):
-        if Scaffolds[scaffold_].s_length < param.contig_threshold:
-            S_obj = Scaffolds[scaffold_]
-            GO.ChangeToSmallContigs(Contigs, S_obj.contigs, small_contigs)
-            small_scaffolds[scaffold_] = S_obj
-            del Scaffolds[scaffold_]
-            singeled_out += 1
-    print('Nr of contigs/scaffolds that was singeled out due to length constraints ' + str(singeled_out),
+    moving = np.flatnonzero(large_len < param.contig_threshold)
+    for k in moving.tolist():
+        scaffold_ = large_ids[k]
+        S_obj = Scaffolds.pop(scaffold_)
+        GO.ChangeToSmallContigs(Contigs, S_obj.contigs, small_contigs)
+        small_scaffolds[scaffold_] = S_obj
+    print('Nr of contigs/scaffolds that was singeled out due to length constraints ' + str(int(moving.size)),
           file=Information)
     return ()
 
 
+def _retire_scaffolds(selected, scaffold_dict, graphs):
+    """Contigs taken out of the scaffolding (low coverage, repeats): their scaffold objects and both scaffold ends go."""
+    for c in selected:
+        scaf_ = c.scaffold
+        del scaffold_dict[scaf_]
+        ends = [(scaf_, 'L'), (scaf_, 'R')]
+        for g in graphs:
+            g.remove_nodes_from(ends)
+
+
+def _coverage_groups(Contigs, Scaffolds, G, G_prime, small_contigs, small_scaffolds, param):
+    """The two contig dictionaries as (objects in dictionary order, coverage column, scaffold dictionary, graphs)."""
+    out = []
+    for contigs, scaffolds, graphs in ((Contigs, Scaffolds, (G, G_prime) if param.extend_paths else (G,)),
+                                       (small_contigs, small_scaffolds, (G_prime,))):
+        objs = list(contigs.values())
+        out.append((objs, _column(objs, 'coverage', np.float64), scaffolds, graphs))
+    return out
+
+
 def filter_low_coverage_contigs(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information):
-    low_coverage_contigs = []
+    """-z_min (CreateGraph.py:407-433): a mask over each dictionary's coverage column."""
     print('Removing low coverage contigs if -z_min specified..', file=Information)
-    for contig in Contigs:
-        if Contigs[contig].coverage < param.lower_cov_cutoff:
-            low_coverage_contigs.append(Contigs[contig])
-            scaf_ = Contigs[contig].scaffold
-            del Scaffolds[scaf_]
-            G.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
-            if param.extend_paths:
-                G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
-    for contig in small_contigs:
-        if small_contigs[contig].coverage < param.lower_cov_cutoff:
-            low_coverage_contigs.append(small_contigs[contig])
-            scaf_ = small_contigs[contig].scaffold
-            del small_scaffolds[scaf_]
-            G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
+    low_coverage_contigs = []
+    for objs, cov, scaffolds, graphs in _coverage_groups(Contigs, Scaffolds, G, G_prime, small_contigs, small_scaffolds, param):
+        chosen = [objs[k] for k in np.flatnonzero(cov < param.lower_cov_cutoff).tolist()]
+        _retire_scaffolds(chosen, scaffolds, graphs)
+        low_coverage_contigs.extend(chosen)
     GO.PrintOut_low_cowerage_contigs(low_coverage_contigs, Contigs, param.output_directory, small_contigs)
     print('Removed a total of: ', len(low_coverage_contigs), ' low coverage contigs. With coverage lower than ',
           param.lower_cov_cutoff, file=Information)
 
 
 def _acc(values):
-    total = 0
-    for v in values:
-        total = total + v
-    return total
+    """sum() of the reference: left to right (np.sum adds pairwise and rounds differently)."""
+    values = np.asarray(values, dtype=np.float64)
+    return float(np.cumsum(values)[-1]) if values.size else 0
 
 
 def _mean_and_std(xs):
-    n = float(len(xs))
+    xs = np.asarray(xs, dtype=np.float64)
+    n = float(xs.size)
     mean = _acc(xs) / n
-    sq = 0
-    for x in xs:
-        sq = sq + (x ** 2 - 2 * x * mean + mean ** 2)
-    return mean, (sq / (n - 1)) ** 0.5
+    return mean, (_acc(xs ** 2 - 2 * xs * mean + mean ** 2) / (n - 1)) ** 0.5
 
 
 def RemoveOutliers(mean_cov, std_dev, cov_list):
     k = MaxObsDistr(len(cov_list), 0.95)
-    filtered_list = [x for x in cov_list if (x < mean_cov + k * std_dev and x < 2 * mean_cov)]
-    return len(cov_list) > len(filtered_list), filtered_list
+    cov_list = np.asarray(cov_list, dtype=np.float64)
+    filtered_list = cov_list[(cov_list < mean_cov + k * std_dev) & (cov_list < 2 * mean_cov)]
+    return cov_list.size > filtered_list.size, filtered_list
 
 
 def CalculateMeanCoverage(Contigs, Information, param):
-    by_length = sorted(((Contigs[c].length, c) for c in Contigs), key=lambda tup: tup[0], reverse=True)[:50000]
-    cov_of_longest_contigs = [Contigs[c].coverage for _, c in by_length if Contigs[c].coverage > 0]
-    if len(cov_of_longest_contigs) <= 1:
+    """Mean / sd of the coverage of the 50 000 longest contigs with the extreme ones trimmed away
+    (CreateGraph.py:875-927), on a length and a coverage column."""
+    objs = list(Contigs.values())
+    lengths = _column(objs, 'length', np.int64)
+    longest = np.argsort(-lengths, kind='stable')[:50000]                 # ties keep dictionary order, as sorted() does
+    cov = _column(objs, 'coverage', np.float64)[longest]
+    cov_of_longest_contigs = cov[cov > 0]
+    if cov_of_longest_contigs.size <= 1:
         sys.exit('Too few contigs to calculate coverage on. Got: {0} contigs. If you have specified  -z_min or '
                  '--min_mapq, consider lower them. If not, check the BAM file for proper alignments. Exiting here '
-                 'before scaffolding...'.format(len(cov_of_longest_contigs)))
+                 'before scaffolding...'.format(int(cov_of_longest_contigs.size)))
     mean_cov, std_dev = _mean_and_std(cov_of_longest_contigs)
-    n = float(len(cov_of_longest_contigs))
+    n = float(cov_of_longest_contigs.size)
     print('Mean coverage before filtering out extreme observations = ', mean_cov, file=Information)
     print('Std dev of coverage before filtering out extreme observations= ', std_dev, file=Information)
     print('Number of contigs used in calc of coverage before filtering: ', n, file=Information)
     extreme_obs_occur = True
     while extreme_obs_occur:
         extreme_obs_occur, filtered_list = RemoveOutliers(mean_cov, std_dev, cov_of_longest_contigs)
-        n = float(len(filtered_list))
+        n = float(filtered_list.size)
         if n == 0 or _acc(filtered_list) == 0:
             break
         mean_cov, std_dev = _mean_and_std(filtered_list)
@@ -367,41 +386,28 @@ def CalculateMeanCoverage(Contigs, Information, param):
     print('Mean coverage after filtering = ', mean_cov, file=Information)
     print('Std coverage after filtering = ', std_dev, file=Information)
     print('Number of contigs used in calc of coverage after filtering: ', n, file=Information)
-    print('Length of longest contig in calc of coverage: ', by_length[0][0], file=Information)
-    print('Length of shortest contig in calc of coverage: ', by_length[-1][0], file=Information)
+    print('Length of longest contig in calc of coverage: ', int(lengths[longest[0]]), file=Information)
+    print('Length of shortest contig in calc of coverage: ', int(lengths[longest[-1]]), file=Information)
     return (mean_cov, std_dev)
 
 
 def RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information):
+    """Contigs above the repeat coverage threshold leave the graphs, contigs at half coverage are marked as potential
+    haplotypes (CreateGraph.py:959-1018): two masks over each dictionary's coverage column."""
     mean_cov, std_dev = param.mean_coverage, param.std_dev_coverage
+    k = MaxObsDistr(len(Contigs), 0.95)
+    repeat_thresh = param.cov_cutoff if param.cov_cutoff else max(mean_cov + k * std_dev, 2 * mean_cov - 3 * std_dev)
+    print('Detecting repeats..', file=Information)
     Repeats = []
     count_hapl = 0
-    k = MaxObsDistr(len(Contigs), 0.95)
-    if param.cov_cutoff:
-        repeat_thresh = param.cov_cutoff
-    else:
-        repeat_thresh = max(mean_cov + k * std_dev, 2 * mean_cov - 3 * std_dev)
-    print('Detecting repeats..', file=Information)
-    for contig in Contigs:
-        if Contigs[contig].coverage > repeat_thresh:
-            Repeats.append(Contigs[contig])
-            scaf_ = Contigs[contig].scaffold
-            del Scaffolds[scaf_]
-            G.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
-            if param.extend_paths:
-                G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
-        if param.detect_haplotype and Contigs[contig].coverage < mean_cov / 2.0 + param.hapl_threshold * std_dev:
-            count_hapl += 1
-            Contigs[contig].is_haplotype = True
-    for contig in small_contigs:
-        if small_contigs[contig].coverage > repeat_thresh:
-            Repeats.append(small_contigs[contig])
-            scaf_ = small_contigs[contig].scaffold
-            del small_scaffolds[scaf_]
-            G_prime.remove_nodes_from([(scaf_, 'L'), (scaf_, 'R')])
-        if param.detect_haplotype and small_contigs[contig].coverage < mean_cov / 2.0 + param.hapl_threshold * std_dev:
-            count_hapl += 1
-            small_contigs[contig].is_haplotype = True
+    for objs, cov, scaffolds, graphs in _coverage_groups(Contigs, Scaffolds, G, G_prime, small_contigs, small_scaffolds, param):
+        chosen = [objs[j] for j in np.flatnonzero(cov > repeat_thresh).tolist()]
+        _retire_scaffolds(chosen, scaffolds, graphs)
+        Repeats.extend(chosen)
+        if param.detect_haplotype:
+            for j in np.flatnonzero(cov < mean_cov / 2.0 + param.hapl_threshold * std_dev).tolist():
+                objs[j].is_haplotype = True
+                count_hapl += 1
     GO.repeat_contigs_logger(Repeats, Contigs, param.output_directory, small_contigs, param)
     GO.PrintOutRepeats(Repeats, Contigs, param.output_directory, small_contigs)
     print('Removed a total of: ', len(Repeats), ' repeats. With coverage larger than ', repeat_thresh, file=Information)
