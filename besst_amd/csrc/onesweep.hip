@@ -43,7 +43,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // win - 256 x 16 keys 1.55 ms, 512 x 12 1.38, 512 x 16 1.12, 1024 x 16 1.02 for the five passes - as long as the
 // keys per thread stay at 16 (24 / 32 keys per thread: 1.41 / 1.69 ms, the ranking rounds of a wave are serial).
 #ifndef BESST_OS_THREADS
-#define BESST_OS_THREADS 512
+#define BESST_OS_THREADS 1024
 #endif
 #ifndef BESST_OS_ITEMS
 #define BESST_OS_ITEMS 16
@@ -373,10 +373,8 @@ static_assert(kBkBits >= 6 && kBkBits <= 10, "bucket digit width");
 // start[b] = first position of the sorted-by-top-digits stream whose bucket number is >= b (binary search)
 __global__ __launch_bounds__(256) void os_bucket_start_kernel(const uint64_t* __restrict__ words,
                                                               const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                              int bucket_shift, uint32_t* __restrict__ start,
-                                                              uint32_t* __restrict__ big_count) {
+                                                              int bucket_shift, uint32_t* __restrict__ start) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) *big_count = 0;
     if (b > (uint32_t)kTopBuckets) return;
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
@@ -454,8 +452,9 @@ __device__ __forceinline__ void bk_excl_scan(uint32_t* vals, uint32_t* s_wtot, i
 // partner: C3 has a median of 815 tuples and 4 keys per bucket, at most 15).  ONE WAVE per bucket, no LDS: find the
 // smallest key not yet placed (a min over the lane's words, then over the wave), match it against every word of the
 // bucket (one compare + mbcnt per round of 64) - the words of that key go, in stream order, right behind the ones
-// placed so far - and repeat.  A bucket of more than kBwCap words or more than kBwKeys distinct keys, or whose eight
-// smallest keys cover less than a sixth of it, is put on the list of os_bucket_sort_kernel (digit passes in LDS).
+// placed so far - and repeat.  A bucket of more than kBwKeys distinct keys, or whose eight smallest keys cover less than
+// a sixth of it, goes on the list of os_bucket_wave_lds_kernel (digit passes, still one wave per bucket), one of more
+// than kBwCap words on the list of os_bucket_sort_kernel (a workgroup per bucket).
 #ifndef BESST_BW_ITEMS
 #define BESST_BW_ITEMS 24
 #endif
@@ -464,7 +463,13 @@ __device__ __forceinline__ void bk_excl_scan(uint32_t* vals, uint32_t* s_wtot, i
 #endif
 constexpr int kBwItems = BESST_BW_ITEMS;
 constexpr int kBwCap = 64 * kBwItems;
-constexpr int kBwKeys = 48;
+#ifndef BESST_BW_KEYS
+#define BESST_BW_KEYS 48
+#endif
+// a key costs ~280 wave instructions against ~4400 for the digit passes of a bucket, but those run at three waves per
+// SIMD and a fixed ~20 us per bucket: measured, the peel-off is the faster one up to ~50 keys (30 M random tuples, 30
+// keys per bucket: 0.81 ms against 1.3)
+constexpr int kBwKeys = BESST_BW_KEYS;
 static_assert(kBwItems % 4 == 0 && kBwItems <= 32, "rounds are dispatched in steps of four");
 
 __device__ __forceinline__ uint32_t bw_wave_min(uint32_t v) {
@@ -612,8 +617,7 @@ __device__ __forceinline__ bool bw_bucket(const uint64_t* __restrict__ words, ui
 __global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(const uint64_t* __restrict__ words,
                                                                     const uint32_t* __restrict__ start,
                                                                     int low_shift, int low_bits,
-                                                                    uint32_t* __restrict__ big_list,
-                                                                    uint32_t* __restrict__ big_count, BwOut o) {
+                                                                    uint32_t* __restrict__ bucket_class, BwOut o) {
     const int lane = threadIdx.x & 63;
     // wave-uniform values, and the compiler is told so: the round and key loops are scalar control flow
     const uint32_t bucket = blockIdx.x * kBkWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(const uint64
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket + 1]) - s0;
     o.bucket_rows += bucket;
     if (n == 0) {
-        if (lane == 0) o.bucket_rows[0] = 0;
+        if (lane == 0) { o.bucket_rows[0] = 0; bucket_class[bucket] = 0u; }
         return;
     }
     bool placed = false;
@@ -646,7 +650,198 @@ __global__ __launch_bounds__(kBkThreads) void os_bucket_wave_kernel(const uint64
             default: break;
         }
     }
-    if (!placed && lane == 0) big_list[atomicAdd(big_count, 1u)] = bucket;
+    // who finishes the bucket (a plain store per bucket: 65 536 appends to one list counter took 0.7 ms when every
+    // bucket had to be handed on): 0 done, 1 many keys -> os_bucket_wave_lds_kernel, 2 many words -> os_bucket_sort_kernel
+    if (lane == 0) bucket_class[bucket] = placed ? 0u : (n <= (uint32_t)kBwCap ? 1u : 2u);
+}
+
+// The buckets of the wave kernel's size class that hold MANY distinct keys (a library whose edges carry one or two links
+// each, or a stream of unrelated keys): still one wave per bucket, four buckets per workgroup, but digit passes - words
+// in registers, 7-bit stable passes through the wave's own LDS buffer with the peel-off ranking of the stream passes, no
+// workgroup barrier (a wave's LDS operations complete in order) - then the reduction of the sorted words: observations
+// gathered and written coalesced, head flags by comparing neighbours, row sums by a segmented scan per round of 64 with
+// the open tail of a round carried into the next one as wave-uniform values.
+constexpr int kBlPer = kBkRadix / 64;
+static_assert(kBkRadix % 64 == 0, "digits per lane of the wave-level scan");
+
+__global__ __launch_bounds__(kBkThreads) void os_bucket_wave_lds_kernel(const uint64_t* __restrict__ words,
+                                                                        const uint32_t* __restrict__ start,
+                                                                        int low_shift, int low_bits,
+                                                                        const uint32_t* __restrict__ bucket_class, BwOut o) {
+    __shared__ uint64_t s_words_all[kBkWaves][kBwCap];
+    __shared__ uint32_t s_hist_all[kBkWaves][kBkRadix];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint64_t* s_words = s_words_all[wave];
+    uint32_t* s_hist = s_hist_all[wave];
+    const uint64_t idx_mask = (1ull << low_shift) - 1ull;
+    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int n_pass = (low_bits + kBkBits - 1) / kBkBits;
+    // the wave's buckets: wave_id, wave_id + waves, ... - their classes are fetched together (one round trip), then only
+    // the marked ones are visited
+    const uint32_t n_waves = gridDim.x * kBkWaves, wave_id = blockIdx.x * kBkWaves + (uint32_t)wave;
+    const uint32_t mine = wave_id + (uint32_t)lane * n_waves;
+    unsigned long long todo = __ballot(mine < (uint32_t)kTopBuckets && bucket_class[mine] == 1u);
+    static_assert(kTopBuckets <= 64 * 2048 * kBkWaves, "one class per lane covers the wave's buckets (grid of 2048)");
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t bucket = wave_id + (uint32_t)j * n_waves;
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket]);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)start[bucket + 1]) - s0;
+        const int rounds = (int)((n + 63) >> 6);
+        uint64_t w[kBwItems];
+#pragma unroll
+        for (int r = 0; r < kBwItems; ++r) {
+            const uint32_t p = r * 64 + lane;
+            w[r] = (r < rounds && p < n) ? words[s0 + p] : ~0ull;
+        }
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int shift = low_shift + pass * kBkBits;
+            const int bits = low_bits - pass * kBkBits < kBkBits ? low_bits - pass * kBkBits : kBkBits;
+            const uint32_t dmask = (1u << bits) - 1u;
+#pragma unroll
+            for (int j = 0; j < kBlPer; ++j) s_hist[j * 64 + lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t dig_rank[kBwItems];
+#pragma unroll
+            for (int r = 0; r < kBwItems; ++r) {
+                dig_rank[r] = 0;
+                if (r < rounds) {
+                    const uint32_t p = r * 64 + lane;
+                    const bool valid = p < n;
+                    const uint32_t d = (uint32_t)(w[r] >> shift) & dmask;
+                    const uint32_t info = bk_wave_rank(d, valid);
+                    uint32_t pre = 0;
+                    if (valid) {
+                        volatile uint32_t* slot = &s_hist[d];
+                        pre = *slot;
+                        if ((info & 0xffu) == 0u) *slot = pre + (info >> 8);
+                    }
+                    dig_rank[r] = d | ((pre + (info & 0xffu)) << kBkBits);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            {   // digit counts -> exclusive starts, lane l owns digits [l * per, l * per + per)
+                uint32_t c[kBlPer];
+                uint32_t tot = 0;
+#pragma unroll
+                for (int j = 0; j < kBlPer; ++j) {
+                    c[j] = s_hist[lane * kBlPer + j];
+                    tot += c[j];
+                }
+                uint32_t x = tot;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t v = (uint32_t)__shfl_up((int)x, dd, 64);
+                    if (lane >= dd) x += v;
+                }
+                uint32_t off = x - tot;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < kBlPer; ++j) {
+                    s_hist[lane * kBlPer + j] = off;
+                    off += c[j];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < kBwItems; ++r) {
+                if (r < rounds) {
+                    const uint32_t p = r * 64 + lane;
+                    if (p < n) s_words[s_hist[dig_rank[r] & (kBkRadix - 1)] + (dig_rank[r] >> kBkBits)] = w[r];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < kBwItems; ++r) {
+                if (r < rounds) {
+                    const uint32_t p = r * 64 + lane;
+                    w[r] = p < n ? s_words[p] : ~0ull;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the sorted bucket -> observations (all gathers of the bucket in flight together) ...
+        uint32_t ov[kBwItems], mk[kBwItems];
+#pragma unroll
+        for (int r = 0; r < kBwItems; ++r) {
+            ov[r] = 0; mk[r] = 0;
+            if (r < rounds) {
+                const uint32_t p = r * 64 + lane;
+                if (p < n) {
+                    const uint64_t pl = o.payload[(uint32_t)(w[r] & idx_mask)];
+                    const uint32_t l = (uint32_t)pl, h = (uint32_t)(pl >> 32) & 0x3fffffffu;
+                    o.obs_lo[s0 + p] = (int32_t)l;
+                    o.obs_hi[s0 + p] = (int32_t)h;
+                    ov[r] = l + h;
+                    mk[r] = (uint32_t)(pl >> 62);
+                }
+            }
+        }
+        // ... and staged rows (carry_*: the row open at the end of the round before)
+        uint32_t rows_before = 0, carry_c = 0;
+        unsigned long long carry_s = 0, carry_q = 0;
+        uint64_t prev_last = ~0ull;                          // key of the last word of the round before
+#pragma unroll
+        for (int r = 0; r < kBwItems; ++r) {
+            if (r < rounds) {
+                const uint32_t p = r * 64 + lane;
+                const bool valid = p < n;
+                const uint64_t key = w[r] >> low_shift;
+                uint64_t before = __shfl_up(key, 1, 64);
+                if (lane == 0) before = prev_last;
+                const bool head = valid && (p == 0 || key != before);
+                const unsigned long long hm = __ballot(head);
+                const uint32_t row = s0 + rows_before + (uint32_t)__popcll(hm & le_mask) - 1u;   // never below s0: word 0 is a head
+                if (r > 0 && (hm & 1ull) && lane == 0) {     // the carried row ended with the round before
+                    StagedRow* sr = o.staged + (s0 + rows_before - 1u);
+                    sr->n = carry_c;
+                    sr->sum = carry_s;
+                    sr->sq = carry_q;
+                }
+                if (head) {
+                    const uint32_t src = (uint32_t)(w[r] & idx_mask);
+                    StagedRow* sr = o.staged + row;
+                    sr->key = key + o.key_base;
+                    sr->first = o.first_map ? o.first_map[src] : src;
+                    sr->off = s0 + p;
+                    sr->mask = mk[r];
+                }
+                uint32_t c = valid ? 1u : 0u;
+                unsigned long long sm = (unsigned long long)ov[r], sq = sm * sm;
+                bool fl = head || lane == 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t oc = (uint32_t)__shfl_up((int)c, d, 64);
+                    const unsigned long long os = __shfl_up(sm, d, 64), oq = __shfl_up(sq, d, 64);
+                    const int of = __shfl_up((int)fl, d, 64);
+                    if (lane >= d && !fl) { c += oc; sm += os; sq += oq; fl = of != 0; }
+                }
+                if ((hm & le_mask) == 0ull) { c += carry_c; sm += carry_s; sq += carry_q; }   // still the carried row
+                const int tail_lane = (int)(n - (uint32_t)r * 64u > 64u ? 63u : n - (uint32_t)r * 64u - 1u);
+                const bool seg_end = valid && (lane == tail_lane || ((hm >> (lane + 1)) & 1ull));
+                const bool bucket_end = p + 1u == n;
+                if (seg_end && (lane != tail_lane || bucket_end)) {
+                    StagedRow* sr = o.staged + row;
+                    sr->n = c;
+                    sr->sum = sm;
+                    sr->sq = sq;
+                }
+                // the open tail travels on
+                carry_c = (uint32_t)__builtin_amdgcn_readlane((int)c, tail_lane);
+                carry_s = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(sm >> 32), tail_lane) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)sm, tail_lane);
+                carry_q = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(sq >> 32), tail_lane) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)sq, tail_lane);
+                prev_last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), tail_lane) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)key, tail_lane);
+                rows_before += (uint32_t)__popcll(hm);
+            }
+        }
+        if (lane == 0) o.bucket_rows[bucket] = rows_before;
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __device__ void bk_sort_bucket(uint64_t* words, uint64_t* scratch, uint32_t s0, uint32_t n, int low_shift, int low_bits) {
@@ -881,11 +1076,21 @@ __device__ void bk_reduce_bucket(const uint64_t* words, uint32_t s0, uint32_t n,
 __global__ __launch_bounds__(kBkThreads) void os_bucket_sort_kernel(uint64_t* words, uint64_t* scratch,
                                                                     const uint32_t* __restrict__ start,
                                                                     int low_shift, int low_bits,
-                                                                    const uint32_t* __restrict__ big_list,
-                                                                    const uint32_t* __restrict__ big_count, BwOut o) {
-    const uint32_t count = *big_count;
-    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-        const uint32_t b = big_list[li];
+                                                                    const uint32_t* __restrict__ bucket_class, BwOut o) {
+    // the workgroup's buckets: blockIdx, blockIdx + grid, ... - classes fetched together, only the marked ones visited
+    __shared__ unsigned long long s_todo;
+    {
+        const uint32_t mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+        const unsigned long long m = __ballot(mine < (uint32_t)kTopBuckets && bucket_class[mine] == 2u);
+        if (threadIdx.x == 0) s_todo = m;
+    }
+    static_assert(kTopBuckets <= 64 * 1024, "one class per lane of the first wave covers the workgroup's buckets (grid of 1024)");
+    __syncthreads();
+    unsigned long long todo = s_todo;
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t b = blockIdx.x + (uint32_t)j * gridDim.x;
         const uint32_t s0 = start[b];
         const uint32_t n = start[b + 1] - s0;
         if (n > 1) bk_sort_bucket(words, scratch, s0, n, low_shift, low_bits);
@@ -1228,7 +1433,7 @@ struct OsWorkspace {
     unsigned long long* lead_s;
     unsigned long long* lead_s2;
     uint32_t* bucket_start;     // kTopBuckets + 1
-    uint32_t* big_list;         // kTopBuckets, then the counter
+    uint32_t* bucket_class;     // kTopBuckets: which kernel finishes the bucket
     uint32_t* bucket_rows;      // kTopBuckets
     char* staged;               // 40 bytes per tuple of capacity: the buckets' rows before they are numbered
     size_t total;
@@ -1253,7 +1458,7 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     w.lead_s = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
     w.lead_s2 = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
-    w.big_list = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
+    w.bucket_class = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
     w.staged = p + off; off += align_up((size_t)cap * 40, 256);
     w.total = off;
@@ -1355,11 +1560,13 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         {
             ProfScope ps(s, kProfBucketSort);
             hipLaunchKernelGGL(os_bucket_start_kernel, dim3((kTopBuckets + 1 + 255) / 256), dim3(256), 0, s, kin, n_tuples,
-                               (uint32_t)cap, shift0 + packed_bits, w.bucket_start, w.big_list + kTopBuckets);
+                               (uint32_t)cap, shift0 + packed_bits, w.bucket_start);
             hipLaunchKernelGGL(os_bucket_wave_kernel, dim3(kTopBuckets / kBkWaves), dim3(kBkThreads), 0, s, buf_keys[1],
-                               w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets, o);
+                               w.bucket_start, packed_bits, shift0, w.bucket_class, o);
+            hipLaunchKernelGGL(os_bucket_wave_lds_kernel, dim3(2048), dim3(kBkThreads), 0, s, buf_keys[1], w.bucket_start,
+                               packed_bits, shift0, w.bucket_class, o);
             hipLaunchKernelGGL(os_bucket_sort_kernel, dim3(1024), dim3(kBkThreads), 0, s, buf_keys[1], buf_keys[0],
-                               w.bucket_start, packed_bits, shift0, w.big_list, w.big_list + kTopBuckets, o);
+                               w.bucket_start, packed_bits, shift0, w.bucket_class, o);
         }
         {
             ProfScope ps(s, kProfRowReduce);
