@@ -859,13 +859,114 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
 }
 
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------
-// One workgroup, one lane per block and round, kStitchRounds rounds (4096 blocks) per iteration.  The summaries of
-// all rounds are fetched up front (one memory round trip); both scans - "nearest earlier block that reached
-// CreateEdge" (a max-scan of block indexes) and the tuple offsets (a sum-scan) - run as wave scans of every
-// round at once plus ONE wave scan over the 64 (round, wave) totals, so an iteration costs six barriers whatever
-// the number of blocks.  (A barrier-heavy scan per 1024 blocks cost 4.3 us per round.)
+// One workgroup per SPAN of 4096 blocks: one lane per block and round, kStitchRounds rounds.  The summaries of all
+// rounds are fetched up front (one memory round trip); both scans - "nearest earlier block that reached CreateEdge"
+// (a max-scan of block indexes) and the tuple offsets (a sum-scan) - run as wave scans of every round at once plus ONE
+// wave scan over the 64 (round, wave) totals: six barriers per span.  (A barrier-heavy scan per 1024 blocks cost
+// 4.3 us per round.)
+// A stream of more than one span (C3: 24 k blocks = 6 spans; one workgroup walking them took 70 us - every load and
+// instruction of the stage through ONE compute unit) is stitched in two launches without any waiting between
+// workgroups: stitch_spans_kernel leaves per span what the later ones need to know - its last reaching record, its
+// first reaching record (the one that needs a predecessor from an earlier span) and its tuple count with that head's
+// tuple still in - and every workgroup of stitch_kernel replays the aggregates of the spans before its own (a handful
+// of CreateEdge evaluations) to get the prev_obs it starts from and the offset of its first tuple.
 constexpr int kStitchRounds = 4;
+constexpr uint32_t kStitchSpan = 1024u * kStitchRounds;
 static_assert(kStitchRounds * 16 == 64, "the (round, wave) totals are scanned by one wave");
+
+struct StitchAgg {
+    int32_t has_any, l1, l2;            // the span's last record that reached CreateEdge
+    int32_t head_present, f1, f2;       // its first one: resolved against the spans before
+    uint32_t head_info;
+    uint32_t total;                     // tuples of the span, that head's provisional tuple included
+};
+
+__global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint32_t nblocks, uint32_t span, int detect,
+                                                            const int32_t* __restrict__ carry,
+                                                            StitchAgg* __restrict__ agg, int32_t* __restrict__ carry_in) {
+    __shared__ int32_t s_l1[1024 * kStitchRounds], s_l2[1024 * kStitchRounds];
+    __shared__ int s_tab[64];
+    __shared__ int s_total;
+    __shared__ int32_t s_first[4];
+    __shared__ int s_sum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t c0 = blockIdx.x * span;
+    if (blockIdx.x == 0 && t == 0) { carry_in[0] = carry[0]; carry_in[1] = carry[1]; }   // stitch_kernel overwrites carry
+    if (t == 0) { s_first[0] = -1; }
+    uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], has[kStitchRounds];
+    int32_t f1[kStitchRounds], f2[kStitchRounds], l1[kStitchRounds], l2[kStitchRounds];
+#pragma unroll
+    for (int r = 0; r < kStitchRounds; ++r) {
+        const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
+        n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0;
+        if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
+            n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
+            f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
+            l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
+            head_info[r] = summ.at(kSumHeadInfo, b);
+        }
+    }
+    int incl[kStitchRounds];
+#pragma unroll
+    for (int r = 0; r < kStitchRounds; ++r) {
+        int v = has[r] ? r * 1024 + t : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane >= d) v = o > v ? o : v;
+        }
+        incl[r] = v;
+        s_l1[r * 1024 + t] = l1[r];
+        s_l2[r * 1024 + t] = l2[r];
+        if (lane == 63) s_tab[r * 16 + wave] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int v = s_tab[lane];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d, 64);
+            if (lane >= d) v = o > v ? o : v;
+        }
+        const int ex = __shfl_up(v, 1, 64);
+        s_tab[lane] = lane ? ex : -1;
+        if (lane == 63) s_total = v;
+    }
+    __syncthreads();
+    const int last_idx = s_total;
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < kStitchRounds; ++r) {
+        int ex = __shfl_up(incl[r], 1, 64);
+        if (lane == 0) ex = -1;
+        const int wpre = s_tab[r * 16 + wave];
+        const int pi = ex > wpre ? ex : wpre;
+        int n_final = (int)n_emit[r];
+        if (has[r] && pi < 0) {                              // the span's first reaching block (one thread at most)
+            s_first[0] = 1; s_first[1] = f1[r]; s_first[2] = f2[r]; s_first[3] = (int32_t)head_info[r];
+        } else if (has[r]) {
+            const CEDelta d = create_edge(f1[r], f2[r], s_l1[pi], s_l2[pi], head_info[r] & 1u, head_info[r] & 2u,
+                                          head_info[r] & 4u, detect != 0);
+            if ((head_info[r] & 8u) && !d.keep) n_final -= 1;
+        }
+        mine += n_final;
+    }
+    mine = wave_sum(mine);
+    if (lane == 0) s_sum[wave] = mine;
+    __syncthreads();
+    if (t == 0) {
+        StitchAgg a;
+        a.has_any = last_idx >= 0 ? 1 : 0;
+        a.l1 = last_idx >= 0 ? s_l1[last_idx] : 0;
+        a.l2 = last_idx >= 0 ? s_l2[last_idx] : 0;
+        a.head_present = s_first[0] > 0 ? 1 : 0;
+        a.f1 = s_first[1]; a.f2 = s_first[2]; a.head_info = (uint32_t)s_first[3];
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_sum[w];
+        a.total = (uint32_t)tot;
+        agg[blockIdx.x] = a;
+    }
+}
 
 __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nblocks, int32_t* carry, int detect,
                                                       uint32_t* __restrict__ offsets,
@@ -873,14 +974,16 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                                                       uint32_t* n_out,
                                                       unsigned long long* counters,
                                                       const int32_t* __restrict__ tails, int rank,
-                                                      int32_t* __restrict__ slice_info) {
+                                                      int32_t* __restrict__ slice_info,
+                                                      const StitchAgg* __restrict__ agg,
+                                                      const int32_t* __restrict__ carry_in, uint32_t span) {
     // slice_info != nullptr (sharded build without a tail exchange): the slice's FIRST reaching record is left
     // unresolved - its provisional tuple stays, its CreateEdge call is not counted - and described in slice_info
     // { any reaching, last obs1, last obs2, head present, head obs1, head obs2, head info, head tuple position },
     // which travels in the exchange headers; the owners resolve it against the slices before (unpack_kernel).
     __shared__ int32_t s_l1[1024 * kStitchRounds], s_l2[1024 * kStitchRounds];
-    __shared__ int s_any;            // a block before this iteration reached CreateEdge
-    __shared__ int s_head_block;     // block of the slice head (speculative mode), -1 before it is found
+    __shared__ int s_any;            // a block before this span reached CreateEdge
+    __shared__ int s_head_block;     // block of the slice head (speculative mode), -1 unless it lies in this span
     __shared__ int32_t s_head[4];    // its obs1, obs2, info, slot
     __shared__ int s_tab[64];
     __shared__ int s_total;
@@ -888,25 +991,41 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
     __shared__ int s_base;
     __shared__ int s_redc[16][7];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool last_span = blockIdx.x == gridDim.x - 1;
     if (t == 0) {
-        int32_t p1 = carry[0], p2 = carry[1];
+        // prev_obs entering the stream (agg == nullptr: a single span, carry is read before anything overwrites it)
+        int32_t p1 = agg ? carry_in[0] : carry[0], p2 = agg ? carry_in[1] : carry[1];
         // multi-GPU: prev_obs entering this rank = tail {has, obs1, obs2, 0} of the nearest earlier rank that has one
         if (tails)
             for (int j = 0; j < rank; ++j)
                 if (tails[j * 4]) { p1 = tails[j * 4 + 1]; p2 = tails[j * 4 + 2]; }
-        s_carry[0] = p1; s_carry[1] = p2; s_base = 0;
-        s_any = 0; s_head_block = -1;
+        // the spans before this one: what their first reaching records resolve to, where their tuples end
+        int any = 0, base = 0;
+        for (uint32_t j = 0; j < blockIdx.x; ++j) {
+            const StitchAgg a = agg[j];
+            int tot = (int)a.total;
+            if (a.head_present && !(slice_info && !any)) {   // (the slice head keeps its provisional tuple)
+                const CEDelta d = create_edge(a.f1, a.f2, p1, p2, a.head_info & 1u, a.head_info & 2u, a.head_info & 4u,
+                                              detect != 0);
+                if ((a.head_info & 8u) && !d.keep) tot -= 1;
+            }
+            base += tot;
+            if (a.has_any) { p1 = a.l1; p2 = a.l2; any = 1; }
+        }
+        s_carry[0] = p1; s_carry[1] = p2; s_base = base;
+        s_any = any; s_head_block = -1;
     }
     __syncthreads();
     int c_count = 0, c_long = 0, c_dup = 0, c_nus = 0, c_nonuniq = 0, c_fishy = 0, c_reach = 0;
-    for (uint32_t c0 = 0; c0 < nblocks; c0 += 1024 * kStitchRounds) {
+    {
+        const uint32_t c0 = blockIdx.x * span;
         uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], head_slot[kStitchRounds], has[kStitchRounds];
         int32_t f1[kStitchRounds], f2[kStitchRounds], l1[kStitchRounds], l2[kStitchRounds];
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
             const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
             n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0; head_slot[r] = kNoSlot;
-            if (b < nblocks) {
+            if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
                 n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
                 f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
                 l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
@@ -917,7 +1036,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                 c_reach += (int)summ.at(kSumCtr0 + 6, b);
             }
         }
-        // ---- nearest earlier block (of this iteration) with a reaching record
+        // ---- nearest earlier block (of this span) with a reaching record
         int incl[kStitchRounds];
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
@@ -998,15 +1117,15 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
             const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
-            if (b < nblocks) {
+            if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
                 offsets[b] = (uint32_t)(base + s_tab[r * 16 + wave] + sincl[r] - (int)n_final[r]);
                 skip_slot[b] = skip[r];
             }
         }
-        const int iter_total = s_total;
+        const int span_total = s_total;
         __syncthreads();
         if (t == 0) {
-            s_base = base + iter_total;
+            s_base = base + span_total;
             if (last_idx >= 0) { s_carry[0] = s_l1[last_idx]; s_carry[1] = s_l2[last_idx]; s_any = 1; }
         }
         __syncthreads();
@@ -1027,18 +1146,23 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
         if (v) atomicAdd(&counters[t < 6 ? t : 7], (unsigned long long)v);
     }
     if (t == 0) {
-        carry[0] = s_carry[0];
-        carry[1] = s_carry[1];
-        *n_out = (uint32_t)s_base;
-        atomicAdd(&counters[6], (unsigned long long)s_base);
-        if (slice_info) {
-            const bool head = s_head_block >= 0;
-            slice_info[0] = s_any; slice_info[1] = s_carry[0]; slice_info[2] = s_carry[1];
-            slice_info[3] = head ? 1 : 0;
-            slice_info[4] = head ? s_head[0] : 0; slice_info[5] = head ? s_head[1] : 0;
-            slice_info[6] = head ? s_head[2] : 0;
+        if (slice_info && s_head_block >= 0) {               // the span that holds the slice head describes it
+            slice_info[3] = 1;
+            slice_info[4] = s_head[0]; slice_info[5] = s_head[1]; slice_info[6] = s_head[2];
             // position of the head's provisional tuple in the slice's compacted stream (-1: none was emitted)
-            slice_info[7] = head && (s_head[2] & 8) ? (int32_t)(offsets[s_head_block] + (uint32_t)s_head[3]) : -1;
+            slice_info[7] = (s_head[2] & 8) ? (int32_t)(offsets[s_head_block] + (uint32_t)s_head[3]) : -1;
+        }
+        if (last_span) {
+            carry[0] = s_carry[0];
+            carry[1] = s_carry[1];
+            *n_out = (uint32_t)s_base;
+            atomicAdd(&counters[6], (unsigned long long)s_base);
+            if (slice_info) {
+                slice_info[0] = s_any; slice_info[1] = s_carry[0]; slice_info[2] = s_carry[1];
+                if (!s_any) {                                // no record of the slice reached CreateEdge: no head either
+                    slice_info[3] = 0; slice_info[4] = 0; slice_info[5] = 0; slice_info[6] = 0; slice_info[7] = -1;
+                }
+            }
         }
     }
 }
@@ -1104,6 +1228,8 @@ struct ClsWorkspace {
     SummView summ;
     uint32_t* offsets;
     uint32_t* skip;
+    struct StitchAgg* agg;          // one per span of blocks, + the prev_obs entering the stream (2 x int32) behind them
+    uint32_t agg_spans;
     unsigned long long* bitmask;
     int64_t n_groups;
     size_t total;
@@ -1122,6 +1248,10 @@ ClsWorkspace carve(void* ws, int64_t n) {
     off += align_up((size_t)w.summ.stride * kSumPlanes * sizeof(uint32_t), 256);
     w.offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.skip = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
+    // (room for 4096 spans whatever the stream: the test knob BESST_STITCH_SPAN cuts small streams into many)
+    const size_t spans = (size_t)((nblocks + kStitchSpan - 1) / kStitchSpan) + 4096;
+    w.agg_spans = (uint32_t)spans;
+    w.agg = reinterpret_cast<StitchAgg*>(p + off); off += align_up(spans * sizeof(StitchAgg) + 16, 256);
     // candidate bits: stream_kernel writes whole workgroups, so round the group count up to its tile
     const int64_t stream_blocks = (n + kStreamTile - 1) / kStreamTile;
     w.n_groups = stream_blocks * (kStreamTile / kGroup);
@@ -1362,8 +1492,25 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     // is an L2 hot spot.  The single-workgroup stitch stays.)
     {
         ProfScope ps(s, kProfStitch);
-        hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
-                           w.skip, n_out, ctr, tails, rank, slice_info);
+        // BESST_STITCH_SPAN (tests): fewer blocks per span, so that small inputs exercise the hand-over between spans
+        uint32_t span = kStitchSpan;
+        if (const char* e = getenv("BESST_STITCH_SPAN")) {
+            const long v = atol(e);
+            if (v >= 1 && v < (long)kStitchSpan) span = (uint32_t)v;
+        }
+        const uint32_t spans = (nblocks + span - 1) / span;
+        BESST_REQUIRE(spans <= w.agg_spans, "classify: too many stitch spans for the workspace");
+        if (spans > 1) {
+            int32_t* carry_in = reinterpret_cast<int32_t*>(w.agg + w.agg_spans);
+            hipLaunchKernelGGL(stitch_spans_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, span, detect_dup, carry,
+                               w.agg, carry_in);
+            hipLaunchKernelGGL(stitch_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                               w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span);
+        } else {
+            hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                               w.skip, n_out, ctr, tails, rank, slice_info, (const StitchAgg*)nullptr,
+                               (const int32_t*)nullptr, span);
+        }
     }
     {
         ProfScope ps(s, kProfCompact);
