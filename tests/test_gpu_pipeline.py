@@ -238,3 +238,51 @@ def test_large_capacity_with_few_tuples(n):
     assert np.array_equal(get(gb.row_mask, r, np.uint32).astype(np.int64), np.ones(r, np.int64))
     assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
     assert np.array_equal(get(gb.obs_hi, n, np.int32).astype(np.int64), want['obs_hi'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('links_per_edge', [1, 40])
+@pytest.mark.parametrize('key_bits', [25, 26, 31, 33, 40, 41])
+def test_bucket_form_over_the_key_widths(key_bits, links_per_edge):
+    """The two-pass + buckets form of the large-stream sort serves packed keys of 25 to 41 significant bits (with 4.3 M
+    tuples): 9 to 25 key bits are left to the buckets.  One link per edge sends every bucket through the digit-pass
+    kernels (one or more 7-bit passes), forty links per edge through the wave kernel's smallest-key peel."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from besst_amd import pipeline
+    from oracle import c_oracle as CO
+    n = 4_300_000
+    rng = np.random.default_rng(key_bits * 100 + links_per_edge)
+    node_bits = (key_bits - 1) // 2
+    rows = max(1, n // links_per_edge)
+    pair = rng.integers(0, 1 << (2 * node_bits), rows, dtype=np.int64)[rng.integers(0, rows, n)]
+    fishy = (rng.random(n) < 0.01).astype(np.int64)
+    keys = ((pair << 1) | fishy).astype(np.uint64)
+    lo = rng.integers(26, 5000, n).astype(np.uint64)
+    hi = rng.integers(26, 5000, n).astype(np.uint64) | (np.uint64(2) << np.uint64(30))
+    lo[fishy == 1] = 0
+    hi[fishy == 1] = 0
+    payload = lo | (hi << np.uint64(32))
+    dev = torch.device('cuda', 0)
+    lib = dict(read_len=100.0, ins_size_threshold=800.0, min_mapq=11, orientation='fr', detect_duplicate=True,
+               extend_paths=True, no_score=False)
+    gb = pipeline.DeviceGraphBuilder(dev, 4, node_bits, lib, n, n)
+    gb.key_bits = key_bits
+    dk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    dp = torch.from_numpy(payload.view(np.int64)).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    gb.reduce(keys=dk, payload=dp, n_tuples_ptr=C.c_void_p(cnt.data_ptr()), capacity=n)
+    torch.cuda.synchronize()
+    want = CO.edge_rows(keys, payload)
+    r = len(want['key'])
+    raw = gb.small.cpu().numpy()
+    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
+    assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
+    assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
+    assert np.array_equal(get(gb.row_sum, r, np.int64), want['sum_obs'])
+    assert np.array_equal(get(gb.row_sum_sq, r, np.int64), want['sum_obs_sq'])
+    assert np.array_equal(get(gb.row_first, r, np.uint32).astype(np.int64), want['first_idx'])
+    assert np.array_equal(get(gb.obs_lo, n, np.int32).astype(np.int64), want['obs_lo'])
+    assert np.array_equal(get(gb.obs_hi, n, np.int32).astype(np.int64), want['obs_hi'])
