@@ -26,7 +26,9 @@ class LibParams(C.Structure):
 
 class Presort(C.Structure):          # include/besst_amd.h: besst_presort
     _fields_ = [('table', C.c_void_p), ('rows', C.c_int32), ('shift', C.c_int32), ('key_base', C.c_uint64),
-                ('capacity', C.c_uint32), ('reserved', C.c_uint32)]
+                ('capacity', C.c_uint32), ('reserved', C.c_uint32), ('segmented', C.c_int32), ('in_record_loop', C.c_int32),
+                ('seg_keys', C.c_void_p), ('seg_payload', C.c_void_p), ('seg_offsets', C.c_void_p), ('seg_skip', C.c_void_p),
+                ('seg_blocks', C.c_uint32), ('seg_tile', C.c_uint32), ('payload_out', C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -92,7 +94,7 @@ _SIGNATURES = {
                                              C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t,
                                              C.POINTER(Presort)]),
     'besst_dev_reduce_presorted': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                             _P, _P, C.c_size_t, _P, C.c_uint64]),
+                                             _P, _P, C.c_size_t, _P, C.c_uint64, C.POINTER(Presort)]),
     'besst_dev_classify_scan': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                           C.POINTER(LibParams), C.c_int32, _P, _P, _P, C.c_size_t]),
     'besst_dev_classify_tail': (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t]),

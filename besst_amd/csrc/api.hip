@@ -396,6 +396,7 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     a.extend_paths = p->extend_paths;
     a.no_score = p->no_score;
     a.record_path = p->record_path;
+    a.ps_table = nullptr; a.ps_rows = 0; a.ps_shift = 0; a.ps_base = 0;
     BESST_REQUIRE(p->record_path == 0 || p->record_path == 1, "classify: record_path must be 0 or 1");
     return BESST_OK;
 }
@@ -413,6 +414,14 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                            workspace, workspace_bytes);
 }
 
+static void presort_to_spec(const besst_presort* h, PresortSpec& ps) {
+    ps = PresortSpec{};
+    if (!h || !h->table) return;
+    ps.table = h->table; ps.rows = h->rows; ps.shift = h->shift; ps.key_base = h->key_base; ps.cap = h->capacity;
+    ps.segmented = h->segmented; ps.in_record_loop = h->in_record_loop;
+    ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out};
+}
+
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
                              size_t workspace_bytes, besst_presort* h_out) {
     BESST_REQUIRE(h_out, "reduce_presort: null output");
@@ -421,6 +430,7 @@ int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_ba
     if (!sort_presort_spec(capacity, key_bits, key_base, workspace, workspace_bytes, &ps)) return 0;
     h_out->table = ps.table; h_out->rows = ps.rows; h_out->shift = ps.shift; h_out->key_base = ps.key_base;
     h_out->capacity = ps.cap;
+    h_out->segmented = 1;            // every stream that takes the table can also be read from its block segments
     return 1;
 }
 
@@ -429,32 +439,45 @@ int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, cons
                                int64_t n_contigs, const void* contig_table, const besst_lib_params* p, int32_t node_bits,
                                int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
                                besst_counters* counters, void* workspace, size_t workspace_bytes,
-                               const besst_presort* h_presort) {
+                               besst_presort* h_presort) {
     ClassifyArgs a;
     int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
     if (rc) return rc;
     BESST_REQUIRE(carry && aligned && keys && payload && n_out && counters, "classify: null output");
-    PresortSpec ps{};
+    PresortSpec ps;
+    presort_to_spec(h_presort, ps);
+    ps.in_record_loop = 0;
+    rc = launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
+                         workspace, workspace_bytes, ps.table ? &ps : nullptr);
     if (h_presort && h_presort->table) {
-        ps.table = h_presort->table; ps.rows = h_presort->rows; ps.shift = h_presort->shift;
-        ps.key_base = h_presort->key_base; ps.cap = h_presort->capacity;
+        h_presort->segmented = ps.segmented; h_presort->in_record_loop = ps.in_record_loop;
+        h_presort->seg_keys = ps.seg.seg_keys; h_presort->seg_payload = ps.seg.seg_payload;
+        h_presort->seg_offsets = ps.seg.offsets; h_presort->seg_skip = ps.seg.skip;
+        h_presort->seg_blocks = ps.seg.nblocks; h_presort->seg_tile = ps.seg.tile; h_presort->payload_out = ps.seg.payload_out;
     }
-    return launch_classify(static_cast<hipStream_t>(stream), a, carry, aligned, keys, payload, n_out, counters,
-                           workspace, workspace_bytes, ps.table ? &ps : nullptr);
+    return rc;
 }
 
 int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
                                const uint64_t* keys, const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask,
                                uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first,
                                uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows,
-                               void* workspace, size_t workspace_bytes, const uint32_t* first_map, uint64_t key_base) {
+                               void* workspace, size_t workspace_bytes, const uint32_t* first_map, uint64_t key_base,
+                               const besst_presort* h_presort) {
     BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
-    BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
+    BESST_REQUIRE(h_presort && h_presort->table, "reduce_presorted: no hand-over description");
+    PresortSpec ps;
+    presort_to_spec(h_presort, ps);
+    const bool seg = ps.segmented != 0;
+    BESST_REQUIRE(capacity == 0 || ((keys || seg) && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
                                     row_first && row_offset && obs_lo && obs_hi),
                   "reduce: null buffer");
+    BESST_REQUIRE(!seg || (ps.seg.seg_keys && ps.seg.seg_payload && ps.seg.offsets && ps.seg.skip &&
+                           ps.seg.payload_out == payload && ps.seg.tile > 0),
+                  "reduce_presorted: incomplete segment description");
     return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
                               row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
-                              workspace, workspace_bytes, first_map, key_base, true);
+                              workspace, workspace_bytes, first_map, key_base, true, seg ? &ps.seg : nullptr);
 }
 
 int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,

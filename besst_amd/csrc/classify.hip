@@ -600,10 +600,12 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     __shared__ int32_t s_state[2][8];
     __shared__ int32_t s_head[8];                         // the block's first reaching record {present, obs1, obs2, info, slot}
     __shared__ int s_red[4][7];
+    __shared__ uint32_t s_ph[512];                        // the sort's two digit histograms of the block's tuples
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t thr_u32 = ins_thr_u32(a);
+    if (a.ps_table) { s_ph[t] = 0; s_ph[t + 256] = 0; }   // (uniform; ordered before the first use by the barriers below)
     if (t < 8) { s_state[0][t] = 0; s_state[1][t] = 0; s_head[t] = 0; }   // visible after the first sub-tile's barriers
     int round = 0;
     int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
@@ -701,8 +703,22 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
                 const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
                 const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
                 const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
-                seg_keys[block_base + slot] = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+                const uint64_t key = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+                seg_keys[block_base + slot] = key;
                 seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+                if (a.ps_table) {                            // uniform
+                    // the emitting lanes that share the first one's digit add once, together (consecutive tuples of a
+                    // contig share their smaller node half of the time)
+                    const uint64_t k = key - a.ps_base;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t d = (uint32_t)(k >> (a.ps_shift + 8 * q)) & 255u;
+                        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                        const unsigned long long m = __ballot(d == f);
+                        if (d != f) atomicAdd(&s_ph[256 * q + d], 1u);
+                        else if ((m & lt_mask) == 0ull) atomicAdd(&s_ph[256 * q + f], (uint32_t)__popcll(m));
+                    }
+                }
             }
             if (is_head) {                                   // at most one thread of the whole block, once
                 s_head[0] = 1; s_head[1] = o1; s_head[2] = o2;
@@ -842,6 +858,13 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
         }
     }
     __syncthreads();
+    if (a.ps_table) {
+        uint32_t* row = a.ps_table + (size_t)(blockIdx.x & (uint32_t)(a.ps_rows - 1)) * 512u;
+        for (int d = t; d < 512; d += kFusedThreads) {
+            const uint32_t c = s_ph[d];
+            if (c) atomicAdd(&row[d], c);
+        }
+    }
     if (wave != 0) return;
     const int par = round & 1;
     uint32_t v = 0;
@@ -1167,6 +1190,26 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
     }
 }
 
+// The record loop counted the sort digits of every tuple it wrote; the head tuples the stitch has dropped since
+// (skip_slot) are taken out of the counts again (row 0 of the table: only the column sums matter).
+__global__ __launch_bounds__(256) void presort_fixup_kernel(const uint64_t* __restrict__ seg_keys,
+                                                            const uint32_t* __restrict__ skip_slot, uint32_t nblocks,
+                                                            PresortSpec ps, const uint8_t* __restrict__ cls8,
+                                                            int32_t n_contigs, unsigned long long* __restrict__ aligned) {
+    // when compact_kernel does not run, its side job is done here: coverage of contigs that are not in the table is
+    // not part of cont_aligned_len (CreateGraph.py:89-95)
+    if (cls8)
+        for (int32_t c = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); c < n_contigs; c += (int32_t)(gridDim.x * blockDim.x))
+            if (!cls8[c]) aligned[c] = 0;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t skip = skip_slot[b];
+    if (skip == kNoSlot) return;
+    const uint64_t k = seg_keys[(size_t)b * kClsTile + skip] - ps.key_base;
+    atomicSub(&ps.table[(uint32_t)(k >> ps.shift) & 255u], 1u);
+    atomicSub(&ps.table[256u + ((uint32_t)(k >> (ps.shift + 8)) & 255u)], 1u);
+}
+
 __global__ __launch_bounds__(256) void compact_kernel(SummView summ,
                                                       const uint32_t* __restrict__ offsets,
                                                       const uint32_t* __restrict__ skip_slot,
@@ -1470,16 +1513,18 @@ int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* t
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,
-                         const int32_t* tails, int rank, int32_t* slice_info, const PresortSpec* presort) {
+                         const int32_t* tails, int rank, int32_t* slice_info, PresortSpec* presort) {
     PresortSpec pre{};
     if (presort && presort->table) {
         pre = *presort;
         BESST_REQUIRE(pre.rows > 0 && (pre.rows & (pre.rows - 1)) == 0 && pre.shift >= 0 && pre.shift <= 47, "classify: bad presort description");
-        BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
+        // (in_record_loop: launch_classify cleared the table before the record loop ran)
+        if (!pre.in_record_loop) BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
     }
     if (n <= 0) {
         BESST_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(uint32_t), s));
         if (slice_info) BESST_HIP_TRY(hipMemsetAsync(slice_info, 0, 8 * sizeof(int32_t), s));
+        if (presort) presort->segmented = 0;
         return BESST_OK;
     }
     const ClsWorkspace w = carve(ws, n);
@@ -1514,8 +1559,22 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     }
     {
         ProfScope ps(s, kProfCompact);
-        hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
-                           w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned), pre);
+        PresortSpec in_compact = pre;
+        const bool segmented = pre.table && pre.in_record_loop && pre.segmented && !slice_info && !tails;
+        if (pre.table && pre.in_record_loop) {
+            hipLaunchKernelGGL(presort_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, w.seg_keys, w.skip, nblocks, pre,
+                               segmented ? cls8 : nullptr, n_contigs, reinterpret_cast<unsigned long long*>(aligned));
+            in_compact.table = nullptr;
+        }
+        if (segmented) {                                     // the sort's first pass reads the segments: no dense copy
+            presort->segmented = 1;
+            presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload};
+        } else {
+            if (presort) presort->segmented = 0;
+            hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
+                               w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned),
+                               in_compact);
+        }
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
@@ -1523,11 +1582,31 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
 
 int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned, uint64_t* keys,
                     uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws, size_t ws_bytes,
-                    const PresortSpec* presort) {
-    int rc = launch_classify_scan(s, a, aligned, counters, ws, ws_bytes);
+                    PresortSpec* presort) {
+    PresortSpec pre{};
+    ClassifyArgs b = a;
+    if (presort && presort->table) {
+        pre = *presort;
+        static const int knob = [] { const char* e = getenv("BESST_PRESORT_IN_LOOP"); return e ? atoi(e) : 1; }();
+        pre.in_record_loop = knob && a.record_path == 1 && a.n > 0;
+        if (pre.in_record_loop) {
+            BESST_REQUIRE(pre.rows > 0 && (pre.rows & (pre.rows - 1)) == 0, "classify: bad presort description");
+            BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
+            b.ps_table = pre.table; b.ps_rows = pre.rows; b.ps_shift = pre.shift; b.ps_base = pre.key_base;
+        }
+    }
+    int rc = launch_classify_scan(s, b, aligned, counters, ws, ws_bytes);
     if (rc) return rc;
-    return launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
-                                a.n_contigs, aligned, nullptr, 0, nullptr, presort);
+    static const int seg_knob = [] { const char* e = getenv("BESST_SEGMENTED"); return e ? atoi(e) : 1; }();
+    pre.segmented = pre.segmented && seg_knob;
+    rc = launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
+                              a.n_contigs, aligned, nullptr, 0, nullptr, pre.table ? &pre : nullptr);
+    if (presort) {
+        presort->in_record_loop = pre.in_record_loop;
+        presort->segmented = pre.table ? pre.segmented : 0;
+        presort->seg = pre.seg;
+    }
+    return rc;
 }
 
 }  // namespace besst

@@ -124,6 +124,10 @@ struct ClassifyArgs {
     int32_t extend_paths;
     int32_t no_score;
     int32_t record_path;   // 0: stream_kernel + ordered_kernel (sparse candidates), 1: fused_kernel (dense)
+    // fused_kernel counts the sort's two stream-pass digits of every tuple it emits (PresortSpec; nullptr: off)
+    uint32_t* ps_table;
+    int32_t ps_rows, ps_shift;
+    uint64_t ps_base;
 };
 
 // ---- sort / reduce geometry -------------------------------------------------------------------------
@@ -198,18 +202,34 @@ __host__ __device__ inline uint32_t owner_of_scaffold(uint32_t scaffold_id, uint
 // registers (saves the sort its own read of the key stream): table[rows][2][256], rows a power of two, a block adds
 // its counts to row (block & (rows - 1)); digits of key - key_base at `shift` and `shift + 8`; tuples at or beyond
 // `cap` (the sort's capacity) are not counted.  Filled in by sort_presort_spec for the streams whose sort uses it.
+// The ordered tuple stream as the record loop and the stitch leave it - one segment of kClsTile slots per block, the
+// dense position of each block's first tuple, the slot of the head tuple the stitch dropped - for a sort whose first
+// stream pass reads the segments itself (and writes the dense payload on its way), so that compact_kernel need not run.
+struct SegSource {
+    const uint64_t* seg_keys;
+    const uint64_t* seg_payload;
+    const uint32_t* offsets;
+    const uint32_t* skip;
+    uint32_t nblocks, tile;
+    uint64_t* payload_out;
+};
+
 struct PresortSpec {
     uint32_t* table;
     int rows, shift;
     uint64_t key_base;
     uint32_t cap;
+    int in_record_loop;      // the fused record loop counts while it emits (the head tuples the stitch drops are taken
+                             // out again); else compact_kernel counts
+    int segmented;           // in: the sort can read block segments; out: it has to (compact_kernel did not run, `seg`)
+    SegSource seg;
 };
 
 // ---- stage launchers (defined in the .hip files) -----------------------------------------------------
 size_t classify_workspace_bytes(int64_t n);
 int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_t* aligned,
                     uint64_t* keys, uint64_t* payload, uint32_t* n_out, besst_counters* counters,
-                    void* ws, size_t ws_bytes, const PresortSpec* presort = nullptr);
+                    void* ws, size_t ws_bytes, PresortSpec* presort = nullptr);
 // the same split in three phases for the multi-GPU path (the duplicate chain crosses rank boundaries)
 int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
                          void* ws, size_t ws_bytes);
@@ -221,7 +241,7 @@ int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* t
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,
-                         const int32_t* tails, int rank, int32_t* slice_info, const PresortSpec* presort = nullptr);
+                         const int32_t* tails, int rank, int32_t* slice_info, PresortSpec* presort = nullptr);
 
 size_t reduce_workspace_bytes(int64_t cap);
 // true (and *out filled in): launch_sort_reduce with these arguments takes its histograms from out->table when called
@@ -233,7 +253,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr,
-                       uint64_t key_base = 0, bool hist_ready = false);
+                       uint64_t key_base = 0, bool hist_ready = false, const SegSource* seg = nullptr);
 // chained-scan sort + atomic-free reduction for large streams (onesweep.hip); buf_* = the ping-pong buffers of the
 // sort/reduce workspace
 size_t onesweep_workspace_bytes(int64_t cap);
@@ -242,7 +262,8 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
                                 int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
                                 int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
-                                const uint32_t* first_map, uint64_t key_base, bool hist_ready = false);
+                                const uint32_t* first_map, uint64_t key_base, bool hist_ready = false,
+                                const SegSource* seg = nullptr);
 size_t exchange_region_bytes(int64_t pair_cap);
 size_t exchange_stride_bytes(int64_t pair_cap, int64_t rider_bytes);
 int launch_partition(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int node_bits, int world,

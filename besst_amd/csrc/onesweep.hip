@@ -221,12 +221,15 @@ __global__ __launch_bounds__(256) void os_offsets_kernel(const uint32_t* __restr
 #endif
 constexpr int kPeel = BESST_OS_PEEL;
 
-template <int BITS, bool kFirst, bool kPacked>
+constexpr int kSegWin = 255;            // block offsets a tile keeps in LDS: a tile that spans more blocks searches in memory
+
+template <int BITS, bool kFirst, bool kPacked, bool kSeg = false>
 __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ n_ptr,
     uint32_t cap, int shift, int pass, int packed_bits, uint64_t key_base, const uint32_t* __restrict__ digit_base,
     unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err) {
+    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err, SegSource seg = SegSource{},
+    const uint32_t* __restrict__ tile_first = nullptr, int seg_win = kSegWin) {
     constexpr int RADIX = 1 << BITS;
     // the raw key stream (first pass) and unpacked keys carry key_base; packed words hold key - key_base already
     const uint64_t sub = (kFirst || !kPacked) ? key_base : 0ull;
@@ -247,11 +250,67 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
     const uint32_t wbase = tile * (uint32_t)kOsTile + (uint32_t)wave * (kOsItems * 64);
     uint64_t key[kOsItems];
     uint32_t idx[kIdxRegs];
+    if constexpr (kSeg) {
+        // The stream still lies in the record loop's block segments (SegSource): dense position i belongs to the last
+        // block whose first-tuple offset is <= i (empty blocks share their successor's offset), slot i - offset, one
+        // further when the stitch dropped that block's head tuple at or before it.  The offsets of the blocks a tile
+        // touches sit in LDS (the tile's first block was looked up by os_seg_tiles_kernel); the payload goes to its
+        // dense place on the way - what compact_kernel would have done with a pass of its own.
+        __shared__ uint32_t s_woff[kSegWin + 1], s_wskip[kSegWin + 1];
+        const uint32_t b0 = tile_first[tile];
+        const uint32_t n_all = *n_ptr;
+        for (int q = t; q <= kSegWin; q += kOsThreads) {
+            const uint32_t b = b0 + (uint32_t)q;
+            // (seg_win < kSegWin, a test knob: the window ends early, so small streams take the search in memory too)
+            const uint32_t bb = q <= seg_win ? b : b0 + (uint32_t)seg_win;
+            s_woff[q] = bb < seg.nblocks ? seg.offsets[bb] : n_all;
+            s_wskip[q] = b < seg.nblocks ? seg.skip[b] : 0xffffffffu;
+        }
+        __syncthreads();
+        const uint32_t tile_end = (tile + 1u) * (uint32_t)kOsTile < n ? (tile + 1u) * (uint32_t)kOsTile : n;
+        const bool in_window = s_woff[kSegWin] >= tile_end;  // uniform: every position of the tile lies in a windowed block
+        int wq = 0;                                          // window index of the block of the lane's last position
+        if (in_window) {                                     // the wave's first position: one search; 64 further on is
+            int lo = 0, hi = kSegWin;                        // nearly always the same block or the next one
+            const uint32_t i = wbase + lane;
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (s_woff[mid] <= i) lo = mid; else hi = mid;
+            }
+            wq = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < kOsItems; ++r) {
+            const uint32_t i = wbase + r * 64 + lane;
+            key[r] = ~0ull;
+            if (i < n) {
+                uint32_t b, off, skip;
+                if (in_window) {
+                    while (s_woff[wq + 1] <= i) ++wq;        // (s_woff[kSegWin] > i: ends inside the window)
+                    b = b0 + (uint32_t)wq; off = s_woff[wq]; skip = s_wskip[wq];
+                } else {
+                    uint32_t lo = b0, hi = seg.nblocks;      // largest block in [b0, nblocks) with offsets[block] <= i
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = lo + ((hi - lo) >> 1);
+                        if (seg.offsets[mid] <= i) lo = mid; else hi = mid;
+                    }
+                    b = lo; off = seg.offsets[lo]; skip = seg.skip[lo];
+                }
+                uint32_t j = i - off;
+                j += j >= skip ? 1u : 0u;
+                const size_t src = (size_t)b * seg.tile + j;
+                key[r] = seg.seg_keys[src];
+                seg.payload_out[i] = seg.seg_payload[src];
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < kOsItems; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
         key[r] = i < n ? keys_in[i] : ~0ull;
         if (!kPacked) idx[r] = kFirst ? i : (i < n ? idx_in[i] : 0u);
+    }
     }
     uint32_t* my_hist = &s_whist[wave][0];
     uint32_t dig_rank[kOsItems];                            // digit | rank inside the wave's share << BITS
@@ -333,6 +392,8 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
         if (i < n) {
             const uint32_t d = dig_rank[r] & (uint32_t)(RADIX - 1);
             const uint32_t dst = s_base[d] + s_whist[wave][d] + (dig_rank[r] >> BITS);
+            if (dst >= cap) continue;                        // (only if the histograms counted more tuples than fit: the
+                                                             // caller's capacity check reports that pass as overflowed)
             if (kPacked) {
                 keys_out[dst] = kFirst ? (((key[r] - key_base) << packed_bits) | i) : key[r];
             } else {
@@ -341,6 +402,23 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
             }
         }
     }
+}
+
+// first block of every scatter tile of a segmented stream: the last block whose first-tuple offset is <= the tile's
+// first position
+__global__ __launch_bounds__(256) void os_seg_tiles_kernel(SegSource seg, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                           uint32_t* __restrict__ tile_first) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    if (tile >= os_nblocks(n, kOsTile)) return;
+    const uint32_t p0 = tile * (uint32_t)kOsTile;
+    uint32_t lo = 0, hi = seg.nblocks;
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (seg.offsets[mid] <= p0) lo = mid; else hi = mid;
+    }
+    tile_first[tile] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1434,6 +1512,7 @@ struct OsWorkspace {
     unsigned long long* lead_s2;
     uint32_t* bucket_start;     // kTopBuckets + 1
     uint32_t* bucket_class;     // kTopBuckets: which kernel finishes the bucket
+    uint32_t* tile_first;       // per scatter tile: its first block of a segmented stream
     uint32_t* bucket_rows;      // kTopBuckets
     char* staged;               // 40 bytes per tuple of capacity: the buckets' rows before they are numbered
     size_t total;
@@ -1459,6 +1538,7 @@ OsWorkspace os_carve(void* ws, int64_t cap, int bits) {
     w.lead_s2 = reinterpret_cast<unsigned long long*>(p + off); off += align_up(nt_red * 8, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)kTopBuckets + 1) * 4, 256);
     w.bucket_class = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
+    w.tile_first = reinterpret_cast<uint32_t*>(p + off); off += align_up(nt_sort * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)kTopBuckets * 4, 256);
     w.staged = p + off; off += align_up((size_t)cap * 40, 256);
     w.total = off;
@@ -1503,7 +1583,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                 uint32_t* buf_idx[2], uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n,
                                 int64_t* row_sum, int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset,
                                 int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows, void* ws, size_t ws_bytes,
-                                const uint32_t* first_map, uint64_t key_base, bool hist_ready) {
+                                const uint32_t* first_map, uint64_t key_base, bool hist_ready, const SegSource* seg) {
     const OsWorkspace w = os_carve(ws, cap, kOsBits);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: chained-scan workspace too small");
     int passes = (key_bits + kOsBits - 1) / kOsBits;
@@ -1519,6 +1599,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     const uint32_t nt_red = (uint32_t)((cap + kOsRedTile - 1) / kOsRedTile);
     constexpr int RADIX = 1 << kOsBits;
     BESST_HIP_TRY(hipMemsetAsync(w.err, 0, 4, s));
+    BESST_REQUIRE(!seg || (hist_ready && hybrid), "reduce: a segmented stream needs the bucket form and its histograms");
     if (hist_ready && hybrid) {
         // the histograms came with the tuples (PresortSpec: compact_kernel); only the descriptors are left to clear
         BESST_HIP_TRY(hipMemsetAsync(w.granules, 0, w.granule_words * 8, s));
@@ -1543,7 +1624,18 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     hipLaunchKernelGGL((os_scatter_kernel<kOsBits, FIRST, PACKED>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,      \
                        n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX, w.granules, \
                        w.tickets + p, kout, iout, w.err)
-        if (packed_bits) {
+        if (seg && p == 0) {
+            int seg_win = kSegWin;                           // BESST_SEG_WINDOW (tests): see os_scatter_kernel
+            if (const char* e = getenv("BESST_SEG_WINDOW")) {
+                const int v = atoi(e);
+                if (v >= 1 && v < kSegWin) seg_win = v;
+            }
+            hipLaunchKernelGGL(os_seg_tiles_kernel, dim3((nt_sort + 255) / 256), dim3(256), 0, s, *seg, n_tuples, (uint32_t)cap,
+                               w.tile_first);
+            hipLaunchKernelGGL((os_scatter_kernel<kOsBits, true, true, true>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,
+                               n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX,
+                               w.granules, w.tickets + p, kout, iout, w.err, *seg, w.tile_first, seg_win);
+        } else if (packed_bits) {
             if (p == 0) BESST_OS_LAUNCH(true, true); else BESST_OS_LAUNCH(false, true);
         } else {
             if (p == 0) BESST_OS_LAUNCH(true, false); else BESST_OS_LAUNCH(false, false);

@@ -992,7 +992,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base,
-                       bool hist_ready) {
+                       bool hist_ready, const SegSource* seg) {
     // key_bits counts the significant bits of key - key_base: every path below sorts that difference (the order is
     // the same) and puts key_base back when it writes a row's key
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
@@ -1003,6 +1003,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     }
     const RedWorkspace w = carve(ws, cap);
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: workspace too small");
+    BESST_REQUIRE(!seg || takes_large_stream_path(cap, key_bits), "reduce: a segmented stream needs the large-stream sort");
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
     const uint32_t nb_red = (uint32_t)((cap + kRedTile - 1) / kRedTile);
     auto* zsum = reinterpret_cast<unsigned long long*>(row_sum);
@@ -1055,7 +1056,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         uint32_t* bi[2] = {w.idx[0], w.idx[1]};
         return launch_onesweep_sort_reduce(s, cap, n_tuples, key_bits, keys, payload, bk, bi, row_key, row_mask, row_n,
                                            row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows, w.os_ws,
-                                           w.os_bytes, first_map, key_base, hist_ready);
+                                           w.os_bytes, first_map, key_base, hist_ready, seg);
     }
     const int rscanned = nb_red > (uint32_t)kRowScanFreeMaxBlocks ? 1 : 0;
     {

@@ -174,7 +174,9 @@ class DeviceGraphBuilder(object):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ref = self._presort_ref(presort)
         _lib.check(self.lib.besst_dev_classify_presort(C.c_void_p(stream), *args, ref), 'dev_classify')
-        self._presorted = ref is not None               # the next reduce() of the builder's own tuples may trust the table
+        # the next reduce() of the builder's own tuples may trust the table (and, spec.segmented, must read the tuples
+        # from the block segments: self.keys was not written then)
+        self._presorted = ref is not None
 
     def _presort_ref(self, on):
         """The hand-over of the sort's digit histograms from stage 1 to stage 2 (include/besst_amd.h, besst_presort)
@@ -187,7 +189,10 @@ class DeviceGraphBuilder(object):
             used = self.lib.besst_dev_reduce_presort(self.tup_cap, self.key_bits, self.key_base, _p(self.ws2),
                                                      self.ws2.numel(), C.byref(spec))
             spec = self._args['presort'] = (spec, bool(used == 1 and spec.table))
-        return C.byref(spec[0]) if spec[1] else None
+        if not spec[1]:
+            return None
+        spec[0].segmented = 1                               # asked for anew on every pass (classify answers in place)
+        return C.byref(spec[0])
 
     def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None, first_map=None):
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -199,9 +204,12 @@ class DeviceGraphBuilder(object):
                     _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
                     _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
                     _p(self.ws2), self.ws2.numel(), None, self.key_base)
-            fn = self.lib.besst_dev_reduce_presorted if self._presorted else self.lib.besst_dev_reduce
-            self._presorted = False
-            _lib.check(fn(C.c_void_p(stream), *args), 'dev_reduce')
+            if self._presorted:
+                self._presorted = False
+                _lib.check(self.lib.besst_dev_reduce_presorted(C.c_void_p(stream), *args,
+                                                               C.byref(self._args['presort'][0])), 'dev_reduce')
+            else:
+                _lib.check(self.lib.besst_dev_reduce(C.c_void_p(stream), *args), 'dev_reduce')
             return
         self._presorted = False
         keys = self.keys if keys is None else keys

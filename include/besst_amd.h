@@ -286,8 +286,9 @@ int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, i
  * 1 and fills *out when besst_dev_reduce with this capacity / key_bits / key_base / workspace would take its
  * histograms from `out->table` (a region of that workspace), 0 when it would not (small streams, keys that do not
  * pack).  besst_dev_classify_presort is besst_dev_classify that also fills the table (presort may be NULL);
- * besst_dev_reduce_presorted is besst_dev_reduce that trusts it - same workspace, same capacity, same key range, and
- * the tuples of exactly that classify call.  (Replaces nothing in the reference: it is the seam between
+ * besst_dev_reduce_presorted is besst_dev_reduce that trusts it (h_presort: the structure that classify call filled in;
+ * keys may be NULL when it says `segmented`) - same workspace, same capacity, same key range, and the tuples of
+ * exactly that classify call.  (Replaces nothing in the reference: it is the seam between
  * CreateGraph.py:141-206, where links are found, and :842-862, where they are summed per edge.) */
 typedef struct besst_presort {
     uint32_t* table;      /* device: [rows][2][256] counters inside the stage-2 workspace */
@@ -296,6 +297,21 @@ typedef struct besst_presort {
     uint64_t key_base;
     uint32_t capacity;    /* tuples at or beyond it are not counted (stage 2 ignores them too) */
     uint32_t reserved;
+    /* The tuple stream itself can be handed over as the record loop leaves it - one segment per 16 384-record block,
+     * ordered by the block offsets of the stitch - when stage 2's first stream pass can read it that way:
+     * besst_dev_reduce_presort sets `segmented` to say so, besst_dev_classify_presort leaves it 1 (and fills the seg_*
+     * fields) when it did NOT write the dense keys / payload, and besst_dev_reduce_presorted then reads the segments and
+     * writes the dense payload (the `payload` argument of both calls) itself.  in_record_loop (out): the record loop
+     * counted the digits while it emitted. */
+    int32_t segmented;
+    int32_t in_record_loop;
+    const uint64_t* seg_keys;
+    const uint64_t* seg_payload;
+    const uint32_t* seg_offsets;
+    const uint32_t* seg_skip;
+    uint32_t seg_blocks;
+    uint32_t seg_tile;
+    uint64_t* payload_out;
 } besst_presort;
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
                              size_t workspace_bytes, besst_presort* h_out);
@@ -305,13 +321,13 @@ int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, cons
                                const void* contig_table, const besst_lib_params* h_params, int32_t node_bits,
                                int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload,
                                uint32_t* n_out, besst_counters* counters, void* workspace,
-                               size_t workspace_bytes, const besst_presort* h_presort);
+                               size_t workspace_bytes, besst_presort* h_presort);
 int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
                                const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
                                uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                                uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                                uint32_t* n_rows, void* workspace, size_t workspace_bytes,
-                               const uint32_t* first_map, uint64_t key_base);
+                               const uint32_t* first_map, uint64_t key_base, const besst_presort* h_presort);
 
 /* ---- multi-GPU path ----------------------------------------------------
  * Ranks own contiguous slices of the (tid,pos)-sorted stream.  The duplicate chain of CreateEdge

@@ -106,14 +106,19 @@ def test_split_distribution_from_device_histogram():
                 (g['mean1'], g['stddev1'], g['mean2'], g['stddev2'])
 
 
-def test_resident_builder_step_large_stream():
+@pytest.mark.parametrize('seg_window', [None, '2'])
+def test_resident_builder_step_large_stream(seg_window, monkeypatch):
     """DeviceGraphBuilder.step() - what bench.py times - on a mate-pair library large enough for the large-stream sort
-    (6.4 M link tuples): fused record loop, compact_kernel handing the sort its digit histograms
-    (besst_dev_classify_presort / besst_dev_reduce_presorted), two chained-scan passes, wave-per-bucket sort + reduction.
-    Twice on the same builder (the second pass starts from the first one's leftovers in every workspace), against the
-    C oracle."""
+    (6.4 M link tuples): the sort gets its digit histograms from stage 1 (besst_dev_classify_presort /
+    besst_dev_reduce_presorted) - counted by compact_kernel after the two-pass record loop, by the fused record loop
+    itself otherwise, and then the first chained-scan pass reads the tuples from the block segments (seg_window '2':
+    with a two-block window, so that the tiles look their blocks up in memory) -, two chained-scan passes,
+    wave-per-bucket sort + reduction.  Twice on the same builder (the second pass starts from the first one's leftovers
+    in every workspace), against the C oracle."""
     import torch
     from besst_amd import pipeline
+    if seg_window:
+        monkeypatch.setenv('BESST_SEG_WINDOW', seg_window)
     dev = torch.device('cuda', 0)
     wl = workload.make_device(dev, 'C3', 0, pairs=30_000_000, nc=20_000)
     rec = pipeline.DeviceRecords.from_columns(wl['cols'])
@@ -129,6 +134,8 @@ def test_resident_builder_step_large_stream():
     for _ in range(2):
         gb.step(rec)
     assert gb._args['presort'][1], 'the large-stream sort should take its histograms from stage 1'
+    spec = gb._args['presort'][0]
+    assert bool(spec.segmented) == bool(spec.in_record_loop) == (gb.params.record_path == 1)
     table = gb.fetch_table()
     ctr = gb.read_counters()
     assert_table_equals_c_oracle(table, gb.aligned.cpu().numpy(), ctr, wl['batch'], wl)
