@@ -16,7 +16,8 @@ STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kerne
                 'radix_rowscan_kernel', 'radix_scatter_kernel', 'bucket_sort_kernel', 'bucket_reduce_kernel',
                 'row_heads_kernel', 'row_scan_kernel', 'row_reduce_kernel', 'os_hist_kernel', 'os_offsets_kernel',
                 'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel', 'os_bucket_start_kernel', 'os_bucket_wave_kernel',
-                'os_bucket_sort_kernel', 'os_bucket_rows_kernel')
+                'os_bucket_sort_kernel', 'os_bucket_rows_kernel', 'os_bucket_wave_lds_kernel', 'os_seg_tiles_kernel',
+                'stitch_spans_kernel', 'presort_fixup_kernel')
 
 
 def source_hash():
@@ -52,9 +53,12 @@ def main():
         fm = sum(f[k]) / max(1, len(f[k]))
         wm = sum(w[k]) / max(1, len(w[k]))
         # dispatches per step: relative to a kernel that runs exactly once per record loop / once per sort
-        classify = k in ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel')
+        classify = k in ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel', 'stitch_spans_kernel',
+                        'presort_fixup_kernel')
         anchor = 'stitch_kernel' if classify else ('os_offsets_kernel' if 'os_offsets_kernel' in f else 'radix_hist_kernel')
         per_step = len(f[k]) / float(max(1, len(f.get(anchor, []))))
+        if per_step < 0.5:          # not a kernel of the step (compact_kernel of the capacity probe, when the sort reads segments)
+            continue
         kernels[k] = {'FETCH_SIZE_KB_mean': round(fm, 1), 'WRITE_SIZE_KB_mean': round(wm, 1),
                       'dispatches_per_step': round(per_step, 2),
                       'traffic_bytes_per_step': int((2 * fm + wm) * 1024 * per_step)}
