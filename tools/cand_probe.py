@@ -16,3 +16,6 @@ for sub in (1024, 768, 512):
     rounds = torch.ceil(per / 256).clamp(min=0)
     print(sub, 'share', float(cand.double().mean()), 'per sub-tile quantiles', torch.quantile(per[:4000000], q).tolist(), 'mean rounds', float(rounds.mean()),
           'lane use', float(per.sum() / (rounds.sum() * 256)))
+for g in (8, 16, 64, 256, 1024):
+    m = cand.numel() // g * g
+    print('groups of', g, 'records without a candidate:', float((~cand[:m].view(-1, g).any(1)).double().mean()))
