@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     // decile - one round per started 256 of a sub-tile left a quarter of the lanes idle)
     __shared__ uint32_t s_buf[5][kFusedRing];
     __shared__ uint32_t s_qlen[kFusedRing / 2];           // 16 bits per candidate
-    __shared__ int s_wcnt[4];
+    __shared__ int s_wcnt[2][4];                          // candidates per wave, double buffered by sub-tile
     __shared__ int32_t s_tail[4][4];                      // per wave: {has, obs1, obs2} of its last reaching record
     __shared__ int s_ecnt[4];                             // per wave: tuples emitted this round
     // running state of the block, double buffered by round: {prev known, prev obs1, prev obs2, emit base, any reach}
@@ -823,19 +823,24 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
         const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
         const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
         const int wcount = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        if (lane == 0) s_wcnt[wave] = wcount;
+        int* wcnt = s_wcnt[st & 1];
+        if (lane == 0) wcnt[wave] = wcount;
         __syncthreads();
-        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
-        int total = 0;
+        int before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w < wave) slot += s_wcnt[w];
-            total += s_wcnt[w];
+            if (w < wave) before += wcnt[w];
+            total += wcnt[w];
         }
         total = __builtin_amdgcn_readfirstlane(total);
+        // uniform: a third of C3's sub-tiles hold no candidate at all (the counts are double buffered: the next sub-tile
+        // writes the other set, and nobody reaches the one after it before all have read this one)
+        if (total == 0) continue;
+        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask) + before;
         slot += q_head + q_count;                           // behind the queued ones (at most 255 + 1024 entries in all)
         slot = slot >= kFusedRing ? slot - kFusedRing : slot;
         slot = slot >= kFusedRing ? slot - kFusedRing : slot;
+        if (wcount)                                         // uniform per wave
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (cand[k]) {
