@@ -469,6 +469,14 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
     runner = SingleGpu(device, wl, copies)
     n_rec = runner.rec.n
     n_pairs = n_rec // 2
+    # setup, not measurement: the clocks of an idle GPU take a few hundred milliseconds of work to settle (one box of the
+    # pool measured 5.3 ms per step in a 30 ms timed region that its own per-kernel breakdown, taken right after, put
+    # at 2.9), so the passes run untimed for 0.3 s before the W warm-up steps
+    t_setup = time.perf_counter()
+    while time.perf_counter() - t_setup < 0.3:
+        for _ in range(4):
+            runner.step()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         runner.step()
     torch.cuda.synchronize()
