@@ -774,9 +774,12 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
             job.step()
 
     # setup, not measurement: RCCL opens its channels and the builders size their exchange regions on the first passes
-    # (a run whose only untimed passes were two warm-up steps once measured 2.8 ms per step instead of 1.36)
-    for _ in range(2):
+    # (a run whose only untimed passes were two warm-up steps once measured 2.8 ms per step instead of 1.36), and an idle
+    # GPU's clocks settle: 150 passes (0.2-0.5 s)
+    for k in range(150):                                 # (a FIXED count: every pass holds collectives)
         step()
+        if k % 8 == 7:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
