@@ -638,8 +638,10 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
                 c2 = a.table[mtid];
             }
             const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
-            if (wave * 64 < cnt)                             // uniform per wave: the candidates' own coverage
-                wave_add_runs(aligned, live ? tid : -1, (live && (e.bits & EV_COV)) ? (int)qlen : 0, lane);
+            // the candidate's coverage was credited with the streamed records (any in-range pair whose mapq qualifies);
+            // [:127-139] also wants both contigs in the table: taken back here when they are not
+            if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
+                atomicAdd(&aligned[tid], 0ull - (unsigned long long)qlen);
             const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
             const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
             const bool dbl = (e.bits & EV_DOUBLE) != 0;
@@ -791,7 +793,10 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
             cand[k] = r_tid[k] != r_mtid[k];
             uni = uni && (r_tid[k] == ref);
             const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-            if (!cand[k] && cov) mine += (int)r_qlen[k];
+            // a candidate's own coverage is credited here too, with its neighbours' (same contig, same reduction): all it
+            // takes beyond theirs is a mate on a contig of the header; the evaluation round takes it back in the rare case
+            // that one of the two contigs is not in the table (a reduction per round for it cost 0.1 ms on C3)
+            if (cov && (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs)) mine += (int)r_qlen[k];
         }
         if (__all(uni)) {
             const int s = wave_sum(mine);
@@ -811,7 +816,8 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-                const bool act = !cand[k] && cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs;
+                const bool act = cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs &&
+                                 (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs);
                 if (!act) continue;
                 if (lane_uni) val += (int)r_qlen[k];
                 else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
