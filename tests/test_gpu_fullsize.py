@@ -121,6 +121,12 @@ def test_resident_builder_step_large_stream(seg_window, monkeypatch):
         monkeypatch.setenv('BESST_SEG_WINDOW', seg_window)
     dev = torch.device('cuda', 0)
     wl = workload.make_device(dev, 'C3', 0, pairs=30_000_000, nc=20_000)
+    # every 37th contig is not in the table (a later pass: repeats and low-coverage contigs are gone): records on them
+    # or with their mate on them add no coverage - the fused loop credits candidates early and has to take that back -
+    # and the coverage of the contigs themselves is cleared by whichever kernel runs after the stitch
+    table = {k: np.array(v, copy=True) for k, v in wl['table'].items()}
+    table['cls'][::37] = 0
+    wl['table'] = table
     rec = pipeline.DeviceRecords.from_columns(wl['cols'])
     probe = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, 1)
     probe.set_contigs(**wl['table'])
