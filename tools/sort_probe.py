@@ -21,6 +21,10 @@ for n in sizes:
         pair = (np.maximum(a2, 0) << node_bits) | b2
     else:
         pair = rng.integers(0, 1 << (2 * node_bits), rows, dtype=np.int64)[rng.integers(0, rows, n)]
+        noise = float(os.environ.get('BESST_PROBE_NOISE', '0'))          # share of tuples on edges of their own (chimeras)
+        if noise > 0:
+            m = rng.random(n) < noise
+            pair[m] = rng.integers(0, 1 << (2 * node_bits), int(m.sum()), dtype=np.int64)
     keys = (pair << 1).astype(np.uint64)
     lo = rng.integers(26, 5000, n).astype(np.uint64); hi = rng.integers(26, 5000, n).astype(np.uint64) | (np.uint64(3) << np.uint64(30))
     payload = lo | (hi << np.uint64(32))
