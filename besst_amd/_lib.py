@@ -26,9 +26,10 @@ class LibParams(C.Structure):
 
 class Presort(C.Structure):          # include/besst_amd.h: besst_presort
     _fields_ = [('table', C.c_void_p), ('rows', C.c_int32), ('shift', C.c_int32), ('key_base', C.c_uint64),
-                ('capacity', C.c_uint32), ('reserved', C.c_uint32), ('segmented', C.c_int32), ('in_record_loop', C.c_int32),
+                ('capacity', C.c_uint32), ('flags', C.c_uint32), ('segmented', C.c_int32), ('in_record_loop', C.c_int32),
                 ('seg_keys', C.c_void_p), ('seg_payload', C.c_void_p), ('seg_offsets', C.c_void_p), ('seg_skip', C.c_void_p),
-                ('seg_blocks', C.c_uint32), ('seg_tile', C.c_uint32), ('payload_out', C.c_void_p)]
+                ('seg_blocks', C.c_uint32), ('seg_tile', C.c_uint32), ('payload_out', C.c_void_p),
+                ('seg_chunk_first', C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -89,6 +90,8 @@ _SIGNATURES = {
                                               C.POINTER(C.c_int32)]),
     'besst_dev_reduce': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, C.c_size_t, _P, C.c_uint64]),
+    'besst_dev_reduce_flags': (C.c_int, [_P, C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                         _P, _P, C.c_size_t, _P, C.c_uint64, C.c_uint32]),
     'besst_dev_reduce_presort': (C.c_int, [C.c_int64, C.c_int32, C.c_uint64, _P, C.c_size_t, C.POINTER(Presort)]),
     'besst_dev_classify_presort': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                              C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t,

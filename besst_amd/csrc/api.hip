@@ -169,7 +169,7 @@ const char* besst_prof_slot_name(int slot) {
     static const char* names[kProfSlots] = {"stream_kernel", "(unused)", "ordered_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
                                             "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "row_heads_kernel",
                                             "row_scan_kernel", "row_reduce_kernel",
-                                            "metrics_kernels", "score_kernels"};
+                                            "metrics_kernels", "score_kernels", "rg_group_kernel", "rg_sort_runs", "rg_copy_kernel"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
 }
 
@@ -351,18 +351,28 @@ int besst_dev_classify(void* stream, int64_t n, const int32_t* tid, const int32_
                        int32_t* carry, int64_t* aligned, uint64_t* keys, uint64_t* payload, uint32_t* n_out,
                        besst_counters* counters, void* workspace, size_t workspace_bytes);
 
-int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
-                     const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
-                     int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
-                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
-                     uint64_t key_base) {
+int besst_dev_reduce_flags(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
+                           const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
+                           int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                           uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
+                           uint64_t key_base, uint32_t flags) {
     BESST_REQUIRE(n_tuples && n_rows, "reduce: null size pointer");
     BESST_REQUIRE(capacity == 0 || (keys && payload && row_key && row_mask && row_n && row_sum && row_sum_sq &&
                                     row_first && row_offset && obs_lo && obs_hi),
                   "reduce: null buffer");
     return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
                               row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
-                              workspace, workspace_bytes, first_map, key_base);
+                              workspace, workspace_bytes, first_map, key_base, false, nullptr, flags);
+}
+
+int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits, const uint64_t* keys,
+                     const uint64_t* payload, uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum,
+                     int64_t* row_sum_sq, uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                     uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
+                     uint64_t key_base) {
+    return besst_dev_reduce_flags(stream, capacity, n_tuples, key_bits, keys, payload, row_key, row_mask, row_n, row_sum,
+                                  row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows, workspace, workspace_bytes,
+                                  first_map, key_base, 0u);
 }
 
 static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos,
@@ -419,7 +429,8 @@ static void presort_to_spec(const besst_presort* h, PresortSpec& ps) {
     if (!h || !h->table) return;
     ps.table = h->table; ps.rows = h->rows; ps.shift = h->shift; ps.key_base = h->key_base; ps.cap = h->capacity;
     ps.segmented = h->segmented; ps.in_record_loop = h->in_record_loop;
-    ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out};
+    ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out,
+                       h->seg_chunk_first};
 }
 
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
@@ -454,6 +465,7 @@ int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, cons
         h_presort->seg_keys = ps.seg.seg_keys; h_presort->seg_payload = ps.seg.seg_payload;
         h_presort->seg_offsets = ps.seg.offsets; h_presort->seg_skip = ps.seg.skip;
         h_presort->seg_blocks = ps.seg.nblocks; h_presort->seg_tile = ps.seg.tile; h_presort->payload_out = ps.seg.payload_out;
+        h_presort->seg_chunk_first = ps.seg.chunk_first;
     }
     return rc;
 }
@@ -477,7 +489,8 @@ int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n
                   "reduce_presorted: incomplete segment description");
     return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
                               row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
-                              workspace, workspace_bytes, first_map, key_base, true, seg ? &ps.seg : nullptr);
+                              workspace, workspace_bytes, first_map, key_base, true, seg ? &ps.seg : nullptr,
+                              h_presort->flags);
 }
 
 int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
@@ -669,12 +682,23 @@ int besst_ctx_build_graph(besst_ctx* c) {
     if ((rc = c->obs_lo.ensure(cap2))) return rc;
     if ((rc = c->obs_hi.ensure(cap2))) return rc;
     if ((rc = c->ws.ensure(reduce_workspace_bytes(L)))) return rc;
-    rc = besst_dev_reduce(c->stream, L, &sb->n_out, c->key_bits, c->keys.p, c->payload.p, c->row_key.p,
-                          c->row_mask.p, c->row_n.p, c->row_sum.p, c->row_sum_sq.p, c->row_first.p, c->row_offset.p,
-                          c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap, nullptr, c->key_base);
-    if (rc) return rc;
-    BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
-    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    // large streams take the run-grouped form first; one whose keys do not cluster says so in n_rows and is sorted
+    // tuple by tuple instead (include/besst_amd.h, BESST_ROWS_*)
+    for (uint32_t flags = 0;; flags = BESST_REDUCE_NO_RUNS) {
+        rc = besst_dev_reduce_flags(c->stream, L, &sb->n_out, c->key_bits, c->keys.p, c->payload.p, c->row_key.p,
+                                    c->row_mask.p, c->row_n.p, c->row_sum.p, c->row_sum_sq.p, c->row_first.p,
+                                    c->row_offset.p, c->obs_lo.p, c->obs_hi.p, &sb->n_rows, c->ws.p, c->ws.cap, nullptr,
+                                    c->key_base, flags);
+        if (rc) return rc;
+        BESST_HIP_TRY(hipMemcpyAsync(&host, sb, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (host.n_rows == BESST_ROWS_RUN_OVERFLOW && flags == 0) continue;
+        break;
+    }
+    if (host.n_rows == BESST_ROWS_SORT_FAILED || host.n_rows == BESST_ROWS_RUN_OVERFLOW) {
+        set_error("build_graph: the sort could not finish (status word 0x%08x): a chained-scan look-back gave up", host.n_rows);
+        return BESST_ERR_HIP;
+    }
     c->n_rows = host.n_rows;
     c->built = true;
     return BESST_OK;

@@ -1214,7 +1214,10 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
 __global__ __launch_bounds__(256) void presort_fixup_kernel(const uint64_t* __restrict__ seg_keys,
                                                             const uint32_t* __restrict__ skip_slot, uint32_t nblocks,
                                                             PresortSpec ps, const uint8_t* __restrict__ cls8,
-                                                            int32_t n_contigs, unsigned long long* __restrict__ aligned) {
+                                                            int32_t n_contigs, unsigned long long* __restrict__ aligned,
+                                                            const uint32_t* __restrict__ offsets,
+                                                            const uint32_t* __restrict__ n_out,
+                                                            uint32_t* __restrict__ chunk_first) {
     // when compact_kernel does not run, its side job is done here: coverage of contigs that are not in the table is
     // not part of cont_aligned_len (CreateGraph.py:89-95)
     if (cls8)
@@ -1222,6 +1225,12 @@ __global__ __launch_bounds__(256) void presort_fixup_kernel(const uint64_t* __re
             if (!cls8[c]) aligned[c] = 0;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
+    if (chunk_first) {
+        // a stage 2 that reads the segments chunk by chunk (runs.hip) starts every chunk at a known block: the chunks
+        // whose first dense position lies in this block's range
+        const uint32_t lo = offsets[b], hi = b + 1u < nblocks ? offsets[b + 1u] : *n_out;
+        for (uint32_t c = (lo + (uint32_t)kRunChunk - 1u) / (uint32_t)kRunChunk; (uint64_t)c * kRunChunk < hi; ++c) chunk_first[c] = b;
+    }
     const uint32_t skip = skip_slot[b];
     if (skip == kNoSlot) return;
     const uint64_t k = seg_keys[(size_t)b * kClsTile + skip] - ps.key_base;
@@ -1290,6 +1299,7 @@ struct ClsWorkspace {
     SummView summ;
     uint32_t* offsets;
     uint32_t* skip;
+    uint32_t* chunk_first;          // per chunk of kRunChunk tuples of the dense stream: its first block
     struct StitchAgg* agg;          // one per span of blocks, + the prev_obs entering the stream (2 x int32) behind them
     uint32_t agg_spans;
     unsigned long long* bitmask;
@@ -1310,6 +1320,7 @@ ClsWorkspace carve(void* ws, int64_t n) {
     off += align_up((size_t)w.summ.stride * kSumPlanes * sizeof(uint32_t), 256);
     w.offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.skip = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
+    w.chunk_first = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)n / kRunChunk + 2) * 4, 256);
     // (room for 4096 spans whatever the stream: the test knob BESST_STITCH_SPAN cuts small streams into many)
     const size_t spans = (size_t)((nblocks + kStitchSpan - 1) / kStitchSpan) + 4096;
     w.agg_spans = (uint32_t)spans;
@@ -1582,12 +1593,13 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
         const bool segmented = pre.table && pre.in_record_loop && pre.segmented && !slice_info && !tails;
         if (pre.table && pre.in_record_loop) {
             hipLaunchKernelGGL(presort_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, w.seg_keys, w.skip, nblocks, pre,
-                               segmented ? cls8 : nullptr, n_contigs, reinterpret_cast<unsigned long long*>(aligned));
+                               segmented ? cls8 : nullptr, n_contigs, reinterpret_cast<unsigned long long*>(aligned),
+                               w.offsets, n_out, segmented ? w.chunk_first : nullptr);
             in_compact.table = nullptr;
         }
         if (segmented) {                                     // the sort's first pass reads the segments: no dense copy
             presort->segmented = 1;
-            presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload};
+            presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload, w.chunk_first};
         } else {
             if (presort) presort->segmented = 0;
             hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,

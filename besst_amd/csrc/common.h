@@ -32,7 +32,7 @@ void set_error(const char* fmt, ...);
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
     kProfClassify = 0, kProfCandidate, kProfOrdered, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter, kProfBucketSort,
-    kProfRowHeads, kProfRowScan, kProfRowReduce, kProfMetrics, kProfScore, kProfSlots
+    kProfRowHeads, kProfRowScan, kProfRowReduce, kProfMetrics, kProfScore, kProfRunGroup, kProfRunSort, kProfRunCopy, kProfSlots
 };
 struct ProfScope {
     hipStream_t s;
@@ -205,6 +205,13 @@ __host__ __device__ inline uint32_t owner_of_scaffold(uint32_t scaffold_id, uint
 // The ordered tuple stream as the record loop and the stitch leave it - one segment of kClsTile slots per block, the
 // dense position of each block's first tuple, the slot of the head tuple the stitch dropped - for a sort whose first
 // stream pass reads the segments itself (and writes the dense payload on its way), so that compact_kernel need not run.
+// tuples per chunk of the run-grouped form (runs.hip): one wave, BESST_RG_ROUNDS words per lane (build knob).  Measured
+// on full C3 (42.7 M tuples): 16 words (1024-tuple chunks, 161 VGPRs, three waves per SIMD) 308 us for the grouping
+// kernel, 8 words (five waves per SIMD, a third more runs) 231 us, 4 words 235 us - with the run sort growing.
+#ifndef BESST_RG_ROUNDS
+#define BESST_RG_ROUNDS 8
+#endif
+constexpr int kRunChunk = 64 * BESST_RG_ROUNDS;
 struct SegSource {
     const uint64_t* seg_keys;
     const uint64_t* seg_payload;
@@ -212,6 +219,7 @@ struct SegSource {
     const uint32_t* skip;
     uint32_t nblocks, tile;
     uint64_t* payload_out;
+    const uint32_t* chunk_first;     // per chunk of kRunChunk dense positions: the block its first position lies in (or null)
 };
 
 struct PresortSpec {
@@ -253,7 +261,18 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map = nullptr,
-                       uint64_t key_base = 0, bool hist_ready = false, const SegSource* seg = nullptr);
+                       uint64_t key_base = 0, bool hist_ready = false, const SegSource* seg = nullptr,
+                       uint32_t flags = 0 /* BESST_REDUCE_* */);
+// run-grouped form for large streams (runs.hip): the chunks' runs of equal keys are sorted, not the tuples.  grouped:
+// cap words for the payload grouped by run; staged_rows: cap 40-byte records (the chained-scan workspace's row staging)
+bool runs_enabled(int64_t cap);
+size_t runs_workspace_bytes(int64_t cap);
+int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits, const uint64_t* keys,
+                       const uint64_t* payload, const SegSource* seg, uint64_t* grouped, void* staged_rows,
+                       uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                       uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows,
+                       void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base);
+void* onesweep_staged_rows(void* ws, int64_t cap);
 // chained-scan sort + atomic-free reduction for large streams (onesweep.hip); buf_* = the ping-pong buffers of the
 // sort/reduce workspace
 size_t onesweep_workspace_bytes(int64_t cap);

@@ -75,6 +75,12 @@ constexpr int kOsRedItems = 16;
 constexpr int kOsRedTile = kOsRedThreads * kOsRedItems; // 4096 tuples per reduce tile
 constexpr uint32_t kStAgg = 1u, kStPrefix = 2u;
 constexpr uint32_t kSpinLimit = 1u << 22;               // ~ seconds; a healthy look-back waits microseconds
+// BESST_OS_SPIN_LIMIT (tests): a limit of 0 makes the first unanswered poll give up, so that the error path - the
+// workspace's error word, BESST_ROWS_SORT_FAILED in *n_rows - can be exercised on a healthy GPU
+static uint32_t os_spin_limit() {
+    static const uint32_t v = [] { const char* e = getenv("BESST_OS_SPIN_LIMIT"); return e ? (uint32_t)strtoul(e, nullptr, 10) : kSpinLimit; }();
+    return v;
+}
 
 __device__ __forceinline__ void granule_store(unsigned long long* p, uint32_t tag, uint32_t value) {
     __hip_atomic_store((gu64*)p, ((unsigned long long)tag << 32) | value, BESST_RLX_AGENT);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ n_ptr,
     uint32_t cap, int shift, int pass, int packed_bits, uint64_t key_base, const uint32_t* __restrict__ digit_base,
     unsigned long long* __restrict__ desc, uint32_t* __restrict__ ticket, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err, SegSource seg = SegSource{},
+    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ err, uint32_t spin_limit, SegSource seg = SegSource{},
     const uint32_t* __restrict__ tile_first = nullptr, int seg_win = kSegWin) {
     constexpr int RADIX = 1 << BITS;
     // the raw key stream (first pass) and unpacked keys carry key_base; packed words hold key - key_base already
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(kOsThreads, BESST_OS_MIN_WAVES) void os_scatter_ker
                 const uint32_t tg = (uint32_t)(g >> 32);
                 if (tg == tag_pre) { excl += (uint32_t)g; break; }
                 if (tg == tag_agg) { excl += (uint32_t)g; --k; continue; }   // tile 0 always publishes a prefix
-                if (++spins > kSpinLimit) { *err = 1u; break; }
+                if (++spins > spin_limit) { *err = 1u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             granule_store(mine, tag_pre, excl + run);
@@ -1188,6 +1194,7 @@ __global__ __launch_bounds__(kBkThreads) void os_bucket_sort_kernel(uint64_t* wo
 constexpr int kRowsThreads = 1024;
 
 __global__ __launch_bounds__(kRowsThreads) void os_bucket_rows_kernel(const uint32_t* __restrict__ start, BwOut o,
+                                                                      const uint32_t* __restrict__ err,
                                                                       uint32_t* __restrict__ n_rows,
                                                                       uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask,
                                                                       uint32_t* __restrict__ row_n,
@@ -1222,7 +1229,8 @@ __global__ __launch_bounds__(kRowsThreads) void os_bucket_rows_kernel(const uint
     }
     s_excl[t] = off;
     if (t == 0) s_excl[kRowsThreads] = total;
-    if (blockIdx.x == gridDim.x - 1 && t == 0) *n_rows = base + total;
+    // (a stream pass whose look-back gave up has left a wrong partition behind: the caller must not trust the table)
+    if (blockIdx.x == gridDim.x - 1 && t == 0) *n_rows = *err ? BESST_ROWS_SORT_FAILED : base + total;
     __syncthreads();
     for (uint32_t i = t; i < total; i += kRowsThreads) {
         int lo = 0, hi = kRowsThreads;                       // last bucket whose exclusive count is <= i
@@ -1277,7 +1285,7 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
     uint64_t* __restrict__ row_key, uint32_t* __restrict__ row_mask, uint32_t* __restrict__ row_n,
     unsigned long long* __restrict__ row_sum, unsigned long long* __restrict__ row_sum_sq,
     uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset, int32_t* __restrict__ obs_lo,
-    int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map, uint32_t* __restrict__ err) {
+    int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map, uint32_t* __restrict__ err, uint32_t spin_limit) {
     __shared__ uint32_t s_o[kOsRedTile + kOsRedTile / 16];          // obs1 + obs2 per tuple, padded rows of 16
     __shared__ unsigned long long s_heads[kOsRedTile / 64];         // head flags, one bit per tuple
     __shared__ uint32_t s_tile, s_base;
@@ -1375,7 +1383,7 @@ __global__ __launch_bounds__(kOsRedThreads) void os_reduce_kernel(
                 if (first_pre < first_bad) break;
                 k -= take;
                 if (take == 0) {
-                    if (++spins > kSpinLimit) { if (lane == 0) *err = 1u; break; }
+                    if (++spins > spin_limit) { if (lane == 0) *err = 1u; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
@@ -1485,11 +1493,14 @@ __global__ __launch_bounds__(256) void os_fixup_kernel(const uint32_t* __restric
                                                        const unsigned long long* __restrict__ lead_s2,
                                                        uint32_t* __restrict__ row_n,
                                                        unsigned long long* __restrict__ row_sum,
-                                                       unsigned long long* __restrict__ row_sum_sq) {
+                                                       unsigned long long* __restrict__ row_sum_sq,
+                                                       const uint32_t* __restrict__ err, uint32_t* __restrict__ n_rows) {
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
     const uint32_t ntiles = os_nblocks(n, kOsRedTile);
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the last kernel of this form: a look-back that gave up - in a stream pass or in the row numbering - is reported)
+    if (tile == 0 && *err) *n_rows = BESST_ROWS_SORT_FAILED;
     if (tile == 0 || tile >= ntiles) return;
     const uint32_t c = lead_n[tile];
     if (c == 0) return;
@@ -1573,6 +1584,8 @@ bool onesweep_presort_spec(int64_t cap, int key_bits, uint64_t key_base, void* w
     return true;
 }
 
+void* onesweep_staged_rows(void* ws, int64_t cap) { return os_carve(ws, cap < 1 ? 1 : cap, kOsBits).staged; }
+
 size_t onesweep_workspace_bytes(int64_t cap) {
     if (cap < 1) cap = 1;
     return os_carve(nullptr, cap, kOsBits).total;
@@ -1598,6 +1611,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
     const uint32_t nt_sort = (uint32_t)((cap + kOsTile - 1) / kOsTile);
     const uint32_t nt_red = (uint32_t)((cap + kOsRedTile - 1) / kOsRedTile);
     constexpr int RADIX = 1 << kOsBits;
+    const uint32_t spin_limit = os_spin_limit();
     BESST_HIP_TRY(hipMemsetAsync(w.err, 0, 4, s));
     BESST_REQUIRE(!seg || (hist_ready && hybrid), "reduce: a segmented stream needs the bucket form and its histograms");
     if (hist_ready && hybrid) {
@@ -1623,7 +1637,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
 #define BESST_OS_LAUNCH(FIRST, PACKED)                                                                                   \
     hipLaunchKernelGGL((os_scatter_kernel<kOsBits, FIRST, PACKED>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,      \
                        n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX, w.granules, \
-                       w.tickets + p, kout, iout, w.err)
+                       w.tickets + p, kout, iout, w.err, spin_limit)
         if (seg && p == 0) {
             int seg_win = kSegWin;                           // BESST_SEG_WINDOW (tests): see os_scatter_kernel
             if (const char* e = getenv("BESST_SEG_WINDOW")) {
@@ -1634,7 +1648,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                w.tile_first);
             hipLaunchKernelGGL((os_scatter_kernel<kOsBits, true, true, true>), dim3(nt_sort), dim3(kOsThreads), 0, s, kin, iin,
                                n_tuples, (uint32_t)cap, shift, p, packed_bits, key_base, w.digit_base + (size_t)p * RADIX,
-                               w.granules, w.tickets + p, kout, iout, w.err, *seg, w.tile_first, seg_win);
+                               w.granules, w.tickets + p, kout, iout, w.err, spin_limit, *seg, w.tile_first, seg_win);
         } else if (packed_bits) {
             if (p == 0) BESST_OS_LAUNCH(true, true); else BESST_OS_LAUNCH(false, true);
         } else {
@@ -1663,7 +1677,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         {
             ProfScope ps(s, kProfRowReduce);
             hipLaunchKernelGGL(os_bucket_rows_kernel, dim3(kTopBuckets / kRowsThreads), dim3(kRowsThreads), 0, s,
-                               w.bucket_start, o, n_rows, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
+                               w.bucket_start, o, w.err, n_rows, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                                reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset);
         }
         BESST_HIP_TRY(hipGetLastError());
@@ -1675,13 +1689,13 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                            (uint32_t)cap, packed_bits, key_base, w.granules + w.desc_words, w.tickets + kOsMaxPasses, w.tile_base,
                            w.lead_n, w.lead_s, w.lead_s2, n_rows, row_key, row_mask, row_n,
                            reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),
-                           row_first, row_offset, obs_lo, obs_hi, first_map, w.err);
+                           row_first, row_offset, obs_lo, obs_hi, first_map, w.err, spin_limit);
     }
     {
         ProfScope ps(s, kProfRowScan);
         hipLaunchKernelGGL(os_fixup_kernel, dim3((nt_red + 255) / 256), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.tile_base,
                            w.lead_n, w.lead_s, w.lead_s2, row_n, reinterpret_cast<unsigned long long*>(row_sum),
-                           reinterpret_cast<unsigned long long*>(row_sum_sq));
+                           reinterpret_cast<unsigned long long*>(row_sum_sq), w.err, n_rows);
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;

@@ -1,0 +1,636 @@
+// Large tuple streams, run-grouped form: the edge table without a stream-wide sort of the tuples.
+//
+// A (tid,pos)-ordered alignment stream emits its link tuples contig by contig: 512 consecutive tuples of a mate-pair
+// library concern one or two contigs and carry about six distinct keys (C3: mean 6.2; 9.4 in 1024 tuples, 99th
+// percentile 18), each of them dozens to hundreds of times.  So the tuples are never sorted one by one:
+//
+//   1. rg_group_kernel    one wave per chunk of kRunChunk consecutive tuples, words in registers: the distinct keys of
+//                         the chunk are peeled off in order of first occurrence (first lane not yet placed -> its key
+//                         -> one compare + ballot + mbcnt per round of 64), the tuples of a key go - in stream order -
+//                         right behind those placed so far, and the key's RUN is described by one 40-byte record
+//                         (key, count, sum obs, sum obs^2, first stream index, start, graph mask).  Reads the record
+//                         loop's block segments (or the compacted stream) once, writes the payload grouped by run.
+//                         After 63 keys the rest of a chunk travels as runs of one tuple (chimeric pairs).
+//   2. rg_compact_kernel  the chunks' run lists -> one dense, stream-ordered list of (key, count | start) pairs
+//   3. the small-stream sort + reduction of sortreduce.hip on the RUNS (C3: 0.5 M runs for 42.7 M tuples): runs sorted
+//                         stably by key = the tuples sorted stably by key, because a run holds the equal keys of a
+//                         chunk in stream order and the chunks are in stream order
+//   4. rg_tile_sums / rg_dst_kernel   exclusive scan of the sorted runs' counts: where every run's observations go
+//   5. rg_rows_kernel     one thread per edge row: the sums of its runs, first index and mask of its first run
+//   6. rg_copy_kernel     one wave per eight sorted runs: observations from their grouped places to their sorted places
+//
+// Semantics as everywhere in stage 2 (CreateGraph.py:842-862): an edge is the unordered node pair, its observations stay
+// in BAM order, the row's first tuple is its first occurrence, nr_links / obs / obs_sq are exact integers.
+//
+// Measured on full C3 (42.7 M tuples, 263 k rows; round 2's two chained-scan passes + wave-per-bucket kernels: 0.87 ms
+// and 3.3 GB of traffic): 0.49 ms - grouping 0.23 (0.68 GB read, 0.34 GB written), copy 0.14 (0.34 + 0.34 GB), the
+// run sort and the scans 0.12 in nine small launches.  Where the grouping kernel's time goes (parts left out, timings
+// only): segment reads alone 0.19 ms, the peel 0.08, the grouped stores 0.03 - it is bound by the life of a wave (block
+// look-up -> window of block offsets -> tuples -> peel -> stores, nothing overlapped inside a wave), so occupancy was
+// the lever: 16 words per lane 0.31 ms at three waves per SIMD, 8 words 0.23 at five.  The two wave sums per key are
+// DPP reductions (as ds_bpermute shuffles they were a chain of 24 dependent LDS operations per key: 0.38 -> 0.33 ms).
+// The segments' sparse layout (14 KB used of every 128 KB) costs nothing: tools/probe_stride.hip reads and writes that
+// pattern at the rate of a dense array.
+//
+// A stream whose keys do not cluster (name-sorted input, mostly chimeric pairs) has about as many runs as tuples; when the
+// runs do not fit their buffers (kRunCapMax) nothing is produced, *n_rows reads BESST_ROWS_RUN_OVERFLOW and the caller
+// repeats the call with BESST_REDUCE_NO_RUNS (the chained-scan passes of onesweep.hip).
+#include "common.h"
+
+namespace besst {
+
+namespace {
+
+constexpr int kRgRounds = BESST_RG_ROUNDS;
+constexpr int kRgMinWaves = kRgRounds >= 16 ? 3 : kRgRounds >= 8 ? 5 : 8;   // what the registers of a chunk allow per SIMD
+constexpr int kRgChunk = 64 * kRgRounds;                 // tuples per wave
+static_assert(kRgChunk == kRunChunk, "the record loop's chunk table is cut for this chunk size");
+constexpr int kRgWaves = 4;
+constexpr int kRgPeel = 63;                              // keys peeled per chunk; lane k of the wave keeps run k
+constexpr uint32_t kRgNoSlot = 0xffffffffu;
+constexpr int kRgCopyRuns = 8;                           // sorted runs per wave of the copy kernel
+constexpr int kRsThreads = 256, kRsItems = 16, kRsTile = kRsThreads * kRsItems;
+
+struct RunRec {                                          // 40 bytes: a run is written and read as a whole
+    uint64_t key;
+    unsigned long long sum, sq;
+    uint32_t n, first, off, mask;
+};
+static_assert(sizeof(RunRec) == 40, "run record layout");
+
+__device__ __forceinline__ uint64_t rg_readlane64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+// Sum over the wave, in every lane's... no: in lane 63, read back as a wave-uniform value.  DPP moves (row_shr 1, 2, 4, 8
+// inside the rows of 16, then row_bcast 15 and 31), no LDS round trips: with shuffles (ds_bpermute) the two sums per
+// key were a chain of 24 dependent LDS operations and set the life of a chunk.
+__device__ __forceinline__ unsigned long long rg_wave_sum64(unsigned long long v) {
+#define BESST_RG_STEP(ctrl, rows)                                                                                  \
+    {                                                                                                              \
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, ctrl, rows, 0xf, false);    \
+        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), ctrl, rows, 0xf, false); \
+        v += ((unsigned long long)h2 << 32) | l2;                                                                  \
+    }
+    BESST_RG_STEP(0x111, 0xf)
+    BESST_RG_STEP(0x112, 0xf)
+    BESST_RG_STEP(0x114, 0xf)
+    BESST_RG_STEP(0x118, 0xf)
+    BESST_RG_STEP(0x142, 0xa)
+    BESST_RG_STEP(0x143, 0xc)
+#undef BESST_RG_STEP
+    return rg_readlane64(v, 63);
+}
+__device__ __forceinline__ uint32_t rg_obs(uint64_t pl) { return (uint32_t)pl + ((uint32_t)(pl >> 32) & 0x3fffffffu); }
+
+// ---------------------------------------------------------------------------------------------------
+// 1. chunks of 512 tuples -> runs
+// ---------------------------------------------------------------------------------------------------
+template <bool kSeg>
+__global__ __launch_bounds__(kRgWaves * 64, kRgMinWaves) void rg_group_kernel(
+    const uint64_t* __restrict__ keys, const uint64_t* __restrict__ payload, SegSource seg,
+    const uint32_t* __restrict__ n_ptr, uint32_t cap, const uint32_t* __restrict__ first_map,
+    uint64_t* __restrict__ grouped, RunRec* __restrict__ staged, uint16_t* __restrict__ starts,
+    uint32_t* __restrict__ chunk_runs) {
+    constexpr int R = kRgRounds;
+    const int lane = threadIdx.x & 63;
+    const uint32_t chunk = blockIdx.x * kRgWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n_all = *n_ptr;
+    const uint32_t n = n_all < cap ? n_all : cap;
+    const uint32_t base = chunk * (uint32_t)kRgChunk;
+    if (base >= n) {
+        if (lane == 0) chunk_runs[chunk] = 0;
+        return;
+    }
+    const uint32_t cnt = n - base < (uint32_t)kRgChunk ? n - base : (uint32_t)kRgChunk;
+    const uint32_t end = base + cnt;
+    uint64_t key[R], pl[R];
+    if constexpr (kSeg) {
+        // The stream lies in the record loop's block segments (SegSource): dense position i belongs to the last block
+        // whose first-tuple offset is <= i (empty blocks share their successor's offset), slot i - offset, one further
+        // when the stitch dropped that block's head tuple at or before it.  The chunk's first block by a 64-way search
+        // (three round trips for 24 k blocks), the offsets of the 64 blocks from there on in the wave's lanes.
+        uint32_t lo = 0, hi = seg.nblocks;
+        if (seg.chunk_first) {                               // uniform: the record loop's side has left the answer
+            lo = seg.chunk_first[chunk];
+            hi = lo + 1u;
+        }
+        while (hi - lo > 1u) {                               // uniform: lo, hi come out of ballots
+            const uint32_t step = (hi - lo + 63u) >> 6;
+            const uint32_t b = lo + (uint32_t)(lane + 1) * step;
+            const bool le = b < hi && seg.offsets[b] <= base;
+            const uint32_t c = (uint32_t)__popcll(__ballot(le));     // the offsets are monotone: a prefix of the lanes
+            const uint32_t nhi = lo + (c + 1u) * step;
+            lo += c * step;
+            hi = nhi < hi ? nhi : hi;
+        }
+        const uint32_t b0 = lo;
+        const uint32_t wb = b0 + (uint32_t)lane;
+        const uint32_t w_off = wb < seg.nblocks ? seg.offsets[wb] : 0xffffffffu;
+        const uint32_t w_skip = wb < seg.nblocks ? seg.skip[wb] : kRgNoSlot;
+        const uint32_t after = b0 + 64u < seg.nblocks ? seg.offsets[b0 + 64u] : 0xffffffffu;
+        const bool in_window = after >= end;                 // uniform: every position of the chunk lies in a windowed block
+        uint32_t wq[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wq[r] = 0;
+        if (in_window) {
+            for (int q = 1; q < 64; ++q) {                   // uniform loop: the blocks that begin inside the chunk
+                const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane((int)w_off, q);
+                if (oq >= end) break;
+#pragma unroll
+                for (int r = 0; r < R; ++r) wq[r] += base + (uint32_t)(r * 64 + lane) >= oq ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + (uint32_t)(r * 64 + lane);
+            key[r] = ~0ull;
+            pl[r] = 0ull;
+            uint32_t b, off, skip;
+            if (in_window) {
+                b = b0 + wq[r];
+                off = (uint32_t)__shfl((int)w_off, (int)wq[r], 64);
+                skip = (uint32_t)__shfl((int)w_skip, (int)wq[r], 64);
+            } else if (i < end) {                            // a chunk that spans more than 64 blocks: search in memory
+                uint32_t l2 = b0, h2 = seg.nblocks;
+                while (h2 - l2 > 1u) {
+                    const uint32_t mid = l2 + ((h2 - l2) >> 1);
+                    if (seg.offsets[mid] <= i) l2 = mid; else h2 = mid;
+                }
+                b = l2; off = seg.offsets[l2]; skip = seg.skip[l2];
+            } else {
+                b = 0; off = 0; skip = kRgNoSlot;
+            }
+            if (i < end) {
+                uint32_t j = i - off;
+                j += j >= skip ? 1u : 0u;
+                const size_t src = (size_t)b * seg.tile + j;
+                key[r] = seg.seg_keys[src];
+                pl[r] = seg.seg_payload[src];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + (uint32_t)(r * 64 + lane);
+            key[r] = i < end ? keys[i] : ~0ull;              // (a key is below 2^59: the padding matches nothing)
+            pl[r] = i < end ? payload[i] : 0ull;
+        }
+    }
+    // ---- peel the distinct keys off, first occurrence first
+    uint32_t placed = 0;                                     // bit r: the lane's tuple of round r is placed (or padding)
+    uint32_t pos[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!(base + (uint32_t)(r * 64 + lane) < end)) placed |= 1u << r;
+        pos[r] = 0;
+    }
+    uint32_t covered = 0;
+    int K = 0;
+    uint64_t my_key = 0;
+    unsigned long long my_sum = 0, my_sq = 0;
+    uint32_t my_start = 0, my_cnt = 0, my_first = 0, my_mask = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < R; ++r0) {
+        unsigned long long rest = __ballot(!((placed >> r0) & 1u));
+        while (rest != 0ull && K < kRgPeel) {                // uniform
+            const int src = __ffsll((long long)rest) - 1;
+            const uint64_t f = rg_readlane64(key[r0], src);
+            uint32_t run = covered;
+            unsigned long long s = 0, q = 0;
+#pragma unroll
+            for (int r = r0; r < R; ++r) {
+                const bool hit = key[r] == f;                // (a placed tuple has another key: keys are placed whole)
+                const unsigned long long mm = __ballot(hit);
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, run));
+                // (the observation is formed from the selected words: nothing here is invariant in the key loop, so
+                // the compiler does not keep sixteen sums and squares alive across it)
+                const uint32_t ol = hit ? (uint32_t)pl[r] : 0u;
+                const uint32_t oh = (hit ? (uint32_t)(pl[r] >> 32) : 0u) & 0x3fffffffu;
+                const unsigned long long o = (unsigned long long)(ol + oh);
+                s += o;
+                q += o * o;
+                if (hit) {
+                    pos[r] = rk;
+                    placed |= 1u << r;
+                }
+                run += (uint32_t)__popcll(mm);
+                if (r == r0) rest &= ~mm;
+            }
+            s = rg_wave_sum64(s);
+            q = rg_wave_sum64(q);
+            const uint32_t msk = (uint32_t)__builtin_amdgcn_readlane((int)(pl[r0] >> 32), src) >> 30;
+            if (lane == K) {
+                my_key = f; my_sum = s; my_sq = q; my_start = covered; my_cnt = run - covered;
+                my_first = base + (uint32_t)(r0 * 64 + src); my_mask = msk;
+            }
+            covered = run;
+            ++K;
+        }
+    }
+    uint32_t n_runs = (uint32_t)K;
+    if (covered < cnt) {
+        // more than kRgPeel distinct keys: what is left travels as runs of one tuple (their order among themselves is
+        // stream order, and a key that shows up here has none of its tuples among the peeled runs)
+        uint32_t run = covered;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool un = !((placed >> r) & 1u);
+            const unsigned long long mm = __ballot(un);
+            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, run));
+            if (un) {
+                pos[r] = rk;
+                const uint32_t i = base + (uint32_t)(r * 64 + lane);
+                const unsigned long long o = (unsigned long long)rg_obs(pl[r]);
+                RunRec rec;
+                rec.key = key[r]; rec.sum = o; rec.sq = o * o; rec.n = 1u;
+                rec.first = first_map ? first_map[i] : i;
+                rec.off = base + rk;
+                rec.mask = (uint32_t)(pl[r] >> 62);
+                staged[base + rk] = rec;
+                starts[base + (uint32_t)kRgPeel + (rk - covered)] = (uint16_t)rk;
+            }
+            run += (uint32_t)__popcll(mm);
+        }
+        n_runs = (uint32_t)kRgPeel + (run - covered);
+    }
+    if (lane < K) {
+        RunRec rec;
+        rec.key = my_key; rec.sum = my_sum; rec.sq = my_sq; rec.n = my_cnt;
+        rec.first = first_map ? first_map[my_first] : my_first;
+        rec.off = base + my_start;
+        rec.mask = my_mask;
+        staged[base + my_start] = rec;                       // a run's start is its own: one record per run, found by `off`
+        starts[base + (uint32_t)lane] = (uint16_t)my_start;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (base + (uint32_t)(r * 64 + lane) < end) grouped[base + pos[r]] = pl[r];
+    if (lane == 0) chunk_runs[chunk] = n_runs;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2. run lists of the chunks -> one dense list in stream order
+// ---------------------------------------------------------------------------------------------------
+// Workgroup g owns chunks [256 g, 256 g + 256): it sums the run counts of all chunks before them (coalesced, from L2),
+// scans its own and moves its runs, one thread per run - 1024 threads for a couple of thousand runs: a run costs three
+// dependent loads, so the depth per workgroup is what sets the kernel's time (1024 chunks per workgroup: 46 -> 24 us).  The
+// last workgroup writes the run count - or, when the runs do not fit, the overflow word (and a count of zero: the
+// stages behind find nothing to do).
+constexpr int kRcThreads = 1024;
+constexpr int kRcChunks = 256;
+
+__global__ __launch_bounds__(kRcThreads) void rg_compact_kernel(
+    const uint32_t* __restrict__ chunk_runs, const uint32_t* __restrict__ n_ptr, uint32_t cap,
+    const RunRec* __restrict__ staged, const uint16_t* __restrict__ starts, uint32_t run_cap,
+    uint64_t* __restrict__ run_keys, uint64_t* __restrict__ run_payload, uint32_t* __restrict__ n_runs,
+    uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_excl[kRcChunks + 1];
+    __shared__ uint32_t s_w[kRcChunks / 64], s_b[kRcThreads / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nchunks = (n + (uint32_t)kRgChunk - 1u) / (uint32_t)kRgChunk;
+    const uint32_t c0 = blockIdx.x * (uint32_t)kRcChunks;
+    uint32_t before = 0;
+    const uint32_t lim = c0 < nchunks ? c0 : nchunks;
+    for (uint32_t i = t; i < lim; i += kRcThreads) before += chunk_runs[i];
+    const uint32_t mine = (t < kRcChunks && c0 + t < nchunks) ? chunk_runs[c0 + t] : 0u;
+    uint32_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= d) x += v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+    if (lane == 63 && wave < kRcChunks / 64) s_w[wave] = x;
+    if (lane == 0) s_b[wave] = before;
+    __syncthreads();
+    uint32_t off = x - mine, basev = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < kRcChunks / 64; ++q) {
+        if (q < wave) off += s_w[q];
+        total += s_w[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kRcThreads / 64; ++q) basev += s_b[q];
+    if (t < kRcChunks) s_excl[t] = off;
+    if (t == 0) s_excl[kRcChunks] = total;
+    if (blockIdx.x == gridDim.x - 1 && t == 0) {
+        const uint32_t all = basev + total;                  // (the chunks of the last workgroup end the stream)
+        if (all > run_cap) {
+            status[1] = 1u;
+            status[2] = all;
+            *n_runs = 0u;
+        } else {
+            *n_runs = all;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < total; i += kRcThreads) {
+        int lo = 0, hi = kRcChunks;                          // last chunk whose exclusive count is <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_excl[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t dst = basev + i;
+        if (dst >= run_cap) continue;                        // (overflow: reported by the last workgroup)
+        const uint32_t cb = (c0 + (uint32_t)lo) * (uint32_t)kRgChunk;
+        const uint32_t at = cb + (uint32_t)starts[cb + (i - s_excl[lo])];
+        run_keys[dst] = staged[at].key;
+        run_payload[dst] = (uint64_t)staged[at].n | ((uint64_t)at << 32);   // "obs_lo" = the run's length, "obs_hi" = where it lies
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 4. where the observations of every sorted run go: exclusive scan of the run lengths
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRsThreads) void rg_tile_sums_kernel(const int32_t* __restrict__ run_len,
+                                                                 const uint32_t* __restrict__ n_runs,
+                                                                 uint32_t* __restrict__ tile_sum) {
+    __shared__ uint32_t s_w[kRsThreads / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n = *n_runs;
+    const uint32_t j0 = blockIdx.x * (uint32_t)kRsTile;
+    uint32_t v = 0;
+    if (j0 < n) {
+#pragma unroll
+        for (int q = 0; q < kRsItems; ++q) {
+            const uint32_t j = j0 + (uint32_t)(q * kRsThreads + t);
+            v += j < n ? (uint32_t)run_len[j] : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int q = 0; q < kRsThreads / 64; ++q) tot += s_w[q];
+        tile_sum[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(kRsThreads) void rg_dst_kernel(const int32_t* __restrict__ run_len,
+                                                           const uint32_t* __restrict__ n_runs,
+                                                           const uint32_t* __restrict__ tile_sum,
+                                                           uint32_t* __restrict__ run_dst) {
+    __shared__ uint32_t s_w[kRsThreads / 64], s_b[kRsThreads / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n = *n_runs;
+    const uint32_t j0 = blockIdx.x * (uint32_t)kRsTile;
+    if (j0 >= n) return;                                     // uniform
+    uint32_t before = 0;
+    for (uint32_t i = t; i < blockIdx.x; i += kRsThreads) before += tile_sum[i];
+    uint32_t len[kRsItems];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < kRsItems; ++q) {                     // thread t owns runs [16 t, 16 t + 16) of the tile
+        const uint32_t j = j0 + (uint32_t)(t * kRsItems + q);
+        len[q] = j < n ? (uint32_t)run_len[j] : 0u;
+        tot += len[q];
+    }
+    uint32_t x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= d) x += v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+    if (lane == 63) s_w[wave] = x;
+    if (lane == 0) s_b[wave] = before;
+    __syncthreads();
+    uint32_t off = x - tot;
+#pragma unroll
+    for (int q = 0; q < kRsThreads / 64; ++q) {
+        if (q < wave) off += s_w[q];
+        off += s_b[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kRsItems; ++q) {
+        const uint32_t j = j0 + (uint32_t)(t * kRsItems + q);
+        if (j < n) run_dst[j] = off;
+        off += len[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 5. edge rows: the sums of a row's runs
+// ---------------------------------------------------------------------------------------------------
+// The sort of the runs has left per row its key (already in the table), the number of its runs and the sorted position
+// of its first run.  status: a failed stage in front of this one turns into the value *n_rows carries out.
+__global__ __launch_bounds__(256) void rg_rows_kernel(const uint32_t* __restrict__ status, uint32_t* __restrict__ n_rows,
+                                                      const uint32_t* __restrict__ r_runs, const uint32_t* __restrict__ r_first_run,
+                                                      const int32_t* __restrict__ run_at, const uint32_t* __restrict__ run_dst,
+                                                      const RunRec* __restrict__ staged, uint32_t* __restrict__ row_mask,
+                                                      uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
+                                                      unsigned long long* __restrict__ row_sum_sq,
+                                                      uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset) {
+    const uint32_t st_err = status[0], st_over = status[1];
+    if (st_err | st_over) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_rows = st_err ? BESST_ROWS_SORT_FAILED : BESST_ROWS_RUN_OVERFLOW;
+        return;
+    }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_rows) return;
+    const uint32_t j0 = r_first_run[r], c = r_runs[r];
+    uint32_t nn = 0, first = 0, mask = 0;
+    unsigned long long s = 0, q = 0;
+    for (uint32_t j = j0; j < j0 + c; ++j) {
+        const RunRec rec = staged[(uint32_t)run_at[j]];
+        nn += rec.n;
+        s += rec.sum;
+        q += rec.sq;
+        if (j == j0) { first = rec.first; mask = rec.mask; }
+    }
+    row_mask[r] = mask;
+    row_n[r] = nn;
+    row_sum[r] = s;
+    row_sum_sq[r] = q;
+    row_first[r] = first;
+    row_offset[r] = run_dst[j0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 6. observations to their sorted places, run by run
+// ---------------------------------------------------------------------------------------------------
+// One wave per kRgCopyRuns consecutive sorted runs, their tuples taken as one flat range: position p of the range lies
+// in the run whose prefix is the last one <= p.  All loads of a wave's range (<= 1024 tuples at a time) are in flight
+// before its first store.
+__global__ __launch_bounds__(256) void rg_copy_kernel(const uint32_t* __restrict__ n_runs, const int32_t* __restrict__ run_len,
+                                                      const int32_t* __restrict__ run_at, const uint32_t* __restrict__ run_dst,
+                                                      const uint64_t* __restrict__ grouped, int32_t* __restrict__ obs_lo,
+                                                      int32_t* __restrict__ obs_hi) {
+    constexpr int G = kRgCopyRuns;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = *n_runs;
+    const uint32_t j = w * (uint32_t)G + (uint32_t)lane;
+    if (w * (uint32_t)G >= n) return;                        // uniform
+    const bool live = lane < G && j < n;
+    const uint32_t len = live ? (uint32_t)run_len[j] : 0u;
+    const uint32_t at = live ? (uint32_t)run_at[j] : 0u;
+    const uint32_t dst = live ? run_dst[j] : 0u;
+    uint32_t incl = len;                                     // prefix sums over the first G lanes
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const uint32_t excl = incl - len;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, G - 1);
+    uint32_t pre[G];                                         // uniform: prefix of run k
+#pragma unroll
+    for (int k = 0; k < G; ++k) pre[k] = (uint32_t)__builtin_amdgcn_readlane((int)excl, k);
+    const uint32_t a_rel = at - excl, d_rel = dst - excl;    // lane k: source / target of range position p is *_rel + p
+    for (uint32_t p0 = 0; p0 < total; p0 += 1024u) {
+        uint64_t v[16];
+        uint32_t to[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t p = p0 + (uint32_t)(u * 64 + lane);
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q < G; ++q) k += p >= pre[q] ? 1 : 0;
+            // (runs of length 0 do not exist: a prefix equal to p belongs to the run that starts there)
+            const uint32_t src = (uint32_t)__shfl((int)a_rel, k, 64) + p;
+            to[u] = (uint32_t)__shfl((int)d_rel, k, 64) + p;
+            v[u] = 0ull;
+            if (p0 + (uint32_t)(u * 64) < total) {           // uniform
+                if (p < total) v[u] = grouped[src];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t p = p0 + (uint32_t)(u * 64 + lane);
+            if (p < total) {
+                obs_lo[to[u]] = (int32_t)(uint32_t)v[u];
+                obs_hi[to[u]] = (int32_t)((uint32_t)(v[u] >> 32) & 0x3fffffffu);
+            }
+        }
+    }
+}
+
+struct RgWorkspace {
+    uint32_t* status;           // [0] a look-back gave up, [1] run overflow, [2] runs wanted
+    uint32_t* n_runs;
+    uint32_t* chunk_runs;
+    uint16_t* starts;
+    uint64_t* run_keys;
+    uint64_t* run_payload;
+    int32_t* run_len;           // sorted runs: length ("obs_lo" of the nested reduction) ...
+    int32_t* run_at;            // ... and where the run lies ("obs_hi")
+    uint32_t* run_dst;
+    uint32_t* tile_sum;
+    uint32_t* r_mask;           // nested row outputs nobody reads, the number of runs per row, its first sorted run
+    uint32_t* r_runs;
+    int64_t* r_sum;
+    int64_t* r_sq;
+    uint32_t* r_first;
+    uint32_t* r_first_run;
+    char* nested;
+    size_t nested_bytes;
+    uint32_t run_cap;
+    size_t total;
+};
+
+}  // namespace
+
+// the small-stream form of launch_sort_reduce (MSD partition + per-bucket sort, kMsdMaxBlocks tiles) serves up to this many runs
+constexpr int64_t kRunCapMax = (int64_t)4 << 20;
+
+static int64_t rg_run_cap(int64_t cap) { return cap < kRunCapMax ? cap : kRunCapMax; }
+
+static RgWorkspace rg_carve(void* ws, int64_t cap) {
+    RgWorkspace w;
+    char* p = static_cast<char*>(ws);
+    size_t off = 0;
+    const size_t rc = (size_t)rg_run_cap(cap);
+    const size_t nchunks = align_up((size_t)((cap + kRgChunk - 1) / kRgChunk), kRgWaves);
+    w.run_cap = (uint32_t)rc;
+    w.status = reinterpret_cast<uint32_t*>(p + off); off += 256;
+    w.n_runs = w.status + 8;
+    w.chunk_runs = reinterpret_cast<uint32_t*>(p + off); off += align_up(nchunks * 4, 256);
+    w.starts = reinterpret_cast<uint16_t*>(p + off); off += align_up((size_t)cap * 2, 256);
+    w.run_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(rc * 8, 256);
+    w.run_payload = reinterpret_cast<uint64_t*>(p + off); off += align_up(rc * 8, 256);
+    w.run_len = reinterpret_cast<int32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.run_at = reinterpret_cast<int32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.run_dst = reinterpret_cast<uint32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.tile_sum = reinterpret_cast<uint32_t*>(p + off); off += align_up(((rc + kRsTile - 1) / kRsTile) * 4, 256);
+    w.r_mask = reinterpret_cast<uint32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.r_runs = reinterpret_cast<uint32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.r_sum = reinterpret_cast<int64_t*>(p + off); off += align_up(rc * 8, 256);
+    w.r_sq = reinterpret_cast<int64_t*>(p + off); off += align_up(rc * 8, 256);
+    w.r_first = reinterpret_cast<uint32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.r_first_run = reinterpret_cast<uint32_t*>(p + off); off += align_up(rc * 4, 256);
+    w.nested = p + off;
+    w.nested_bytes = reduce_workspace_bytes((int64_t)rc);   // (rc <= 4 M: no run workspace inside)
+    off += align_up(w.nested_bytes, 256);
+    w.total = off;
+    return w;
+}
+
+size_t runs_workspace_bytes(int64_t cap) {
+    if (cap < 1) cap = 1;
+    return rg_carve(nullptr, cap).total;
+}
+
+bool runs_enabled(int64_t cap) {
+    static const int knob = [] { const char* e = getenv("BESST_SORT_RUNS"); return e ? atoi(e) : 1; }();
+    return knob != 0 && cap >= 1 && cap <= ((int64_t)1 << 30);
+}
+
+int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits, const uint64_t* keys,
+                       const uint64_t* payload, const SegSource* seg, uint64_t* grouped, void* staged_rows,
+                       uint64_t* row_key, uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                       uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi, uint32_t* n_rows,
+                       void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base) {
+    const RgWorkspace w = rg_carve(ws, cap);
+    BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "reduce: run workspace too small");
+    BESST_REQUIRE(grouped != nullptr && staged_rows != nullptr, "reduce: run buffers missing");
+    RunRec* staged = static_cast<RunRec*>(staged_rows);
+    const uint32_t nchunks = (uint32_t)((cap + kRgChunk - 1) / kRgChunk);
+    const uint32_t grid1 = (nchunks + kRgWaves - 1) / kRgWaves;
+    BESST_HIP_TRY(hipMemsetAsync(w.status, 0, 64, s));
+    {
+        ProfScope ps(s, kProfRunGroup);
+        if (seg)
+            hipLaunchKernelGGL((rg_group_kernel<true>), dim3(grid1), dim3(kRgWaves * 64), 0, s, keys, payload, *seg, n_tuples,
+                               (uint32_t)cap, first_map, grouped, staged, w.starts, w.chunk_runs);
+        else
+            hipLaunchKernelGGL((rg_group_kernel<false>), dim3(grid1), dim3(kRgWaves * 64), 0, s, keys, payload, SegSource{},
+                               n_tuples, (uint32_t)cap, first_map, grouped, staged, w.starts, w.chunk_runs);
+    }
+    {
+        ProfScope ps(s, kProfRunSort);
+        hipLaunchKernelGGL(rg_compact_kernel, dim3((nchunks + kRcChunks - 1) / kRcChunks), dim3(kRcThreads), 0, s,
+                           w.chunk_runs, n_tuples, (uint32_t)cap, staged, w.starts, w.run_cap, w.run_keys, w.run_payload,
+                           w.n_runs, w.status);
+        // the runs, sorted stably by key and cut into rows: row_key is final, the other columns describe the runs
+        const int rc = launch_sort_reduce(s, (int64_t)w.run_cap, w.n_runs, key_bits, w.run_keys, w.run_payload, row_key, w.r_mask,
+                                          w.r_runs, w.r_sum, w.r_sq, w.r_first, w.r_first_run, w.run_len, w.run_at, n_rows,
+                                          w.nested, w.nested_bytes, nullptr, key_base, false, nullptr, BESST_REDUCE_NO_RUNS);
+        if (rc) return rc;
+        const uint32_t tiles = (w.run_cap + kRsTile - 1) / kRsTile;
+        hipLaunchKernelGGL(rg_tile_sums_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum);
+        hipLaunchKernelGGL(rg_dst_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum, w.run_dst);
+        hipLaunchKernelGGL(rg_rows_kernel, dim3((w.run_cap + 255) / 256), dim3(256), 0, s, w.status, n_rows, w.r_runs,
+                           w.r_first_run, w.run_at, w.run_dst, staged, row_mask, row_n,
+                           reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),
+                           row_first, row_offset);
+    }
+    {
+        ProfScope ps(s, kProfRunCopy);
+        const uint32_t waves = (w.run_cap + kRgCopyRuns - 1) / kRgCopyRuns;
+        hipLaunchKernelGGL(rg_copy_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, w.n_runs, w.run_len, w.run_at, w.run_dst,
+                           grouped, obs_lo, obs_hi);
+    }
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+}  // namespace besst

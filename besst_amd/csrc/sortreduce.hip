@@ -867,6 +867,8 @@ struct RedWorkspace {
     uint32_t stride;
     char* os_ws;          // chained-scan path (onesweep.hip)
     size_t os_bytes;
+    char* rg_ws;          // run-grouped path (runs.hip)
+    size_t rg_bytes;
     size_t total;
 };
 
@@ -930,6 +932,11 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.os_ws = p + off;
     w.os_bytes = nb_sort > (size_t)kScanFreeMaxBlocks ? onesweep_workspace_bytes(cap) : 0;
     off += align_up(w.os_bytes, 256);
+    w.rg_ws = p + off;
+    // (streams beyond the MSD path's 4 M tuples; the runs themselves are at most that many, so the reduction the
+    // run-grouped form runs on them never asks for a run workspace of its own)
+    w.rg_bytes = (nb_sort > (size_t)kMsdMaxBlocks && runs_enabled(cap)) ? runs_workspace_bytes(cap) : 0;
+    off += align_up(w.rg_bytes, 256);
     w.total = off;
     return w;
 }
@@ -971,6 +978,7 @@ size_t reduce_workspace_bytes(int64_t cap) {
     return carve(nullptr, cap).total;
 }
 
+
 // which streams launch_sort_reduce hands to the chained-scan passes (the test of its large-stream branch)
 static bool takes_large_stream_path(int64_t cap, int key_bits) {
     const uint32_t nb_sort = (uint32_t)((cap + kSortTile - 1) / kSortTile);
@@ -992,7 +1000,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                        uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
                        uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                        uint32_t* n_rows, void* ws, size_t ws_bytes, const uint32_t* first_map, uint64_t key_base,
-                       bool hist_ready, const SegSource* seg) {
+                       bool hist_ready, const SegSource* seg, uint32_t flags) {
     // key_bits counts the significant bits of key - key_base: every path below sorts that difference (the order is
     // the same) and puts key_base back when it writes a row's key
     BESST_REQUIRE(cap >= 0 && cap < ((int64_t)1 << 32), "reduce: capacity out of range");
@@ -1051,7 +1059,14 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         kin = w.keys[0];
         iin = w.idx[0];
     } else {
-        // large streams: one histogram read, chained-scan partition passes, atomic-free row reduction (onesweep.hip)
+        // large streams whose keys cluster (any coordinate-sorted library): chunks of the stream -> runs of equal keys,
+        // and only the runs are sorted (runs.hip); a stream that overflows the run buffers says so in *n_rows and the
+        // caller repeats the call with BESST_REDUCE_NO_RUNS
+        if (w.rg_bytes && !(flags & BESST_REDUCE_NO_RUNS))
+            return launch_runs_reduce(s, cap, n_tuples, key_bits, keys, payload, seg, seg ? seg->payload_out : w.keys[0],
+                                      onesweep_staged_rows(w.os_ws, cap), row_key, row_mask, row_n, row_sum, row_sum_sq,
+                                      row_first, row_offset, obs_lo, obs_hi, n_rows, w.rg_ws, w.rg_bytes, first_map, key_base);
+        // else: one histogram read, chained-scan partition passes, atomic-free row reduction (onesweep.hip)
         uint64_t* bk[2] = {w.keys[0], w.keys[1]};
         uint32_t* bi[2] = {w.idx[0], w.idx[1]};
         return launch_onesweep_sort_reduce(s, cap, n_tuples, key_bits, keys, payload, bk, bi, row_key, row_mask, row_n,

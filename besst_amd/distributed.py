@@ -238,10 +238,17 @@ class HipBackend(object):
 
     def reduce(self):
         g, p = self.gb, self.pipeline._p
-        self._call('dev_reduce', self.lib.besst_dev_reduce, lambda: (
-            self.recv_cap, C.c_void_p(self.flags.data_ptr()), g.key_bits, p(self.rkeys), p(self.rpayload),
-            p(g.row_key), p(g.row_mask), p(g.row_n), p(g.row_sum), p(g.row_sum_sq), p(g.row_first), p(g.row_offset),
-            p(g.obs_lo), p(g.obs_hi), g._n_rows, p(g.ws2), g.ws2.numel(), p(self.gidx), g.key_base))
+        args = self._args.get('dev_reduce')
+        if args is None:
+            args = self._args['dev_reduce'] = (
+                self.recv_cap, C.c_void_p(self.flags.data_ptr()), g.key_bits, p(self.rkeys), p(self.rpayload),
+                p(g.row_key), p(g.row_mask), p(g.row_n), p(g.row_sum), p(g.row_sum_sq), p(g.row_first), p(g.row_offset),
+                p(g.obs_lo), p(g.obs_hi), g._n_rows, p(g.ws2), g.ws2.numel(), p(self.gidx), g.key_base)
+
+        def again():        # (g.read_sizes() repeats the call with BESST_REDUCE_NO_RUNS when the run-grouped form overflows)
+            _lib.check(self.lib.besst_dev_reduce_flags(self._stream(), *args, g.sort_flags), 'dev_reduce')
+        g._redo = again
+        again()
 
     def pack_for_allreduce(self):
         return self._sum_buf

@@ -15,6 +15,10 @@ from . import _lib
 from ._lib import Counters, LibParams
 
 COUNTER_BYTES = C.sizeof(Counters)
+# include/besst_amd.h: what *n_rows carries when stage 2 could not build the table, and the flag that answers the second
+ROWS_SORT_FAILED = 0xFFFFFFFF
+ROWS_RUN_OVERFLOW = 0xFFFFFFFE
+REDUCE_NO_RUNS = 1
 
 
 def _p(t):
@@ -105,6 +109,11 @@ class DeviceGraphBuilder(object):
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
         self._presorted = False
         self.candidate_share = None
+        # BESST_REDUCE_* flags of this builder's stage-2 calls.  A large stream is first reduced in the run-grouped form;
+        # if its keys do not cluster (read_sizes() sees BESST_ROWS_RUN_OVERFLOW) the builder repeats the call with
+        # BESST_REDUCE_NO_RUNS and keeps that flag for the passes that follow.
+        self.sort_flags = 0
+        self._redo = None
 
     # device addresses inside the small block
     def _small(self, off):
@@ -206,20 +215,33 @@ class DeviceGraphBuilder(object):
                     _p(self.ws2), self.ws2.numel(), None, self.key_base)
             if self._presorted:
                 self._presorted = False
-                _lib.check(self.lib.besst_dev_reduce_presorted(C.c_void_p(stream), *args,
-                                                               C.byref(self._args['presort'][0])), 'dev_reduce')
+                spec = self._args['presort'][0]
+
+                def again():
+                    spec.flags = self.sort_flags
+                    st = torch.cuda.current_stream(self.device).cuda_stream
+                    _lib.check(self.lib.besst_dev_reduce_presorted(C.c_void_p(st), *args, C.byref(spec)), 'dev_reduce')
             else:
-                _lib.check(self.lib.besst_dev_reduce(C.c_void_p(stream), *args), 'dev_reduce')
+                def again():
+                    st = torch.cuda.current_stream(self.device).cuda_stream
+                    _lib.check(self.lib.besst_dev_reduce_flags(C.c_void_p(st), *args, self.sort_flags), 'dev_reduce')
+            self._redo = again
+            again()
             return
         self._presorted = False
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
         cap = self.tup_cap if capacity is None else int(capacity)
-        _lib.check(self.lib.besst_dev_reduce(
-            C.c_void_p(stream), cap, n_tuples_ptr or self._n_out, self.key_bits, _p(keys), _p(payload),
-            _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
-            _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
-            _p(self.ws2), self.ws2.numel(), _p(first_map), self.key_base), 'dev_reduce')
+        args = (cap, n_tuples_ptr or self._n_out, self.key_bits, _p(keys), _p(payload),
+                _p(self.row_key), _p(self.row_mask), _p(self.row_n), _p(self.row_sum), _p(self.row_sum_sq),
+                _p(self.row_first), _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), self._n_rows,
+                _p(self.ws2), self.ws2.numel(), _p(first_map), self.key_base)
+
+        def again():
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self.lib.besst_dev_reduce_flags(C.c_void_p(st), *args, self.sort_flags), 'dev_reduce')
+        self._redo = again
+        again()
 
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
         """Score rows of the table this builder holds (besst_dev_score_edges) -> (gap, sd0, ks_h, flags) numpy arrays.
@@ -257,9 +279,20 @@ class DeviceGraphBuilder(object):
         self.reduce()
 
     def read_sizes(self):
-        """(n_tuples, n_rows) - synchronises."""
-        raw = self.small.cpu().numpy()
-        n_out, n_rows = np.frombuffer(raw[COUNTER_BYTES + 8:COUNTER_BYTES + 16].tobytes(), dtype=np.uint32)
+        """(n_tuples, n_rows) - synchronises.  Where stage 2 reported a stream that does not fit its run-grouped form,
+        the call is repeated tuple by tuple (once; ``sort_flags`` remembers); a sort that gave up raises."""
+        for attempt in range(2):
+            raw = self.small.cpu().numpy()
+            n_out, n_rows = np.frombuffer(raw[COUNTER_BYTES + 8:COUNTER_BYTES + 16].tobytes(), dtype=np.uint32)
+            if int(n_rows) == ROWS_RUN_OVERFLOW and attempt == 0 and self._redo is not None \
+                    and not (self.sort_flags & REDUCE_NO_RUNS):
+                self.sort_flags |= REDUCE_NO_RUNS
+                self._redo()
+                continue
+            break
+        if int(n_rows) in (ROWS_SORT_FAILED, ROWS_RUN_OVERFLOW):
+            raise _lib.BesstDeviceError('stage 2 could not build the edge table (n_rows word 0x%08x): %s' % (
+                int(n_rows), 'a chained-scan look-back gave up' if int(n_rows) == ROWS_SORT_FAILED else 'run overflow'))
         return int(n_out), int(n_rows)
 
     def read_counters(self):

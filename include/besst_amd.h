@@ -43,6 +43,15 @@ extern "C" {
 #define BESST_ERR_STATE 3   /* call order violated (e.g. build before set_library) */
 #define BESST_ERR_NOMEM 4
 
+/* Stage 2 (besst_dev_reduce*) reports a table it could not build in the size word the caller reads anyway: *n_rows is
+ * one of these instead of a row count, and no other output of the call is valid.  (The besst_ctx_* layer turns the first
+ * into BESST_ERR_HIP and handles the second itself.) */
+#define BESST_ROWS_SORT_FAILED 0xFFFFFFFFu  /* a chained-scan look-back gave up waiting for its predecessor tile        */
+#define BESST_ROWS_RUN_OVERFLOW 0xFFFFFFFEu /* run-grouped form: more runs of equal keys than its buffers hold (a stream
+                                             * whose keys do not cluster); repeat the call with BESST_REDUCE_NO_RUNS   */
+/* flags of besst_dev_reduce_flags / besst_presort.flags */
+#define BESST_REDUCE_NO_RUNS 1u             /* large streams: sort the tuples (chained-scan passes), not runs of them   */
+
 /* contig classes (membership in Contigs / small_contigs, CreateGraph.py:127-130) */
 #define BESST_CLS_ABSENT 0
 #define BESST_CLS_LARGE 1
@@ -266,7 +275,8 @@ int besst_dev_candidate_density(void* stream, int64_t n, const int32_t* tid, con
 
 /* Stage 2: sort of the tuples by (key, position in the stream) - observably a stable sort by key - and segmented
  * reduction into edge rows (up to 4 M tuples: one MSD partition + per-bucket sort and reduction; beyond, up to 2^30:
- * chained-scan radix passes + atomic-free tile reduction).
+ * run-grouped - every 1024 consecutive tuples are grouped into runs of equal keys and the runs are sorted - or, with
+ * BESST_REDUCE_NO_RUNS, chained-scan radix passes over the tuples).  *n_rows may come back as BESST_ROWS_*.
  *   n_tuples  uint32 device: number of valid tuples in keys/payload (<= capacity)
  *   key_base  a lower bound of every key (0 is always valid).  Scaffold ids keep growing across passes
  *             (param.scaffold_indexer, MakeScaffolds.py:276), so from the second library on all keys share a long
@@ -279,6 +289,13 @@ int besst_dev_reduce(void* stream, int64_t capacity, const uint32_t* n_tuples, i
                      uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
                      uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
                      uint64_t key_base);
+/* the same with BESST_REDUCE_* flags (besst_dev_reduce passes 0) */
+int besst_dev_reduce_flags(void* stream, int64_t capacity, const uint32_t* n_tuples, int32_t key_bits,
+                           const uint64_t* keys, const uint64_t* payload, uint64_t* row_key,
+                           uint32_t* row_mask, uint32_t* row_n, int64_t* row_sum, int64_t* row_sum_sq,
+                           uint32_t* row_first, uint32_t* row_offset, int32_t* obs_lo, int32_t* obs_hi,
+                           uint32_t* n_rows, void* workspace, size_t workspace_bytes, const uint32_t* first_map,
+                           uint64_t key_base, uint32_t flags);
 
 /* Stage 1 + 2 on buffers that stay allocated (a resident builder): the large-stream form of stage 2 starts with a
  * histogram read of the whole key stream, which stage 1 can take on its way out (it has every key in registers when it
@@ -296,7 +313,7 @@ typedef struct besst_presort {
     int32_t shift;        /* digits of key - key_base at shift and shift + 8 */
     uint64_t key_base;
     uint32_t capacity;    /* tuples at or beyond it are not counted (stage 2 ignores them too) */
-    uint32_t reserved;
+    uint32_t flags;       /* in, read by besst_dev_reduce_presorted: BESST_REDUCE_* */
     /* The tuple stream itself can be handed over as the record loop leaves it - one segment per 16 384-record block,
      * ordered by the block offsets of the stitch - when stage 2's first stream pass can read it that way:
      * besst_dev_reduce_presort sets `segmented` to say so, besst_dev_classify_presort leaves it 1 (and fills the seg_*
@@ -312,6 +329,7 @@ typedef struct besst_presort {
     uint32_t seg_blocks;
     uint32_t seg_tile;
     uint64_t* payload_out;
+    const uint32_t* seg_chunk_first; /* per 1024 positions of the ordered stream: the block the first of them lies in */
 } besst_presort;
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
                              size_t workspace_bytes, besst_presort* h_out);

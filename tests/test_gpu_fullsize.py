@@ -106,14 +106,16 @@ def test_split_distribution_from_device_histogram():
                 (g['mean1'], g['stddev1'], g['mean2'], g['stddev2'])
 
 
-@pytest.mark.parametrize('seg_window', [None, '2'])
-def test_resident_builder_step_large_stream(seg_window, monkeypatch):
+@pytest.mark.parametrize('seg_window,sort_form', [(None, 'runs'), (None, 'tuples'), ('2', 'tuples')])
+def test_resident_builder_step_large_stream(seg_window, sort_form, monkeypatch):
     """DeviceGraphBuilder.step() - what bench.py times - on a mate-pair library large enough for the large-stream sort
     (6.4 M link tuples): the sort gets its digit histograms from stage 1 (besst_dev_classify_presort /
     besst_dev_reduce_presorted) - counted by compact_kernel after the two-pass record loop, by the fused record loop
     itself otherwise, and then the first chained-scan pass reads the tuples from the block segments (seg_window '2':
     with a two-block window, so that the tiles look their blocks up in memory) -, two chained-scan passes,
-    wave-per-bucket sort + reduction.  Twice on the same builder (the second pass starts from the first one's leftovers
+    wave-per-bucket sort + reduction ('tuples': BESST_REDUCE_NO_RUNS); 'runs' is the default form, chunks of the stream
+    grouped into runs of equal keys and only the runs sorted (csrc/runs.hip), reading the same segments or the compacted
+    stream.  Twice on the same builder (the second pass starts from the first one's leftovers
     in every workspace), against the C oracle."""
     import torch
     from besst_amd import pipeline
@@ -137,11 +139,13 @@ def test_resident_builder_step_large_stream(seg_window, monkeypatch):
     assert n_tuples > 4_500_000
     gb = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, int(n_tuples * 1.25) + 4096)
     gb.set_contigs(**wl['table'])
+    gb.sort_flags = pipeline.REDUCE_NO_RUNS if sort_form == 'tuples' else 0
     for _ in range(2):
         gb.step(rec)
     assert gb._args['presort'][1], 'the large-stream sort should take its histograms from stage 1'
     spec = gb._args['presort'][0]
     assert bool(spec.segmented) == bool(spec.in_record_loop) == (gb.params.record_path == 1)
     table = gb.fetch_table()
+    assert gb.sort_flags == (pipeline.REDUCE_NO_RUNS if sort_form == 'tuples' else 0)
     ctr = gb.read_counters()
     assert_table_equals_c_oracle(table, gb.aligned.cpu().numpy(), ctr, wl['batch'], wl)

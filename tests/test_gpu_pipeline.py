@@ -100,9 +100,7 @@ def test_sort_reduce_on_synthetic_tuples(n, key_bits, hub):
     torch.cuda.synchronize()
     want = CO.edge_rows(keys, payload)
     r = len(want['key'])
-    raw = gb.small.cpu().numpy()
-    n_rows = int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0])
-    assert n_rows == r
+    assert gb.read_sizes()[1] == r        # (random keys beyond 4 M tuples: the run-grouped form overflows, the call is repeated)
     get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
     assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
     assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
@@ -183,8 +181,7 @@ def test_sort_reduce_with_offset_scaffold_ids(n):
     torch.cuda.synchronize()
     want = CO.edge_rows(keys, payload)
     r = len(want['key'])
-    raw = gb.small.cpu().numpy()
-    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    assert gb.read_sizes()[1] == r
     get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
     assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
     assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
@@ -227,8 +224,7 @@ def test_large_capacity_with_few_tuples(n):
     torch.cuda.synchronize()
     want = CO.edge_rows(keys, payload)
     r = len(want['key'])
-    raw = gb.small.cpu().numpy()
-    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    assert gb.read_sizes()[1] == r
     get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
     assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
     assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
@@ -276,8 +272,7 @@ def test_bucket_form_over_the_key_widths(key_bits, links_per_edge):
     torch.cuda.synchronize()
     want = CO.edge_rows(keys, payload)
     r = len(want['key'])
-    raw = gb.small.cpu().numpy()
-    assert int(np.frombuffer(raw[pipeline.COUNTER_BYTES + 12:pipeline.COUNTER_BYTES + 16].tobytes(), np.uint32)[0]) == r
+    assert gb.read_sizes()[1] == r
     get = lambda t, m, dt: t[:m].cpu().numpy().view(dt)
     assert np.array_equal(get(gb.row_key, r, np.uint64), want['key'])
     assert np.array_equal(get(gb.row_n, r, np.uint32).astype(np.int64), want['n'])
