@@ -250,8 +250,14 @@ int besst_dev_pack_contigs(void* stream, int64_t n, const int32_t* scaf_id, cons
     BESST_REQUIRE(n == 0 || (scaf_id && scaf_len && ctg_pos && ctg_len && direction && cls && d_table),
                   "pack_contigs: null pointer");
     std::vector<ContigRow> rows((size_t)n);
+    // the class bytes follow the rows, and behind them one byte that says "every contig of the header is in the table"
+    // (true for a first library: the record loop then never has to look a class up to know that a record counts)
+    std::vector<uint8_t> cls_x((size_t)n + 1);
+    uint8_t all_present = 1;
     for (int64_t i = 0; i < n; ++i) {
         BESST_REQUIRE(cls[i] <= BESST_CLS_SMALL, "pack_contigs: class must be 0, 1 or 2");
+        cls_x[(size_t)i] = cls[i];
+        if (cls[i] == BESST_CLS_ABSENT) all_present = 0;
         if (cls[i] != BESST_CLS_ABSENT)
             BESST_REQUIRE(scaf_id[i] >= 1 && (uint32_t)scaf_id[i] <= kScafIdMask,
                           "pack_contigs: scaffold id must be in [1, 2^28)");
@@ -265,7 +271,8 @@ int besst_dev_pack_contigs(void* stream, int64_t n, const int32_t* scaf_id, cons
         BESST_HIP_TRY(hipMemcpyAsync(d_table, rows.data(), (size_t)n * sizeof(ContigRow), hipMemcpyHostToDevice,
                                      static_cast<hipStream_t>(stream)));
         // class bytes follow the rows (the streaming kernel needs only the class of a contig)
-        BESST_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_table) + (size_t)n * sizeof(ContigRow), cls, (size_t)n,
+        cls_x[(size_t)n] = all_present;
+        BESST_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_table) + (size_t)n * sizeof(ContigRow), cls_x.data(), (size_t)n + 1,
                                      hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
         BESST_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // rows is a local
     }

@@ -900,6 +900,312 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
     if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fused_wave_kernel: the same single pass with ONE WAVE per block and no workgroup barrier anywhere.
+// fused_kernel's four waves meet at ~65 barriers per block (three per sub-tile, two per evaluation round) and pass
+// the chain's state through LDS; whenever one wave waits for memory the other three wait with it.  Here a block of
+// 16 384 records belongs to a single-wave workgroup that walks it in 64 sub-tiles of 256 records: its candidates queue
+// up in the wave's own LDS ring and are evaluated 64 at a time, the duplicate chain / acceptance / ordered emission
+// are ballots and wave-uniform (scalar) state - prev_obs, emission base, head - and waves on a SIMD overlap freely.
+// Same loads (candidate-free lanes skip pos / mpos / flag), same coverage scheme, same block summary and segments as
+// fused_kernel, so everything behind the record loop is shared.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFwSub = 256;                              // records per sub-tile: four per lane
+constexpr int kFwRing = kFwSub + 64;                     // a sub-tile's worth of candidates + an unfinished round
+#ifndef BESST_FW_MIN_WAVES
+#define BESST_FW_MIN_WAVES 5
+#endif
+
+__device__ __forceinline__ int wave_sum_dpp(int v) {     // the sum in every lane?  no: wave-uniform, read from lane 63
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
+    ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
+    uint64_t* __restrict__ seg_payload, SummView summ) {
+    __shared__ uint32_t s_buf[5][kFwRing];                // tid, mtid, pos, mpos, flag | mapq << 16 of the queued candidates
+    __shared__ unsigned short s_qlen[kFwRing];
+    __shared__ uint32_t s_ph[256];                        // the sort's two digit histograms, 16 bits per counter (<= 16 384 tuples)
+    const int lane = threadIdx.x;
+    const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t thr_u32 = ins_thr_u32(a);
+    const bool all_present = a.cls8[a.n_contigs] != 0;    // (uniform: the byte behind the class bytes, besst_dev_pack_contigs)
+    if (a.ps_table) {                                     // uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_ph[q * 64 + lane] = 0;
+    }
+    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
+    int32_t run_tid = -1;                                 // the wave's running coverage (uniform)
+    int run_sum = 0;
+    int q_head = 0, q_count = 0;                          // the queue of candidates not yet evaluated (uniform)
+    // the chain's state (uniform): the last record of the block so far that reached CreateEdge, where the next tuple goes,
+    // and the block's first reaching record (the one stitch_kernel resolves against the blocks before)
+    int st_known = 0, st_p1 = 0, st_p2 = 0, st_emit = 0;
+    int hd_present = 0, hd_o1 = 0, hd_o2 = 0, hd_info = 0, hd_slot = (int)kNoSlot;
+    auto run_round = [&](const int cnt) {
+        const bool live = lane < cnt;
+        int32_t tid = -1, mtid = -1, pos = 0, mpos = 0;
+        uint32_t fm = 0, qlen = 0;
+        if (live) {
+            int j = q_head + lane;
+            j = j >= kFwRing ? j - kFwRing : j;
+            tid = (int32_t)s_buf[0][j]; mtid = (int32_t)s_buf[1][j];
+            pos = (int32_t)s_buf[2][j]; mpos = (int32_t)s_buf[3][j];
+            fm = s_buf[4][j];
+            qlen = s_qlen[j];
+        }
+        const bool in_range = live && (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs;
+        ContigRow c1, c2;
+        c1.w0 = c2.w0 = 0; c1.scaf_len = c2.scaf_len = 0; c1.ctg_pos = c2.ctg_pos = 0; c1.ctg_len = c2.ctg_len = 0;
+        if (in_range) {
+            c1 = a.table[tid];
+            c2 = a.table[mtid];
+        }
+        const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
+        // (see fused_kernel: the coverage credited with the streamed records is taken back when a contig is not in the table)
+        if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
+            atomicAdd(&aligned[tid], 0ull - (unsigned long long)qlen);
+        const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
+        const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
+        const bool dbl = (e.bits & EV_DOUBLE) != 0;
+        c_nonuniq += (live && (e.bits & EV_NONUNIQ)) ? 1 : 0;
+        c_fishy += fishy ? 1 : 0;
+        c_reach += reach ? 1 : 0;
+        const int32_t o1 = e.o1, o2 = e.o2;
+        const unsigned long long has_mask = __ballot(reach);
+        const unsigned long long below = has_mask & lt_mask;
+        // "previous record that reached CreateEdge" [:835-838, 869-870]: the nearest reaching lane below, else the state
+        bool pk = below != 0ull;
+        int32_t p1, p2;
+        {
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            p1 = __shfl(o1, src, 64);
+            p2 = __shfl(o2, src, 64);
+        }
+        if (reach && !pk) { pk = st_known != 0; p1 = st_p1; p2 = st_p2; }
+        const bool accept = reach && o1 > 25 && o2 > 25 && ((uint32_t)o1 + (uint32_t)o2 < thr_u32);
+        bool emit = fishy, is_head = false;
+        if (reach) {
+            if (!pk) {
+                is_head = true;                              // first reaching record of the block: stitch_kernel's
+                emit = accept;
+            } else {
+                const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
+                c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                emit = d.keep;
+            }
+        }
+        const unsigned long long emit_mask = __ballot(emit);
+        const int slot = st_emit + __popcll(emit_mask & lt_mask);
+        if (emit) {
+            const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
+            const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+            const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
+            const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+            const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+            const uint64_t key = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+            seg_keys[block_base + slot] = key;
+            seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+            if (a.ps_table) {                                // uniform
+                const uint64_t k = key - a.ps_base;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t d = (uint32_t)(k >> (a.ps_shift + 8 * q)) & 255u;
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                    const unsigned long long m = __ballot(d == f);
+                    uint32_t add = 0, at = d;
+                    if (d != f) add = 1u;
+                    else if ((m & lt_mask) == 0ull) { add = (uint32_t)__popcll(m); at = f; }
+                    if (add) atomicAdd(&s_ph[128 * q + (at >> 1)], add << (16 * (at & 1u)));
+                }
+            }
+        }
+        const unsigned long long head_mask = __ballot(is_head);
+        if (head_mask) {                                     // uniform; at most once per block
+            const int hl = __ffsll((long long)head_mask) - 1;
+            hd_present = 1;
+            hd_o1 = __builtin_amdgcn_readlane(o1, hl);
+            hd_o2 = __builtin_amdgcn_readlane(o2, hl);
+            const int info = (int)((accept ? 9u : 0u) | (dbl ? 2u : 0u) | (mapq0 ? 4u : 0u));
+            hd_info = __builtin_amdgcn_readlane(info, hl);
+            hd_slot = __builtin_amdgcn_readlane(accept ? slot : (int)kNoSlot, hl);
+        }
+        if (has_mask) {                                      // uniform
+            const int last = 63 - __clzll((long long)has_mask);
+            st_known = 1;
+            st_p1 = __builtin_amdgcn_readlane(o1, last);
+            st_p2 = __builtin_amdgcn_readlane(o2, last);
+        }
+        st_emit += __popcll(emit_mask);
+        q_head += cnt;
+        q_head = q_head >= kFwRing ? q_head - kFwRing : q_head;
+        q_count -= cnt;
+    };
+    for (int st = 0; st < kClsTile / kFwSub; ++st) {
+        const int64_t sub_base = block_base + (int64_t)st * kFwSub;
+        if (sub_base >= a.n) break;                         // uniform
+        const int64_t i0 = sub_base + (int64_t)lane * 4;
+        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
+        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
+        if (sub_base + kFwSub <= a.n) {
+            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
+            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
+            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
+            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
+            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
+            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
+            // (see fused_kernel: pos, mpos and flag only where the lane holds a candidate)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r_pos[k] = 0; r_mpos[k] = 0; r_flag[k] = 0; }
+            if (v_tid.x != v_mtid.x || v_tid.y != v_mtid.y || v_tid.z != v_mtid.z || v_tid.w != v_mtid.w) {
+                const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
+                const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
+                const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
+                r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
+                r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
+                r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                r_tid[k] = in ? a.tid[i] : -1;
+                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
+                r_pos[k] = in ? a.pos[i] : 0;
+                r_mpos[k] = in ? a.mpos[i] : 0;
+                r_flag[k] = in ? a.flag[i] : 0;
+                r_mapq[k] = in ? a.mapq[i] : 0;
+                r_qlen[k] = in ? a.qlen[i] : 0;
+            }
+        }
+        // ---- coverage [:138-139], candidates included on the cheap part of their condition (see fused_kernel)
+        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
+        bool uni = true;
+        int mine = 0;
+        bool cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cand[k] = r_tid[k] != r_mtid[k];
+            uni = uni && (r_tid[k] == ref);
+            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+            if (cov && (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs)) mine += (int)r_qlen[k];
+        }
+        if (__all(uni)) {
+            const int s = wave_sum_dpp(mine);
+            if (ref != run_tid) {
+                if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
+                    atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+                run_tid = ref;
+                run_sum = 0;
+            }
+            run_sum += s;
+        } else {
+            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
+            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);
+            int val = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
+                const bool act = cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs &&
+                                 (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs);
+                if (!act) continue;
+                if (lane_uni) val += (int)r_qlen[k];
+                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
+            }
+            if (lane_uni) key = r_tid[0];
+            wave_add_runs(aligned, key, val, lane);
+        }
+        // ---- Only a candidate that can become a link [:169: read 2, mapped, mapq >= min_mapq] or a BWA-quirk read
+        // [:141: unmapped read 1] has to be evaluated.  The others - every read 1 with its mate elsewhere: half of the
+        // candidates - can only count as non-unique [:166-167] and, when one of the two contigs is not in the table
+        // [:127-130], lose the coverage they were credited with above; both need the contigs' classes only, and when
+        // every contig of the header is in the table (all_present) not even those.  They never enter the ring: the
+        // evaluation rounds halve.  (With four waves per block and a barrier behind the queue this filter put the flag
+        // loads on every wave's critical path and lost; a wave on its own waits for them here either way.)
+        bool full[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t fl = r_flag[k];
+            const bool link = (fl & kFlagRead2) && !(fl & kFlagUnmapped) && (int32_t)r_mapq[k] >= a.min_mapq;
+            const bool quirk = (fl & kFlagUnmapped) && (fl & kFlagRead1);
+            full[k] = cand[k] && (link || quirk);
+            if (cand[k] && !full[k] && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs) {
+                bool present = true;
+                if (!all_present) present = a.cls8[r_tid[k]] != BESST_CLS_ABSENT && a.cls8[r_mtid[k]] != BESST_CLS_ABSENT;
+                if (present) c_nonuniq += r_mapq[k] == 0 ? 1 : 0;
+                else if ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0)
+                    atomicAdd(&aligned[r_tid[k]], 0ull - (unsigned long long)r_qlen[k]);
+            }
+        }
+        // ---- candidates -> the wave's ring, in record order (record = 4 * lane + k)
+        const unsigned long long b0 = __ballot(full[0]), b1 = __ballot(full[1]);
+        const unsigned long long b2 = __ballot(full[2]), b3 = __ballot(full[3]);
+        const int total = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+        if (total == 0) continue;                            // uniform
+        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
+        slot += q_head + q_count;                            // behind the queued ones (at most 63 + 256 entries in all)
+        slot = slot >= kFwRing ? slot - kFwRing : slot;
+        slot = slot >= kFwRing ? slot - kFwRing : slot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (full[k]) {
+                s_buf[0][slot] = (uint32_t)r_tid[k];
+                s_buf[1][slot] = (uint32_t)r_mtid[k];
+                s_buf[2][slot] = (uint32_t)r_pos[k];
+                s_buf[3][slot] = (uint32_t)r_mpos[k];
+                s_buf[4][slot] = (r_flag[k] & 0xffffu) | (r_mapq[k] << 16);
+                s_qlen[slot] = (unsigned short)r_qlen[k];
+                ++slot;
+                slot = slot == kFwRing ? 0 : slot;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS operations complete in order)
+        q_count += total;
+        while (q_count >= 64) run_round(64);
+    }
+    if (q_count > 0) run_round(q_count);                    // the unfinished round (uniform)
+    if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
+        atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
+    // ---- block summary (same planes as fused_kernel / ordered_kernel)
+    const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
+    int tot[7];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) tot[f] = wave_sum_dpp(vals[f]);
+    if (a.ps_table) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t* row = a.ps_table + (size_t)(blockIdx.x & (uint32_t)(a.ps_rows - 1)) * 512u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int d = q * 64 + lane;
+            const uint32_t c = (s_ph[d >> 1] >> (16 * (d & 1))) & 0xffffu;
+            if (c) atomicAdd(&row[d], c);
+        }
+    }
+    uint32_t v = 0;
+    if (lane == kSumEmit) v = (uint32_t)st_emit;
+    if (lane == kSumHas) v = st_known ? 1u : 0u;
+    if (lane == kSumFirst1) v = hd_present ? (uint32_t)hd_o1 : 0u;
+    if (lane == kSumFirst2) v = hd_present ? (uint32_t)hd_o2 : 0u;
+    if (lane == kSumLast1) v = (uint32_t)st_p1;
+    if (lane == kSumLast2) v = (uint32_t)st_p2;
+    if (lane == kSumHeadInfo) v = hd_present ? (uint32_t)hd_info : 0u;
+    if (lane == kSumHeadSlot) v = hd_present ? (uint32_t)hd_slot : kNoSlot;
+#pragma unroll
+    for (int f = 0; f < 7; ++f)
+        if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
+    if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
+}
+
 // ---- stitch: resolve block heads, fix counters, scan tuple counts ------------------------------------
 // One workgroup per SPAN of 4096 blocks: one lane per block and round, kStitchRounds rounds.  The summaries of all
 // rounds are fetched up front (one memory round trip); both scans - "nearest earlier block that reached CreateEdge"
@@ -1474,6 +1780,12 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     // latency bound at 3 waves per SIMD.  The split design below serves every library.)
     if (a.record_path == 1) {
         ProfScope ps(s, kProfClassify);
+        // BESST_FUSED_FORM (experiments): 0 = four waves per block with workgroup barriers, 1 = one wave per block
+        static const int form = [] { const char* e = getenv("BESST_FUSED_FORM"); return e ? atoi(e) : 1; }();
+        if (form == 1)
+            hipLaunchKernelGGL(fused_wave_kernel, dim3(nblocks), dim3(64), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
+        else
         hipLaunchKernelGGL(fused_kernel, dim3(nblocks), dim3(kFusedThreads), 0, s, a,
                            reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
         BESST_HIP_TRY(hipGetLastError());

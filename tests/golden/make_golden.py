@@ -3,7 +3,14 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                # replay: the committed inputs through the reference again
+    python tests/golden/make_golden.py --resimulate   # draw NEW input streams from besst_amd.synth (changes the fixtures)
+
+The default mode reads every committed scenario's inputs - the record stream (stream_*.npz), header, parameter overrides,
+FASTA names, object layout, all stored in the scenario's JSON - runs the reference on them and writes the JSON again:
+with an unchanged reference and harness `git diff tests/golden` stays empty, whatever has happened to the synthetic
+generator since the streams were drawn (tests/test_golden_replay.py asserts exactly that).  --resimulate is how the
+streams were made in the first place; it re-pins every oracle to new data and is only for adding scenarios.
 
 The reference modules are imported in place through tests/refharness (no reference source is
 copied).  Each scenario stores its INPUTS (record columns, header, parameters, initial object
@@ -47,25 +54,51 @@ def jsonable(o):
     return o
 
 
+def run_reference(mods, name, stream, batch, overrides, fasta_names=None, layout=None, layout_threshold=None):
+    """One scenario through the reference's get_metrics + PE -> the document that is stored (as jsonable objects)."""
+    import builtins
+    cg = mods['CreateGraph']
+    patched = name == 'fr_lognormal'          # see lognormal_scenario: Python 2's integer `range` arguments (:490)
+    if patched:
+        cg.range = lambda *a: builtins.range(*[int(v) for v in a])
+    try:
+        param = driver.make_param(mods, **overrides)
+        metrics = driver.run_get_metrics(mods, batch, param)
+        state = None
+        if layout is not None:
+            thr = layout_threshold if layout_threshold is not None else param.contig_threshold
+            state = driver.build_state(mods, layout, batch.references, batch.lengths, thr)
+            param.scaffold_indexer = int(layout['next_scaffold_id'])
+            param.tot_assembly_length = int(sum(batch.lengths))
+        fasta = list(batch.references) if fasta_names is None else list(fasta_names)
+        snap, final, _ = driver.run_pe(mods, batch, param, fasta, state)
+    finally:
+        if patched:
+            del cg.range
+    return jsonable(dict(name=name, stream=stream, references=list(batch.references), lengths=list(batch.lengths),
+                         fasta_names=fasta, overrides=overrides, metrics=metrics, after_loop=snap, final=final,
+                         layout=None if layout is None else {k: np.asarray(v).tolist() for k, v in layout.items()},
+                         layout_threshold=layout_threshold))
+
+
+def replay(mods, name):
+    """The committed scenario `name` - its stored inputs - through the reference again -> (stored doc, fresh doc)."""
+    from tests import golden_util as GU
+    doc, batch = GU.load(name)
+    fresh = run_reference(mods, doc['name'], doc['stream'], batch, doc['overrides'], doc['fasta_names'], doc['layout'],
+                          doc['layout_threshold'])
+    return doc, json.loads(json.dumps(fresh))            # (what a reader of the file would get: tuples as lists, ...)
+
+
+def write_doc(doc):
+    with open(os.path.join(HERE, doc['name'] + '.json'), 'w') as fh:
+        json.dump(doc, fh)
+    snap, final = doc['after_loop'], doc['final']
+    print('%-26s G=%d Gp=%d counters=%s' % (doc['name'], len(final['G']), len(final['G_prime']), snap and snap['counter']))
+
+
 def scenario(mods, name, stream, batch, overrides, fasta_names=None, layout=None, layout_threshold=None):
-    param = driver.make_param(mods, **overrides)
-    metrics = driver.run_get_metrics(mods, batch, param)
-    state = None
-    if layout is not None:
-        thr = layout_threshold if layout_threshold is not None else param.contig_threshold
-        state = driver.build_state(mods, layout, batch.references, batch.lengths, thr)
-        param.scaffold_indexer = int(layout['next_scaffold_id'])
-        param.tot_assembly_length = int(sum(batch.lengths))
-    fasta = list(batch.references) if fasta_names is None else list(fasta_names)
-    snap, final, _ = driver.run_pe(mods, batch, param, fasta, state)
-    doc = dict(name=name, stream=stream, references=list(batch.references), lengths=list(batch.lengths),
-               fasta_names=fasta, overrides=overrides, metrics=metrics, after_loop=snap, final=final,
-               layout=None if layout is None else {k: np.asarray(v).tolist() for k, v in layout.items()},
-               layout_threshold=layout_threshold)
-    with open(os.path.join(HERE, name + '.json'), 'w') as fh:
-        json.dump(jsonable(doc), fh)
-    print('%-14s records=%d G=%d Gp=%d counters=%s' % (
-        name, len(batch), len(final['G']), len(final['G_prime']), snap and snap['counter']))
+    write_doc(run_reference(mods, name, stream, batch, overrides, fasta_names, layout, layout_threshold))
 
 
 def edgecase_stream(asm, spec, seed):
@@ -110,21 +143,20 @@ def lognormal_scenario(mods):
     TypeError on Python 3 (:490) - so the reference module gets ONE patch for this scenario: a `range` that truncates
     its arguments to int, i.e. Python 2's integer division.  lnpe.GapEstimator is the shim's restatement
     (tests/refharness/stubs/mathstats/log_normal_param_est.py): like the normal gap it pins plumbing only."""
-    import builtins
-    cg = mods['CreateGraph']
-    cg.range = lambda *a: builtins.range(*[int(v) for v in a])
-    try:
-        asm = synth.make_assembly(300, 6000, 501)
-        ln = synth.simulate_library(asm, synth.LibrarySpec('fr', 1500.0, 150.0, lognormal_sigma=0.35), 30000, 502)
-        save_batch('stream_ln', ln)
-        scenario(mods, 'fr_lognormal', 'stream_ln', ln, {})
-    finally:
-        del cg.range
+    asm = synth.make_assembly(300, 6000, 501)
+    ln = synth.simulate_library(asm, synth.LibrarySpec('fr', 1500.0, 150.0, lognormal_sigma=0.35), 30000, 502)
+    save_batch('stream_ln', ln)
+    scenario(mods, 'fr_lognormal', 'stream_ln', ln, {})          # (run_reference applies the `range` patch by name)
 
 
 def main():
     mods = loader.load()
-    if len(sys.argv) > 1 and sys.argv[1] == 'lognormal':     # only the scenario added in round 2
+    if '--resimulate' not in sys.argv[1:]:
+        from tests import golden_util as GU
+        for name in GU.scenario_names():
+            write_doc(replay(mods, name)[1])
+        return None
+    if 'lognormal' in sys.argv[1:]:                          # only the scenario added in round 2
         return lognormal_scenario(mods)
 
     # ---- PE library, short contigs: many contig-spanning pairs --------------------------------
