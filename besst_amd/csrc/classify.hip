@@ -912,8 +912,10 @@ __global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_ke
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFwSub = 256;                              // records per sub-tile: four per lane
 constexpr int kFwRing = kFwSub + 64;                     // a sub-tile's worth of candidates + an unfinished round
+// (the loop below keeps two sub-tiles of column loads and one round of contig rows in flight: 123 VGPRs.  Forced
+// into the 96 of five waves per SIMD it spills and is 3 % slower than at four.)
 #ifndef BESST_FW_MIN_WAVES
-#define BESST_FW_MIN_WAVES 5
+#define BESST_FW_MIN_WAVES 4
 #endif
 
 __device__ __forceinline__ int wave_sum_dpp(int v) {     // the sum in every lane?  no: wave-uniform, read from lane 63
@@ -949,26 +951,45 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     // and the block's first reaching record (the one stitch_kernel resolves against the blocks before)
     int st_known = 0, st_p1 = 0, st_p2 = 0, st_emit = 0;
     int hd_present = 0, hd_o1 = 0, hd_o2 = 0, hd_info = 0, hd_slot = (int)kNoSlot;
-    auto run_round = [&](const int cnt) {
-        const bool live = lane < cnt;
-        int32_t tid = -1, mtid = -1, pos = 0, mpos = 0;
-        uint32_t fm = 0, qlen = 0;
-        if (live) {
+    // An evaluation round in two halves: round_fetch takes up to 64 candidates off the queue into registers and issues
+    // the gathers of their two contig rows; round_finish does the rest once the rows are there.  In the pipelined loop
+    // below the gathers of a round travel with the column loads of the sub-tiles ahead and are waited for together
+    // (vmcnt counts in order: a wait for a gather issued behind a prefetch would wait for the prefetch as well).
+    struct Round {
+        int cnt;
+        int32_t tid, mtid, pos, mpos;
+        uint32_t fm, qlen;
+        ContigRow c1, c2;
+    };
+    auto round_fetch = [&](const int cnt) {
+        Round r;
+        r.cnt = cnt;
+        r.tid = -1; r.mtid = -1; r.pos = 0; r.mpos = 0; r.fm = 0; r.qlen = 0;
+        if (lane < cnt) {
             int j = q_head + lane;
             j = j >= kFwRing ? j - kFwRing : j;
-            tid = (int32_t)s_buf[0][j]; mtid = (int32_t)s_buf[1][j];
-            pos = (int32_t)s_buf[2][j]; mpos = (int32_t)s_buf[3][j];
-            fm = s_buf[4][j];
-            qlen = s_qlen[j];
+            r.tid = (int32_t)s_buf[0][j]; r.mtid = (int32_t)s_buf[1][j];
+            r.pos = (int32_t)s_buf[2][j]; r.mpos = (int32_t)s_buf[3][j];
+            r.fm = s_buf[4][j];
+            r.qlen = s_qlen[j];
         }
+        // (every lane gathers - row 0 where it has nothing to look up -, so the number of loads in flight does not
+        // depend on the data)
+        const bool in_range = lane < cnt && (uint32_t)r.tid < (uint32_t)a.n_contigs && (uint32_t)r.mtid < (uint32_t)a.n_contigs;
+        r.c1 = a.table[in_range ? r.tid : 0];
+        r.c2 = a.table[in_range ? r.mtid : 0];
+        q_head += cnt;
+        q_head = q_head >= kFwRing ? q_head - kFwRing : q_head;
+        q_count -= cnt;
+        return r;
+    };
+    auto round_finish = [&](const Round& r) {
+        const int cnt = r.cnt;
+        const bool live = lane < cnt;
+        const int32_t tid = r.tid, mtid = r.mtid, pos = r.pos, mpos = r.mpos;
+        const uint32_t fm = r.fm, qlen = r.qlen;
         const bool in_range = live && (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs;
-        ContigRow c1, c2;
-        c1.w0 = c2.w0 = 0; c1.scaf_len = c2.scaf_len = 0; c1.ctg_pos = c2.ctg_pos = 0; c1.ctg_len = c2.ctg_len = 0;
-        if (in_range) {
-            c1 = a.table[tid];
-            c2 = a.table[mtid];
-        }
-        const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
+        const Eval e = eval_record(a, in_range, r.c1, r.c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
         // (see fused_kernel: the coverage credited with the streamed records is taken back when a contig is not in the table)
         if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
             atomicAdd(&aligned[tid], 0ull - (unsigned long long)qlen);
@@ -1044,50 +1065,15 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             st_p2 = __builtin_amdgcn_readlane(o2, last);
         }
         st_emit += __popcll(emit_mask);
-        q_head += cnt;
-        q_head = q_head >= kFwRing ? q_head - kFwRing : q_head;
-        q_count -= cnt;
     };
-    for (int st = 0; st < kClsTile / kFwSub; ++st) {
-        const int64_t sub_base = block_base + (int64_t)st * kFwSub;
-        if (sub_base >= a.n) break;                         // uniform
-        const int64_t i0 = sub_base + (int64_t)lane * 4;
-        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
-        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
-        if (sub_base + kFwSub <= a.n) {
-            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
-            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
-            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
-            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
-            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
-            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
-            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
-            // (see fused_kernel: pos, mpos and flag only where the lane holds a candidate)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r_pos[k] = 0; r_mpos[k] = 0; r_flag[k] = 0; }
-            if (v_tid.x != v_mtid.x || v_tid.y != v_mtid.y || v_tid.z != v_mtid.z || v_tid.w != v_mtid.w) {
-                const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
-                const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
-                const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
-                r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
-                r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
-                r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t i = i0 + k;
-                const bool in = i < a.n;
-                r_tid[k] = in ? a.tid[i] : -1;
-                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
-                r_pos[k] = in ? a.pos[i] : 0;
-                r_mpos[k] = in ? a.mpos[i] : 0;
-                r_flag[k] = in ? a.flag[i] : 0;
-                r_mapq[k] = in ? a.mapq[i] : 0;
-                r_qlen[k] = in ? a.qlen[i] : 0;
-            }
-        }
+    auto run_round = [&](const int cnt) {
+        const Round r = round_fetch(cnt);
+        round_finish(r);
+    };
+    // ---- one sub-tile of 256 records, its seven columns in registers
+    auto process = [&](const int32_t (&r_tid)[4], const int32_t (&r_mtid)[4], const int32_t (&r_pos)[4],
+                       const int32_t (&r_mpos)[4], const uint32_t (&r_flag)[4], const uint32_t (&r_mapq)[4],
+                       const uint32_t (&r_qlen)[4]) {
         // ---- coverage [:138-139], candidates included on the cheap part of their condition (see fused_kernel)
         const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
         bool uni = true;
@@ -1151,7 +1137,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         const unsigned long long b0 = __ballot(full[0]), b1 = __ballot(full[1]);
         const unsigned long long b2 = __ballot(full[2]), b3 = __ballot(full[3]);
         const int total = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        if (total == 0) continue;                            // uniform
+        if (total == 0) return;                              // uniform
         int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
         slot += q_head + q_count;                            // behind the queued ones (at most 63 + 256 entries in all)
         slot = slot >= kFwRing ? slot - kFwRing : slot;
@@ -1171,7 +1157,91 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         }
         __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS operations complete in order)
         q_count += total;
-        while (q_count >= 64) run_round(64);
+    };
+    if (block_base + kClsTile <= a.n) {
+        // A block that lies inside the stream (all but the last): ONE wait per sub-tile.  By the counters a wave of the
+        // unpipelined loop sat in s_waitcnt for 72 % of its life - tid / mtid first, then pos / mpos / flag where they
+        // are needed, then the contig rows of every evaluation round, each a memory latency with nothing of the wave's
+        // own to do meanwhile - while the SIMDs issued vector instructions half of the time.  Here everything the next
+        // iteration needs is issued together at the top of this one, in front of the sub-tile's arithmetic: pos / mpos /
+        // flag of sub-tile st + 1 (tid / mtid of st + 1 arrived an iteration ago), tid / mtid / mapq / qlen of st + 2,
+        // and the contig rows of the next 64 queued candidates, whose round is finished at the top of the next
+        // iteration.  (Issued at the END of an iteration the same loads are needed at once: 1.53 -> 1.71 ms.)  The candidate columns are
+        // loaded by every lane - a lane without a candidate reads the sub-tile's first sector again - so that the
+        // number of outstanding loads is the same on every path and the waits the compiler places are exact.
+        struct ColsA { int4 tid, mtid; uchar4 mapq; ushort4 qlen; };
+        struct ColsC { int4 pos, mpos; ushort4 flag; };
+        auto load_a = [&](int st) {
+            const int64_t i0 = block_base + (int64_t)st * kFwSub + (int64_t)lane * 4;
+            ColsA v;
+            v.tid = *reinterpret_cast<const int4*>(a.tid + i0);
+            v.mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
+            v.mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
+            v.qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            return v;
+        };
+        auto load_c = [&](int st, const ColsA& v) {
+            const bool need = v.tid.x != v.mtid.x || v.tid.y != v.mtid.y || v.tid.z != v.mtid.z || v.tid.w != v.mtid.w;
+            const int64_t i0 = block_base + (int64_t)st * kFwSub + (need ? (int64_t)lane * 4 : 0);
+            ColsC c;
+            c.pos = *reinterpret_cast<const int4*>(a.pos + i0);
+            c.mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
+            c.flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
+            return c;
+        };
+        constexpr int kSubs = kClsTile / kFwSub;
+        ColsA a0 = load_a(0), a1 = load_a(1);
+        ColsC c0 = load_c(0, a0);
+        Round pend;                                          // the round whose rows are in flight (cnt == 0: none)
+        pend.cnt = 0; pend.tid = pend.mtid = -1; pend.pos = pend.mpos = 0; pend.fm = pend.qlen = 0;
+        pend.c1 = a.table[0]; pend.c2 = pend.c1;
+        for (int st = 0; st < kSubs; ++st) {
+            // everything issued at the top of the iteration before - it had that iteration's arithmetic to arrive - is
+            // waited for here, once
+            if (pend.cnt) round_finish(pend);                // uniform
+            while (q_count >= 128) run_round(64);            // a burst of candidates: rounds with a wait of their own
+            // ---- the loads of the iterations to come, issued together
+            const int st1 = st + 1 < kSubs ? st + 1 : kSubs - 1, st2 = st + 2 < kSubs ? st + 2 : kSubs - 1;
+            const ColsC c1 = load_c(st1, a1);
+            const ColsA a2 = load_a(st2);
+            pend = round_fetch(q_count >= 64 ? 64 : 0);      // (fewer than 64 are left queued: the ring holds the 256 to come)
+            {
+                const int32_t r_tid[4] = {a0.tid.x, a0.tid.y, a0.tid.z, a0.tid.w};
+                const int32_t r_mtid[4] = {a0.mtid.x, a0.mtid.y, a0.mtid.z, a0.mtid.w};
+                const int32_t r_pos[4] = {c0.pos.x, c0.pos.y, c0.pos.z, c0.pos.w};
+                const int32_t r_mpos[4] = {c0.mpos.x, c0.mpos.y, c0.mpos.z, c0.mpos.w};
+                const uint32_t r_flag[4] = {c0.flag.x, c0.flag.y, c0.flag.z, c0.flag.w};
+                const uint32_t r_mapq[4] = {a0.mapq.x, a0.mapq.y, a0.mapq.z, a0.mapq.w};
+                const uint32_t r_qlen[4] = {a0.qlen.x, a0.qlen.y, a0.qlen.z, a0.qlen.w};
+                process(r_tid, r_mtid, r_pos, r_mpos, r_flag, r_mapq, r_qlen);
+            }
+            a0 = a1; a1 = a2; c0 = c1;
+        }
+        if (pend.cnt) round_finish(pend);
+        while (q_count >= 64) run_round(64);                 // what the last sub-tiles queued
+    } else {
+        // the stream's last block: element-wise loads behind the end check
+        for (int st = 0; st < kClsTile / kFwSub; ++st) {
+            const int64_t sub_base = block_base + (int64_t)st * kFwSub;
+            if (sub_base >= a.n) break;                     // uniform
+            const int64_t i0 = sub_base + (int64_t)lane * 4;
+            int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
+            uint32_t r_flag[4], r_mapq[4], r_qlen[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                const bool in = i < a.n;
+                r_tid[k] = in ? a.tid[i] : -1;
+                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
+                r_pos[k] = in ? a.pos[i] : 0;
+                r_mpos[k] = in ? a.mpos[i] : 0;
+                r_flag[k] = in ? a.flag[i] : 0;
+                r_mapq[k] = in ? a.mapq[i] : 0;
+                r_qlen[k] = in ? a.qlen[i] : 0;
+            }
+            process(r_tid, r_mtid, r_pos, r_mpos, r_flag, r_mapq, r_qlen);
+            while (q_count >= 64) run_round(64);
+        }
     }
     if (q_count > 0) run_round(q_count);                    // the unfinished round (uniform)
     if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
