@@ -17,10 +17,11 @@ Split of work:
 """
 from __future__ import print_function
 
+import gc
 import math
 import os
 import sys
-from collections import Counter
+from itertools import repeat
 from time import time
 
 import numpy as np
@@ -34,6 +35,20 @@ from .nxcompat import Graph
 
 
 def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file):
+    """CreateGraph.PE (CreateGraph.py:45).  The cyclic garbage collector is paused for the duration of the call: the
+    objects and graphs built here are hundreds of thousands of small containers that reference nothing but numbers and
+    each other, and every allocation burst makes the collector re-walk the growing heap (building the two graphs of a
+    100 k-contig assembly: 1.8 s with it, 0.4 s without)."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file)
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file):
     G = Graph()
     G_prime = Graph()
     print('Parsing BAM file...', file=Information)
@@ -54,16 +69,19 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
             open(param.output_directory + '/repeats.fa', 'w').close()
         return (G, G_prime)
 
+    # The scaffold ends every graph starts with (InitializeGraph, CreateGraph.py:710-722) are noted as columns; the
+    # graphs themselves are built ONCE, at the end, from what the filters below leave (GraphPlan.build).
     tot_start = time()
+    plan_G, plan_Gp = GraphPlan(), GraphPlan()
     if param.no_score:
-        InitializeGraph(small_scaffolds, G_prime, Information)
-        InitializeGraph(Scaffolds, G_prime, Information)
+        InitializeGraph(small_scaffolds, plan_Gp, Information)
+        InitializeGraph(Scaffolds, plan_Gp, Information)
     elif param.extend_paths:
-        InitializeGraph(Scaffolds, G, Information)
-        InitializeGraph(small_scaffolds, G_prime, Information)
-        InitializeGraph(Scaffolds, G_prime, Information)
+        InitializeGraph(Scaffolds, plan_G, Information)
+        InitializeGraph(small_scaffolds, plan_Gp, Information)
+        InitializeGraph(Scaffolds, plan_Gp, Information)
     else:
-        InitializeGraph(Scaffolds, G, Information)
+        InitializeGraph(Scaffolds, plan_G, Information)
     print('Total time elapsed for initializing Graph: ', time() - tot_start, file=Information)
 
     # ---- record loop on the device ------------------------------------------------------------------------
@@ -77,7 +95,9 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
     table, aligned, ctr = ctx.build_graph()
     counter = counters(ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates,
                        ctr.prev_obs1, ctr.prev_obs2, ctr.reads_with_too_long_insert)
-    fishy_rows = add_link_edges(table, G, G_prime)
+    links = LinkTable(table)
+    plan_G.take(links, MASK_G)
+    plan_Gp.take(links, MASK_GPRIME)
 
     print('ELAPSED reading file:', time() - staart, file=Information)
     print('NR OF FISHY READ LINKS: ', ctr.fishy_reads, file=Information)
@@ -86,9 +106,9 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
           '(filtered out from scaffolding): ', counter.non_unique, file=Information)
     print('Reads with too large insert size from "USEFUL READS" (filtered out): ',
           counter.reads_with_too_long_insert, file=Information)
-    print('Initial number of edges in G (the graph with large contigs): ', G.number_of_edges(), file=Information)
+    print('Initial number of edges in G (the graph with large contigs): ', plan_G.number_of_edges(), file=Information)
     print('Initial number of edges in G_prime (the full graph of all contigs before removal of repats): ',
-          G_prime.number_of_edges(), file=Information)
+          plan_Gp.number_of_edges(), file=Information)
     if param.detect_duplicate:
         print('Number of duplicated reads indicated and removed: ', counter.nr_of_duplicates, file=Information)
 
@@ -104,41 +124,38 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
         cont.coverage = (aligned[tid] if tid is not None else 0) / float(cont.length)
 
     if param.first_lib and param.lower_cov_cutoff:
-        filter_low_coverage_contigs(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_scaffolds, Information)
+        filter_low_coverage_contigs(Contigs, Scaffolds, plan_G, param, plan_Gp, small_contigs, small_scaffolds, Information)
 
     mean_cov, std_dev_cov = CalculateMeanCoverage(Contigs, Information, param)
     param.mean_coverage = mean_cov
     param.std_dev_coverage = std_dev_cov
 
     if param.first_lib:
-        Contigs, Scaffolds, G = RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs,
-                                               small_scaffolds, Information)
-    print('Number of edges in G (after repeat removal): ', G.number_of_edges(), file=Information)
-    print('Number of edges in G_prime (after repeat removal): ', G_prime.number_of_edges(), file=Information)
+        RepeatDetector(Contigs, Scaffolds, plan_G, param, plan_Gp, small_contigs, small_scaffolds, Information)
+    print('Number of edges in G (after repeat removal): ', plan_G.number_of_edges(), file=Information)
+    print('Number of edges in G_prime (after repeat removal): ', plan_Gp.number_of_edges(), file=Information)
 
-    RemoveBugEdges(G, G_prime, fishy_rows, param, Information)
-    print('Number of edges in G (after filtering for buggy flag stats reporting): ', G.number_of_edges(), file=Information)
-    print('Number of edges in G_prime  (after filtering for buggy flag stats reporting): ', G_prime.number_of_edges(),
+    RemoveBugEdges(plan_G, plan_Gp, links, param, Information)
+    print('Number of edges in G (after filtering for buggy flag stats reporting): ', plan_G.number_of_edges(), file=Information)
+    print('Number of edges in G_prime  (after filtering for buggy flag stats reporting): ', plan_Gp.number_of_edges(),
           file=Information)
 
-    infer_spurious_link_count_threshold(G_prime, param)
+    infer_spurious_link_count_threshold(plan_Gp, param)
     if not param.edgesupport:
         param.edgesupport = 5
         print('Letting -e be {0} for this library.'.format(param.edgesupport), file=Information)
     else:
         print('User has set -e to be {0} for this library.'.format(param.edgesupport), file=Information)
 
-    counter_low_support = 0
-    for u, v, d in G.edges(data=True):
-        nr = d['nr_links']
-        if nr is not None and nr < param.edgesupport:
-            G.remove_edge(u, v)
-            counter_low_support += 1
+    counter_low_support = plan_G.drop(links.n < param.edgesupport)
     print('Removed {0} edges from graph G of border contigs.'.format(counter_low_support), file=Information)
-    remove_edges_below_threshold(G_prime, param)
+    remove_edges_below_threshold(plan_Gp, param)
 
+    scores = None
     if not param.no_score:
-        GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, 'G', ctx)
+        scores = GiveScoreOnEdges(plan_G, Scaffolds, small_scaffolds, Contigs, param, Information, 'G', ctx)
+    plan_G.build(G, scores)
+    plan_Gp.build(G_prime, None)
     print('Number of edges in G_prime  (after removing edges under -e threshold (if not specified, default is '
           '-e 3): ', G_prime.number_of_edges(), file=Information)
     print('\n -------------------------------------------------------------\n', file=Information)
@@ -176,59 +193,224 @@ def contig_table(references, Contigs, small_contigs, Scaffolds, small_scaffolds)
     return cols, tid_of
 
 
-def _node(code):
-    return (code >> 1, 'R' if code & 1 else 'L')
+class LinkData(dict):
+    """Attribute dict of a link edge.  'observations' - one int per link, in BAM order (CreateGraph.py:849,862) - is cut
+    out of the device's observation column the first time anything asks for it (its readers are
+    MakeScaffolds.py:322,331,425,1139: a few edges per extended path); every other key is an ordinary item."""
+    __slots__ = ('_col', '_lo', '_hi')
+
+    def _cut(self):
+        col = self._col
+        if col is not None:
+            self._col = None
+            dict.__setitem__(self, 'observations', col[self._lo:self._hi].tolist())
+
+    def __missing__(self, key):
+        if key == 'observations' and self._col is not None:
+            self._cut()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    # whatever looks at the dict as a whole sees the complete dict
+    def __iter__(self):
+        self._cut()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._cut()
+        return dict.__len__(self)
+
+    def __contains__(self, key):
+        if key == 'observations':
+            self._cut()
+        return dict.__contains__(self, key)
+
+    def __eq__(self, other):
+        self._cut()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def get(self, key, default=None):
+        if key == 'observations':
+            self._cut()
+        return dict.get(self, key, default)
+
+    def keys(self):
+        self._cut()
+        return dict.keys(self)
+
+    def items(self):
+        self._cut()
+        return dict.items(self)
+
+    def values(self):
+        self._cut()
+        return dict.values(self)
+
+    def copy(self):
+        self._cut()
+        return dict(self)
+
+    def __repr__(self):
+        self._cut()
+        return dict.__repr__(self)
 
 
-def add_link_edges(table, G, G_prime):
-    """Insert the device's edge rows into the graphs in first-occurrence order.
+class LinkTable(object):
+    """The device's edge rows as columns, link rows in order of first occurrence in the BAM.
 
-    The reference creates an edge the first time CreateEdge accepts a link for it (CreateGraph.py:842-849),
-    so adjacency order = order of first occurrence in the BAM; ``first_idx`` is monotone in that order.
-    Returns the fishy rows as {(node_a, node_b): count} for RemoveBugEdges.
-    """
-    n_rows = len(table)
-    fishy = {}
-    link_rows = []
-    is_fishy = table.is_fishy.tolist()
-    u_l, v_l, n_l = table.u.tolist(), table.v.tolist(), table.n.tolist()
-    for i in range(n_rows):
-        if is_fishy[i]:
-            fishy[(_node(u_l[i]), _node(v_l[i]))] = n_l[i]
+    The reference creates an edge the first time CreateEdge accepts a link for it (CreateGraph.py:842-849), so the
+    adjacency order of its graphs = order of first occurrence; ``first_idx`` is monotone in that order.  ``u < v`` are
+    node codes (scaffold id * 2 + (side == 'R')); fishy rows (BWA-quirk counts, :141-163) are kept by node pair."""
+
+    def __init__(self, table):
+        fishy = np.flatnonzero(table.is_fishy)
+        rows = np.flatnonzero(~table.is_fishy)
+        rows = rows[np.argsort(table.first_idx[rows], kind='stable')]
+        self.rows = rows                                     # device row of every link (for the scoring stage)
+        self.u, self.v = table.u[rows], table.v[rows]
+        self.n = table.n[rows].astype(np.int64)
+        self.obs, self.obs_sq = table.sum_obs[rows], table.sum_obs_sq[rows]
+        self.mask = table.mask[rows]
+        self.lo = table.offset[rows].astype(np.int64)
+        self.pair = table.key[rows] >> np.uint64(1)
+        self.fishy_pair = table.key[fishy] >> np.uint64(1)
+        self.fishy_n = table.n[fishy].astype(np.int64)
+        # one observation per link: obs1 + obs2 (the device keeps the two ends apart for the scoring stage)
+        self.observations = table.obs_lo + table.obs_hi
+
+    def __len__(self):
+        return int(self.rows.shape[0])
+
+
+class GraphPlan(object):
+    """One of the two graphs while it is still columns: the scaffolds whose two ends are its nodes (in InitializeGraph
+    order) and a liveness flag per link row.  Every filter of PE is a mask over the link columns; node and adjacency
+    order of the graph built at the end equal those of a graph that had the edges inserted and removed one by one,
+    because removing dictionary entries keeps the order of the rest."""
+
+    def __init__(self):
+        self.sid, self.length = [], []
+        self.links = None
+        self.alive = None
+
+    def add_scaffolds(self, scaffolds):
+        self.sid.extend(scaffolds)
+        self.length.extend(s.s_length for s in scaffolds.values())
+
+    def take(self, links, mask_bit):
+        self.links = links
+        self.alive = (links.mask & mask_bit) != 0
+        self.sid_arr = np.asarray(self.sid, dtype=np.int64)
+        self.len_arr = np.asarray(self.length, dtype=np.int64)
+        size = int(max(self.sid_arr.max() if self.sid_arr.size else 0,
+                       (links.v.max() >> 1) if len(links) else 0)) + 1
+        self.node_alive = np.zeros(size, dtype=bool)          # by scaffold id
+        self.node_alive[self.sid_arr] = True
+
+    def remove_scaffolds(self, sids):
+        """remove_nodes_from of both ends of every scaffold: the nodes and every edge at them go."""
+        sids = np.asarray([s for s in sids if s < self.node_alive.shape[0]], dtype=np.int64)
+        if sids.size == 0:
+            return
+        self.node_alive[sids] = False
+        lk = self.links
+        self.alive &= self.node_alive[lk.u >> 1] & self.node_alive[lk.v >> 1]
+
+    def drop(self, which):
+        """remove_edge for the live links selected by the mask; returns how many went."""
+        hit = self.alive & which
+        self.alive &= ~which
+        return int(hit.sum())
+
+    def number_of_nodes(self):
+        return 2 * int(self.node_alive[self.sid_arr].sum())
+
+    def number_of_edges(self):
+        return self.number_of_nodes() // 2 + int(self.alive.sum())
+
+    def node_rank(self):
+        """Position of every node code in the graph's node order (scaffolds in InitializeGraph order, 'L' before 'R')."""
+        keep = self.sid_arr[self.node_alive[self.sid_arr]]
+        rank = np.full(2 * self.node_alive.shape[0], np.iinfo(np.int64).max, dtype=np.int64)
+        rank[2 * keep] = 2 * np.arange(keep.shape[0])
+        rank[2 * keep + 1] = 2 * np.arange(keep.shape[0]) + 1
+        return rank
+
+    def edges_order(self, select=None):
+        """Live link rows (optionally only the selected ones) in the order G.edges() lists them, and for each whether the
+        edge is reported from its larger node code: networkx walks the nodes in node order and lists every edge at its
+        first endpoint, in adjacency (= first occurrence) order."""
+        idx = np.flatnonzero(self.alive if select is None else (self.alive & select))
+        rank = self.node_rank()
+        ru, rv = rank[self.links.u[idx]], rank[self.links.v[idx]]
+        order = np.lexsort((idx, np.minimum(ru, rv)))
+        return idx[order], (rv < ru)[order]
+
+    def build(self, graph, scores):
+        """Fill the (empty) graph: nodes with their 'length', the intra-scaffold edges (CreateGraph.py:710-722), the
+        surviving links - every container made once, in comprehensions, and handed to the graph's dictionaries in bulk."""
+        keep = self.node_alive[self.sid_arr]
+        sids, lengths = self.sid_arr[keep].tolist(), self.len_arr[keep].tolist()
+        count = len(sids)
+        left, right = list(zip(sids, repeat('L'))), list(zip(sids, repeat('R')))
+        inner = [{'nr_links': None} for _ in sids]
+        nodes, attrs, nbrs = [None] * (2 * count), [None] * (2 * count), [None] * (2 * count)
+        nodes[0::2], nodes[1::2] = left, right
+        attrs[0::2], attrs[1::2] = [{'length': n} for n in lengths], [{'length': n} for n in lengths]
+        nbrs[0::2], nbrs[1::2] = [{r: d} for r, d in zip(right, inner)], [{l: d} for l, d in zip(left, inner)]
+        if graph._node:                                      # (a graph that is not empty: the general way)
+            for scaffold_, length in zip(sids, lengths):
+                graph.add_scaffold(scaffold_, length)
+            nbrs = [graph._adj[n] for n in nodes]
         else:
-            link_rows.append(i)
-    first = table.first_idx.tolist()
-    link_rows.sort(key=lambda i: first[i])
-    mask, off = table.mask.tolist(), table.offset.tolist()
-    s1, s2 = table.sum_obs.tolist(), table.sum_obs_sq.tolist()
-    obs_all = (table.obs_lo.astype(np.int64) + table.obs_hi.astype(np.int64))
-    for i in link_rows:
-        u, v = _node(u_l[i]), _node(v_l[i])
-        lo, hi = off[i], off[i] + n_l[i]
-        observations = obs_all[lo:hi].tolist()
-        if mask[i] & MASK_G:
-            # device_row lets GiveScoreOnEdges find the per-end observation lists without copying them
-            data = dict(nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=list(observations), device_row=i,
-                        device_min_node=u)
-            if u in G._adj and v in G._adj and v not in G._adj[u]:
-                G.add_link(u, v, data)
-            else:
-                G.add_edge(u, v, **data)
-        if mask[i] & MASK_GPRIME:
-            data = dict(nr_links=n_l[i], obs=s1[i], obs_sq=s2[i], observations=observations)
-            if u in G_prime._adj and v in G_prime._adj and v not in G_prime._adj[u]:
-                G_prime.add_link(u, v, data)
-            else:
-                G_prime.add_edge(u, v, **data)
-    return fishy
+            graph._node.update(zip(nodes, attrs))
+            graph._adj.update(zip(nodes, nbrs))
+        lk = self.links
+        idx = np.flatnonzero(self.alive)
+        if idx.size == 0:
+            return
+        col = lk.observations
+        lo = lk.lo[idx]
+        datas = [LinkData(nr_links=n, obs=s1, obs_sq=s2)
+                 for n, s1, s2 in zip(lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist())]
+        for data, span in zip(datas, zip(lo.tolist(), (lo + lk.n[idx]).tolist())):
+            data._col = col
+            data._lo, data._hi = span
+        if scores is not None:
+            at = dict(zip(idx.tolist(), datas))
+            for k, gap, score in zip(scores[0].tolist(), scores[1], scores[2]):
+                data = at[k]
+                data['gap'] = gap
+                data['score'] = score
+        # where every node code sits in `nodes`: the link's two adjacency dictionaries without hashing a node twice
+        slot = np.full(2 * self.node_alive.shape[0], -1, dtype=np.int64)
+        kept = self.sid_arr[keep]
+        slot[2 * kept] = 2 * np.arange(count)
+        slot[2 * kept + 1] = 2 * np.arange(count) + 1
+        su, sv = slot[lk.u[idx]], slot[lk.v[idx]]
+        if (su < 0).any() or (sv < 0).any():
+            # an end no InitializeGraph call has seen (cannot happen with the record loop's rules): as add_edge would
+            side = ('L', 'R')
+            for data, a, b in zip(datas, lk.u[idx].tolist(), lk.v[idx].tolist()):
+                graph.add_edge((a >> 1, side[a & 1]), (b >> 1, side[b & 1]))
+                graph._adj[(a >> 1, side[a & 1])][(b >> 1, side[b & 1])] = data
+                graph._adj[(b >> 1, side[b & 1])][(a >> 1, side[a & 1])] = data
+            return
+        for data, i, j in zip(datas, su.tolist(), sv.tolist()):
+            nbrs[i][nodes[j]] = data
+            nbrs[j][nodes[i]] = data
 
 
 # -----------------------------------------------------------------------------------------------------------
 # host-side stages, same names as the reference
 # -----------------------------------------------------------------------------------------------------------
 def InitializeGraph(dict_with_scaffolds, graph, Information):
-    for scaffold_, obj in dict_with_scaffolds.items():
-        graph.add_scaffold(scaffold_, obj.s_length)
+    graph.add_scaffolds(dict_with_scaffolds)
     return ()
 
 
@@ -307,12 +489,11 @@ def CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_sc
 
 def _retire_scaffolds(selected, scaffold_dict, graphs):
     """Contigs taken out of the scaffolding (low coverage, repeats): their scaffold objects and both scaffold ends go."""
-    for c in selected:
-        scaf_ = c.scaffold
+    gone = [c.scaffold for c in selected]
+    for scaf_ in gone:
         del scaffold_dict[scaf_]
-        ends = [(scaf_, 'L'), (scaf_, 'R')]
-        for g in graphs:
-            g.remove_nodes_from(ends)
+    for g in graphs:
+        g.remove_scaffolds(gone)
 
 
 def _coverage_groups(Contigs, Scaffolds, G, G_prime, small_contigs, small_scaffolds, param):
@@ -416,20 +597,22 @@ def RepeatDetector(Contigs, Scaffolds, G, param, G_prime, small_contigs, small_s
     return (Contigs, Scaffolds, G)
 
 
-def RemoveBugEdges(G, G_prime, fishy_edges, param, Information):
-    """Drop an edge when the BWA-quirk read count reaches its link count (CreateGraph.py:690-708)."""
+def RemoveBugEdges(G, G_prime, links, param, Information):
+    """Drop an edge when the BWA-quirk read count of its node pair reaches its link count (CreateGraph.py:690-708)."""
     edges_removed = 0
-    for (a, b), nr_links in list(fishy_edges.items()):
+    if links.fishy_pair.size and len(links):
+        by_pair = np.argsort(links.pair, kind='stable')
+        at = np.searchsorted(links.pair[by_pair], links.fishy_pair)
+        at[at >= by_pair.shape[0]] = 0
+        k = by_pair[at]
+        hit = (links.pair[k] == links.fishy_pair) & (links.fishy_n >= links.n[k])
+        bug = np.zeros(len(links), dtype=bool)
+        bug[k[hit]] = True
         if param.extend_paths:
-            if b in G_prime and a in G_prime[b] and nr_links >= G_prime[a][b]['nr_links']:
-                G_prime.remove_edge(a, b)
-                edges_removed += 1
-            if b in G and a in G[b] and nr_links >= G[a][b]['nr_links']:
-                G.remove_edge(a, b)
+            edges_removed = G_prime.drop(bug)
+            G.drop(bug)
         else:
-            if b in G and a in G[b] and nr_links >= G[a][b]['nr_links']:
-                G.remove_edge(a, b)
-                edges_removed += 1
+            edges_removed = G.drop(bug)
     print('Number of BWA buggy edges removed: ', edges_removed, file=Information)
     return ()
 
@@ -441,10 +624,10 @@ def infer_spurious_link_count_threshold(G_prime, param):
     link_params = e_nr_links.Param(param.mean_ins_size, param.std_dev_ins_size, cov, param.read_len, 0)
     gap = param.mean_ins_size + param.std_dev_ins_size - 2 * param.read_len
     expected = e_nr_links.ExpectedLinks(100000, 100000, gap, link_params)
-    link_counter = Counter(d['nr_links'] for _, _, d in G_prime.edges(data=True) if d['nr_links'] is not None)
+    link_number, count = np.unique(G_prime.links.n[G_prime.alive], return_counts=True)
     total_included_edges = 0
-    for link_number in sorted(link_counter, reverse=True):
-        total_included_edges += link_counter[link_number]
+    for link_number, count in zip(link_number[::-1].tolist(), count[::-1].tolist()):
+        total_included_edges += count
         print('Nodes: {0}.\t Total edges with over {1} links:{2}. \tAverage density: {3}'.format(
             nr_nodes, link_number, total_included_edges, total_included_edges / float(nr_nodes)),
             file=param.information_file)
@@ -454,23 +637,27 @@ def infer_spurious_link_count_threshold(G_prime, param):
 
 
 def remove_edges_below_threshold(graph, param):
-    """Dense-region pruning; order dependent, so it runs on the host in graph iteration order (:355-404)."""
+    """Dense-region pruning (CreateGraph.py:355-404).  Order dependent: the thin edges are visited in G.edges() order and
+    an edge goes only while both its ends still have more than four neighbours - a sequential sweep over the thin edges
+    with the degrees in a column (every node starts with its intra-scaffold edge plus its live links)."""
     print('Remove edges in high complexity areas.', file=param.information_file)
+    lk = graph.links
     limit = param.expected_links_over_mean_plus_stddev
-    thin = [(u, v) for u, v, d in graph.edges(data=True) if d['nr_links'] is not None and d['nr_links'] < limit]
+    thin, _ = graph.edges_order(lk.n < limit)
     removed = 0
-    adj = graph.edge                                     # degrees change as edges go: read them at visiting time
-    for u, v in thin:
-        if len(adj[u]) > 4 and len(adj[v]) > 4:
-            graph.remove_edge(u, v)
-            removed += 1
+    if thin.size:
+        live = np.flatnonzero(graph.alive)
+        degree = (np.bincount(np.concatenate([lk.u[live], lk.v[live]]), minlength=2 * graph.node_alive.shape[0]) + 1).tolist()
+        gone = []
+        for k, a, b in zip(thin.tolist(), lk.u[thin].tolist(), lk.v[thin].tolist()):
+            if degree[a] > 4 and degree[b] > 4:
+                degree[a] -= 1
+                degree[b] -= 1
+                gone.append(k)
+        removed = len(gone)
+        graph.alive[gone] = False
     print('Removed total of {0} edges in high density areas.'.format(removed), file=param.information_file)
-    counter_low_support = 0
-    for u, v, d in graph.edges(data=True):
-        nr = d['nr_links']
-        if nr is not None and nr < param.edgesupport:
-            graph.remove_edge(u, v)
-            counter_low_support += 1
+    counter_low_support = graph.drop(lk.n < param.edgesupport)
     print('Removed an additional of {0} edges with low support from full graph G_prime of all contigs.'.format(
         counter_low_support), file=param.information_file)
 
@@ -527,54 +714,52 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
         print('scf1/ctg1\to1\tscf2/ctg2\to2\tgap\tlink_variation_score\tlink_dispersity_score\tnumber_of_links',
               file=score_file)
 
-    def s_length(sid):
-        try:
-            return Scaffolds[sid].s_length
-        except KeyError:
-            return small_scaffolds[sid].s_length
-
-    edges, rows, swap, len1, len2 = [], [], [], [], []
-    for u, v, data in G.edges(data=True):
-        if data['nr_links'] is None:
-            continue
-        edges.append((u, v))
-        rows.append(data['device_row'])
-        swap.append(0 if u == data['device_min_node'] else 1)    # l1 belongs to the first endpoint (:568-579)
-        len1.append(s_length(u[0]))
-        len2.append(s_length(v[0]))
-    gap_d, sd0_d, ks_h, flags = ctx.score_edges(rows, swap, len1, len2, param.mean_ins_size, param.std_dev_ins_size,
-                                                param.read_len)
+    lk = G.links
+    idx, from_v = G.edges_order()                            # G.edges(): every link, reported from its first endpoint
+    first = np.where(from_v, lk.v[idx], lk.u[idx])
+    second = np.where(from_v, lk.u[idx], lk.v[idx])
+    s_length = np.zeros(G.node_alive.shape[0], dtype=np.int64)
+    for group in (small_scaffolds, Scaffolds):
+        if group:
+            ids = np.fromiter(group, dtype=np.int64, count=len(group))
+            ids_in = ids < s_length.shape[0]
+            s_length[ids[ids_in]] = _column(list(group.values()), 's_length', np.int64)[ids_in]
+    len1_a, len2_a = s_length[first >> 1], s_length[second >> 1]
+    # l1 belongs to the first endpoint (:568-579); the device keeps the observations of the smaller node code first
+    gap_d, sd0_d, ks_h, flags = ctx.score_edges(lk.rows[idx], from_v.astype(np.uint8), len1_a, len2_a, param.mean_ins_size,
+                                                param.std_dev_ins_size, param.read_len)
     gap_d, sd0_d, ks_h, flags = gap_d.tolist(), sd0_d.tolist(), ks_h.tolist(), flags.tolist()
-    for j, (u, v) in enumerate(edges):
-        data = G[u][v]
-        data.pop('device_row')
-        data.pop('device_min_node')
-        n = data['nr_links']
-        mean_ = data['obs'] / float(n)
+    len1, len2 = len1_a.tolist(), len2_a.tolist()
+    n_l, obs_l, obs_sq_l, lo_l = lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist(), lk.lo[idx].tolist()
+    gaps, scores = [0] * len(n_l), [None] * len(n_l)
+    side = ('L', 'R')
+    for j, n in enumerate(n_l):
+        mean_ = obs_l[j] / float(n)
         if cond_sd is not None:               # log-normal branch (:522-531, :549-553): host, per edge
             long_enough = 2 * param.std_dev_ins_size < len1[j] and 2 * param.std_dev_ins_size < len2[j]
             if long_enough:
                 gap = mathstats_compat.lognormal_GapEstimator(param.lognormal_mean, param.lognormal_sigma, param.read_len,
-                                                              data['observations'], len1[j], c2_len=len2[j])
+                                                              lk.observations[lo_l[j]:lo_l[j] + n].tolist(), len1[j],
+                                                              c2_len=len2[j])
                 if gap > log_norm_max_gap:
                     gap = log_norm_max_gap
             else:
-                gap = (n * param.mean_ins_size - data['obs']) / float(n)
-            data['gap'] = int(gap)
+                gap = (n * param.mean_ins_size - obs_l[j]) / float(n)
+            gaps[j] = int(gap)
             if -gap > len1[j] or -gap > len2[j]:
-                data['score'] = 0
+                scores[j] = 0
                 continue
             std_dev_d_eq_0 = (cond_sd[int(gap)] if gap > 0 else cond_sd[0]) if long_enough else 2 ** 32
         else:
             # integer-valued when the ML estimator was used (int in the reference), float otherwise
             gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
-            data['gap'] = int(gap)
+            gaps[j] = int(gap)
             if flags[j] & 2:                      # -gap > len1 or -gap > len2
-                data['score'] = 0
+                scores[j] = 0
                 continue
             std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
         try:
-            std_dev = ((data['obs_sq'] - n * mean_ ** 2) / (n - 1)) ** 0.5
+            std_dev = ((obs_sq_l[j] - n * mean_ ** 2) / (n - 1)) ** 0.5
         except ZeroDivisionError:
             std_dev = 2 ** 32
         span_score = 0 if n < 5 else 1 - ks_h[j] * 1.0 / n
@@ -583,11 +768,13 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
         except ZeroDivisionError:
             std_dev_score = 0
             sys.stderr.write(str(std_dev) + ' ' + str(std_dev_d_eq_0) + ' ' + str(span_score) + '\n')
-        data['score'] = std_dev_score + span_score if std_dev_score > 0.5 and span_score > 0.5 else 0
+        scores[j] = std_dev_score + span_score if std_dev_score > 0.5 and span_score > 0.5 else 0
         if score_file is not None:
             # --print_scores rows as the reference writes them (:622-651): the contig names of each scaffold, listed
             # from the far end towards the link, and one sign per contig - '+' throughout for an 'R' end on the left
             # and an 'L' end on the right, '-' throughout otherwise (the reference's `'+' if True else '-'`)
+            u = (int(first[j]) >> 1, side[int(first[j]) & 1])
+            v = (int(second[j]) >> 1, side[int(second[j]) & 1])
             objs1 = Scaffolds[u[0]].contigs if u[1] == 'R' else Scaffolds[u[0]].contigs[::-1]
             objs2 = Scaffolds[v[0]].contigs if v[1] == 'L' else Scaffolds[v[0]].contigs[::-1]
             print('{0}\t{1}\t{2}\t{3}\t{4}\t{5}\t{6}\t{7}'.format(
@@ -597,4 +784,4 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
     if score_file is not None:
         score_file.close()
     print('Number of significantly spurious edges:', 0, file=Information)
-    return ()
+    return idx, gaps, scores

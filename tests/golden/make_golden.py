@@ -149,6 +149,51 @@ def lognormal_scenario(mods):
     scenario(mods, 'fr_lognormal', 'stream_ln', ln, {})          # (run_reference applies the `range` patch by name)
 
 
+def dense_stream(asm, spec, seed, hubs=12):
+    """A PE stream plus a tangle: chimeric pairs, one to four per edge, between the ends of the `hubs` longest contigs, so
+    that most hub ends have a dozen thin link edges - the case remove_edges_below_threshold (CreateGraph.py:355-404)
+    exists for.  Which of them survive depends on the order G_prime.edges() lists them in: an edge goes only while both
+    of its ends still have more than four neighbours."""
+    from besst_amd.records import FLAG_MATE_REVERSE, FLAG_PAIRED, FLAG_READ1, FLAG_READ2, FLAG_REVERSE
+    b = synth.simulate_library(asm, spec, 12000, seed)
+    rng = np.random.default_rng(seed + 1)
+    hub = np.argsort(asm.lengths)[-hubs:]
+    ends = [(int(c), side) for c in hub for side in (0, 1)]              # side 1 = 'R': forward read near the right end
+    add = {c: [] for c in COLS}
+
+    def place(c, side):
+        jitter = int(rng.integers(30, 200))
+        return (int(asm.lengths[c]) - jitter - 100, 0) if side else (jitter, FLAG_REVERSE)
+
+    for i in range(len(ends)):
+        for j in range(i + 1, len(ends)):
+            (ca, sa), (cb, sb) = ends[i], ends[j]
+            if ca == cb or rng.random() < 0.45:
+                continue
+            for _ in range(int(rng.integers(1, 5))):
+                (pa, ra), (pb, rb) = place(ca, sa), place(cb, sb)
+                first_a = rng.random() < 0.5
+                fa = FLAG_PAIRED + ra + (FLAG_MATE_REVERSE if rb else 0) + (FLAG_READ1 if first_a else FLAG_READ2)
+                fb = FLAG_PAIRED + rb + (FLAG_MATE_REVERSE if ra else 0) + (FLAG_READ2 if first_a else FLAG_READ1)
+                for tid, mtid, pos, mpos, flag in ((ca, cb, pa, pb, fa), (cb, ca, pb, pa, fb)):
+                    for c, v in (('tid', tid), ('mtid', mtid), ('pos', pos), ('mpos', mpos), ('tlen', 0), ('flag', flag),
+                                 ('mapq', 60), ('qlen', 100), ('rlen', 100), ('alen', 100)):
+                        add[c].append(v)
+    cat = {c: np.concatenate((getattr(b, c), np.asarray(add[c], dtype=getattr(b, c).dtype))) for c in COLS}
+    order = np.argsort((cat['tid'].astype(np.int64) << 32) | cat['pos'].astype(np.int64), kind='stable')
+    return RecordBatch(list(b.references), list(b.lengths), **{c: v[order] for c, v in cat.items()})
+
+
+def dense_scenario(mods):
+    """Hub contigs whose ends are tangled by chimeric pairs: the dense-region pruning and the link-count filters of
+    CreateGraph.py:323-404 all remove edges here (in the other scenarios the pruning finds nothing to do)."""
+    asm = synth.make_assembly(220, 2500, 601)
+    dn = dense_stream(asm, synth.LibrarySpec('fr', 500.0, 50.0), 602)
+    save_batch('stream_dense', dn)
+    scenario(mods, 'fr_dense', 'stream_dense', dn, {})
+    scenario(mods, 'fr_dense_e2', 'stream_dense', dn, dict(edgesupport=2))
+
+
 def main():
     mods = loader.load()
     if '--resimulate' not in sys.argv[1:]:
@@ -158,6 +203,8 @@ def main():
         return None
     if 'lognormal' in sys.argv[1:]:                          # only the scenario added in round 2
         return lognormal_scenario(mods)
+    if 'dense' in sys.argv[1:]:                              # only the scenarios added in round 3
+        return dense_scenario(mods)
 
     # ---- PE library, short contigs: many contig-spanning pairs --------------------------------
     asm = synth.make_assembly(300, 1500, 101)
@@ -196,6 +243,7 @@ def main():
     scenario(mods, 'fr_edgecases', 'stream_edge', ec, {}, fasta_names=fasta)
 
     lognormal_scenario(mods)
+    dense_scenario(mods)
 
 
 if __name__ == '__main__':

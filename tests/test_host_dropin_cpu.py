@@ -64,6 +64,42 @@ def test_host_side_reproduces_reference_goldens(fake_gpu, name):
     for k in ('mean_coverage', 'std_dev_coverage', 'edgesupport', 'expected_links_over_mean_plus_stddev',
               'scaffold_indexer', 'tot_assembly_length', 'current_N50', 'current_L50'):
         assert getattr(param, k) == fin['param'][k], (name, k)
+    # the observation lists (cut out of the device column on first access) keep BAM order, in both graphs
+    for graph, snap in ((G, doc['after_loop']['G']), (G_prime, doc['after_loop']['G_prime'])):
+        want_obs = {frozenset((tuple(e['u']), tuple(e['v']))): e['observations'] for e in snap}
+        for u, v in graph.edges():
+            d = graph[u][v]
+            if d['nr_links'] is not None:
+                assert 'observations' not in dict.keys(d)           # not cut yet ...
+                assert d['observations'] == want_obs[frozenset((u, v))]
+                assert dict.__contains__(d, 'observations') and len(d['observations']) == d['nr_links']
+
+
+def test_link_data_is_a_complete_dict_to_whatever_looks_at_it_whole():
+    col = numpy.arange(100, dtype=numpy.int32)
+
+    def fresh():
+        d = CreateGraph.LinkData(nr_links=3, obs=33, obs_sq=365)
+        d._col, d._lo, d._hi = col, 10, 13
+        return d
+    want = dict(nr_links=3, obs=33, obs_sq=365, observations=[10, 11, 12])
+    assert fresh()['observations'] == [10, 11, 12]
+    assert fresh() == want and want == fresh() and not (fresh() != want)
+    assert dict(fresh()) == want and fresh().copy() == want and dict(**fresh()) == want
+    assert sorted(fresh()) == sorted(want) and len(fresh()) == 4
+    assert 'observations' in fresh() and fresh().get('observations') == [10, 11, 12]
+    assert dict(fresh().items()) == want and sorted(fresh().keys()) == sorted(want)
+    plain = {}
+    plain.update(fresh())                                    # what networkx's add_edges_from does with edge data
+    assert plain == want
+    d = fresh()
+    d['observations'].append(7)                              # the cut list is the edge's own, mutable list
+    assert d['observations'] == [10, 11, 12, 7]
+    with pytest.raises(KeyError):
+        fresh()['gap']
+    d = fresh()
+    d['observations'] = [1]                                  # an explicit assignment wins over the column
+    assert d['observations'] == [1] and len(d) == 4
 
 
 def _scaffold_summary(Scaffolds, small_scaffolds):

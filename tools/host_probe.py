@@ -56,6 +56,21 @@ def timed_build():
     a = time.perf_counter(); r = orig(); spent['build'] = time.perf_counter() - a; return r
 ctx.build_graph = timed_build
 Contigs, Scaffolds, sc, ss = {}, {}, {}, {}
+stage = {}
+def timed(owner, name):
+    fn = getattr(owner, name)
+    def w(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            stage[name] = stage.get(name, 0.0) + time.perf_counter() - t
+    setattr(owner, name, w)
+for name in ('InitializeObjects', 'contig_table', 'LinkTable', 'GiveScoreOnEdges', 'remove_edges_below_threshold',
+             'RemoveBugEdges', 'RepeatDetector', 'CalculateMeanCoverage', 'filter_low_coverage_contigs',
+             'infer_spurious_link_count_threshold'):
+    timed(CreateGraph, name)
+timed(CreateGraph.GraphPlan, 'build'); timed(CreateGraph.GraphPlan, 'take')
 pr = cProfile.Profile()
 if prof: pr.enable()
 t2 = time.perf_counter()
@@ -64,5 +79,6 @@ t3 = time.perf_counter()
 if prof: pr.disable()
 print('get_metrics %.2f s   PE %.2f s of which oracle build_graph %.2f s -> host %.2f s   (G %d edges, G_prime %d edges)' % (
     t1 - t0, t3 - t2, spent['build'], t3 - t2 - spent['build'], G.number_of_edges(), Gp.number_of_edges()))
+print('  '.join('%s %.2f' % kv for kv in sorted(stage.items(), key=lambda kv: -kv[1])))
 if prof:
     s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(22); print(s.getvalue()[:5000])
