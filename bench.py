@@ -14,7 +14,8 @@ afterwards and rides along as the "c2" object of the same line.
 
 Prints ONE JSON line on rank 0 (see the repo prompt for the contract) with two extra objects:
   roofline     - the WHOLE step priced at SURVEY 8(d)'s (38 + 32 f) bytes per read pair over the step time and
-                 the 8 TB/s peak; the streaming kernel's own bytes over its HIP-event duration as an extra;
+                 the 8 TB/s peak; the record loop's kernel (the dominant one) under its own name, with its algorithmic
+                 bytes and its PMC bytes over its HIP-event duration, as an extra;
                  traffic = HBM bytes per step from the committed rocprofv3 PMC passes of this very build
   cpu_baseline - the pure-Python oracle (port of the reference's record loop) timed on this box's
                  host cores over a bounded sample of the same stream, with the port's measured speed
@@ -33,7 +34,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
-CLASSIFY_SLOT = 0
+RECORD_LOOP_SLOTS = 0b111   # stream_kernel, fused_kernel, fused_wave_kernel: besst_prof_slot_name(0..2)
+RECORD_LOOP_KERNELS = ('stream_kernel', 'fused_kernel', 'fused_wave_kernel')
 
 
 def parse_args():
@@ -57,6 +59,8 @@ def parse_args():
                          '(default: 3 for C2, 1 for C3 whose 9.2 GB of records cannot stay cached)')
     ap.add_argument('--no-verify', action='store_true', help='skip the full-size check against the C oracle')
     ap.add_argument('--no-stages', action='store_true', help='skip the separate metrics / scoring stage timings')
+    ap.add_argument('--no-robustness', action='store_true',
+                    help='skip the "robustness" object (C3 with chimeric pairs, name-sorted C2)')
     ap.add_argument('--in-flight', type=int, default=3,
                     help='library passes kept in flight (one HIP stream each) for the extra "overlapped" figure; '
                          '0 skips it.  The headline value is always measured with ONE pass at a time.')
@@ -426,8 +430,8 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_step_traffic(config, n_rec):
-    """HBM bytes per graph-build step (all kernels of one step) from the committed rocprofv3 PMC passes of THIS build
+def pmc_step_traffic(config, n_rec, kernel=None):
+    """HBM bytes per graph-build step (all kernels of one step; of one kernel when it is named) from the committed rocprofv3 PMC passes of THIS build
     on THIS workload (profiles/r03_<config>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
     passes, gfx950 x2 correction on FETCH_SIZE, tools/pmc_summary.py), else None - a summary collected on other
     kernel sources or another record count says nothing about this run."""
@@ -439,6 +443,8 @@ def pmc_step_traffic(config, n_rec):
         return None
     if doc.get('source_hash') != source_hash() or doc.get('records') != n_rec:
         return None
+    if kernel is not None:
+        return (doc.get('kernels', {}).get(kernel) or {}).get('traffic_bytes_per_step')
     return doc.get('step_traffic_bytes')
 
 
@@ -455,14 +461,14 @@ def reference_calibration():
         return None
 
 
-def measure_single(args, device, config, steps, warmup, copies, pairs=None, contigs=None, verify=True):
+def measure_single(args, device, config, steps, warmup, copies, pairs=None, contigs=None, verify=True, **variant):
     """One GPU, one library pass at a time, records resident: timed steps, per-kernel breakdown, full-size check.
     Returns (result dict, workload, runner)."""
     import torch
     from besst_amd import _lib, pipeline, workload
     lib_h = _lib.load()
     t0 = time.perf_counter()
-    wl = workload.make_device(device, config, 0, pairs=pairs, nc=contigs)
+    wl = workload.make_device(device, config, 0, pairs=pairs, nc=contigs, **variant)
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     lib = wl['lib']
@@ -484,7 +490,7 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
     # the streaming kernel is timed with HIP events inside the timed region, on every 4th launch: an event pair costs
     # the stream ~3 us, i.e. ~5 % of a C2 step when every launch carries one
     lib_h.besst_prof_sample_every(4 if steps >= 8 else 1)
-    lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
+    lib_h.besst_prof_enable(RECORD_LOOP_SLOTS)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -504,9 +510,14 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
     f = n_tuples / float(n_pairs)
     step_s = elapsed / steps
     alg_step = n_pairs * (38.0 + 32.0 * f)               # 2 x 19 B of records + 16 B per tuple written and read
-    cls_ms, cls_launches = prof.get('stream_kernel', (0.0, 0))
+    # the record loop's kernel - the dominant one of every config - under its own name, priced at ITS algorithmic bytes:
+    # stream_kernel reads tid, mtid, mapq, qlen of every record (11 B; the candidates' other columns are ordered_kernel's);
+    # the fused forms read all seven columns once (19 B) and write every tuple (16 B)
+    loop_kernel = next((k for k in RECORD_LOOP_KERNELS if k in prof), None)
+    cls_ms, cls_launches = prof.get(loop_kernel, (0.0, 0))
     cls_avg_s = (cls_ms / max(1, cls_launches)) * 1e-3
-    own = n_rec * 11.0                                   # tid, mtid, mapq, qlen of every record
+    own = n_rec * 11.0 if loop_kernel == 'stream_kernel' else n_rec * 19.0 + n_tuples * 16.0
+    own_pmc = pmc_step_traffic(config, n_rec, loop_kernel)
     dominant = max(breakdown.items(), key=lambda kv: kv[1])[0] if breakdown else None
     verified = None
     if verify and not args.no_verify and not args.no_cpu_baseline:
@@ -517,7 +528,8 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
         'workload': '%s: %d contigs / %d read-pairs, one %s library%s, %d records resident in HBM (%d cop%s cycled)'
                     % (config, wl['asm'].nc, n_pairs, lib['orientation'],
                        ' with %.0f %% PE contamination' % (100 * wl['spec'].contam_frac) if wl['spec'].contam_frac else '',
-                       n_rec, copies, 'y' if copies == 1 else 'ies'),
+                       n_rec, copies, 'y' if copies == 1 else 'ies')
+                    + (' [variant: %s]' % ', '.join('%s=%s' % kv for kv in sorted(variant.items())) if variant else ''),
         'records': n_rec, 'link_tuples_per_pair': round(f, 5), 'link_tuples': n_tuples, 'edge_rows': n_rows,
         'roofline': {
             'bound': 'hbm', 'scope': 'whole graph-build step, SURVEY 8(d): (38 + 32 f) bytes per read pair',
@@ -526,15 +538,46 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
             'traffic': pmc_step_traffic(config, n_rec),
             'algorithmic_bytes_per_step': alg_step, 'bytes_per_pair': round(38.0 + 32.0 * f, 3),
             'dominant_kernel': dominant,
-            'stream_kernel': {'own_bytes_per_launch': own, 'avg_launch_ms': round(cls_avg_s * 1e3, 4),
-                              'launches_timed': int(cls_launches),
-                              'GBps': round(own / cls_avg_s / 1e9, 1) if cls_avg_s > 0 else None,
-                              'frac': round(own / cls_avg_s / 1e9 / HBM_PEAK_GBS, 4) if cls_avg_s > 0 else None}},
+            'record_loop_kernel': {'name': loop_kernel, 'algorithmic_bytes_per_launch': own,
+                                   'bytes': '11 B/record' if loop_kernel == 'stream_kernel' else '19 B/record + 16 B/tuple',
+                                   'avg_launch_ms': round(cls_avg_s * 1e3, 4), 'launches_timed': int(cls_launches),
+                                   'GBps': round(own / cls_avg_s / 1e9, 1) if cls_avg_s > 0 else None,
+                                   'frac': round(own / cls_avg_s / 1e9 / HBM_PEAK_GBS, 4) if cls_avg_s > 0 else None,
+                                   'pmc_bytes_per_launch': own_pmc,
+                                   'pmc_GBps': round(own_pmc / cls_avg_s / 1e9, 1) if own_pmc and cls_avg_s > 0 else None}},
         'kernel_ms': breakdown,
         'verified_vs_c_oracle': verified,
         'generate_s': round(gen_s, 2),
+        'stage2_form': 'tuple by tuple (the runs overflowed)' if runner.gb.sort_flags else 'default',
     }
     return res, wl, runner
+
+
+def robustness(args, device):
+    """The regimes DESIGN.md section 6 names as leaving a fast path, measured the same way as the headline (results stay
+    exact: each is checked against the C oracle on its own stream):
+      * C3 with 3 % of the contig-spanning pairs chimeric - their links sit on edges of their own, so the run-grouped
+        stage 2 sees more runs per chunk and the edge table gets an order of magnitude more rows;
+      * C2 name-sorted - mates adjacent, pairs in random order: no wave shares a contig, candidates do not cluster and
+        consecutive tuples share no key (stage 2 falls back from runs to the tuple-by-tuple sort)."""
+    import torch
+    out = {}
+    for label, config, steps, variant in (('c3_chimeric_3pct', 'C3', 10, dict(chimeric_frac=0.03)),
+                                          ('c2_name_sorted', 'C2', 20, dict(order='name'))):
+        C_PORT_TIMING.clear()
+        try:
+            res, wl, runner = measure_single(args, device, config, steps, 3, 1 if config == 'C3' else 3, **variant)
+        except Exception as e:                               # noqa: BLE001 - the bench line must still be printed
+            out[label] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
+            continue
+        out[label] = {k: res[k] for k in ('workload', 'ms_per_step', 'value', 'link_tuples', 'edge_rows', 'kernel_ms',
+                                          'verified_vs_c_oracle', 'stage2_form')}
+        out[label]['variant'] = variant
+        out[label]['roofline_frac'] = res['roofline']['frac']
+        del res, wl, runner
+        torch.cuda.empty_cache()
+    C_PORT_TIMING.clear()
+    return out
 
 
 def cpu_legs(args, wl, with_stage_ports):
@@ -615,6 +658,8 @@ def main_single(args, device, result_fd):
         if not args.no_cpu_baseline and C_PORT_TIMING:
             second['c_port'] = {'value': C_PORT_TIMING['records'] / 2.0 / C_PORT_TIMING['seconds'], 'cores': 1}
         out[args.also.lower()] = second
+    if not args.no_robustness and not args.no_stages and args.pairs is None and args.config == 'C3':
+        out['robustness'] = robustness(args, device)
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + '\n').encode())
 
@@ -787,7 +832,7 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     for job in jobs:
         job.check_capacity()
     lib_h.besst_prof_sample_every(1)
-    lib_h.besst_prof_enable(1 << CLASSIFY_SLOT)
+    lib_h.besst_prof_enable(RECORD_LOOP_SLOTS)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

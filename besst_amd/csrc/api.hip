@@ -166,10 +166,16 @@ void besst_prof_sample_every(uint32_t n) { g_prof_every = n ? n : 1; }
 int besst_prof_slots(void) { return kProfSlots; }
 
 const char* besst_prof_slot_name(int slot) {
-    static const char* names[kProfSlots] = {"stream_kernel", "(unused)", "ordered_kernel", "stitch_kernel", "compact_kernel", "radix_hist_kernel",
-                                            "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "row_heads_kernel",
-                                            "row_scan_kernel", "row_reduce_kernel",
-                                            "metrics_kernels", "score_kernels", "rg_group_kernel", "rg_sort_runs", "rg_copy_kernel"};
+    static const char* names[kProfSlots] = {
+        "stream_kernel", "fused_kernel", "fused_wave_kernel", "ordered_kernel", "stitch_spans_kernel+stitch_kernel",
+        "presort_fixup_kernel", "compact_kernel",
+        "radix_hist_kernel", "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "bucket_reduce_kernel",
+        "row_heads_kernel", "row_scan_kernel", "row_reduce_kernel",
+        "os_hist_kernel", "os_offsets_kernel", "os_seg_tiles_kernel+os_scatter_kernel",
+        "os_bucket_start_kernel+os_bucket_wave_kernel+os_bucket_wave_lds_kernel+os_bucket_sort_kernel", "os_bucket_rows_kernel",
+        "os_reduce_kernel", "os_fixup_kernel",
+        "metrics_kernels", "score_kernels", "rg_group_kernel", "rg_compact_kernel",
+        "rg_tile_sums_kernel+rg_dst_kernel+rg_rows_kernel", "rg_copy_kernel"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
 }
 

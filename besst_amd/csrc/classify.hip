@@ -1849,9 +1849,9 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     // against 0.16 + 0.42 ms for the two passes; at 135 VGPRs and a barrier-separated chain per 1024 records it is
     // latency bound at 3 waves per SIMD.  The split design below serves every library.)
     if (a.record_path == 1) {
-        ProfScope ps(s, kProfClassify);
         // BESST_FUSED_FORM (experiments): 0 = four waves per block with workgroup barriers, 1 = one wave per block
         static const int form = [] { const char* e = getenv("BESST_FUSED_FORM"); return e ? atoi(e) : 1; }();
+        ProfScope ps(s, form == 1 ? kProfFusedWave : kProfFused);
         if (form == 1)
             hipLaunchKernelGGL(fused_wave_kernel, dim3(nblocks), dim3(64), 0, s, a,
                                reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
@@ -1862,7 +1862,7 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
         return BESST_OK;
     }
     {
-        ProfScope ps(s, kProfClassify);
+        ProfScope ps(s, kProfStream);
         hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
                            reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
     }
@@ -1970,10 +1970,10 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
         }
     }
     {
-        ProfScope ps(s, kProfCompact);
         PresortSpec in_compact = pre;
         const bool segmented = pre.table && pre.in_record_loop && pre.segmented && !slice_info && !tails;
         if (pre.table && pre.in_record_loop) {
+            ProfScope ps(s, kProfFixup);
             hipLaunchKernelGGL(presort_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, w.seg_keys, w.skip, nblocks, pre,
                                segmented ? cls8 : nullptr, n_contigs, reinterpret_cast<unsigned long long*>(aligned),
                                w.offsets, n_out, segmented ? w.chunk_first : nullptr);
@@ -1984,6 +1984,7 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
             presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload, w.chunk_first};
         } else {
             if (presort) presort->segmented = 0;
+            ProfScope ps(s, kProfCompact);
             hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(256), 0, s, w.summ, w.offsets, w.skip, w.seg_keys,
                                w.seg_payload, keys, payload, cls8, n_contigs, reinterpret_cast<unsigned long long*>(aligned),
                                in_compact);

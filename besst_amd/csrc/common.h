@@ -31,9 +31,14 @@ void set_error(const char* fmt, ...);
 
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
-    kProfClassify = 0, kProfCandidate, kProfOrdered, kProfStitch, kProfCompact, kProfSortHist, kProfSortScan, kProfSortScatter, kProfBucketSort,
-    kProfRowHeads, kProfRowScan, kProfRowReduce, kProfMetrics, kProfScore, kProfRunGroup, kProfRunSort, kProfRunCopy, kProfSlots
+    // one slot per kernel (or per group of kernels that always run back to back): the names besst_prof_slot_name returns
+    // are the kernels' own names, the ones a rocprofv3 trace of the same run shows
+    kProfStream = 0, kProfFused, kProfFusedWave, kProfOrdered, kProfStitch, kProfFixup, kProfCompact,
+    kProfRadixHist, kProfRadixScan, kProfRadixScatter, kProfBucketSort, kProfBucketReduce, kProfRowHeads, kProfRowScan, kProfRowReduce,
+    kProfOsHist, kProfOsOffsets, kProfOsScatter, kProfOsBucket, kProfOsBucketRows, kProfOsReduce, kProfOsFixup,
+    kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfSlots
 };
+static_assert(kProfSlots <= 32, "besst_prof_enable takes a 32-bit slot mask");
 struct ProfScope {
     hipStream_t s;
     int idx;

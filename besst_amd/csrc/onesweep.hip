@@ -1618,19 +1618,19 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         // the histograms came with the tuples (PresortSpec: compact_kernel); only the descriptors are left to clear
         BESST_HIP_TRY(hipMemsetAsync(w.granules, 0, w.granule_words * 8, s));
     } else {
-        ProfScope ps(s, kProfSortHist);
+        ProfScope ps(s, kProfOsHist);
         hipLaunchKernelGGL((os_hist_kernel<kOsBits>), dim3(kOsHistBlocks), dim3(kOsHistThreads), 0, s, keys, n_tuples,
                            (uint32_t)cap, passes, shift0, key_base, w.table, w.granules, w.granule_words);
     }
     {
-        ProfScope ps(s, kProfSortScan);
+        ProfScope ps(s, kProfOsOffsets);
         hipLaunchKernelGGL((os_offsets_kernel<kOsBits>), dim3(passes), dim3(256), 0, s, w.table,
                            hist_ready && hybrid ? kOsPresortRows : kOsHistBlocks, passes, w.digit_base, w.tickets);
     }
     const uint64_t* kin = keys;
     const uint32_t* iin = nullptr;
     for (int p = 0; p < passes; ++p) {
-        ProfScope ps(s, kProfSortScatter);
+        ProfScope ps(s, kProfOsScatter);
         uint64_t* kout = buf_keys[p & 1];
         uint32_t* iout = buf_idx[p & 1];
         const int shift = shift0 + p * kOsBits + (p > 0 ? packed_bits : 0);
@@ -1664,7 +1664,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         o.staged = reinterpret_cast<StagedRow*>(w.staged);
         o.bucket_rows = w.bucket_rows;
         {
-            ProfScope ps(s, kProfBucketSort);
+            ProfScope ps(s, kProfOsBucket);
             hipLaunchKernelGGL(os_bucket_start_kernel, dim3((kTopBuckets + 1 + 255) / 256), dim3(256), 0, s, kin, n_tuples,
                                (uint32_t)cap, shift0 + packed_bits, w.bucket_start);
             hipLaunchKernelGGL(os_bucket_wave_kernel, dim3(kTopBuckets / kBkWaves), dim3(kBkThreads), 0, s, buf_keys[1],
@@ -1675,7 +1675,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                                w.bucket_start, packed_bits, shift0, w.bucket_class, o);
         }
         {
-            ProfScope ps(s, kProfRowReduce);
+            ProfScope ps(s, kProfOsBucketRows);
             hipLaunchKernelGGL(os_bucket_rows_kernel, dim3(kTopBuckets / kRowsThreads), dim3(kRowsThreads), 0, s,
                                w.bucket_start, o, w.err, n_rows, row_key, row_mask, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                                reinterpret_cast<unsigned long long*>(row_sum_sq), row_first, row_offset);
@@ -1684,7 +1684,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
         return BESST_OK;
     }
     {
-        ProfScope ps(s, kProfRowReduce);
+        ProfScope ps(s, kProfOsReduce);
         hipLaunchKernelGGL(os_reduce_kernel, dim3(nt_red), dim3(kOsRedThreads), 0, s, kin, iin, payload, n_tuples,
                            (uint32_t)cap, packed_bits, key_base, w.granules + w.desc_words, w.tickets + kOsMaxPasses, w.tile_base,
                            w.lead_n, w.lead_s, w.lead_s2, n_rows, row_key, row_mask, row_n,
@@ -1692,7 +1692,7 @@ int launch_onesweep_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tu
                            row_first, row_offset, obs_lo, obs_hi, first_map, w.err, spin_limit);
     }
     {
-        ProfScope ps(s, kProfRowScan);
+        ProfScope ps(s, kProfOsFixup);
         hipLaunchKernelGGL(os_fixup_kernel, dim3((nt_red + 255) / 256), dim3(256), 0, s, n_tuples, (uint32_t)cap, w.tile_base,
                            w.lead_n, w.lead_s, w.lead_s2, row_n, reinterpret_cast<unsigned long long*>(row_sum),
                            reinterpret_cast<unsigned long long*>(row_sum_sq), w.err, n_rows);

@@ -606,15 +606,18 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
                                n_tuples, (uint32_t)cap, first_map, grouped, staged, w.starts, w.chunk_runs);
     }
     {
-        ProfScope ps(s, kProfRunSort);
+        ProfScope ps(s, kProfRunCompact);
         hipLaunchKernelGGL(rg_compact_kernel, dim3((nchunks + kRcChunks - 1) / kRcChunks), dim3(kRcThreads), 0, s,
                            w.chunk_runs, n_tuples, (uint32_t)cap, staged, w.starts, w.run_cap, w.run_keys, w.run_payload,
                            w.n_runs, w.status);
+    }
+    {
         // the runs, sorted stably by key and cut into rows: row_key is final, the other columns describe the runs
         const int rc = launch_sort_reduce(s, (int64_t)w.run_cap, w.n_runs, key_bits, w.run_keys, w.run_payload, row_key, w.r_mask,
                                           w.r_runs, w.r_sum, w.r_sq, w.r_first, w.r_first_run, w.run_len, w.run_at, n_rows,
                                           w.nested, w.nested_bytes, nullptr, key_base, false, nullptr, BESST_REDUCE_NO_RUNS);
         if (rc) return rc;
+        ProfScope ps(s, kProfRunScan);
         const uint32_t tiles = (w.run_cap + kRsTile - 1) / kRsTile;
         hipLaunchKernelGGL(rg_tile_sums_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum);
         hipLaunchKernelGGL(rg_dst_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum, w.run_dst);

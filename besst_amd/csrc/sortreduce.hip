@@ -951,16 +951,16 @@ void launch_pass(hipStream_t s, const RedWorkspace& w, uint32_t nb_sort, uint32_
     const int scanned = nb_sort > (uint32_t)kScanFreeMaxBlocks ? 1 : 0;
     const uint32_t stride = ITEMS == kSortItems ? w.stride : nb_sort;
     {
-        ProfScope ps(s, kProfSortHist);
+        ProfScope ps(s, kProfRadixHist);
         hipLaunchKernelGGL((radix_hist_kernel<BITS, ITEMS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, n_tuples, cap, ds,
                            w.table, stride, scanned, zero_n, zero_sum, zero_sum_sq);
     }
     if (scanned) {
-        ProfScope ps(s, kProfSortScan);
+        ProfScope ps(s, kProfRadixScan);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << BITS), dim3(256), 0, s, n_tuples, cap, w.table, stride,
                            w.row_total, (uint32_t)(kSortThreads * ITEMS));
     }
-    ProfScope ps(s, kProfSortScatter);
+    ProfScope ps(s, kProfRadixScatter);
     if (first)
         hipLaunchKernelGGL((radix_scatter_kernel<BITS, true, ITEMS>), dim3(nb_sort), dim3(kSortThreads), 0, s, kin, iin,
                            n_tuples, cap, ds, w.table, stride, w.row_total, scanned, kout, iout, bucket_start,
@@ -1049,7 +1049,7 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         }
         if (packed_bits) {
             // rows are local to a bucket: one launch instead of head counts + tile-based reduction
-            ProfScope ps(s, kProfRowReduce);
+            ProfScope ps(s, kProfBucketReduce);
             hipLaunchKernelGGL(bucket_reduce_kernel, dim3(1u << kMsdBits), dim3(256), 0, s, w.keys[0], payload, n_tuples,
                                w.bucket_start, w.bucket_rows, packed_bits, shift, n_rows, row_key, row_mask, row_n, zsum, zsq,
                                row_first, row_offset, obs_lo, obs_hi, first_map, key_base);

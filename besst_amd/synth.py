@@ -48,7 +48,8 @@ def make_assembly(nc, median_len, seed, sigma_log=1.0, min_len=500, max_len=2000
 
 class LibrarySpec(object):
     def __init__(self, orientation='fr', mean=500.0, sd=50.0, contam_frac=0.0, contam_mean=350.0,
-                 contam_sd=60.0, read_len=100, dup_frac=0.01, fishy_frac=0.001, softclip_frac=0.05, lognormal_sigma=None):
+                 contam_sd=60.0, read_len=100, dup_frac=0.01, fishy_frac=0.001, softclip_frac=0.05, lognormal_sigma=None,
+                 chimeric_frac=0.0):
         self.orientation = orientation
         self.mean = mean
         self.sd = sd
@@ -60,6 +61,9 @@ class LibrarySpec(object):
         self.fishy_frac = fishy_frac
         self.softclip_frac = softclip_frac
         self.lognormal_sigma = lognormal_sigma      # insert sizes exp(N(ln mean, .)) instead of N(mean, sd): a skewed library
+        # share of the contig-spanning pairs whose second read is moved, at the same offset, to a contig drawn at random
+        # (chimeric fragments: links on edges of their own; simulate_library_device only)
+        self.chimeric_frac = chimeric_frac
 
 
 def simulate_library(asm, spec, n_pairs, seed, chunk=4_000_000):
@@ -184,12 +188,13 @@ def config_seed(name):
     return BASE_SEED + int(name[1:])
 
 
-def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000):
+def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, order='coordinate'):
     """The generator of ``simulate_library`` written with torch ops, so that the full-size configs (C3: 400 M
     records) are drawn, sorted and left resident on the GPU in seconds instead of minutes of numpy on the host.
     Same model, same record semantics, its own random stream (torch.Generator seeded with ``seed``).
     Returns a dict of device tensors {tid mtid pos mpos tlen: int32, flag qlen: int16 bit patterns, mapq: uint8}
-    in (tid, pos) order.  Bench / test scaffolding, not the product."""
+    in (tid, pos) order - or, order='name', the two records of a pair next to each other and the pairs in the order
+    they were drawn (a name-sorted BAM).  Bench / test scaffolding, not the product."""
     import torch
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -224,6 +229,11 @@ def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000):
         lp = lpos - starts[lt]
         rp = rpos - starts[rt]
         del lpos, rpos, start, ok
+        if getattr(spec, 'chimeric_frac', 0.0) > 0:
+            other = torch.randint(0, asm.nc, (k,), generator=g, device=dev)
+            move = (lt != rt) & (rand(k) < spec.chimeric_frac) & (other != lt) & (rp + r <= lengths[other])
+            rt = torch.where(move, other, rt)
+            del other, move
         innie = contam.logical_not() if spec.orientation == 'fr' else contam
         l_rev = innie.logical_not()
         r_rev = innie
@@ -258,10 +268,15 @@ def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000):
         done += int(sel.shape[0])
         for name, left, right in (('tid', lt, rt), ('mtid', rt, lt), ('pos', lp, rp), ('mpos', rp, lp),
                                   ('tlen', tl, -tl), ('flag', fl, fr_), ('mapq', mapq, mapq), ('qlen', ql, qr)):
-            parts[name].append(torch.cat((left[sel], right[sel])).to(tdt[name]))
+            if order == 'name':
+                parts[name].append(torch.stack((left[sel], right[sel]), dim=1).reshape(-1).to(tdt[name]))
+            else:
+                parts[name].append(torch.cat((left[sel], right[sel])).to(tdt[name]))
         del lt, rt, lp, rp, tl, fl, fr_, mapq, ql, qr, x, contam, same, sel
     cat = {name: torch.cat(parts[name]) for name in names}
     parts.clear()
+    if order == 'name':
+        return cat
     key = (cat['tid'].to(torch.int64) << 32) | cat['pos'].to(torch.int64)
     order = torch.sort(key, stable=True)[1]
     del key

@@ -55,17 +55,25 @@ class DeviceWorkload(dict):
         raise KeyError(key)
 
 
-def make_device(device, config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, reads_seed_offset=0):
+def make_device(device, config='C2', lib_index=0, pairs=None, nc=None, seed_offset=0, reads_seed_offset=0,
+                chimeric_frac=None, order='coordinate'):
     """``make`` with the records generated on ``device`` (a torch device): the full-size mate-pair configs take
     seconds instead of minutes.  Same assembly, table and library constants as ``make``; the read pairs come from
-    torch's generator instead of numpy's, so the two streams are different samples of the same model."""
+    torch's generator instead of numpy's, so the two streams are different samples of the same model.  chimeric_frac /
+    order: the variants of a config that bench.py's `robustness` object measures (chimeric pairs that put links on
+    edges of their own; a name-sorted stream)."""
+    import copy
     cfg = synth.CONFIGS[config]
     spec = cfg['libs'][lib_index]
+    if chimeric_frac is not None:
+        spec = copy.copy(spec)
+        spec.chimeric_frac = float(chimeric_frac)
     n_pairs = int(pairs if pairs is not None else cfg['pairs'] // len(cfg['libs']))
     n_ctg = int(nc if nc is not None else cfg['nc'])
     seed = synth.config_seed(config) + 1000 * seed_offset
     asm = synth.make_assembly(n_ctg, cfg['median'], seed)
-    cols = synth.simulate_library_device(asm, spec, n_pairs, seed + 100 + lib_index + 7919 * reads_seed_offset, device)
+    cols = synth.simulate_library_device(asm, spec, n_pairs, seed + 100 + lib_index + 7919 * reads_seed_offset, device,
+                                         order=order)
     lib = dict(read_len=float(spec.read_len), ins_size_threshold=spec.mean + 6 * spec.sd, min_mapq=11,
                orientation=spec.orientation, detect_duplicate=True, extend_paths=True, no_score=False,
                mean=spec.mean, sd=spec.sd)

@@ -34,6 +34,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
     assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline'])
     assert d['stages']['linearize_calls_agree'] is True
+    # kernels go by their own names: the record loop of a mate-pair library is the one-wave fused kernel
+    loop = d['roofline']['record_loop_kernel']
+    assert loop['name'] == 'fused_wave_kernel' and loop['name'] in d['kernel_ms'] and loop['avg_launch_ms'] > 0
+    assert d['roofline']['dominant_kernel'] in d['kernel_ms']
     assert abs(d['value'] - 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
 
 

@@ -200,3 +200,29 @@ def test_resident_builder_step_large_stream(seg_window, sort_form, monkeypatch):
     assert gb.sort_flags == (pipeline.REDUCE_NO_RUNS if sort_form == 'tuples' else 0)
     ctr = gb.read_counters()
     assert_table_equals_c_oracle(table, gb.aligned.cpu().numpy(), ctr, wl['batch'], wl)
+
+
+@pytest.mark.parametrize('config,pairs,nc,variant', [('C3', 6_000_000, 20_000, dict(chimeric_frac=0.03)),
+                                                    ('C3', 6_000_000, 20_000, dict(chimeric_frac=0.5)),
+                                                    ('C2', 3_000_000, 5_000, dict(order='name')),
+                                                    ('C3', 3_000_000, 5_000, dict(order='name'))])
+def test_variant_streams_resident_builder(config, pairs, nc, variant):
+    """The workloads of bench.py's `robustness` object at reduced size, through DeviceGraphBuilder.step(): chimeric pairs
+    (links on edges of their own: many runs per chunk, ten times the rows) and name-sorted streams (mates adjacent,
+    pairs in random order: no clustering anywhere, stage 2 leaves the run-grouped form when the runs overflow)."""
+    import torch
+    from besst_amd import pipeline
+    dev = torch.device('cuda', 0)
+    wl = workload.make_device(dev, config, 0, pairs=pairs, nc=nc, **variant)
+    rec = pipeline.DeviceRecords.from_columns(wl['cols'])
+    gb = pipeline.DeviceGraphBuilder(dev, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, rec.n)
+    gb.set_contigs(**wl['table'])
+    for _ in range(2):
+        gb.step(rec)
+    table = gb.fetch_table()
+    ctr = gb.read_counters()
+    assert_table_equals_c_oracle(table, gb.aligned.cpu().numpy(), ctr, wl['batch'], wl)
+    if 'chimeric_frac' in variant:
+        plain = workload.make_device(dev, config, 0, pairs=pairs, nc=nc)
+        keys, _, _, _ = CO.record_loop(plain['batch'], plain['table'], plain['lib'], plain['node_bits'])
+        assert len(table) > 1.5 * len(np.unique(keys))                           # the chimeric links did make edges
