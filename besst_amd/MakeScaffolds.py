@@ -264,8 +264,48 @@ def _edge_gap(data, c1_len, c2_len, dValuesTable, param):
     return int(data_observation), int(data_observation)
 
 
+def _relabel_path_ends(G_prime, name, start, end, old_nodes):
+    """The new scaffold's two nodes in G_prime, with the link edges of the path's two ends (MakeScaffolds.py:309-339)."""
+    import networkx as nx
+    G_prime.add_node((name, 'L'))
+    G_prime.add_node((name, 'R'))
+    G_prime.add_edge((name, 'L'), (name, 'R'), nr_links=None)
+    try:
+        for new_side, old in (('L', start), ('R', end)):
+            for nbr in G_prime.neighbors(old):
+                d = G_prime[old][nbr]
+                if d['nr_links']:
+                    G_prime.add_edge((name, new_side), nbr, nr_links=d['nr_links'], obs=d['obs'],
+                                     obs_sq=d['obs_sq'], observations=d['observations'])
+        G_prime.remove_nodes_from(old_nodes)
+    except (nx.exception.NetworkXError, KeyError):
+        pass
+
+
+def _extend_within_components(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param, dValuesTable,
+                              already_visited, within_scaffold):
+    """What the reference's loop does per component apart from the walk (:272-339), for all components, in its order:
+    the path search between the component's scaffolds (`within_scaffold` = BESST's PROWithinScaf: it moves small
+    scaffolds into G and out of G_prime), then the relabelling of the path's two ends in G_prime to the scaffold the
+    component becomes.  The searches only read G_prime, the scaffold lengths of their own component and
+    `already_visited`; the walk of an earlier component (contig positions, the Scaffolds entries of ITS scaffolds) is
+    nothing a later search looks at, so the walks can wait until every component has been extended."""
+    import networkx as nx
+    components = [G.subgraph(c) for c in nx.connected_components(G)]
+    name = param.scaffold_indexer
+    for component in components:
+        name += 1
+        within_scaffold(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param, component, dValuesTable,
+                        already_visited)
+        ends = [node for node in component if len(G.neighbors(node)) == 1]
+        if not ends:
+            continue
+        # (:287-293: the first such node is the start, the last other one the end; a single scaffold has both of its own)
+        _relabel_path_ends(G_prime, name, ends[0], ends[-1] if len(ends) > 1 else ends[0], list(component))
+
+
 def NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, Information, dValuesTable, param,
-                        already_visited, device=0):
+                        already_visited, device=0, within_scaffold=None):
     """Mirror of MakeScaffolds.NewContigsScaffolds (:270-341) with UpdateInfo (:344-482): every connected component of
     the linearised G - a path of scaffolds - becomes one new scaffold.  Same arguments, same mutations: contigs get the
     new scaffold id, their position along the path and (for scaffolds the walk enters through 'R') the flipped
@@ -274,10 +314,21 @@ def NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_sca
     itself - which end a path starts from, every scaffold's position and orientation - comes from the device
     (besst_chain_scaffolds, list ranking); the per-edge gap values follow the reference's rules on the host.
 
-    Not provided: PROWithinScaf (:283-285), the path search the reference runs per component when param.extend_paths
-    (ExtendLargeScaffolds' search is sequential and stays with BESST); components are taken as they are."""
-    import networkx as nx
+    PROWithinScaf (:283-285), the path search the reference runs per component when param.extend_paths, is BESST's
+    own sequential code and is not rebuilt here: hand it in as ``within_scaffold`` (same signature) and it runs per
+    component, in the reference's order, before the chains are extracted (_extend_within_components).  Without it the
+    components are taken as they are - with param.extend_paths set (BESST's default) that is NOT what BESST computes,
+    and the Information log says so."""
     from . import Scaffold
+    relabelled = False
+    if param.extend_paths:
+        if within_scaffold is not None:
+            _extend_within_components(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param, dValuesTable,
+                                      already_visited, within_scaffold)
+            relabelled = True
+        else:
+            print('WARNING: extend_paths is set but no within_scaffold (PROWithinScaf) was handed to NewContigsScaffolds: '
+                  'small contigs are not placed inside the new scaffolds in this step.', file=Information)
     nodes = G.nodes()
     order_of = {n: i for i, n in enumerate(nodes)}
     index = {}
@@ -299,8 +350,8 @@ def NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_sca
     for node, i in order_of.items():
         order[code(node)] = i
     for u, v, data in G.edges(data=True):
-        if data['nr_links'] is None:
-            continue
+        if u[0] == v[0]:                                     # the edge inside a scaffold (the path search's insertions carry
+            continue                                         # no 'nr_links' at all: the walk tells the two kinds apart by ends)
         avg_gap, app = _edge_gap(data, Scaffolds[u[0]].s_length, Scaffolds[v[0]].s_length, dValuesTable, param)
         if avg_gap <= 1:
             avg_gap = 1
@@ -354,18 +405,6 @@ def NewContigsScaffolds(G, G_prime, Contigs, small_contigs, Scaffolds, small_sca
         old_nodes = [node_of[2 * j + side] for j in path for side in (0, 1)]
         old_nodes.sort(key=lambda nd: order_of[nd])
         G.remove_nodes_from(old_nodes)
-        if param.extend_paths:
-            G_prime.add_node((S.name, 'L'))
-            G_prime.add_node((S.name, 'R'))
-            G_prime.add_edge((S.name, 'L'), (S.name, 'R'), nr_links=None)
-            try:
-                for new_side, old in (('L', start), ('R', end)):
-                    for nbr in G_prime.neighbors(old):
-                        d = G_prime[old][nbr]
-                        if d['nr_links']:
-                            G_prime.add_edge((S.name, new_side), nbr, nr_links=d['nr_links'], obs=d['obs'],
-                                             obs_sq=d['obs_sq'], observations=d['observations'])
-                G_prime.remove_nodes_from(old_nodes)
-            except (nx.exception.NetworkXError, KeyError):
-                pass
+        if param.extend_paths and not relabelled:
+            _relabel_path_ends(G_prime, S.name, start, end, old_nodes)
     return (Contigs, Scaffolds, param)

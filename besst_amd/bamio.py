@@ -38,6 +38,11 @@ def read_bam(path, threads=None, chunk_records=8_000_000):
             for (k, _), b in zip(spec, bufs):
                 parts[k].append(b[:got])
         cols = {k: (np.concatenate(v) if v else np.empty(0, dtype=dt)) for (k, dt), v in zip(spec, parts.values())}
+        clamped = lib.besst_bam_clamped_records(handle)
+        if clamped > 0:
+            import warnings
+            warnings.warn('%s: %d record(s) align more than 65535 query bases; their qlen (the coverage numerator of '
+                          'CreateGraph.py:138-139) is stored as 65535' % (path, clamped))
     finally:
         lib.besst_bam_close(handle)
     return RecordBatch(names, lengths[:n_ref].tolist(), **cols)

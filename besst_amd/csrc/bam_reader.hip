@@ -214,6 +214,7 @@ struct besst_bam {
     std::vector<BlockRecs> brecs;    // speculative per-block walks of the current batch, in stream order
     std::vector<uint32_t> blk_offs;
     size_t next_brec = 0;            // first block whose start is >= cursor
+    int64_t n_clamped = 0;           // records whose aligned query length was saturated at 65535
 
     // Inflate the next batch of BGZF blocks and append to `inflated` (after dropping consumed bytes).
     bool fill(size_t want_blocks) {
@@ -346,6 +347,8 @@ void besst_bam_close(besst_bam* b) {
     delete b;
 }
 
+int64_t besst_bam_clamped_records(const besst_bam* b) { return b ? b->n_clamped : -1; }
+
 int64_t besst_bam_n_references(const besst_bam* b) { return b ? (int64_t)b->ref_names.size() : -1; }
 
 const char* besst_bam_reference_name(const besst_bam* b, int64_t i) {
@@ -359,7 +362,8 @@ int besst_bam_reference_lengths(const besst_bam* b, int32_t* out) {
 }
 
 // Decode up to max_records alignment records into the columns; returns the number decoded (0 = end of file) or
-// a negative status.  qlen is clamped to 65535 (the device column is 16 bit; paired short reads never get near).
+// a negative status.  qlen saturates at 65535 (the device column is 16 bit; paired short reads never get near) and
+// besst_bam_clamped_records counts the records it happened to.
 int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, int32_t* mtid, int32_t* pos,
                                int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen,
                                int32_t* rlen, int32_t* alen) {
@@ -411,7 +415,8 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
         const auto tw1 = std::chrono::steady_clock::now();
         const size_t m = b->rec_off.size();
         const size_t n_tasks = m < 4096 ? 1 : (size_t)b->pool->size() * 4;
-        std::atomic<bool> corrupt(false), too_long(false);
+        std::atomic<bool> corrupt(false);
+        std::atomic<int64_t> clamped(0);
         const uint8_t* base = b->inflated.data();
         const size_t* offs = b->rec_off.data();
         b->pool->parallel_for(n_tasks, [&](size_t task, int) {
@@ -454,7 +459,7 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
                         else if (op != 5) in_lead = false;
                     }
                 }
-                for (uint32_t c = n_cigar; c-- > 0;) {
+                for (uint32_t c = n_cigar; c-- > 1;) {      // (pysam's getQueryEnd never looks at the first operation)
                     const uint32_t v = le32(cg + 4 * c);
                     const uint32_t op = v & 15u, len = v >> 4;
                     if (op == 4) trail += len;
@@ -462,17 +467,17 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
                 }
                 int64_t q_aln = (l_seq ? (int64_t)l_seq : q_total) - lead - trail;
                 if (q_aln < 0) q_aln = 0;                    // a CIGAR of clips only: pysam gives a negative length
-                if (q_aln > 65535) { too_long = true; return; }   // the qlen column is 16 bits wide, like RecordBatch's
+                if (q_aln > 65535) {                         // the qlen column is 16 bits wide, like RecordBatch's: saturate
+                    q_aln = 65535;                           // and count (besst_bam_clamped_records) - paired short reads
+                    clamped.fetch_add(1, std::memory_order_relaxed);   // never get near, one long alignment must not
+                }                                            // make the file unreadable
                 qlen[o] = (uint16_t)q_aln;
                 rlen[o] = (int32_t)l_seq;
                 alen[o] = (int32_t)ref_len;
             }
         });
         if (corrupt.load()) { besst::set_error("bam_read_records: corrupt record"); return -BESST_ERR_ARG; }
-        if (too_long.load()) {
-            besst::set_error("bam_read_records: an aligned query longer than 65535 bases does not fit the 16-bit qlen column");
-            return -BESST_ERR_ARG;
-        }
+        b->n_clamped += clamped.load();
         b->cursor = cur;
         n += (int64_t)m;
         const auto tw2 = std::chrono::steady_clock::now();

@@ -268,10 +268,11 @@ def lognormal_GapEstimator(mu, sigma, read_length, samples, c1_len, c2_len=None)
     def loglik(ds):
         ds = np.asarray(ds, dtype=np.int64)
         out = np.empty(ds.shape[0], dtype=np.float64)
-        for a in range(0, ds.shape[0], 4096):                # bounded (gaps x observations) blocks
-            blk = ds[a:a + 4096]
+        step = max(16, (1 << 22) // max(1, n))               # (gaps x observations) blocks of at most 32 MB per temporary
+        for a in range(0, ds.shape[0], step):
+            blk = ds[a:a + step]
             lx = np.log((obs[None, :] + blk[:, None]).astype(np.float64))
-            out[a:a + 4096] = (-lx - ((lx - mu) ** 2) / (2.0 * sigma * sigma)).sum(axis=1)
+            out[a:a + step] = (-lx - ((lx - mu) ** 2) / (2.0 * sigma * sigma)).sum(axis=1)
         return out - n * _lognormal_log_g(ds, x_max, F0, F1, c_min, c_max, r)
     coarse = np.arange(d_lo, d_hi + 1, 64, dtype=np.int64)
     best = int(coarse[int(np.argmax(loglik(coarse)))])

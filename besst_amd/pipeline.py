@@ -7,6 +7,7 @@ ctypes drop-in (CreateGraph.PE) uses the host-buffer layer in device.py instead.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -104,10 +105,14 @@ class DeviceGraphBuilder(object):
         init_small[COUNTER_BYTES:COUNTER_BYTES + 8] = torch.from_numpy(np.array([-1, -1], dtype=np.int32).view(np.uint8))
         self._init = init.to(device)
         self._args = {}
-        self._paths = {}
+        # per record set: the marshalled argument list and the form of the record loop, dropped with the record set
+        # (keyed by the object, weakly: an id() could be inherited by a later record set at the same address)
+        self._rec_args = weakref.WeakKeyDictionary()
+        self._paths = weakref.WeakKeyDictionary()
         self.key_base, self.key_bits = 0, 2 * self.node_bits + 1
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
         self._presorted = False
+        self.keys_valid = False                              # self.keys / self.payload hold the last pass's dense tuple stream
         self.candidate_share = None
         # BESST_REDUCE_* flags of this builder's stage-2 calls.  A large stream is first reduced in the run-grouped form;
         # if its keys do not cluster (read_sizes() sees BESST_ROWS_RUN_OVERFLOW) the builder repeats the call with
@@ -155,7 +160,7 @@ class DeviceGraphBuilder(object):
     def record_path(self, rec):
         """Which form of the record loop serves this record set (include/besst_amd.h, besst_lib_params.record_path):
         sampled once per record set with besst_dev_candidate_density (synchronises), BESST_RECORD_PATH overrides."""
-        path = self._paths.get(id(rec))
+        path = self._paths.get(rec)
         if path is None:
             forced = os.environ.get('BESST_RECORD_PATH')
             if forced in ('0', '1'):
@@ -168,15 +173,15 @@ class DeviceGraphBuilder(object):
                                                                 C.byref(share), C.byref(out)), 'candidate_density')
                 path = int(out.value)
                 self.candidate_share = float(share.value)
-            self._paths[id(rec)] = path
+            self._paths[rec] = path
         return path
 
     def classify(self, rec, presort=False):
         self.params.record_path = self.record_path(rec)
         # argument lists are marshalled once per record set (every buffer is allocated once)
-        args = self._args.get(id(rec))
+        args = self._rec_args.get(rec)
         if args is None:
-            args = self._args[id(rec)] = (
+            args = self._rec_args[rec] = (
                 rec.n, _p(rec.tid), _p(rec.mtid), _p(rec.pos), _p(rec.mpos), _p(rec.flag), _p(rec.mapq), _p(rec.qlen),
                 self.n_contigs, _p(self.table), C.byref(self.params), self.node_bits, self._carry, _p(self.aligned),
                 _p(self.keys), _p(self.payload), self._n_out, self._small(0), _p(self.ws1), self.ws1.numel())
@@ -186,6 +191,7 @@ class DeviceGraphBuilder(object):
         # the next reduce() of the builder's own tuples may trust the table (and, spec.segmented, must read the tuples
         # from the block segments: self.keys was not written then)
         self._presorted = ref is not None
+        self.keys_valid = not (ref is not None and self._args['presort'][0].segmented)
 
     def _presort_ref(self, on):
         """The hand-over of the sort's digit histograms from stage 1 to stage 2 (include/besst_amd.h, besst_presort)
@@ -229,6 +235,9 @@ class DeviceGraphBuilder(object):
             again()
             return
         self._presorted = False
+        if keys is None and not self.keys_valid:
+            raise _lib.BesstDeviceError('reduce: the last classify(presort=True) left its tuples in the block segments; '
+                                        'self.keys holds an earlier pass (classify without presort to get the dense stream)')
         keys = self.keys if keys is None else keys
         payload = self.payload if payload is None else payload
         cap = self.tup_cap if capacity is None else int(capacity)

@@ -212,7 +212,9 @@ void besst_bam_close(besst_bam* bam);
 int64_t besst_bam_n_references(const besst_bam* bam);
 const char* besst_bam_reference_name(const besst_bam* bam, int64_t index);
 int besst_bam_reference_lengths(const besst_bam* bam, int32_t* out);
-/* Returns the number of records decoded (0 at end of file) or a negative status. */
+/* Returns the number of records decoded (0 at end of file) or a negative status.  qlen is a 16-bit column: an aligned
+ * query longer than 65535 bases (no paired short read is) is stored as 65535 and counted. */
+int64_t besst_bam_clamped_records(const besst_bam* bam);
 int64_t besst_bam_read_records(besst_bam* bam, int64_t max_records, int32_t* tid, int32_t* mtid, int32_t* pos,
                                int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen,
                                int32_t* rlen, int32_t* alen);

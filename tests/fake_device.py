@@ -88,3 +88,23 @@ class FakeGraphContext(object):
             m2 = sum(s2) / float(n)
             ks[j] = O.ks_h([x - m1 for x in s1], [x - m2 for x in s2])
         return gap, sd0, ks, flags
+
+
+def fake_chain_arrays(n_scaffolds, link, gap, scaffold_length, node_order, device=0):
+    """Sequential stand-in for besst_amd.MakeScaffolds.chain_arrays (besst_chain_scaffolds, csrc/chain.hip): per scaffold
+    end the terminal of the path on that side, what lies beyond it and the smallest node order there - by walking."""
+    n = int(n_scaffolds)
+    terminal = np.zeros(2 * n, np.int32)
+    beyond = np.zeros(2 * n, np.int64)
+    lowest = np.full(2 * n, 0x7fffffff, np.int32)
+    for h in range(2 * n):
+        cur, dist, low, steps = h, 0, 0x7fffffff, 0
+        while 0 <= link[cur] < 2 * n and steps <= 2 * n:
+            v = int(link[cur])
+            far = v ^ 1
+            dist += int(gap[cur]) + int(scaffold_length[v >> 1])
+            low = min(low, int(node_order[v]), int(node_order[far]))
+            cur = far
+            steps += 1
+        terminal[h], beyond[h], lowest[h] = cur, dist, low
+    return terminal, beyond, lowest, 0

@@ -137,3 +137,60 @@ def test_unchanged_reference_makescaffolds_accepts_the_graph(fake_gpu, name):
     MS.Algorithm(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param.information_file, param)
     assert _scaffold_summary(Scaffolds, small_scaffolds) == want
     assert sum(len(s.contigs) > 1 for s in Scaffolds.values()) > 5
+
+
+def _chain_state(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param):
+    return dict(contigs=sorted((c.name, c.scaffold, c.position, c.direction) for c in Contigs.values()),
+                small=sorted((c.name, c.scaffold, c.position, c.direction) for c in small_contigs.values()),
+                scaffolds=[(k, s.s_length, [c.name for c in s.contigs]) for k, s in Scaffolds.items()],
+                small_scaffolds=list(small_scaffolds), indexer=param.scaffold_indexer,
+                gaps=sorted(param.gap_estimations), G_nodes=G.nodes(),
+                prime_nodes=sorted(G_prime.nodes()),
+                prime_links=sorted((min(u, v), max(u, v), G_prime[u][v]['nr_links'], G_prime[u][v].get('obs'))
+                                   for u, v in G_prime.edges()))
+
+
+@pytest.mark.skipif(not loader.available(), reason='reference checkout not present (build container only)')
+@pytest.mark.parametrize('name', ['fr_infer', 'fr_given', 'rf_contam', 'fr_dense_e2', 'rf_second_lib', 'fr_edgecases', 'fr_nodup'])
+def test_new_contigs_scaffolds_with_the_reference_path_search_as_hook(fake_gpu, monkeypatch, name):
+    """param.extend_paths (BESST's default): the reference runs PROWithinScaf per component inside NewContigsScaffolds
+    (MakeScaffolds.py:283-285).  The drop-in's NewContigsScaffolds takes that function as `within_scaffold`; with the
+    reference's own function handed in, every object, both graphs and the indexer end up as the reference leaves them."""
+    import copy
+    from besst_amd import MakeScaffolds as OURS
+    mods = loader.load()
+    MS = importlib.import_module('BESST.MakeScaffolds')
+    importlib.import_module('BESST.lp_solve').Inf = numpy.inf
+    monkeypatch.setattr(OURS, 'chain_arrays', fake_device.fake_chain_arrays)
+    doc, batch = GU.load(name)
+    common = dict(path_threshold=100000, score_cutoff=1.5, max_extensions=None, NO_ILP=False, FASTER_ILP=False,
+                  dfs_traversal=True, multiprocess=False, development=False, plots=False, hapl_ratio=1.3,
+                  hapl_threshold=3, bamfile='synthetic.bam', path_gaps_estimated=0, gap_estimations=[])
+    results, moved = [], []
+    for ours in (False, True):
+        param, G, G_prime, Contigs, Scaffolds, small_contigs, small_scaffolds = run_dropin(doc, batch, **common)
+        param.gap_estimations = []
+        info = io.StringIO()
+        table = MS.GC.PreCalcMLvaluesOfdLongContigs(param.mean_ins_size, param.std_dev_ins_size, param.read_len)
+        already_visited = set(G) if param.extend_paths else set()
+        G = MS.RemoveIsolatedContigs(G, info)
+        MS.RemoveAmbiguousRegionsUsingScore(G, G_prime, info, param, 'G')
+        G = MS.RemoveIsolatedContigs(G, info)
+        G, Contigs, Scaffolds = MS.RemoveLoops(G, G_prime, Scaffolds, Contigs, info, param)
+        n_small = len(small_scaffolds)
+        args = (G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, info, table, param, already_visited)
+        try:
+            if ours:
+                OURS.NewContigsScaffolds(*args, within_scaffold=MS.PROWithinScaf)
+            else:
+                MS.NewContigsScaffolds(*args)
+        except Exception as exc:                              # the reference's path search is not Python-3 clean everywhere
+            if not ours:
+                pytest.skip('reference NewContigsScaffolds itself fails on this scenario here: %r' % (exc,))
+            raise
+        moved.append(n_small - len(small_scaffolds))
+        results.append(_chain_state(G, G_prime, Contigs, small_contigs, Scaffolds, small_scaffolds, param))
+    assert moved[0] == moved[1]
+    for k in results[0]:
+        assert results[0][k] == results[1][k], k
+    print('small scaffolds placed inside new scaffolds:', moved[0])
