@@ -802,6 +802,20 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     asm = synth.make_assembly(n_ctg, cfg['median'], seed)
     per_lib = int(args.pairs if args.pairs is not None else cfg['pairs'] // len(cfg['libs']) // 8)
     cap_env = os.environ.get('BESST_PAIR_CAPACITY')     # start from a (too small) region capacity: grow-and-retry path
+    # the step's HBM budget, item by item (distributed.memory_budget), against what the GPU has free - before anything
+    # is allocated.  Tuples per record as in tools/memory_budget.py: twice what the libraries' streams measure.
+    budget = {}
+    for li, spec in enumerate(cfg['libs']):
+        n_tup = int(2 * per_lib * (0.214 if spec.orientation == 'rf' else 0.014))
+        budget['library %d' % (li + 1)] = distributed.memory_budget(
+            2 * per_lib, n_ctg, world, int(cap_env) if cap_env else int(n_tup * 1.5 / world) + 4096,
+            int(n_tup * 1.25) + 4096)['total']
+    free_hbm, total_hbm = torch.cuda.mem_get_info(device)
+    need = sum(budget.values())
+    if need > 0.9 * free_hbm:
+        raise SystemExit('bench.py --gpus %d: the step needs %.1f GB of HBM per GPU (%s), %.1f GB are free'
+                         % (world, need / 1e9, ', '.join('%s %.1f GB' % (k, v / 1e9) for k, v in budget.items()),
+                            free_hbm / 1e9))
     jobs, wls = [], []
     for li, spec in enumerate(cfg['libs']):
         cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device)
@@ -887,7 +901,8 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
                                    'records resident in HBM; a step = every library\'s pass'
                                    % (config, asm.nc, len(jobs), per_lib, total_pairs),
                        'records_per_gpu': 2 * per_lib * len(jobs), 'link_tuples_per_pair': round(f, 5),
-                       'parallelism': 'stream-slice x%d + key-owner all-to-all (RCCL)' % world, 'libraries': libs_out},
+                       'parallelism': 'stream-slice x%d + key-owner all-to-all (RCCL)' % world, 'libraries': libs_out,
+                       'hbm_budget_bytes_per_gpu': need, 'hbm_allocated_bytes_rank0': int(torch.cuda.max_memory_allocated(device))},
             'roofline': {'bound': 'hbm', 'scope': 'whole step, SURVEY 8(d): (38 + 32 f) bytes per read pair, over the '
                                                   'aggregate peak of all GPUs',
                          'achieved': round(alg_step / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s',

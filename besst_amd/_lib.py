@@ -103,8 +103,6 @@ _SIGNATURES = {
                                           C.POINTER(LibParams), C.c_int32, _P, _P, _P, C.c_size_t]),
     'besst_dev_classify_tail': (C.c_int, [_P, C.c_int64, _P, _P, C.c_size_t]),
     'besst_dev_resolve_carry': (C.c_int, [_P, _P, C.c_int32, _P]),
-    'besst_dev_classify_tail_search': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
-                                                 C.POINTER(LibParams), C.c_int32, _P, _P]),
     'besst_dev_classify_emit': (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_size_t, C.c_int64,
                                           _P, _P, _P, C.c_int32, _P]),
     'besst_dev_gap_condition_table': (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, _P]),

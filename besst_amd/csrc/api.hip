@@ -546,19 +546,6 @@ int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, in
     return launch_resolve_carry(static_cast<hipStream_t>(stream), tails, rank, carry);
 }
 
-int besst_dev_classify_tail_search(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
-                                   const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
-                                   const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
-                                   const void* contig_table, const besst_lib_params* p, int32_t node_bits,
-                                   int32_t* tail, void* scratch16) {
-    ClassifyArgs a;
-    int rc = fill_classify_args(a, n, tid, mtid, pos, mpos, flag, mapq, qlen, n_contigs, contig_table, p, node_bits);
-    if (rc) return rc;
-    BESST_REQUIRE(tail && scratch16, "classify_tail_search: null output");
-    return launch_classify_tail_search(static_cast<hipStream_t>(stream), a, tail,
-                                       static_cast<unsigned long long*>(scratch16));
-}
-
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,
                             size_t workspace_bytes, int64_t n_contigs, const void* contig_table, int64_t* aligned,

@@ -1741,64 +1741,6 @@ __global__ __launch_bounds__(256) void tail_kernel(SummView summ, uint32_t nbloc
     }
 }
 
-// The same tail WITHOUT the per-record pass: prev_obs is overwritten by every record that reaches CreateEdge, so
-// the slice's tail is simply its LAST reaching record, and whether a record reaches depends on nothing but the
-// record (eval_record's REACH).  256 single-wave workgroups walk 256-record chunks from the end of the slice,
-// chunk c, c + 256, ...; a chunk's finder publishes {chunk rank, obs} with two 64-bit atomicMax (the later chunk
-// wins both words), and a wave stops as soon as a find at or after its chunk is published.  On a real stream
-// the last chunk finds within a few hundred records and the launch costs ~8 us; a slice without any link is
-// walked 65 536 records per round.  (Covering every chunk with its own workgroup was 150 us: they all start
-// before the first find is published.)  This lets the multi-GPU path all-gather the tails on a side stream
-// WHILE stream_kernel / ordered_kernel run.
-constexpr int kTailChunk = 256;
-constexpr int kTailWaves = 256;
-
-__global__ __launch_bounds__(64) void tail_search_kernel(ClassifyArgs a, unsigned long long* __restrict__ best) {
-    const int lane = threadIdx.x;
-    const int64_t n_chunks = (a.n + kTailChunk - 1) / kTailChunk;
-    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {          // c = 0 is the LAST chunk of the slice
-        const unsigned long long seen = __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen != 0ull && (int64_t)(0x7fffffffull - (seen >> 32)) < c) return;   // a later record already reached
-        const int64_t chunk_end = a.n - c * kTailChunk;
-        for (int k = 0; k < kTailChunk / 64; ++k) {
-            const int64_t i = chunk_end - 1 - (k * 64 + lane);
-            bool reach = false;
-            int32_t o1 = 0, o2 = 0;
-            if (i >= 0) {
-                const int32_t tid = a.tid[i], mtid = a.mtid[i];
-                const uint32_t flag = a.flag[i], mapq = a.mapq[i];
-                if (tid != mtid && (flag & kFlagRead2) && !(flag & kFlagUnmapped) && (int32_t)mapq >= a.min_mapq &&
-                    (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs) {
-                    const Eval e = eval_record(a, true, a.table[tid], a.table[mtid], tid, mtid, a.pos[i], a.mpos[i],
-                                               flag, mapq);
-                    reach = (e.bits & EV_REACH) != 0;
-                    o1 = e.o1;
-                    o2 = e.o2;
-                }
-            }
-            const unsigned long long m = __ballot(reach);
-            if (m) {                                                     // lowest lane = latest record
-                if (lane == __ffsll((long long)m) - 1) {
-                    const unsigned long long tag = (0x7fffffffull - (unsigned long long)c) << 32;
-                    atomicMax(&best[0], tag | (uint32_t)o1);
-                    atomicMax(&best[1], tag | (uint32_t)o2);
-                }
-                return;
-            }
-            if (chunk_end - (int64_t)(k + 1) * 64 <= 0) break;           // the slice starts inside this chunk (uniform)
-        }
-    }
-}
-
-__global__ void tail_decode_kernel(const unsigned long long* __restrict__ best, int32_t* __restrict__ tail) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long w0 = best[0], w1 = best[1];
-    tail[0] = w0 != 0ull ? 1 : 0;
-    tail[1] = (int32_t)(uint32_t)w0;
-    tail[2] = (int32_t)(uint32_t)w1;
-    tail[3] = 0;
-}
-
 __global__ void zero_tail_kernel(int32_t* tail) {
     if (threadIdx.x < 4) tail[threadIdx.x] = 0;
 }
@@ -1906,18 +1848,6 @@ int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size
 
 int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry) {
     hipLaunchKernelGGL(resolve_carry_kernel, dim3(1), dim3(64), 0, s, tails, rank, carry);
-    BESST_HIP_TRY(hipGetLastError());
-    return BESST_OK;
-}
-
-int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* tail, unsigned long long* scratch) {
-    BESST_HIP_TRY(hipMemsetAsync(scratch, 0, 16, s));
-    if (a.n > 0) {
-        const int64_t n_chunks = (a.n + kTailChunk - 1) / kTailChunk;
-        const uint32_t grid = (uint32_t)(n_chunks < kTailWaves ? n_chunks : kTailWaves);
-        hipLaunchKernelGGL(tail_search_kernel, dim3(grid), dim3(64), 0, s, a, scratch);
-    }
-    hipLaunchKernelGGL(tail_decode_kernel, dim3(1), dim3(64), 0, s, scratch, tail);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -250,7 +250,6 @@ int launch_candidate_density(hipStream_t s, int64_t n, const int32_t* tid, const
                              unsigned long long* counts);
 int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes);
 int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry);
-int launch_classify_tail_search(hipStream_t s, const ClassifyArgs& a, int32_t* tail, unsigned long long* scratch);
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,
                          uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* ws,
                          size_t ws_bytes, const uint8_t* cls8, int32_t n_contigs, int64_t* aligned,

@@ -74,6 +74,38 @@ def _all_reduce(x, group, op=dist.ReduceOp.SUM, async_op=False):
 
 
 RIDER_MAX_BYTES = 256 * 1024
+RECORD_BYTES = 23                # tid mtid pos mpos tlen i32, flag qlen u16, mapq u8
+
+
+def memory_budget(n_records, n_contigs, world, pair_capacity, tuple_capacity=None, coverage_mode='auto'):
+    """HBM bytes one rank needs for one library of a sharded build: what DeviceRecords, HipBackend and the exchange of
+    ShardedGraphBuild allocate, item by item, from the library's own workspace-size functions (no GPU needed).
+    bench.py --gpus N checks the total of its libraries against the free HBM before it allocates anything, and DESIGN.md
+    section 5 carries the table for BASELINE.json configs[3] / configs[4] on eight GPUs (tools/memory_budget.py)."""
+    from . import pipeline
+    lib = _lib.load()
+    n_records, n_contigs, world = int(n_records), int(n_contigs), int(world)
+    pair_cap = int(pair_capacity + (pair_capacity & 1))
+    recv_cap = pair_cap * world
+    part_cap = min(int(tuple_capacity), n_records) if tuple_capacity else n_records
+    sum_bytes = (n_contigs + 8) * 8
+    rider = sum_bytes if coverage_mode == 'rider' or (coverage_mode == 'auto' and sum_bytes <= RIDER_MAX_BYTES) else 0
+    region = int(lib.besst_dev_exchange_stride_bytes(pair_cap, rider))
+    rec_cap = max(1, n_records)
+    items = {
+        'records (8 columns, resident between get_metrics and PE)': n_records * RECORD_BYTES,
+        'contig table + coverage / counter state': int(lib.besst_dev_contig_table_bytes(n_contigs))
+                                                   + 2 * (n_contigs + (pipeline.COUNTER_BYTES + 32) // 8 + 2) * 8,
+        'tuple stream of the slice (key + payload per record slot)': rec_cap * 16,
+        'record-loop workspace (block segments, summaries)': int(lib.besst_dev_classify_workspace_bytes(rec_cap)),
+        'partition workspace': int(lib.besst_dev_reduce_workspace_bytes(part_cap)),
+        'all-to-all regions, send + receive (world x region each)': 2 * world * region,
+        'received tuples (key, payload, emit index)': recv_cap * 20,
+        'sort / reduce workspace of the owned tuples': int(lib.besst_dev_reduce_workspace_bytes(recv_cap)),
+        'edge rows + observations of the owned tuples': recv_cap * 48,
+    }
+    return {'items': items, 'total': int(sum(items.values())), 'pair_capacity': pair_cap, 'region_bytes': region,
+            'received_capacity': recv_cap}
 
 
 def device_records(wl, device):
@@ -127,7 +159,6 @@ class HipBackend(object):
         self.slice_info = torch.zeros(8, dtype=torch.int32, device=device)
         self.all_slice_info = torch.zeros(world * 8, dtype=torch.int32, device=device)
         self.heads_ride_exchange = False
-        self.tail_scratch = torch.zeros(2, dtype=torch.int64, device=device)
         self._args = {}
         self.rkeys = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
         self.rpayload = torch.empty(self.recv_cap, dtype=torch.int64, device=device)
@@ -171,15 +202,6 @@ class HipBackend(object):
         g = self.gb
         self._call('classify_tail', self.lib.besst_dev_classify_tail, lambda: (
             self.rec.n, self.pipeline._p(self.tail), self.pipeline._p(g.ws1), g.ws1.numel()))
-        return self.tail
-
-    def classify_tail_early(self, stream=None):
-        """The same tail from the record columns alone (backward search for the last reaching record): independent
-        of classify_scan, so the orchestration runs it - and the tail all-gather - on a side stream meanwhile."""
-        g, r, p = self.gb, self.rec, self.pipeline._p
-        self._call('classify_tail_search', self.lib.besst_dev_classify_tail_search, lambda: (
-            r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
-            g.n_contigs, p(g.table), C.byref(g.params), g.node_bits, p(self.tail), p(self.tail_scratch)), stream)
         return self.tail
 
     def classify_emit(self, tails):
@@ -290,20 +312,21 @@ class ShardedGraphBuild(object):
             backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
         self.backend = backend
         self._tails = None
-        self._side_stream = None
-        # How the 16-byte tails travel (see step()).  'late' is the default: on one GPU (RCCL, world = 1) the three
-        # variants are within 4 % of each other because the step is bound by the host's launch rate there; 'side'
-        # hides the gather behind the per-record pass and should win once the gather crosses xGMI, but that could
-        # not be measured on the single-GPU development box.
-        self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'exchange')   # 'exchange' | 'late' | 'side' | 'inline'
+        # How a slice learns the duplicate chain's state at its first record (see step()): 'exchange' (default) - it does
+        # not, the heads are resolved by the owners after the all-to-all; 'late' - an all-gather of the slices' 16-byte
+        # tails between the per-record pass and the emit stage (the fallback: one more collective on the critical path,
+        # nothing speculative).  Two more variants of round 2 - a backward search for the tail run before or beside the
+        # per-record pass - were never measurable across devices and have been removed.
+        self.tail_mode = os.environ.get('BESST_TAIL_MODE', 'exchange')   # 'exchange' | 'late'
+        if self.tail_mode not in ('exchange', 'late'):
+            raise ValueError("BESST_TAIL_MODE must be 'exchange' or 'late'")
         self._recv = None
         # BESST_ALLREDUCE_ASYNC=1: the coverage/counter all-reduce overlaps the tuple exchange and the sort on its own
         # communicator (so that it is not serialised behind the all-to-all); BESST_SIDE_GROUP=0 keeps even that on
         # the default communicator.  See step() for why the default is the plain in-order all-reduce.
         self.allreduce_async = os.environ.get('BESST_ALLREDUCE_ASYNC', '0') == '1'
         want_side = (dist.is_initialized() and group is None and os.environ.get('BESST_SIDE_GROUP', '1') != '0'
-                     and ((self.allreduce_async and not getattr(backend, 'sums_ride_exchange', False))
-                          or self.tail_mode == 'side'))
+                     and self.allreduce_async and not getattr(backend, 'sums_ride_exchange', False))
         self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
@@ -324,7 +347,8 @@ class ShardedGraphBuild(object):
     def step(self):
         b = self.backend
         b.reset()
-        mode = self.tail_mode if hasattr(b, 'classify_tail_early') else 'late'
+        device_backend = hasattr(b, 'classify_emit_speculative')
+        mode = self.tail_mode if device_backend else 'late'
         if mode == 'exchange':
             # No tail exchange at all: every slice emits with its first reaching record unresolved and describes it
             # in the headers of the all-to-all regions; the owners replay the chain over the slices, resolve the heads,
@@ -333,34 +357,7 @@ class ShardedGraphBuild(object):
             b.classify_scan()
             b.classify_emit_speculative()
             tails = None
-        elif mode == 'side':
-            # The tail of a slice is its last record that reaches CreateEdge - found by a backward search that is
-            # independent of the per-record pass - so the search and the tail all-gather run on a side stream while
-            # stream_kernel / ordered_kernel occupy the main one: the gather's latency is hidden.
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(b.device)
-                self._ev_main = torch.cuda.Event()
-                self._ev_side = torch.cuda.Event()
-            if self._tails is None:
-                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
-            main, side = torch.cuda.current_stream(b.device), self._side_stream
-            self._ev_main.record(main)                   # the previous step's stitch has read the old tails
-            side.wait_event(self._ev_main)
-            tail = b.classify_tail_early(stream=side)
-            with torch.cuda.stream(side):
-                _all_gather_into(self._tails, tail, self.side_group)
-            self._ev_side.record(side)
-            b.classify_scan()
-            main.wait_event(self._ev_side)
-            tails = self._tails
-        elif mode == 'inline':
-            if self._tails is None:
-                self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)
-            tail = b.classify_tail_early()
-            _all_gather_into(self._tails, tail, self.group)
-            b.classify_scan()
-            tails = self._tails
-        elif hasattr(b, 'classify_tail_early'):
+        elif device_backend:
             # 'late': the tail comes from the per-record pass's block summaries, the gather sits on the critical path
             if self._tails is None:
                 self._tails = torch.zeros(self.world * 4, dtype=torch.int32, device=b.device)

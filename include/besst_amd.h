@@ -358,10 +358,6 @@ int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n
  * besst_dev_classify_emit picks the incoming prev_obs of `rank` from the gathered tails (world x 4 int32; pass
  * NULL for a single slice) - the tail of the nearest earlier rank that has one, else what `carry` holds, i.e. the
  * prev_obs entering rank 0; besst_dev_resolve_carry does only that step.
- * besst_dev_classify_tail_search computes the same tail from the record columns alone (prev_obs is overwritten
- * by every record that reaches CreateEdge, so the tail is the slice's LAST reaching record: a backward search
- * that normally ends within a few hundred records), so it can run - and its all-gather can fly - on a side
- * stream while `scan` is busy; `scratch16` is 16 bytes of device memory.
  * Then tuples are stably partitioned by owner rank (besst_owner_of_scaffold of the key's min scaffold)
  * into `world` fixed-capacity regions for ONE equal-split all-to-all; besst_dev_unpack rebuilds an
  * ordered stream on the receiver with a global emit index per tuple (first_map of besst_dev_reduce)
@@ -373,11 +369,6 @@ int besst_dev_classify_scan(void* stream, int64_t n, const int32_t* tid, const i
                             int64_t* aligned, besst_counters* counters, void* workspace,
                             size_t workspace_bytes);
 int besst_dev_classify_tail(void* stream, int64_t n, int32_t* tail, void* workspace, size_t workspace_bytes);
-int besst_dev_classify_tail_search(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
-                                   const int32_t* pos, const int32_t* mpos, const uint16_t* flag,
-                                   const uint8_t* mapq, const uint16_t* qlen, int64_t n_contigs,
-                                   const void* contig_table, const besst_lib_params* h_params,
-                                   int32_t node_bits, int32_t* tail, void* scratch16);
 int besst_dev_resolve_carry(void* stream, const int32_t* tails, int32_t rank, int32_t* carry);
 int besst_dev_classify_emit(void* stream, int64_t n, int32_t detect_duplicate, int32_t* carry, uint64_t* keys,
                             uint64_t* payload, uint32_t* n_out, besst_counters* counters, void* workspace,

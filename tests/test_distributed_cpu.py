@@ -120,3 +120,23 @@ def test_two_rank_gloo_metrics_sample_matches_single_process_oracle():
         assert p.exitcode == 0
     got = sorted(out.get(timeout=5) for _ in range(WORLD))
     assert got[0][1:] == got[1][1:] and got[0][2] > 0
+
+
+def test_memory_budget_of_the_eight_gpu_configs():
+    """distributed.memory_budget (what bench.py --gpus N checks before allocating): C4 and C5 on
+    eight GPUs fit 288 GB of HBM with every library resident at once, and the budget grows with its inputs."""
+    from besst_amd import distributed, synth
+    for config, limit in (('C4', 40e9), ('C5', 150e9)):
+        cfg = synth.CONFIGS[config]
+        per_lib = cfg['pairs'] // len(cfg['libs']) // 8
+        total = 0
+        for spec in cfg['libs']:
+            tuples = int(2 * per_lib * (0.214 if spec.orientation == 'rf' else 0.014))
+            b = distributed.memory_budget(2 * per_lib, cfg['nc'], 8, int(tuples * 1.5 / 8) + 4096, int(tuples * 1.25) + 4096)
+            assert b['total'] == sum(b['items'].values()) and b['received_capacity'] == 8 * b['pair_capacity']
+            total += b['total']
+        assert total < limit < 288e9
+    small = distributed.memory_budget(1_000_000, 1000, 2, 10_000)['total']
+    assert distributed.memory_budget(2_000_000, 1000, 2, 10_000)['total'] > small
+    assert distributed.memory_budget(1_000_000, 1000, 2, 20_000)['total'] > small
+    assert distributed.memory_budget(1_000_000, 1000, 4, 10_000)['total'] > small

@@ -30,7 +30,7 @@ def _worker(rank, port, config, tail_mode, pair_cap, coverage, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['BESST_TAIL_MODE'] = tail_mode
-    os.environ['BESST_ALLREDUCE_ASYNC'] = '1' if tail_mode == 'inline' else '0'
+    os.environ['BESST_ALLREDUCE_ASYNC'] = '1' if coverage == 'allreduce' and tail_mode == 'late' else '0'
     os.environ['BESST_COVERAGE_EXCHANGE'] = coverage
     import torch
     import torch.distributed as dist
@@ -45,7 +45,7 @@ def _worker(rank, port, config, tail_mode, pair_cap, coverage, out):
         sub['batch'] = DU.split_batch(wl['batch'], WORLD)[rank]
         job = distributed.ShardedGraphBuild(dev, sub, rank, WORLD, pair_capacity=pair_cap)
         # the side communicator exists only where something runs beside the main one
-        assert (job.side_group is not job.group) == (tail_mode in ('side', 'inline'))
+        assert (job.side_group is not job.group) == (coverage == 'allreduce' and tail_mode == 'late')
         assert job.backend.sums_ride_exchange == (coverage != 'allreduce')
         for _ in range(2):
             job.step()
@@ -80,8 +80,8 @@ def _worker(rank, port, config, tail_mode, pair_cap, coverage, out):
 
 
 @pytest.mark.parametrize('config,tail_mode,pair_cap,coverage', [('C2', 'late', 16384, 'auto'),
-                                                                ('C3', 'side', 65536, 'rider'),
-                                                                ('C2', 'inline', 512, 'allreduce'),
+                                                                ('C3', 'late', 65536, 'rider'),
+                                                                ('C2', 'late', 512, 'allreduce'),
                                                                 ('C2', 'late', 512, 'rider'),
                                                                 ('C2', 'exchange', 16384, 'auto'),
                                                                 ('C3', 'exchange', 65536, 'allreduce'),
@@ -104,3 +104,20 @@ def test_two_processes_one_gpu(config, tail_mode, pair_cap, coverage):
     assert got[0][2] > 0
     if pair_cap == 512:
         assert got[0][1] > 512                            # the regions really grew
+
+
+def test_memory_budget_covers_what_a_rank_allocates():
+    """distributed.memory_budget against the allocator: records + HipBackend of one rank of a two-rank build."""
+    import torch
+    from besst_amd import distributed, workload
+    dev = torch.device('cuda', 0)
+    wl = workload.make('C3', 0, pairs=1_000_000, nc=2000)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    before = torch.cuda.memory_allocated(dev)
+    backend = distributed.HipBackend(dev, wl, 0, 2, 150_000, 500_000)
+    recv = torch.empty_like(backend.send)                # ShardedGraphBuild's receive buffer
+    used = torch.cuda.memory_allocated(dev) - before
+    budget = distributed.memory_budget(len(wl['batch']), wl['asm'].nc, 2, 150_000, 500_000)
+    assert 0.9 * used <= budget['total'] <= 1.15 * used, (used, budget)
+    del backend, recv

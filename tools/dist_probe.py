@@ -29,17 +29,8 @@ recv = torch.empty_like(b.send)
 timed('reset', b.reset)
 timed('classify_scan', b.classify_scan)
 timed('classify_tail', b.classify_tail)
-timed('classify_tail_early', b.classify_tail_early)
 flat = torch.zeros(4, dtype=torch.int32, device=dev)
 timed('all_gather_into_tensor', lambda: dist.all_gather_into_tensor(flat, b.tail))
-side = torch.cuda.Stream(dev)
-def hop():
-    main = torch.cuda.current_stream(dev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        b.classify_tail_early()
-    main.wait_stream(side)
-timed('side-stream hop', hop)
 timed('all_gather(16B)', lambda: dist.all_gather(tails, b.tail))
 timed('classify_emit', lambda: b.classify_emit(flat))
 timed('all_reduce(80KB)', lambda: dist.all_reduce(b.pack_for_allreduce()))
