@@ -119,7 +119,8 @@ def verify_full(runner, wl):
     keys, payload, aligned, c_ctr = CO.record_loop(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
     C_PORT_TIMING['seconds'] = time.perf_counter() - t0
     C_PORT_TIMING['records'] = len(wl['batch'])
-    cores = os.cpu_count() or 1
+    from besst_amd._lib import effective_cpus
+    cores = effective_cpus()                             # (affinity and cgroup quota: not the machine's CPU count)
     best = None
     for _ in range(2):                                   # the first call pays thread start-up and page faults
         t0 = time.perf_counter()
@@ -212,18 +213,7 @@ def dropin_timing(device, config, pairs=None, contigs=None):
     p.information_file = io.StringIO(); p.output_directory = tempfile.mkdtemp(prefix='besst_amd_')
     p.contig_index = dict(enumerate(batch.references))
 
-    class SeqLen(object):                                # PE only takes len() of a contig's sequence and stores it
-        __slots__ = ('n',)
-
-        def __init__(self, n):
-            self.n = n
-
-        def __len__(self):
-            return self.n
-
-        def __getitem__(self, k):                        # a contig filtered for low coverage is written out as FASTA
-            return 'N' * len(range(*k.indices(self.n))) if isinstance(k, slice) else 'N'
-    C_dict = {name: SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
+    C_dict = {name: _SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
     dev_mod.CALL_SECONDS = {}
     t0 = time.perf_counter()
     libmetrics.get_metrics(batch, p, p.information_file)
@@ -238,6 +228,70 @@ def dropin_timing(device, config, pairs=None, contigs=None):
             'library_s': round(sum(lib_s.values()), 3), 'library_calls_s': {k: round(v, 3) for k, v in lib_s.items()},
             'host_share': round(1.0 - sum(lib_s.values()) / total, 3), 'edges_G': G.number_of_edges(),
             'edges_G_prime': Gp.number_of_edges(), 'pairs_per_s': (len(batch) // 2) / total}
+
+
+def bam_to_graph_timing(device, config, pairs=None):
+    """BAM bytes -> scored graphs, everything included (SURVEY 8(f) rank 1 + the path): the config's stream is written as
+    a BAM file (native writer, untimed scaffolding; /dev/shm when there is one), then timed: bamio.ResidentBam - the
+    library's reader inflating and decoding on host threads into pinned staging, chunk k's copies under chunk k + 1's
+    decode - followed by libmetrics.get_metrics and CreateGraph.PE on the resident records."""
+    import io
+    import shutil
+    import tempfile
+    from besst_amd import CreateGraph, Parameter, _lib, bamio, libmetrics, session, workload
+    wl = workload.make_device(device, config, 0, pairs=pairs)
+    batch = wl['batch']
+    del wl['cols']
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > 64 * len(batch) else None
+    tmp = tempfile.mkdtemp(prefix='besst_amd_bam_', dir=base)
+    path = os.path.join(tmp, 'lib.bam')
+    cores = _lib.effective_cpus()
+    try:
+        t0 = time.perf_counter()
+        bamio.write_bam(path, batch)
+        write_s = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        p = Parameter.parameter()
+        p.scaffold_indexer = 1; p.min_mapq = 11; p.lower_cov_cutoff = 0.001; p.cov_cutoff = None; p.first_lib = True
+        p.orientation = wl['lib']['orientation']; p.detect_duplicate = True; p.extend_paths = True; p.no_score = False
+        p.detect_haplotype = False; p.print_scores = False; p.max_contig_overlap = 200; p.pass_number = 1
+        p.information_file = io.StringIO(); p.output_directory = tmp
+        p.contig_index = dict(enumerate(batch.references))
+        C_dict = {name: _SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
+        n_rec = len(batch)
+        del batch, wl
+        threads = bamio.reader_threads()
+        t0 = time.perf_counter()
+        bam = bamio.ResidentBam(path, threads=threads, chunk_records=4 << 20)
+        t1 = time.perf_counter()
+        libmetrics.get_metrics(bam, p, p.information_file)
+        t2 = time.perf_counter()
+        G, Gp = CreateGraph.PE({}, {}, p.information_file, C_dict, p, {}, {}, bam)
+        t3 = time.perf_counter()
+        st = bam.ingest
+        session.close_session(bam)
+        return {'records': n_rec, 'pairs_of_the_config': 'all' if pairs is None else '%d (a slice)' % pairs, 'bam_bytes': size, 'reader_threads': threads, 'usable_cpus': cores, 'machine_cpus': os.cpu_count(),
+                'write_bam_s_untimed': round(write_s, 2), 'ingest_s': round(t1 - t0, 3),
+                'ingest_records_per_s': n_rec / (t1 - t0), 'ingest_compressed_GBps': round(size / (t1 - t0) / 1e9, 2),
+                'ingest_decode_s': round(st.decode_seconds, 3), 'ingest_copy_wait_s': round(st.copy_wait_seconds, 3),
+                'ingest_chunks': int(st.chunks), 'h2d_bytes': int(st.bytes_h2d),
+                'get_metrics_s': round(t2 - t1, 3), 'PE_s': round(t3 - t2, 3), 'total_s': round(t3 - t0, 3),
+                'pairs_per_s': (n_rec // 2) / (t3 - t0), 'edges_G': G.number_of_edges(), 'edges_G_prime': Gp.number_of_edges()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+class _SeqLen(object):                                   # PE only takes len() of a contig's sequence and stores it
+    __slots__ = ('n',)
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, k):                            # a contig filtered for low coverage is written out as FASTA
+        return 'N' * len(range(*k.indices(self.n))) if isinstance(k, slice) else 'N'
 
 
 def linearize_workload(n_scaf, n_edges, seed=20240929):
@@ -255,6 +309,17 @@ def linearize_workload(n_scaf, n_edges, seed=20240929):
     pool = np.array([0.0, 0.5, 0.8, 1.0, 1.0, 1.25, 2.0])
     score = np.where(rng.random(a.shape[0]) < 0.5, rng.choice(pool, a.shape[0]), np.round(rng.random(a.shape[0]) * 2, 2))
     return a, b, score.astype(np.float64)
+
+
+def _host_memory_gib():
+    try:
+        with open('/proc/meminfo') as fh:
+            for line in fh:
+                if line.startswith('MemAvailable:'):
+                    return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
 
 
 def linearize_timing(n_scaf=2_000_000, n_edges=3_000_000):
@@ -644,6 +709,19 @@ def main_single(args, device, result_fd):
         out['stages']['dropin_' + args.config.lower()] = dropin_timing(device, args.config, args.pairs, args.contigs)
         if args.also and args.also != args.config and args.pairs is None:
             out['stages']['dropin_' + args.also.lower()] = dropin_timing(device, args.also)
+        if args.pairs is None:
+            # BAM bytes -> graphs: C2 always, the headline config when the host has the memory for its 400 M-record file
+            for cfg_name in ([args.also] if args.also else []) + [args.config]:
+                # (the headline config as a quarter of its pairs: writing and reading back a 400 M-record BAM file would
+                # double the run time of the default bench on a host limited to 16 CPUs)
+                big = cfg_name not in ('C1', 'C2')
+                if big and _host_memory_gib() < 64:
+                    continue
+                try:
+                    out['stages']['bam_to_graph_' + cfg_name.lower()] = bam_to_graph_timing(
+                        device, cfg_name, pairs=50_000_000 if big else None)
+                except Exception as e:                       # noqa: BLE001 - the bench line must still be printed
+                    out['stages']['bam_to_graph_' + cfg_name.lower()] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
     if args.also and args.also != args.config and args.pairs is None:
         C_PORT_TIMING.clear()
         res2, wl2, runner2 = measure_single(args, device, args.also, 20, 3, 3)
@@ -727,7 +805,8 @@ def verify_sharded_vs_oracle(job, wl, rank, world, device, backend_name):
     b = job.backend
     cpu = torch.device('cpu')
     coll_dev = cpu if backend_name == 'gloo' else device
-    threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    from besst_amd._lib import effective_cpus
+    threads = max(1, effective_cpus() // max(1, world))
     batch, table, lib, nb = wl['batch'], wl['table'], wl['lib'], wl['node_bits']
     keys, payload, aligned, ctr = CO.record_loop(batch, table, lib, nb, threads=threads)
     tails = torch.zeros(world, 3, dtype=torch.int64, device=coll_dev)

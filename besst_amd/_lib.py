@@ -39,9 +39,43 @@ class Counters(C.Structure):
                 ('prev_obs1', C.c_int32), ('prev_obs2', C.c_int32)]
 
 
+class IngestStats(C.Structure):      # include/besst_amd.h: besst_ingest_stats
+    _fields_ = [('records', C.c_int64), ('chunks', C.c_int64), ('bytes_h2d', C.c_int64), ('seconds', C.c_double),
+                ('decode_seconds', C.c_double), ('copy_wait_seconds', C.c_double)]
+
+
 class MetricsCounts(C.Structure):
     _fields_ = [('n_isize', C.c_int64), ('n_contam', C.c_int64), ('counter_total', C.c_int64),
                 ('sample_counter', C.c_int64), ('records_scanned', C.c_int64)]
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down by the cgroup's CFS quota when there is one
+    (cpu.max / cpu.cfs_quota_us).  os.cpu_count() reports the machine - on a container limited to 16 CPUs of a 256-CPU
+    host, 128 busy threads get the whole group throttled for most of every scheduling period (the BAM reader ran at a
+    third of its 32-thread rate there)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:                       # cgroup v2: "<quota|max> <period>"
+            q, period = fh.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fq, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fp:
+                q, period = float(fq.read()), float(fp.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
 
 
 _P = C.c_void_p
@@ -60,6 +94,7 @@ _SIGNATURES = {
     'besst_ctx_set_library': (C.c_int, [_P, C.POINTER(LibParams)]),
     'besst_ctx_clear_records': (C.c_int, [_P]),
     'besst_ctx_push_records': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_ctx_push_bam': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(IngestStats)]),
     'besst_ctx_metrics_sample': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P,
                                            C.POINTER(MetricsCounts)]),
     'besst_ctx_value_histogram': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
@@ -81,6 +116,8 @@ _SIGNATURES = {
     'besst_bam_reference_name': (C.c_char_p, [_P, C.c_int64]),
     'besst_bam_reference_lengths': (C.c_int, [_P, _P]),
     'besst_bam_read_records': (C.c_int64, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_bam_write_records': (C.c_int, [C.c_char_p, C.c_int64, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          C.c_int, C.c_int]),
     'besst_dev_classify_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_reduce_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_contig_table_bytes': (C.c_size_t, [C.c_int64]),

@@ -12,11 +12,78 @@ from . import _lib
 from .records import RecordBatch
 
 
+def reader_threads():
+    """Workers of the reader's pool: twice the CPUs the process may use (_lib.effective_cpus: affinity and cgroup quota -
+    a worker blocked in a page fault leaves its share unused), at most 128."""
+    return min(128, 2 * _lib.effective_cpus())
+
+
+def _open(lib, path, threads):
+    handle = lib.besst_bam_open(os.fsencode(path), int(threads))
+    if not handle:
+        raise IOError('cannot read BAM %s: %s' % (path, _lib.last_error()))
+    n_ref = lib.besst_bam_n_references(handle)
+    names = [lib.besst_bam_reference_name(handle, i).decode() for i in range(n_ref)]
+    lengths = np.zeros(max(n_ref, 1), dtype=np.int32)
+    _lib.check(lib.besst_bam_reference_lengths(handle, _lib.ptr(lengths)), 'bam_reference_lengths')
+    return handle, names, lengths[:n_ref].tolist()
+
+
+class ResidentBam(object):
+    """A BAM file whose records went straight to HBM (besst_ctx_push_bam: decode on host threads, pinned staging, copies
+    under the next chunk's decode) - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
+    on the host needs the record columns.  It carries what the host side of those two does read: the header
+    (``references``, ``lengths``), the record count (``len()``) and ``rlen`` / ``alen`` / ``qlen`` of the first 1000
+    records (the read-length step, libmetrics.py:246-273); ``ctx`` is the GraphContext that holds the records and
+    ``ingest`` the timings of the upload."""
+
+    def __init__(self, path, device_index=0, threads=None, chunk_records=4 << 20):
+        from . import device
+        lib = _lib.load()
+        threads = threads or reader_threads()
+        handle, self.references, self.lengths = _open(lib, path, threads)
+        self.path = path
+        self.ctx = device.GraphContext(device_index)
+        try:
+            zeros = [0] * len(self.references)
+            self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
+            self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records)
+            clamped = lib.besst_bam_clamped_records(handle)
+        except Exception:
+            self.ctx.close()
+            raise
+        finally:
+            lib.besst_bam_close(handle)
+        self._n = int(self.ingest.records)
+        if clamped > 0:
+            import warnings
+            warnings.warn('%s: %d record(s) align more than 65535 query bases; their qlen is stored as 65535' % (path, clamped))
+
+    def __len__(self):
+        return self._n
+
+    def close(self):
+        self.ctx.close()
+
+
+def write_bam(path, batch, threads=None, level=1):
+    """Test / bench scaffolding (besst_bam_write_records): the batch as a BAM file in htslib's block layout."""
+    import ctypes as C
+    lib = _lib.load()
+    names = (C.c_char_p * len(batch.references))(*[n.encode() for n in batch.references])
+    lengths = np.ascontiguousarray(batch.lengths, dtype=np.int32)
+    rlen = batch.rlen if batch.rlen is not None else batch.qlen
+    cols = [_lib.as_col(batch.tid, np.int32), _lib.as_col(batch.mtid, np.int32), _lib.as_col(batch.pos, np.int32),
+            _lib.as_col(batch.mpos, np.int32), _lib.as_col(batch.tlen, np.int32), _lib.as_col(batch.flag, np.uint16),
+            _lib.as_col(batch.mapq, np.uint8), _lib.as_col(batch.qlen, np.uint16), _lib.as_col(rlen, np.int32)]
+    _lib.check(lib.besst_bam_write_records(os.fsencode(path), len(batch.references), names, _lib.ptr(lengths), len(batch),
+                                           *[_lib.ptr(c) for c in cols], int(threads or reader_threads()),
+                                           int(level)), 'bam_write_records')
+
+
 def read_bam(path, threads=None, chunk_records=8_000_000):
     lib = _lib.load()
-    # inflate, the record walk and the column fill are block/record parallel; beyond ~32-64 threads waking the pool
-    # costs more than it buys (76 M records/s at 64 threads, 18 M at 256 on the 256-core bench host)
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or reader_threads()
     handle = lib.besst_bam_open(os.fsencode(path), int(threads))
     if not handle:
         raise IOError('cannot read BAM %s: %s' % (path, _lib.last_error()))

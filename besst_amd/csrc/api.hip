@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -351,6 +353,142 @@ int besst_ctx_push_records(besst_ctx* c, int64_t n, const int32_t* tid, const in
     BESST_HIP_TRY(hipStreamSynchronize(c->stream));   // caller may reuse its host buffers
     c->n_records += n;
     c->built = false;
+    return BESST_OK;
+}
+
+// Reserve room for `total` records in every column (one reallocation + device copy instead of a chain of them).
+static int reserve_records(besst_ctx* c, int64_t total) {
+    const int64_t have = c->n_records;
+    auto grow = [&](auto& buf) -> int {
+        using T = typename std::remove_reference<decltype(*buf.p)>::type;
+        if ((size_t)total <= buf.cap) return BESST_OK;
+        DevBuf<T> bigger;
+        int rc = bigger.ensure((size_t)total);
+        if (rc) return rc;
+        if (have) BESST_HIP_TRY(hipMemcpyAsync(bigger.p, buf.p, (size_t)have * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+        buf.release();
+        buf = bigger;
+        return BESST_OK;
+    };
+    int rc;
+    if ((rc = grow(c->tid)) || (rc = grow(c->mtid)) || (rc = grow(c->pos)) || (rc = grow(c->mpos)) || (rc = grow(c->tlen)) ||
+        (rc = grow(c->flag)) || (rc = grow(c->mapq)) || (rc = grow(c->qlen)))
+        return rc;
+    return BESST_OK;
+}
+
+// BAM file -> resident records, streamed: chunks of the file are inflated and decoded by the reader's host threads into
+// one of two sets of PINNED staging columns while the previous chunk's eight asynchronous copies are still on their way
+// to HBM - decode and upload overlap, no pageable copy, no host-side concatenation of the whole stream.
+int besst_ctx_push_bam(besst_ctx* c, besst_bam* bam, int64_t chunk_records, int64_t head_records, int32_t* head_rlen,
+                       int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
+    BESST_REQUIRE(c && bam, "push_bam: null context or reader");
+    BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)), "push_bam: head buffers missing");
+    if (chunk_records <= 0) chunk_records = (int64_t)4 << 20;
+    if (chunk_records < 1024) chunk_records = 1024;
+    int rc = use_device(c);
+    if (rc) return rc;
+    const auto t_start = std::chrono::steady_clock::now();
+    struct Slot {
+        int32_t *tid = nullptr, *mtid = nullptr, *pos = nullptr, *mpos = nullptr, *tlen = nullptr;
+        uint16_t *flag = nullptr, *qlen = nullptr;
+        uint8_t* mapq = nullptr;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } slot[2];
+    std::vector<int32_t> rlen((size_t)chunk_records), alen((size_t)chunk_records);
+    auto release = [&]() {
+        for (Slot& sl : slot) {
+            void* ptrs[8] = {sl.tid, sl.mtid, sl.pos, sl.mpos, sl.tlen, sl.flag, sl.qlen, sl.mapq};
+            for (void* q : ptrs) if (q) (void)hipHostFree(q);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            sl = Slot();
+        }
+    };
+    auto pinned = [&](void** out, size_t bytes) { return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess; };
+    bool ok = true;
+    for (Slot& sl : slot) {
+        const size_t m = (size_t)chunk_records;
+        ok = ok && pinned((void**)&sl.tid, m * 4) && pinned((void**)&sl.mtid, m * 4) && pinned((void**)&sl.pos, m * 4) &&
+             pinned((void**)&sl.mpos, m * 4) && pinned((void**)&sl.tlen, m * 4) && pinned((void**)&sl.flag, m * 2) &&
+             pinned((void**)&sl.qlen, m * 2) && pinned((void**)&sl.mapq, m) && hipEventCreate(&sl.done) == hipSuccess;
+    }
+    if (!ok) {
+        release();
+        set_error("push_bam: cannot allocate pinned staging buffers (2 x %lld records)", (long long)chunk_records);
+        return BESST_ERR_NOMEM;
+    }
+    double decode_s = 0.0, wait_s = 0.0;
+    int64_t pushed = 0, chunks = 0, bytes = 0;
+    const int64_t file_bytes = bam_file_bytes(bam);
+    rc = BESST_OK;
+    for (int k = 0;; k ^= 1) {
+        Slot& sl = slot[k];
+        if (sl.busy) {                                       // the copies that last used this slot
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(sl.done) != hipSuccess) { set_error("push_bam: a host-to-device copy failed"); rc = BESST_ERR_HIP; break; }
+            wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            sl.busy = false;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        const int64_t got = besst_bam_read_records(bam, chunk_records, sl.tid, sl.mtid, sl.pos, sl.mpos, sl.tlen, sl.flag, sl.mapq,
+                                                   sl.qlen, rlen.data(), alen.data());
+        decode_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (got < 0) { rc = (int)-got; break; }              // (the reader has set the error text)
+        if (got == 0) break;
+        for (int64_t i = 0; i < got && pushed + i < head_records; ++i) {
+            head_rlen[pushed + i] = rlen[(size_t)i];
+            head_alen[pushed + i] = alen[(size_t)i];
+            head_qlen[pushed + i] = sl.qlen[i];
+        }
+        const int64_t have = c->n_records + pushed;
+        if (have + got >= ((int64_t)1 << 32)) { set_error("more than 2^32-1 records in one context"); rc = BESST_ERR_ARG; break; }
+        if ((size_t)(have + got) > c->tid.cap) {
+            // room for the whole file at the rate of the bytes read so far (+ 6 %), at least for this chunk
+            const int64_t at = bam_file_position(bam);
+            int64_t want = have + got;
+            if (file_bytes > 0 && at > 0 && at < file_bytes)
+                want = c->n_records + (int64_t)((double)(pushed + got) * ((double)file_bytes / (double)at) * 1.06) + 4096;
+            if (want < have + got) want = have + got;
+            if (want >= ((int64_t)1 << 32)) want = ((int64_t)1 << 32) - 1;
+            const int64_t keep = c->n_records;
+            c->n_records = have;                             // what reserve_records has to carry over
+            rc = reserve_records(c, want);
+            c->n_records = keep;
+            if (rc) break;
+        }
+        const size_t m = (size_t)got;
+        hipError_t e = hipSuccess;
+        auto up = [&](void* dst, const void* src, size_t nbytes) {
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, c->stream);
+            bytes += (int64_t)nbytes;
+        };
+        up(c->tid.p + have, sl.tid, m * 4); up(c->mtid.p + have, sl.mtid, m * 4); up(c->pos.p + have, sl.pos, m * 4);
+        up(c->mpos.p + have, sl.mpos, m * 4); up(c->tlen.p + have, sl.tlen, m * 4); up(c->flag.p + have, sl.flag, m * 2);
+        up(c->mapq.p + have, sl.mapq, m); up(c->qlen.p + have, sl.qlen, m * 2);
+        if (e == hipSuccess) e = hipEventRecord(sl.done, c->stream);
+        if (e != hipSuccess) { set_error("push_bam: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; break; }
+        sl.busy = true;
+        pushed += got;
+        ++chunks;
+    }
+    const auto tw = std::chrono::steady_clock::now();
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    release();
+    if (rc == BESST_OK && es != hipSuccess) { set_error("push_bam: %s", hipGetErrorString(es)); rc = BESST_ERR_HIP; }
+    if (rc) return rc;
+    c->n_records += pushed;
+    c->built = false;
+    if (stats) {
+        stats->records = pushed;
+        stats->chunks = chunks;
+        stats->bytes_h2d = bytes;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        stats->decode_seconds = decode_s;
+        stats->copy_wait_seconds = wait_s;
+    }
     return BESST_OK;
 }
 

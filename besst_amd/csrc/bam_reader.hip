@@ -10,11 +10,18 @@
 //   alen = reference_length        (CIGAR M/D/N/=/X; 0 when there is no CIGAR)
 // Supplementary / secondary records are passed through unfiltered, like the reference does.
 //
-// BGZF blocks are independent deflate streams of <= 64 KiB: a batch of 1024 blocks is read sequentially and
-// inflated by a persistent pool of threads (libdeflate when the shared object is present, zlib otherwise).  The
-// records - which may straddle block boundaries - are then located by one cheap sequential walk over their
-// length prefixes and decoded into the columns by the same pool, each thread a contiguous range of records.
+// BGZF blocks are independent deflate streams of <= 64 KiB.  The file is mapped; a batch of 4096 blocks is located by
+// walking the block headers in the mapping (two cache lines per block, no copy) and inflated straight out of it by a
+// persistent pool of threads (libdeflate when the shared object is present, zlib otherwise), each worker also walking
+// the block it has just inflated as if it began with a record (htslib never lets a record straddle a block).  The
+// sequential part is then one step per BLOCK - the speculative offsets of a block are the true ones where the walk
+// arrives exactly at its first byte, records of other layouts are located one by one - and the columns are filled by
+// the same pool, a block (or a run of loose records) per task.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -148,7 +155,7 @@ class Pool {
     bool stop_ = false;
 };
 
-constexpr size_t kBatchBlocks = 1024;      // <= 64 MiB of inflated bytes per batch
+constexpr size_t kBatchBlocks = 4096;      // <= 256 MiB of inflated bytes per batch: two pool dispatches per ~1.3 M records
 
 // Byte buffer whose resize() does not zero-fill (std::vector's value-initialisation of every 64 MiB batch was a
 // third of the single-thread read time).
@@ -198,23 +205,28 @@ uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 }  // namespace
 
 struct besst_bam {
-    FILE* fp = nullptr;
+    int fd = -1;
+    const uint8_t* map = nullptr;    // the whole file
+    size_t map_len = 0;
+    size_t file_off = 0;             // first byte of the next BGZF block
     int n_threads = 1;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lengths;
     Bytes inflated;                  // undecoded tail + freshly inflated bytes
     size_t cursor = 0;               // next undecoded byte in `inflated`
     bool eof = false;
-    Bytes raw;                       // compressed batch
     std::string error;
     Pool* pool = nullptr;
     double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0;   // seconds per phase (BESST_BAM_PROFILE=1 prints them)
     std::vector<void*> ld_ctx;       // one libdeflate decompressor per worker
-    std::vector<size_t> rec_off;     // offsets (into `inflated`) of the records located by the last walk
     std::vector<BlockRecs> brecs;    // speculative per-block walks of the current batch, in stream order
     std::vector<uint32_t> blk_offs;
     size_t next_brec = 0;            // first block whose start is >= cursor
     int64_t n_clamped = 0;           // records whose aligned query length was saturated at 65535
+    // the plan of one decode dispatch: whole blocks (their speculative offsets) and runs of loose records
+    struct Seg { size_t block; size_t first, count; int64_t out; };   // block == SIZE_MAX: loose[first .. first + count)
+    std::vector<Seg> plan;
+    std::vector<size_t> loose;
 
     // Inflate the next batch of BGZF blocks and append to `inflated` (after dropping consumed bytes).
     bool fill(size_t want_blocks) {
@@ -226,14 +238,13 @@ struct besst_bam {
         next_brec = 0;
         if (eof) return true;
         const auto tp0 = std::chrono::steady_clock::now();
-        raw.clear();
         std::vector<Block> blocks;
+        blocks.reserve(want_blocks);
         size_t dst_total = inflated.size();
         for (size_t b = 0; b < want_blocks; ++b) {
-            uint8_t hdr[18];
-            const size_t got = fread(hdr, 1, 18, fp);
-            if (got == 0) { eof = true; break; }
-            if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) {
+            if (file_off == map_len) { eof = true; break; }
+            const uint8_t* hdr = map + file_off;
+            if (map_len - file_off < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) {
                 error = "not a BGZF block (bad gzip header)";
                 return false;
             }
@@ -244,16 +255,15 @@ struct besst_bam {
                 return false;
             }
             const size_t bsize = (size_t)le16(hdr + 16) + 1;
+            if (bsize < 18 || map_len - file_off < bsize) { error = "truncated BGZF block"; return false; }
             const size_t rest = bsize - 18;
-            const size_t at = raw.size();
-            raw.resize(at + rest);
-            if (fread(raw.data() + at, 1, rest, fp) != rest) { error = "truncated BGZF block"; return false; }
             const size_t extra_left = xlen - 6;
             if (rest < extra_left + 8) { error = "corrupt BGZF block"; return false; }
             const size_t payload = rest - extra_left - 8;
-            const uint32_t isize = le32(raw.data() + at + rest - 4);
-            blocks.push_back(Block{at + extra_left, payload, dst_total, isize});
+            const uint32_t isize = le32(hdr + bsize - 4);
+            blocks.push_back(Block{file_off + 18 + extra_left, payload, dst_total, isize});
             dst_total += isize;
+            file_off += bsize;
         }
         inflated.resize(dst_total);
         brecs.resize(blocks.size());
@@ -268,7 +278,7 @@ struct besst_bam {
             br.stop = br.start;
             br.count = 0;
             if (k.dst_len == 0) return;           // the empty EOF marker block
-            if (!inflate_raw(raw.data() + k.src_off, k.src_len, inflated.data() + k.dst_off, k.dst_len,
+            if (!inflate_raw(map + k.src_off, k.src_len, inflated.data() + k.dst_off, k.dst_len,
                              ld_ctx.empty() ? nullptr : ld_ctx[(size_t)worker])) {
                 ok = false;
                 return;
@@ -306,11 +316,19 @@ extern "C" {
 
 besst_bam* besst_bam_open(const char* path, int n_threads) {
     if (!path) { besst::set_error("bam_open: null path"); return nullptr; }
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { besst::set_error("bam_open: cannot open %s", path); return nullptr; }
-    setvbuf(fp, nullptr, _IOFBF, 8 << 20);      // the block headers are read with 18-byte freads
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { besst::set_error("bam_open: cannot open %s", path); return nullptr; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); besst::set_error("bam_open: %s is not a regular file", path); return nullptr; }
     besst_bam* b = new besst_bam();
-    b->fp = fp;
+    b->fd = fd;
+    b->map_len = (size_t)st.st_size;
+    if (b->map_len) {
+        void* m = mmap(nullptr, b->map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete b; besst::set_error("bam_open: cannot map %s", path); return nullptr; }
+        (void)madvise(m, b->map_len, MADV_SEQUENTIAL);
+        b->map = static_cast<const uint8_t*>(m);
+    }
     b->n_threads = n_threads > 0 ? n_threads : 1;
     b->pool = new Pool(b->n_threads);
     if (libdeflate().ok())
@@ -341,7 +359,8 @@ besst_bam* besst_bam_open(const char* path, int n_threads) {
 
 void besst_bam_close(besst_bam* b) {
     if (!b) return;
-    if (b->fp) fclose(b->fp);
+    if (b->map) munmap(const_cast<uint8_t*>(b->map), b->map_len);
+    if (b->fd >= 0) close(b->fd);
     delete b->pool;
     for (void* c : b->ld_ctx) libdeflate().free_(c);
     delete b;
@@ -373,14 +392,16 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
     }
     int64_t n = 0;
     while (n < max_records) {
-        // ---- sequential walk: locate the complete records available in the inflated bytes
+        // ---- sequential part: one step per block (or per loose record) up to the call's quota
         if (!b->need(4)) break;
         const auto tw0 = std::chrono::steady_clock::now();
-        b->rec_off.clear();
+        b->plan.clear();
+        b->loose.clear();
         size_t cur = b->cursor;
+        int64_t planned = 0;
         bool bad = false;
         for (;;) {
-            const size_t quota = (size_t)(max_records - n) - b->rec_off.size();
+            const size_t quota = (size_t)(max_records - n - planned);
             if (quota == 0) break;
             while (b->next_brec < b->brecs.size() && b->brecs[b->next_brec].start < cur) ++b->next_brec;
             if (b->next_brec < b->brecs.size() && b->brecs[b->next_brec].start == cur && b->brecs[b->next_brec].count) {
@@ -388,9 +409,8 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
                 const BlockRecs& br = b->brecs[b->next_brec];
                 const uint32_t* offs = b->blk_offs.data() + b->next_brec * kMaxBlockRecs;
                 const size_t take = br.count < quota ? br.count : quota;
-                const size_t at = b->rec_off.size();
-                b->rec_off.resize(at + take);
-                for (size_t i = 0; i < take; ++i) b->rec_off[at + i] = br.start + offs[i];
+                b->plan.push_back(besst_bam::Seg{b->next_brec, 0, take, n + planned});
+                planned += (int64_t)take;
                 cur = take == br.count ? br.stop : br.start + offs[take];
                 continue;
             }
@@ -398,11 +418,16 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
             const uint32_t block_size = le32(b->inflated.data() + cur);
             if (block_size < 32) { bad = true; break; }
             if (b->inflated.size() - cur < 4 + (size_t)block_size) break;
-            b->rec_off.push_back(cur);
+            if (!b->plan.empty() && b->plan.back().block == SIZE_MAX && b->plan.back().count < 1024)
+                ++b->plan.back().count;                      // (runs of up to 1024 loose records per task)
+            else
+                b->plan.push_back(besst_bam::Seg{SIZE_MAX, b->loose.size(), 1, n + planned});
+            b->loose.push_back(cur);
+            ++planned;
             cur += 4 + (size_t)block_size;
         }
         if (bad) { besst::set_error("bam_read_records: corrupt record"); return -BESST_ERR_ARG; }
-        if (b->rec_off.empty()) {
+        if (planned == 0) {
             // the next record straddles the batch: pull more blocks (need() fails at a truncated file)
             const uint32_t block_size = le32(b->inflated.data() + b->cursor);
             if (!b->need(4 + (size_t)block_size)) {
@@ -411,80 +436,83 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
             }
             continue;
         }
-        // ---- parallel decode, a contiguous range of records per task
+        // ---- parallel decode, a block (or a run of loose records) per task
         const auto tw1 = std::chrono::steady_clock::now();
-        const size_t m = b->rec_off.size();
-        const size_t n_tasks = m < 4096 ? 1 : (size_t)b->pool->size() * 4;
         std::atomic<bool> corrupt(false);
         std::atomic<int64_t> clamped(0);
         const uint8_t* base = b->inflated.data();
-        const size_t* offs = b->rec_off.data();
-        b->pool->parallel_for(n_tasks, [&](size_t task, int) {
-            const size_t i0 = m * task / n_tasks, i1 = m * (task + 1) / n_tasks;
-            for (size_t i = i0; i < i1; ++i) {
-                const uint8_t* r = base + offs[i] + 4;
-                const uint32_t block_size = le32(base + offs[i]);
-                const size_t o = (size_t)n + i;
-                tid[o] = (int32_t)le32(r);
-                pos[o] = (int32_t)le32(r + 4);
-                const uint32_t l_read_name = r[8];
-                mapq[o] = r[9];
-                const uint32_t n_cigar = le16(r + 12);
-                flag[o] = le16(r + 14);
-                const uint32_t l_seq = le32(r + 16);
-                mtid[o] = (int32_t)le32(r + 20);
-                mpos[o] = (int32_t)le32(r + 24);
-                tlen[o] = (int32_t)le32(r + 28);
-                if (32 + l_read_name + 4ull * n_cigar > block_size) { corrupt = true; return; }
-                const uint8_t* cg = r + 32 + l_read_name;
-                // pysam 0.8.4's AlignedRead properties, which is what the reference reads (CreateGraph.py:138 qlen;
-                // libmetrics.py:258-262 rlen / alen):
-                //   qlen = query_alignment_length = qend - qstart, qstart = the leading soft clips (hard clips in front
-                //          of them skipped), qend = l_seq - or, for a record without sequence, the M/I/S/=/X total of
-                //          the CIGAR - minus the trailing soft clips.  A record WITHOUT a CIGAR (BWA's unmapped read
-                //          placed at its mate) therefore has qlen = l_seq, and the reference does add it to the
-                //          coverage of the contig it is placed on (mapq 0 passes the test of CreateGraph.py:138-139).
-                //   alen = reference_length = the M/D/N/=/X total (None -> 0 without a CIGAR)
-                // The CG:B,I long-CIGAR convention postdates that pysam: the placeholder <l_seq>S<n>N is read as it stands.
-                int64_t q_total = 0, ref_len = 0, lead = 0, trail = 0;
-                bool in_lead = true;
-                for (uint32_t c = 0; c < n_cigar; ++c) {
-                    const uint32_t v = le32(cg + 4 * c);
-                    const uint32_t op = v & 15u, len = v >> 4;
-                    // M=0 I=1 D=2 N=3 S=4 H=5 P=6 '='=7 X=8
-                    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q_total += len;
-                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += len;
-                    if (in_lead) {
-                        if (op == 4) lead += len;
-                        else if (op != 5) in_lead = false;
-                    }
+        auto decode = [&](const uint8_t* rec, size_t o) {
+            const uint8_t* r = rec + 4;
+            const uint32_t block_size = le32(rec);
+            tid[o] = (int32_t)le32(r);
+            pos[o] = (int32_t)le32(r + 4);
+            const uint32_t l_read_name = r[8];
+            mapq[o] = r[9];
+            const uint32_t n_cigar = le16(r + 12);
+            flag[o] = le16(r + 14);
+            const uint32_t l_seq = le32(r + 16);
+            mtid[o] = (int32_t)le32(r + 20);
+            mpos[o] = (int32_t)le32(r + 24);
+            tlen[o] = (int32_t)le32(r + 28);
+            if (32 + l_read_name + 4ull * n_cigar > block_size) { corrupt = true; return; }
+            const uint8_t* cg = r + 32 + l_read_name;
+            // pysam 0.8.4's AlignedRead properties, which is what the reference reads (CreateGraph.py:138 qlen;
+            // libmetrics.py:258-262 rlen / alen):
+            //   qlen = query_alignment_length = qend - qstart, qstart = the leading soft clips (hard clips in front
+            //          of them skipped), qend = l_seq - or, for a record without sequence, the M/I/S/=/X total of
+            //          the CIGAR - minus the trailing soft clips.  A record WITHOUT a CIGAR (BWA's unmapped read
+            //          placed at its mate) therefore has qlen = l_seq, and the reference does add it to the
+            //          coverage of the contig it is placed on (mapq 0 passes the test of CreateGraph.py:138-139).
+            //   alen = reference_length = the M/D/N/=/X total (None -> 0 without a CIGAR)
+            // The CG:B,I long-CIGAR convention postdates that pysam: the placeholder <l_seq>S<n>N is read as it stands.
+            int64_t q_total = 0, ref_len = 0, lead = 0, trail = 0;
+            bool in_lead = true;
+            for (uint32_t c = 0; c < n_cigar; ++c) {
+                const uint32_t v = le32(cg + 4 * c);
+                const uint32_t op = v & 15u, len = v >> 4;
+                // M=0 I=1 D=2 N=3 S=4 H=5 P=6 '='=7 X=8
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q_total += len;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += len;
+                if (in_lead) {
+                    if (op == 4) lead += len;
+                    else if (op != 5) in_lead = false;
                 }
-                for (uint32_t c = n_cigar; c-- > 1;) {      // (pysam's getQueryEnd never looks at the first operation)
-                    const uint32_t v = le32(cg + 4 * c);
-                    const uint32_t op = v & 15u, len = v >> 4;
-                    if (op == 4) trail += len;
-                    else if (op != 5) break;
-                }
-                int64_t q_aln = (l_seq ? (int64_t)l_seq : q_total) - lead - trail;
-                if (q_aln < 0) q_aln = 0;                    // a CIGAR of clips only: pysam gives a negative length
-                if (q_aln > 65535) {                         // the qlen column is 16 bits wide, like RecordBatch's: saturate
-                    q_aln = 65535;                           // and count (besst_bam_clamped_records) - paired short reads
-                    clamped.fetch_add(1, std::memory_order_relaxed);   // never get near, one long alignment must not
-                }                                            // make the file unreadable
-                qlen[o] = (uint16_t)q_aln;
-                rlen[o] = (int32_t)l_seq;
-                alen[o] = (int32_t)ref_len;
+            }
+            for (uint32_t c = n_cigar; c-- > 1;) {          // (pysam's getQueryEnd never looks at the first operation)
+                const uint32_t v = le32(cg + 4 * c);
+                const uint32_t op = v & 15u, len = v >> 4;
+                if (op == 4) trail += len;
+                else if (op != 5) break;
+            }
+            int64_t q_aln = (l_seq ? (int64_t)l_seq : q_total) - lead - trail;
+            if (q_aln < 0) q_aln = 0;                        // a CIGAR of clips only: pysam gives a negative length
+            if (q_aln > 65535) {                             // the qlen column is 16 bits wide, like RecordBatch's: saturate
+                q_aln = 65535;                               // and count (besst_bam_clamped_records) - paired short reads
+                clamped.fetch_add(1, std::memory_order_relaxed);   // never get near, one long alignment must not
+            }                                                // make the file unreadable
+            qlen[o] = (uint16_t)q_aln;
+            rlen[o] = (int32_t)l_seq;
+            alen[o] = (int32_t)ref_len;
+        };
+        b->pool->parallel_for(b->plan.size(), [&](size_t task, int) {
+            const besst_bam::Seg& sg = b->plan[task];
+            if (sg.block == SIZE_MAX) {
+                for (size_t i = 0; i < sg.count; ++i) decode(base + b->loose[sg.first + i], (size_t)sg.out + i);
+            } else {
+                const BlockRecs& br = b->brecs[sg.block];
+                const uint32_t* offs = b->blk_offs.data() + sg.block * kMaxBlockRecs;
+                for (size_t i = 0; i < sg.count; ++i) decode(base + br.start + offs[sg.first + i], (size_t)sg.out + i);
             }
         });
         if (corrupt.load()) { besst::set_error("bam_read_records: corrupt record"); return -BESST_ERR_ARG; }
         b->n_clamped += clamped.load();
         b->cursor = cur;
-        n += (int64_t)m;
+        n += planned;
         const auto tw2 = std::chrono::steady_clock::now();
         b->t_walk += std::chrono::duration<double>(tw1 - tw0).count();
         b->t_decode += std::chrono::duration<double>(tw2 - tw1).count();
     }
-    if (getenv("BESST_BAM_PROFILE"))
+    if (const char* e = getenv("BESST_BAM_PROFILE"); e && atoi(e))
         fprintf(stderr, "[bam] read %.3f s  inflate %.3f s  walk %.3f s  decode %.3f s (cumulative, %d threads)\n",
                 b->t_read, b->t_inflate, b->t_walk, b->t_decode, b->n_threads);
     if (n == 0 && !b->error.empty()) {
@@ -494,4 +522,129 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
     return n;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Test / bench scaffolding: write record columns as a BAM file with htslib's block layout (a block is flushed before a
+ * record that would not fit, so every block starts with a record).  Per record: name "r<index>", CIGAR [clip S] qlen M
+ * with clip = rlen - qlen, rlen bases and qualities - qlen / rlen / alen round-trip through besst_bam_read_records.
+ * Blocks are built and deflated by n_threads workers.  Nothing in the graph path calls this.
+ * --------------------------------------------------------------------------------------------------------------- */
+int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* ref_names, const int32_t* ref_lengths,
+                            int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos, const int32_t* mpos,
+                            const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                            const int32_t* rlen, int n_threads, int level) {
+    BESST_REQUIRE(path && n_ref >= 0 && n >= 0 && (n_ref == 0 || (ref_names && ref_lengths)), "bam_write_records: bad argument");
+    BESST_REQUIRE(n == 0 || (tid && mtid && pos && mpos && tlen && flag && mapq && qlen && rlen), "bam_write_records: null column");
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { besst::set_error("bam_write_records: cannot create %s", path); return BESST_ERR_ARG; }
+    auto put32 = [](std::vector<uint8_t>& v, uint32_t x) { for (int k = 0; k < 4; ++k) v.push_back((uint8_t)(x >> (8 * k))); };
+    auto bgzf = [&](const uint8_t* data, size_t len, std::vector<uint8_t>& out) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        std::vector<uint8_t> payload(deflateBound(&zs, (uLong)len) + 16);
+        zs.next_in = const_cast<Bytef*>(data);
+        zs.avail_in = (uInt)len;
+        zs.next_out = payload.data();
+        zs.avail_out = (uInt)payload.size();
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t plen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END || plen + 26 > 65536) return false;
+        const uint32_t bsize = (uint32_t)plen + 25;
+        const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)bsize, (uint8_t)(bsize >> 8)};
+        out.assign(head, head + 18);
+        out.insert(out.end(), payload.begin(), payload.begin() + (long)plen);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)len);
+        for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(crc >> (8 * k)));
+        for (int k = 0; k < 4; ++k) out.push_back((uint8_t)((uint32_t)len >> (8 * k)));
+        return true;
+    };
+    // header: blocks of its own
+    std::vector<uint8_t> hdr;
+    const char text[] = "@HD\tVN:1.0\tSO:coordinate\n";
+    hdr.insert(hdr.end(), {'B', 'A', 'M', 1});
+    put32(hdr, (uint32_t)(sizeof(text) - 1));
+    hdr.insert(hdr.end(), text, text + sizeof(text) - 1);
+    put32(hdr, (uint32_t)n_ref);
+    for (int64_t r = 0; r < n_ref; ++r) {
+        const size_t l = strlen(ref_names[r]) + 1;
+        put32(hdr, (uint32_t)l);
+        hdr.insert(hdr.end(), ref_names[r], ref_names[r] + l);
+        put32(hdr, (uint32_t)ref_lengths[r]);
+    }
+    bool ok = true;
+    std::vector<uint8_t> blk;
+    for (size_t off = 0; off < hdr.size() && ok; off += 60000) {
+        const size_t len = hdr.size() - off < 60000 ? hdr.size() - off : 60000;
+        ok = bgzf(hdr.data() + off, len, blk) && fwrite(blk.data(), 1, blk.size(), fp) == blk.size();
+    }
+    // records: sizes -> block boundaries (sequential, arithmetic only) -> blocks built and deflated in parallel, in
+    // groups that are written out in order
+    auto name_len = [](int64_t i) { size_t l = 3; for (int64_t v = i; v >= 10; v /= 10) ++l; return l; };   // 'r' digits NUL
+    auto rec_bytes = [&](int64_t i) {
+        const size_t q = qlen[i], sl = (size_t)(rlen[i] > 0 ? rlen[i] : 0);
+        const size_t clip = sl > q ? sl - q : 0;
+        return 4 + 32 + name_len(i) + 4 * ((clip ? 1 : 0) + (q ? 1 : 0)) + (sl + 1) / 2 + sl;
+    };
+    std::vector<int64_t> first;                              // first record of every block
+    {
+        size_t fill = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t b = rec_bytes(i);
+            if (first.empty() || fill + b > 60000) { first.push_back(i); fill = 0; }
+            fill += b;
+        }
+        first.push_back(n);
+    }
+    const size_t n_blocks = first.size() - 1;
+    Pool pool(n_threads > 0 ? n_threads : 1);
+    const size_t group = 4096;
+    std::vector<std::vector<uint8_t>> outs(group);
+    std::atomic<bool> good(true);
+    for (size_t g0 = 0; g0 < n_blocks && ok; g0 += group) {
+        const size_t g1 = g0 + group < n_blocks ? g0 + group : n_blocks;
+        pool.parallel_for(g1 - g0, [&](size_t k, int) {
+            std::vector<uint8_t> raw;
+            raw.reserve(61000);
+            for (int64_t i = first[g0 + k]; i < first[g0 + k + 1]; ++i) {
+                const uint32_t q = qlen[i], sl = (uint32_t)(rlen[i] > 0 ? rlen[i] : 0);
+                const uint32_t clip = sl > q ? sl - q : 0;
+                const uint32_t n_cig = (clip ? 1u : 0u) + (q ? 1u : 0u);
+                char nm[24];
+                const int nl = snprintf(nm, sizeof(nm), "r%lld", (long long)i) + 1;
+                put32(raw, (uint32_t)(rec_bytes(i) - 4));
+                put32(raw, (uint32_t)tid[i]);
+                put32(raw, (uint32_t)pos[i]);
+                raw.push_back((uint8_t)nl);
+                raw.push_back(mapq[i]);
+                raw.push_back(0x48); raw.push_back(0x12);    // bin 4680
+                raw.push_back((uint8_t)n_cig); raw.push_back(0);
+                raw.push_back((uint8_t)flag[i]); raw.push_back((uint8_t)(flag[i] >> 8));
+                put32(raw, sl);
+                put32(raw, (uint32_t)mtid[i]);
+                put32(raw, (uint32_t)mpos[i]);
+                put32(raw, (uint32_t)tlen[i]);
+                raw.insert(raw.end(), nm, nm + nl);
+                if (clip) put32(raw, (clip << 4) | 4u);
+                if (q) put32(raw, (q << 4) | 0u);
+                raw.insert(raw.end(), (sl + 1) / 2, (uint8_t)0x11);
+                raw.insert(raw.end(), sl, (uint8_t)0xff);
+            }
+            if (!bgzf(raw.data(), raw.size(), outs[k])) good = false;
+        });
+        if (!good.load()) { ok = false; break; }
+        for (size_t k = 0; k < g1 - g0 && ok; ++k) ok = fwrite(outs[k].data(), 1, outs[k].size(), fp) == outs[k].size();
+    }
+    if (ok) ok = bgzf(nullptr, 0, blk) && fwrite(blk.data(), 1, blk.size(), fp) == blk.size();    // the EOF marker block
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) { besst::set_error("bam_write_records: writing %s failed", path); return BESST_ERR_ARG; }
+    return BESST_OK;
+}
+
 }  // extern "C"
+
+namespace besst {
+// for besst_ctx_push_bam (api.hip): how far the reader is through its file
+int64_t bam_file_bytes(besst_bam* b) { return b ? (int64_t)b->map_len : 0; }
+int64_t bam_file_position(besst_bam* b) { return b ? (int64_t)b->file_off : 0; }
+}  // namespace besst

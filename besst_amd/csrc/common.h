@@ -29,6 +29,13 @@ void set_error(const char* fmt, ...);
         }                                        \
     } while (0)
 
+// ---- the BAM reader's position in its file (bam_reader.hip), for the streamed ingest of api.hip
+}  // namespace besst
+struct besst_bam;
+namespace besst {
+int64_t bam_file_bytes(besst_bam* b);
+int64_t bam_file_position(besst_bam* b);
+
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {
     // one slot per kernel (or per group of kernels that always run back to back): the names besst_prof_slot_name returns

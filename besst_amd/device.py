@@ -118,6 +118,20 @@ class GraphContext(object):
         n = cols[0].shape[0]
         _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
 
+    @_timed
+    def push_bam(self, handle, chunk_records=0, head_records=1000):
+        """Stream an open besst_bam (bamio) into the context: decode on the reader's host threads, pinned staging,
+        asynchronous copies under the next chunk's decode.  -> (IngestStats, head rlen, head alen, head qlen)."""
+        from ._lib import IngestStats
+        stats = IngestStats()
+        rlen = np.zeros(head_records, dtype=np.int32)
+        alen = np.zeros(head_records, dtype=np.int32)
+        qlen = np.zeros(head_records, dtype=np.uint16)
+        _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),
+                                                _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats)), 'push_bam')
+        k = min(head_records, stats.records)
+        return stats, rlen[:k], alen[:k], qlen[:k]
+
     # ---- library statistics ----------------------------------------------------------------------
     @_timed
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):

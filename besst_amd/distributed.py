@@ -74,7 +74,7 @@ def _all_reduce(x, group, op=dist.ReduceOp.SUM, async_op=False):
 
 
 RIDER_MAX_BYTES = 256 * 1024
-RECORD_BYTES = 23                # tid mtid pos mpos tlen i32, flag qlen u16, mapq u8
+RECORD_BYTES = 25                # tid mtid pos mpos tlen i32, flag qlen u16, mapq u8
 
 
 def memory_budget(n_records, n_contigs, world, pair_capacity, tuple_capacity=None, coverage_mode='auto'):

@@ -26,6 +26,14 @@ class Session(object):
         self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
         self.ctx.push_records(batch)
 
+    @classmethod
+    def resident(cls, bam):
+        """Session over a bamio.ResidentBam: its records are in HBM already, in its own context."""
+        self = cls.__new__(cls)
+        self.batch = bam
+        self.ctx = bam.ctx
+        return self
+
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize):
         return self.ctx.metrics_sample(top_mask, orientation, min_mapq, read_len, want_isize)
 
@@ -45,8 +53,10 @@ def open_session(bam_file, device_index=0):
             sess = entry[1]
     if sess is not None:
         return sess
-    batch = RecordBatch.from_pysam_like(bam_file)
-    sess = Session(batch, device_index)
+    if hasattr(bam_file, 'ingest') and hasattr(bam_file, 'ctx'):          # bamio.ResidentBam
+        sess = Session.resident(bam_file)
+    else:
+        sess = Session(RecordBatch.from_pysam_like(bam_file), device_index)
     try:
         _sessions[bam_file] = sess
     except TypeError:

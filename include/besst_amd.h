@@ -149,6 +149,24 @@ int besst_ctx_push_records(besst_ctx* ctx, int64_t n, const int32_t* tid, const 
                            const int32_t* pos, const int32_t* mpos, const int32_t* tlen,
                            const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen);
 
+/* The same from a BAM file, streamed (replaces `pysam.Samfile(param.bamfile, 'rb')` + the iteration of runBESST:162,
+ * CreateGraph.py:111, libmetrics.py:63,257,293): the reader's host threads inflate and decode chunk k + 1 into pinned
+ * staging columns while chunk k's asynchronous copies travel to HBM.  `bam` is an open besst_bam (below) positioned at
+ * its first unread record; reads to the end of the file.  The first head_records records' rlen / alen / qlen - all
+ * libmetrics' read-length step looks at (libmetrics.py:246-273: 1000 records) - are returned in the head_* arrays.
+ * chunk_records <= 0 picks 4 Mi records (two staging sets of 19 B per record). */
+typedef struct besst_bam besst_bam;
+typedef struct {
+    int64_t records;             /* records appended to the context */
+    int64_t chunks;
+    int64_t bytes_h2d;
+    double seconds;              /* wall time of the call */
+    double decode_seconds;       /* of which the calling thread spent in the reader (inflate + record decode) */
+    double copy_wait_seconds;    /* and blocked on copies that had not finished */
+} besst_ingest_stats;
+int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, int64_t head_records, int32_t* head_rlen,
+                       int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
+
 /* libmetrics sampling (replaces the three `for read in bam_file` scans, libmetrics.py:63,257,293).
  * top_mask[tid] != 0 marks the 1000 longest references.  orientation/min_mapq/read_len as in
  * besst_lib_params.  isize_out / contam_out receive |tlen| of the qualifying records in stream order
@@ -206,7 +224,6 @@ int besst_ctx_score_edges(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, 
  * libmetrics.py:63,257,293.  qlen = query_alignment_length, rlen = query_length, alen = reference_length
  * (pysam 0.8 attribute names).  n_threads inflate workers (libdeflate if present, else zlib).
  * ---------------------------------------------------------------------------------------------- */
-typedef struct besst_bam besst_bam;
 besst_bam* besst_bam_open(const char* path, int n_threads);
 void besst_bam_close(besst_bam* bam);
 int64_t besst_bam_n_references(const besst_bam* bam);
@@ -218,6 +235,12 @@ int64_t besst_bam_clamped_records(const besst_bam* bam);
 int64_t besst_bam_read_records(besst_bam* bam, int64_t max_records, int32_t* tid, int32_t* mtid, int32_t* pos,
                                int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen,
                                int32_t* rlen, int32_t* alen);
+/* Test / bench scaffolding, not part of the graph path: the columns as a BAM file in htslib's block layout (name
+ * "r<index>", CIGAR [clip S] qlen M, rlen bases) - what tests and bench.py read back through the reader above. */
+int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* ref_names, const int32_t* ref_lengths,
+                            int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos, const int32_t* mpos,
+                            const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,
+                            const int32_t* rlen, int n_threads, int level);
 
 /* ------------------------------------------------------------------------------------------------
  * Host float finishing of libmetrics (no GPU): the statistics on the <= 1,000,000 sampled insert sizes,

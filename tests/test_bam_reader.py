@@ -60,3 +60,22 @@ def test_hand_assembled_bam(name, threads, chunk):
     for i, r in enumerate(want['records']):
         for col in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen', 'rlen', 'alen'):
             assert int(getattr(got, col)[i]) == r[col], (r['name'], r['cigar'], col, int(getattr(got, col)[i]), r[col])
+
+
+@pytest.mark.parametrize('threads', [1, 5])
+def test_native_writer_agrees_with_the_python_writer(threads):
+    """besst_bam_write_records (bench / test scaffolding, parallel deflate) lays the records out as tests/bam_writer.py
+    does with align_records=True: both files inflate to the same bytes, and both read back to the batch."""
+    import gzip
+    asm = synth.make_assembly(80, 1500, 41)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 500.0, 50.0), 7000, 42)
+    batch.rlen[::7] = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        a, b = os.path.join(tmp, 'native.bam'), os.path.join(tmp, 'python.bam')
+        bamio.write_bam(a, batch, threads=threads, level=6)
+        bam_writer.write_bam(b, batch, align_records=True)
+        with gzip.open(a, 'rb') as fa, gzip.open(b, 'rb') as fb:     # BGZF is a series of gzip members
+            assert fa.read() == fb.read()
+        got = bamio.read_bam(a, threads=3, chunk_records=1000)
+    for col in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen', 'rlen'):
+        assert np.array_equal(getattr(got, col), getattr(batch, col)), col

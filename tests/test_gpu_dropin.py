@@ -146,6 +146,45 @@ def test_dropin_from_bam_file(name, tmp_path):
     assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
 
 
+@pytest.mark.parametrize('name,chunk', [('fr_infer', 4096), ('rf_contam', 1024), ('fr_edgecases', 1 << 22)])
+def test_dropin_from_streamed_bam(name, chunk, tmp_path):
+    """BAM file -> besst_ctx_push_bam (decode on host threads, pinned staging, copies under the next chunk's decode; small
+    chunks: many of them, the columns grow on the way) -> get_metrics + PE on the resident records: metrics, graphs and
+    object dicts as the reference's goldens, no host record columns anywhere."""
+    from besst_amd import bamio
+    doc, batch = GU.load(name)
+    path = str(tmp_path / 'mapped.bam')
+    bamio.write_bam(path, batch, threads=3)
+    bam = bamio.ResidentBam(path, threads=4, chunk_records=chunk)
+    assert len(bam) == len(batch) and bam.ingest.chunks == -(-len(batch) // max(1024, chunk))
+    assert bam.ingest.bytes_h2d == 25 * len(batch)
+    param = make_param(doc['overrides'])
+    info = param.information_file
+    libmetrics.get_metrics(bam, param, info)
+    for k, want in doc['metrics'].items():
+        if k == 'empirical_distribution':
+            ed = getattr(param, 'empirical_distribution', None)
+            got = None if ed is None else [ed[i] for i in range(len(ed))]
+        else:
+            got = getattr(param, k, None)
+        assert got == want, (name, k)
+    lens = dict(zip(batch.references, batch.lengths))
+    C_dict = {n: 'A' * int(lens.get(n, 10)) for n in doc['fasta_names']}
+    Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+    G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, bam)
+    session.close_session(bam)
+    fin = doc['final']
+    assert edge_rows(G, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G']]
+    assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
+    # (rf_contam's stream carries a few records whose rlen disagrees with their qlen - inputs of the read-length step -, and
+    # a BAM record has ONE sequence length: their coverage does not survive the file)
+    cov = (lambda c: None) if name == 'rf_contam' else (lambda c: c.coverage)
+    assert [[c.name, c.scaffold, cov(c)] for c in Contigs.values()] == [[n, sc, cov(Contigs[n])] for n, sc, _ in fin['contigs']]
+    if name != 'rf_contam':
+        assert [[c.name, c.scaffold, c.coverage] for c in Contigs.values()] == fin['contigs']
+    assert list(Scaffolds) == fin['scaffolds'] and list(small_scaffolds) == fin['small_scaffolds']
+
+
 def test_cli_end_to_end(tmp_path):
     """FASTA + BAM on disk -> besst_amd.cli -> scored edge table, equal to the reference golden."""
     from besst_amd import cli
