@@ -18,6 +18,9 @@ class BesstDeviceError(RuntimeError):
     pass
 
 
+ERR_UNSUPPORTED = 5     # include/besst_amd.h: BESST_ERR_UNSUPPORTED
+
+
 class LibParams(C.Structure):
     _fields_ = [('read_len', C.c_double), ('ins_size_threshold', C.c_double), ('min_mapq', C.c_int32),
                 ('orientation', C.c_int32), ('detect_duplicate', C.c_int32), ('extend_paths', C.c_int32),
@@ -41,7 +44,8 @@ class Counters(C.Structure):
 
 class IngestStats(C.Structure):      # include/besst_amd.h: besst_ingest_stats
     _fields_ = [('records', C.c_int64), ('chunks', C.c_int64), ('bytes_h2d', C.c_int64), ('seconds', C.c_double),
-                ('decode_seconds', C.c_double), ('copy_wait_seconds', C.c_double)]
+                ('decode_seconds', C.c_double), ('copy_wait_seconds', C.c_double), ('inflated_bytes', C.c_int64),
+                ('blocks', C.c_int64), ('on_device', C.c_int32), ('reserved', C.c_int32)]
 
 
 class MetricsCounts(C.Structure):
@@ -94,7 +98,11 @@ _SIGNATURES = {
     'besst_ctx_set_library': (C.c_int, [_P, C.POINTER(LibParams)]),
     'besst_ctx_clear_records': (C.c_int, [_P]),
     'besst_ctx_push_records': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'besst_ctx_record_count': (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    'besst_ctx_fetch_records': (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_ctx_push_bam': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(IngestStats)]),
+    'besst_ctx_push_bam_device': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(IngestStats)]),
+    'besst_bgzf_inflate_device': (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     'besst_ctx_metrics_sample': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P,
                                            C.POINTER(MetricsCounts)]),
     'besst_ctx_value_histogram': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),

@@ -30,14 +30,15 @@ def _open(lib, path, threads):
 
 
 class ResidentBam(object):
-    """A BAM file whose records went straight to HBM (besst_ctx_push_bam: decode on host threads, pinned staging, copies
-    under the next chunk's decode) - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
+    """A BAM file whose records went straight to HBM - besst_ctx_push_bam_device: the compressed file is uploaded and
+    inflated + decoded on the GPU (files in htslib's block layout); else besst_ctx_push_bam: decode on host threads, pinned
+    staging, copies under the next chunk's decode; ``mode`` as in GraphContext.push_bam - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
     on the host needs the record columns.  It carries what the host side of those two does read: the header
     (``references``, ``lengths``), the record count (``len()``) and ``rlen`` / ``alen`` / ``qlen`` of the first 1000
     records (the read-length step, libmetrics.py:246-273); ``ctx`` is the GraphContext that holds the records and
     ``ingest`` the timings of the upload."""
 
-    def __init__(self, path, device_index=0, threads=None, chunk_records=4 << 20):
+    def __init__(self, path, device_index=0, threads=None, chunk_records=4 << 20, mode=None, chunk_blocks=0):
         from . import device
         lib = _lib.load()
         threads = threads or reader_threads()
@@ -47,7 +48,7 @@ class ResidentBam(object):
         try:
             zeros = [0] * len(self.references)
             self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
-            self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records)
+            self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records, mode=mode, chunk_blocks=chunk_blocks)
             clamped = lib.besst_bam_clamped_records(handle)
         except Exception:
             self.ctx.close()
@@ -64,6 +65,18 @@ class ResidentBam(object):
 
     def close(self):
         self.ctx.close()
+
+
+def inflate_bgzf_device(data, device_index=0, out_cap=None):
+    """Test hook: the BGZF blocks of ``data`` (bytes) inflated by the GPU kernel, concatenated."""
+    import ctypes as C
+    lib = _lib.load()
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(out_cap if out_cap is not None else max(1, 66 * len(data)), dtype=np.uint8)
+    n = C.c_size_t(0)
+    _lib.check(lib.besst_bgzf_inflate_device(int(device_index), _lib.ptr(src), len(data), _lib.ptr(out), out.size, C.byref(n)),
+               'bgzf_inflate_device')
+    return out[:n.value].tobytes()
 
 
 def write_bam(path, batch, threads=None, level=1):

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <type_traits>
 #include <vector>
@@ -356,6 +357,35 @@ int besst_ctx_push_records(besst_ctx* c, int64_t n, const int32_t* tid, const in
     return BESST_OK;
 }
 
+int besst_ctx_record_count(besst_ctx* c, int64_t* n) {
+    BESST_REQUIRE(c && n, "null pointer");
+    *n = c->n_records;
+    return BESST_OK;
+}
+
+int besst_ctx_fetch_records(besst_ctx* c, int64_t first, int64_t n, int32_t* tid, int32_t* mtid, int32_t* pos, int32_t* mpos,
+                            int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen) {
+    BESST_REQUIRE(c, "null context");
+    BESST_REQUIRE(first >= 0 && n >= 0 && first + n <= c->n_records, "fetch_records: range outside the resident records");
+    if (n == 0) return BESST_OK;
+    int rc = use_device(c);
+    if (rc) return rc;
+    auto down = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    };
+    const size_t m = (size_t)n;
+    BESST_HIP_TRY(down(tid, c->tid.p + first, m * 4));
+    BESST_HIP_TRY(down(mtid, c->mtid.p + first, m * 4));
+    BESST_HIP_TRY(down(pos, c->pos.p + first, m * 4));
+    BESST_HIP_TRY(down(mpos, c->mpos.p + first, m * 4));
+    BESST_HIP_TRY(down(tlen, c->tlen.p + first, m * 4));
+    BESST_HIP_TRY(down(flag, c->flag.p + first, m * 2));
+    BESST_HIP_TRY(down(mapq, c->mapq.p + first, m));
+    BESST_HIP_TRY(down(qlen, c->qlen.p + first, m * 2));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
+}
+
 // Reserve room for `total` records in every column (one reallocation + device copy instead of a chain of them).
 static int reserve_records(besst_ctx* c, int64_t total) {
     const int64_t have = c->n_records;
@@ -482,6 +512,7 @@ int besst_ctx_push_bam(besst_ctx* c, besst_bam* bam, int64_t chunk_records, int6
     c->n_records += pushed;
     c->built = false;
     if (stats) {
+        memset(stats, 0, sizeof(*stats));
         stats->records = pushed;
         stats->chunks = chunks;
         stats->bytes_h2d = bytes;
@@ -489,6 +520,346 @@ int besst_ctx_push_bam(besst_ctx* c, besst_bam* bam, int64_t chunk_records, int6
         stats->decode_seconds = decode_s;
         stats->copy_wait_seconds = wait_s;
     }
+    return BESST_OK;
+}
+
+// ---- BAM ingest on the GPU (bgzf_gpu.hip) ----------------------------------------------------------------------------
+namespace {
+
+// The BGZF blocks of [*fpos, ...) that fit one chunk: descriptors with offsets relative to the chunk's first byte,
+// inflated places 256-byte aligned.  Stops at max_blocks, at comp_cap compressed bytes, or at the end of the file.
+// false: not a BGZF block where one should be.
+bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t max_blocks, size_t comp_cap, BgzfBlock* out,
+                     uint32_t* n_out, size_t* comp_bytes, size_t* inflated_bytes) {
+    auto le16 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); };
+    auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    const size_t begin = *fpos;
+    size_t at = begin, dst = 0;
+    uint32_t n = 0;
+    while (n < max_blocks && at < map_len) {
+        const uint8_t* hdr = map + at;
+        if (map_len - at < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return false;
+        const uint32_t xlen = le16(hdr + 10);
+        if (xlen < 6 || hdr[12] != 'B' || hdr[13] != 'C' || le16(hdr + 14) != 2) return false;
+        const size_t bsize = (size_t)le16(hdr + 16) + 1;
+        if (bsize < 18 || map_len - at < bsize) return false;
+        const size_t rest = bsize - 18, extra_left = xlen - 6;
+        if (rest < extra_left + 8) return false;
+        if (at + bsize - begin > comp_cap) {
+            if (n == 0) return false;                        // (a block is at most 64 KiB: the cap is far larger)
+            break;
+        }
+        const uint32_t isize = le32(hdr + bsize - 4);
+        if (isize > 65536u) return false;
+        BgzfBlock& b = out[n++];
+        b.src_off = (uint32_t)(at + 18 + extra_left - begin);
+        b.src_len = (uint32_t)(rest - extra_left - 8);
+        b.dst_off_lo = (uint32_t)dst;
+        b.dst_off_hi = (uint32_t)((uint64_t)dst >> 32);
+        b.dst_len = isize;
+        b.pad = 0;
+        dst += align_up((size_t)isize, 256);
+        at += bsize;
+    }
+    *fpos = at;
+    *n_out = n;
+    *comp_bytes = at - begin;
+    *inflated_bytes = dst;
+    return true;
+}
+
+}  // namespace
+
+// BAM file -> resident records with the inflate and the record decode on the GPU: the file's COMPRESSED bytes are staged
+// through pinned memory (copied off the mapping by the reader's threads) and uploaded chunk by chunk; per chunk one wave
+// per BGZF block inflates, one lane per block walks its records, a scan places them and a thread per record fills the
+// columns.  Chunk j + 1 is staged and uploaded while chunk j inflates.  For files in htslib's layout (every block begins
+// with a record); anything else - and any block the device cannot inflate - returns BESST_ERR_UNSUPPORTED with context and
+// reader untouched, and the caller takes besst_ctx_push_bam.
+int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
+                              int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
+    BESST_REQUIRE(c && bam, "push_bam_device: null context or reader");
+    BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)),
+                  "push_bam_device: head buffers missing");
+    if (chunk_blocks <= 0) chunk_blocks = 16384;
+    if (chunk_blocks < 64) chunk_blocks = 64;
+    if (chunk_blocks > 65536) chunk_blocks = 65536;
+    int rc = use_device(c);
+    if (rc) return rc;
+    const auto t_start = std::chrono::steady_clock::now();
+    int64_t f0 = 0;
+    uint32_t u0 = 0;
+    if (!bam_record_position(bam, &f0, &u0)) {
+        set_error("push_bam_device: the reader is inside a record that straddles two batches");
+        return BESST_ERR_UNSUPPORTED;
+    }
+    const uint8_t* map = bam_file_map(bam);
+    const size_t map_len = (size_t)bam_file_bytes(bam);
+    const size_t nb = (size_t)chunk_blocks;
+    const size_t comp_cap = std::max<size_t>((size_t)128 << 20, nb * 8192);
+    const size_t desc_bytes = align_up(nb * sizeof(BgzfBlock), 4096);
+    const size_t slot_bytes = desc_bytes + comp_cap + 4096;      // (the bit reader's windows run up to 512 bytes past a payload)
+    struct Chunk { uint32_t n_blocks = 0, first_off = 0; size_t comp = 0, inflated = 0; };
+    char* pin[2] = {nullptr, nullptr};
+    char* dev[2] = {nullptr, nullptr};
+    uint8_t* inflated = nullptr;
+    uint16_t* offs = nullptr;
+    uint32_t* words = nullptr;       // status | count | closed | rec_base (nb each), then 2 x 4 summary words, then 2 flag words
+    char* heads = nullptr;           // head_rlen | head_alen | head_qlen on the device
+    uint32_t* summ_host = nullptr;   // pinned: 2 x 4 summary words + 2 flag words
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t h2d_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr}, summ_done[2] = {nullptr, nullptr};
+    const size_t inflated_cap = nb * 65536 + nb * 256 + 4096;
+    auto release = [&]() {
+        for (int k = 0; k < 2; ++k) {
+            if (pin[k]) (void)hipHostFree(pin[k]);
+            if (dev[k]) (void)hipFree(dev[k]);
+            if (h2d_done[k]) (void)hipEventDestroy(h2d_done[k]);
+            if (slot_free[k]) (void)hipEventDestroy(slot_free[k]);
+            if (summ_done[k]) (void)hipEventDestroy(summ_done[k]);
+        }
+        if (inflated) (void)hipFree(inflated);
+        if (offs) (void)hipFree(offs);
+        if (words) (void)hipFree(words);
+        if (heads) (void)hipFree(heads);
+        if (summ_host) (void)hipHostFree(summ_host);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    };
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipHostMalloc((void**)&pin[k], slot_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&dev[k], slot_bytes) == hipSuccess && hipEventCreateWithFlags(&h2d_done[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&slot_free[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&summ_done[k], hipEventDisableTiming) == hipSuccess;
+    const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
+    ok = ok && hipMalloc((void**)&inflated, inflated_cap) == hipSuccess &&
+         hipMalloc((void**)&offs, nb * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
+         hipMalloc((void**)&words, (nb * 4 + 16) * sizeof(uint32_t)) == hipSuccess &&
+         hipMalloc((void**)&heads, head_n * 10) == hipSuccess &&
+         hipHostMalloc((void**)&summ_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+         hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
+        release();
+        set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
+                  (2 * slot_bytes) >> 20, (2 * slot_bytes + inflated_cap) >> 20);
+        return BESST_ERR_NOMEM;
+    }
+    uint32_t* d_status = words;
+    uint32_t* d_count = words + nb;
+    uint32_t* d_closed = words + 2 * nb;
+    uint32_t* d_base = words + 3 * nb;
+    uint32_t* d_summ = words + 4 * nb;          // [slot][4]
+    uint32_t* d_flags = words + 4 * nb + 8;     // corrupt-record bit, saturated-qlen count
+    double stage_s = 0.0, wait_s = 0.0;
+    int64_t pushed = 0, chunks = 0, comp_total = 0, inflated_total = 0, blocks_total = 0;
+    size_t fpos = (size_t)f0;
+    Chunk ck[2];
+    rc = BESST_OK;
+    auto hip_fail = [&](hipError_t e) { set_error("push_bam_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; };
+    // stage chunk j (the next blocks of the file) into slot j & 1 and start its upload
+    auto stage = [&](int64_t j) -> bool {
+        const int k = (int)(j & 1);
+        if (j >= 2) {                                        // the upload that last read this pinned slot
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t e = hipEventSynchronize(h2d_done[k]);
+            wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (e != hipSuccess) { hip_fail(e); return false; }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t begin = fpos;
+        Chunk& q = ck[k];
+        q = Chunk();
+        if (!scan_bgzf_chunk(map, map_len, &fpos, nb, comp_cap, reinterpret_cast<BgzfBlock*>(pin[k]), &q.n_blocks, &q.comp, &q.inflated)) {
+            set_error("push_bam_device: not a BGZF block at file offset %zu", fpos);
+            rc = BESST_ERR_UNSUPPORTED;
+            return false;
+        }
+        q.first_off = j == 0 ? u0 : 0u;
+        if (q.n_blocks == 0) return true;
+        bam_parallel_copy(bam, pin[k] + desc_bytes, map + begin, q.comp);
+        memset(pin[k] + desc_bytes + q.comp, 0, 1024);
+        stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        hipError_t e = hipSuccess;
+        if (j >= 2) e = hipStreamWaitEvent(copy_stream, slot_free[k], 0);   // the kernels that last read this device slot
+        if (e == hipSuccess) e = hipMemcpyAsync(dev[k], pin[k], (size_t)q.n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dev[k] + desc_bytes, pin[k] + desc_bytes, q.comp + 1024, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(h2d_done[k], copy_stream);
+        if (e != hipSuccess) { hip_fail(e); return false; }
+        comp_total += (int64_t)q.comp;
+        inflated_total += (int64_t)q.inflated;
+        blocks_total += q.n_blocks;
+        return true;
+    };
+    // inflate + walk + scan of the chunk in slot k, its summary on the way to the host
+    auto enqueue_inflate = [&](int k) -> bool {
+        const Chunk& q = ck[k];
+        const BgzfBlock* d_blocks = reinterpret_cast<const BgzfBlock*>(dev[k]);
+        hipError_t e = hipStreamWaitEvent(c->stream, h2d_done[k], 0);
+        if (e != hipSuccess) { hip_fail(e); return false; }
+        if (launch_bgzf_inflate(c->stream, reinterpret_cast<const uint8_t*>(dev[k] + desc_bytes), d_blocks, q.n_blocks, inflated, d_status) ||
+            launch_bam_walk_scan(c->stream, inflated, d_blocks, q.n_blocks, q.first_off, d_status, offs, d_count, d_closed, d_base,
+                                 d_summ + 4 * k)) {
+            rc = BESST_ERR_HIP;
+            return false;
+        }
+        e = hipMemcpyAsync(summ_host + 4 * k, d_summ + 4 * k, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(summ_done[k], c->stream);
+        if (e != hipSuccess) { hip_fail(e); return false; }
+        return true;
+    };
+    BamColumns col{};
+    col.head_rlen = reinterpret_cast<int32_t*>(heads);
+    col.head_alen = reinterpret_cast<int32_t*>(heads + head_n * 4);
+    col.head_qlen = reinterpret_cast<uint16_t*>(heads + head_n * 8);
+    {
+        hipError_t e = hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(heads, 0, head_n * 10, c->stream);
+        if (e != hipSuccess) hip_fail(e);
+    }
+    if (rc == BESST_OK && stage(0) && ck[0].n_blocks) enqueue_inflate(0);
+    for (int64_t j = 0; rc == BESST_OK && ck[j & 1].n_blocks; ++j) {
+        const int k = (int)(j & 1);
+        if (!stage(j + 1)) break;                            // while chunk j inflates
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t e = hipEventSynchronize(summ_done[k]);
+            wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (e != hipSuccess) { hip_fail(e); break; }
+        }
+        const uint32_t* sm = summ_host + 4 * k;
+        if (!sm[1]) {
+            if (sm[3]) set_error("push_bam_device: block %u of chunk %lld did not inflate on the device (status %u)", sm[2], (long long)j, sm[3]);
+            else set_error("push_bam_device: a record straddles BGZF blocks (block %u of chunk %lld): not htslib's layout", sm[2], (long long)j);
+            rc = BESST_ERR_UNSUPPORTED;
+            break;
+        }
+        const int64_t got = (int64_t)sm[0];
+        const int64_t have = c->n_records + pushed;
+        if (have + got >= ((int64_t)1 << 32)) { set_error("more than 2^32-1 records in one context"); rc = BESST_ERR_ARG; break; }
+        if ((size_t)(have + got) > c->tid.cap) {
+            // room for the whole file at the rate of the bytes read so far (+ 6 %), at least for this chunk
+            int64_t want = have + got;
+            const size_t at = fpos - ck[(j + 1) & 1].comp;   // end of chunk j in the file
+            if (at > (size_t)f0 && at < map_len)
+                want = c->n_records + (int64_t)((double)(pushed + got) * ((double)(map_len - (size_t)f0) / (double)(at - (size_t)f0)) * 1.06) + 4096;
+            if (want < have + got) want = have + got;
+            if (want >= ((int64_t)1 << 32)) want = ((int64_t)1 << 32) - 1;
+            const int64_t keep = c->n_records;
+            c->n_records = have;
+            rc = reserve_records(c, want);
+            c->n_records = keep;
+            if (rc) break;
+        }
+        col.tid = c->tid.p; col.mtid = c->mtid.p; col.pos = c->pos.p; col.mpos = c->mpos.p; col.tlen = c->tlen.p;
+        col.flag = c->flag.p; col.qlen = c->qlen.p; col.mapq = c->mapq.p;
+        if (launch_bam_decode(c->stream, inflated, reinterpret_cast<const BgzfBlock*>(dev[k]), ck[k].n_blocks, offs, d_count, d_base, col,
+                              have, pushed, head_records, d_flags)) { rc = BESST_ERR_HIP; break; }
+        const hipError_t e = hipEventRecord(slot_free[k], c->stream);
+        if (e != hipSuccess) { hip_fail(e); break; }
+        pushed += got;
+        ++chunks;
+        if (ck[(j + 1) & 1].n_blocks && !enqueue_inflate((int)((j + 1) & 1))) break;
+    }
+    if (rc == BESST_OK) {
+        hipError_t e = hipMemcpyAsync(summ_host + 8, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        const int64_t hn = pushed < head_records ? pushed : head_records;
+        if (e == hipSuccess && hn > 0) {
+            e = hipMemcpyAsync(head_rlen, col.head_rlen, (size_t)hn * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(head_alen, col.head_alen, (size_t)hn * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(head_qlen, col.head_qlen, (size_t)hn * 2, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e != hipSuccess) hip_fail(e);
+    }
+    const auto tw = std::chrono::steady_clock::now();
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    const hipError_t ec = hipStreamSynchronize(copy_stream);
+    wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    if (rc == BESST_OK && (es != hipSuccess || ec != hipSuccess)) hip_fail(es != hipSuccess ? es : ec);
+    if (rc == BESST_OK && (summ_host[8] & 1u)) {
+        set_error("push_bam_device: corrupt record (its name and CIGAR do not fit its length)");
+        rc = BESST_ERR_ARG;
+    }
+    const uint32_t saturated = rc == BESST_OK ? summ_host[9] : 0u;
+    release();
+    if (rc) return rc;
+    c->n_records += pushed;
+    c->built = false;
+    bam_mark_consumed(bam, (int64_t)saturated);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->records = pushed;
+        stats->chunks = chunks;
+        stats->bytes_h2d = comp_total;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        stats->decode_seconds = stage_s;
+        stats->copy_wait_seconds = wait_s;
+        stats->inflated_bytes = inflated_total;
+        stats->blocks = blocks_total;
+        stats->on_device = 1;
+    }
+    return BESST_OK;
+}
+
+int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void* out, size_t out_cap, size_t* out_len) {
+    BESST_REQUIRE(bgzf && out_len && (out || out_cap == 0), "bgzf_inflate_device: null pointer");
+    BESST_HIP_TRY(hipSetDevice(device));
+    const uint8_t* map = static_cast<const uint8_t*>(bgzf);
+    const size_t nb = 4096, comp_cap = nb * 65536;
+    std::vector<BgzfBlock> desc(nb);
+    std::vector<uint32_t> status(nb);
+    std::vector<uint8_t> host;
+    char* d_comp = nullptr;
+    uint8_t* d_inf = nullptr;
+    BgzfBlock* d_desc = nullptr;
+    uint32_t* d_status = nullptr;
+    auto release = [&]() {
+        if (d_comp) (void)hipFree(d_comp);
+        if (d_inf) (void)hipFree(d_inf);
+        if (d_desc) (void)hipFree(d_desc);
+        if (d_status) (void)hipFree(d_status);
+    };
+    size_t fpos = 0, written = 0, block0 = 0;
+    int rc = BESST_OK;
+    while (fpos < n_bytes && rc == BESST_OK) {
+        const size_t begin = fpos;
+        uint32_t n = 0;
+        size_t comp = 0, inflated = 0;
+        if (!scan_bgzf_chunk(map, n_bytes, &fpos, nb, comp_cap, desc.data(), &n, &comp, &inflated)) {
+            set_error("bgzf_inflate_device: not a BGZF block at offset %zu", fpos);
+            rc = BESST_ERR_ARG;
+            break;
+        }
+        if (n == 0) break;
+        release();
+        d_comp = nullptr; d_inf = nullptr; d_desc = nullptr; d_status = nullptr;
+        hipError_t e = hipMalloc((void**)&d_comp, comp + 4096);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_inf, inflated + 4096);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_desc, (size_t)n * sizeof(BgzfBlock));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_status, (size_t)n * 4);
+        if (e == hipSuccess) e = hipMemset(d_comp + comp, 0, 4096);
+        if (e == hipSuccess) e = hipMemcpy(d_comp, map + begin, comp, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(BgzfBlock), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("bgzf_inflate_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; break; }
+        if ((rc = launch_bgzf_inflate(nullptr, reinterpret_cast<const uint8_t*>(d_comp), d_desc, n, d_inf, d_status))) break;
+        host.resize(inflated);
+        e = hipMemcpy(status.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && inflated) e = hipMemcpy(host.data(), d_inf, inflated, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("bgzf_inflate_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; break; }
+        for (uint32_t b = 0; b < n; ++b) {
+            if (status[b]) {
+                set_error("bgzf_inflate_device: block %zu did not inflate (status %u)", block0 + b, status[b]);
+                rc = BESST_ERR_UNSUPPORTED;
+                break;
+            }
+            if (written + desc[b].dst_len > out_cap) { set_error("bgzf_inflate_device: output buffer too small"); rc = BESST_ERR_ARG; break; }
+            memcpy(static_cast<uint8_t*>(out) + written, host.data() + (((size_t)desc[b].dst_off_hi << 32) | desc[b].dst_off_lo), desc[b].dst_len);
+            written += desc[b].dst_len;
+        }
+        block0 += n;
+    }
+    release();
+    if (rc) return rc;
+    *out_len = written;
     return BESST_OK;
 }
 

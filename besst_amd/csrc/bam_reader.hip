@@ -220,6 +220,7 @@ struct besst_bam {
     double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0;   // seconds per phase (BESST_BAM_PROFILE=1 prints them)
     std::vector<void*> ld_ctx;       // one libdeflate decompressor per worker
     std::vector<BlockRecs> brecs;    // speculative per-block walks of the current batch, in stream order
+    std::vector<size_t> brec_file_off;   // where each of those blocks begins in the file
     std::vector<uint32_t> blk_offs;
     size_t next_brec = 0;            // first block whose start is >= cursor
     int64_t n_clamped = 0;           // records whose aligned query length was saturated at 65535
@@ -235,6 +236,7 @@ struct besst_bam {
             cursor = 0;
         }
         brecs.clear();                // coordinates of the previous batch are gone
+        brec_file_off.clear();
         next_brec = 0;
         if (eof) return true;
         const auto tp0 = std::chrono::steady_clock::now();
@@ -262,6 +264,7 @@ struct besst_bam {
             const size_t payload = rest - extra_left - 8;
             const uint32_t isize = le32(hdr + bsize - 4);
             blocks.push_back(Block{file_off + 18 + extra_left, payload, dst_total, isize});
+            brec_file_off.push_back(file_off);
             dst_total += isize;
             file_off += bsize;
         }
@@ -647,4 +650,50 @@ namespace besst {
 // for besst_ctx_push_bam (api.hip): how far the reader is through its file
 int64_t bam_file_bytes(besst_bam* b) { return b ? (int64_t)b->map_len : 0; }
 int64_t bam_file_position(besst_bam* b) { return b ? (int64_t)b->file_off : 0; }
+
+// ---- for the device ingest (besst_ctx_push_bam_device)
+const uint8_t* bam_file_map(besst_bam* b) { return b ? b->map : nullptr; }
+
+// Where the next unread record lies: the file offset of its BGZF block and its offset in that block's inflated bytes.
+// false when the reader holds bytes of a batch that is gone (a record that straddled two batches): not a position a
+// block-wise reader can start from.
+bool bam_record_position(besst_bam* b, int64_t* block_file_off, uint32_t* in_block_off) {
+    if (!b) return false;
+    for (size_t i = 0; i < b->brecs.size(); ++i) {
+        if (b->brecs[i].end <= b->cursor) continue;
+        if (b->brecs[i].start > b->cursor) return false;
+        *block_file_off = (int64_t)b->brec_file_off[i];
+        *in_block_off = (uint32_t)(b->cursor - b->brecs[i].start);
+        return true;
+    }
+    if (b->cursor != b->inflated.size()) return false;
+    *block_file_off = (int64_t)b->file_off;
+    *in_block_off = 0;
+    return true;
+}
+
+void bam_parallel_copy(besst_bam* b, void* dst, const void* src, size_t bytes) {
+    constexpr size_t kPiece = (size_t)4 << 20;
+    const size_t pieces = (bytes + kPiece - 1) / kPiece;
+    if (!b || !b->pool || pieces <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    b->pool->parallel_for(pieces, [&](size_t i, int) {
+        const size_t o = i * kPiece;
+        memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, bytes - o < kPiece ? bytes - o : kPiece);
+    });
+}
+
+void bam_mark_consumed(besst_bam* b, int64_t saturated_qlen) {
+    if (!b) return;
+    b->n_clamped += saturated_qlen;
+    b->file_off = b->map_len;
+    b->eof = true;
+    b->inflated.clear();
+    b->cursor = 0;
+    b->brecs.clear();
+    b->brec_file_off.clear();
+    b->next_brec = 0;
+}
 }  // namespace besst

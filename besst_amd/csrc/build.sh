@@ -10,7 +10,7 @@ out="${here}/../libbesst_amd.so"
 obj="${here}/_build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result ${BESST_EXTRA_FLAGS:-}"
-SRCS="api classify sortreduce onesweep runs metrics score bam_reader hostmath linearize chain scorepaths"
+SRCS="api classify sortreduce onesweep runs metrics score bam_reader bgzf_gpu hostmath linearize chain scorepaths"
 mkdir -p "${obj}"
 stamp="${obj}/flags.txt"
 if [ ! -f "${stamp}" ] || [ "$(cat "${stamp}")" != "${FLAGS}" ]; then

@@ -35,6 +35,35 @@ struct besst_bam;
 namespace besst {
 int64_t bam_file_bytes(besst_bam* b);
 int64_t bam_file_position(besst_bam* b);
+// for the device ingest (besst_ctx_push_bam_device): the mapped file, where the next unread record lies (file offset of
+// its BGZF block + offset inside the inflated block), a parallel copy on the reader's pool, and "read to the end"
+const uint8_t* bam_file_map(besst_bam* b);
+bool bam_record_position(besst_bam* b, int64_t* block_file_off, uint32_t* in_block_off);
+void bam_parallel_copy(besst_bam* b, void* dst, const void* src, size_t bytes);
+void bam_mark_consumed(besst_bam* b, int64_t saturated_qlen);
+
+// ---- BAM ingest on the GPU (bgzf_gpu.hip) ---------------------------------------------------------------
+struct BgzfBlock {             // one BGZF block of a chunk: its DEFLATE payload in the chunk's compressed bytes, its place in
+    uint32_t src_off, src_len; // the chunk's inflated scratch (256-byte aligned) and ISIZE
+    uint32_t dst_off_lo, dst_off_hi;
+    uint32_t dst_len, pad;
+};
+constexpr int kBamBlockRecs = 2048;   // a 64 KiB block holds < 65536 / 36 records
+struct BamColumns {
+    int32_t *tid, *mtid, *pos, *mpos, *tlen;
+    uint16_t *flag, *qlen;
+    uint8_t* mapq;
+    int32_t *head_rlen, *head_alen;   // libmetrics' read-length step: the first records' query_length / reference_length
+    uint16_t* head_qlen;
+};
+int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
+                        uint32_t* status);
+int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint32_t first_off,
+                         const uint32_t* status, uint16_t* offs, uint32_t* count, uint32_t* closed, uint32_t* rec_base,
+                         uint32_t* summary);
+int launch_bam_decode(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, const uint16_t* offs,
+                      const uint32_t* count, const uint32_t* rec_base, const BamColumns& col, int64_t out_base,
+                      int64_t rel_base, int64_t head_records, uint32_t* flags);
 
 // ---- per-kernel timing (HIP events on the launch stream; off unless besst_prof_enable(1)) ----------
 enum ProfSlot {

@@ -119,18 +119,49 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
 
     @_timed
-    def push_bam(self, handle, chunk_records=0, head_records=1000):
-        """Stream an open besst_bam (bamio) into the context: decode on the reader's host threads, pinned staging,
-        asynchronous copies under the next chunk's decode.  -> (IngestStats, head rlen, head alen, head qlen)."""
+    def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0):
+        """Stream an open besst_bam (bamio) into the context.  mode 'device': BGZF inflate + record decode on the GPU, the
+        compressed file crosses PCIe (besst_ctx_push_bam_device; files in htslib's block layout); 'host': inflate + decode
+        on the reader's host threads into pinned staging, copies under the next chunk's decode (besst_ctx_push_bam, any
+        layout); 'auto' (default; BESST_INGEST overrides): the device form, and the host form when the library answers
+        BESST_ERR_UNSUPPORTED (``stats.on_device`` tells which one ran).
+        -> (IngestStats, head rlen, head alen, head qlen)."""
+        import os
         from ._lib import IngestStats
+        mode = mode or os.environ.get('BESST_INGEST', 'auto')
+        if mode not in ('auto', 'device', 'host'):
+            raise ValueError("push_bam: mode must be 'auto', 'device' or 'host'")
         stats = IngestStats()
         rlen = np.zeros(head_records, dtype=np.int32)
         alen = np.zeros(head_records, dtype=np.int32)
         qlen = np.zeros(head_records, dtype=np.uint16)
-        _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),
-                                                _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats)), 'push_bam')
+        done = False
+        if mode in ('auto', 'device'):
+            rc = self._lib.besst_ctx_push_bam_device(self._ctx, handle, int(chunk_blocks), int(head_records), _lib.ptr(rlen),
+                                                     _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
+            if rc == 0:
+                done = True
+            elif rc != _lib.ERR_UNSUPPORTED or mode == 'device':
+                _lib.check(rc, 'push_bam_device')
+            else:
+                self.ingest_fallback = _lib.last_error()
+        if not done:
+            _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),
+                                                    _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats)), 'push_bam')
         k = min(head_records, stats.records)
         return stats, rlen[:k], alen[:k], qlen[:k]
+
+    def fetch_records(self, first=0, n=None):
+        """The resident records as host columns (dict of numpy arrays)."""
+        total = C.c_int64(0)
+        _lib.check(self._lib.besst_ctx_record_count(self._ctx, C.byref(total)), 'record_count')
+        n = total.value - first if n is None else n
+        spec = (('tid', np.int32), ('mtid', np.int32), ('pos', np.int32), ('mpos', np.int32), ('tlen', np.int32),
+                ('flag', np.uint16), ('mapq', np.uint8), ('qlen', np.uint16))
+        cols = {k: np.empty(n, dtype=dt) for k, dt in spec}
+        _lib.check(self._lib.besst_ctx_fetch_records(self._ctx, int(first), int(n), *[_lib.ptr(cols[k]) for k, _ in spec]),
+                   'fetch_records')
+        return cols
 
     # ---- library statistics ----------------------------------------------------------------------
     @_timed

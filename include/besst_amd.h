@@ -42,6 +42,8 @@ extern "C" {
 #define BESST_ERR_HIP 2     /* a HIP runtime call failed; see besst_last_error() */
 #define BESST_ERR_STATE 3   /* call order violated (e.g. build before set_library) */
 #define BESST_ERR_NOMEM 4
+#define BESST_ERR_UNSUPPORTED 5 /* valid input in a form this entry point does not handle; nothing was changed - the
+                                * comment of the function names the general one to call instead */
 
 /* Stage 2 (besst_dev_reduce*) reports a table it could not build in the size word the caller reads anyway: *n_rows is
  * one of these instead of a row count, and no other output of the call is valid.  (The besst_ctx_* layer turns the first
@@ -149,6 +151,12 @@ int besst_ctx_push_records(besst_ctx* ctx, int64_t n, const int32_t* tid, const 
                            const int32_t* pos, const int32_t* mpos, const int32_t* tlen,
                            const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen);
 
+/* The resident records back on the host (any column pointer may be NULL): what a caller that ingested a file straight
+ * into HBM (below) needs to look at the records themselves; also how the tests compare the two ingest forms. */
+int besst_ctx_record_count(besst_ctx* ctx, int64_t* n_records);
+int besst_ctx_fetch_records(besst_ctx* ctx, int64_t first, int64_t n, int32_t* tid, int32_t* mtid, int32_t* pos,
+                            int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen);
+
 /* The same from a BAM file, streamed (replaces `pysam.Samfile(param.bamfile, 'rb')` + the iteration of runBESST:162,
  * CreateGraph.py:111, libmetrics.py:63,257,293): the reader's host threads inflate and decode chunk k + 1 into pinned
  * staging columns while chunk k's asynchronous copies travel to HBM.  `bam` is an open besst_bam (below) positioned at
@@ -161,11 +169,30 @@ typedef struct {
     int64_t chunks;
     int64_t bytes_h2d;
     double seconds;              /* wall time of the call */
-    double decode_seconds;       /* of which the calling thread spent in the reader (inflate + record decode) */
-    double copy_wait_seconds;    /* and blocked on copies that had not finished */
+    double decode_seconds;       /* of which the calling thread spent in the reader (inflate + record decode; device form:
+                                  * copying the compressed bytes off the mapping into pinned staging) */
+    double copy_wait_seconds;    /* and blocked on copies (device form: and kernels) that had not finished */
+    int64_t inflated_bytes;      /* device form: bytes the BGZF blocks inflated to */
+    int64_t blocks;              /* device form: BGZF blocks */
+    int32_t on_device;           /* 1: inflate + record decode ran on the GPU (bytes_h2d = the compressed bytes) */
+    int32_t reserved;
 } besst_ingest_stats;
 int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, int64_t head_records, int32_t* head_rlen,
                        int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
+
+/* The same with BGZF inflate, record walk and record decode ON THE GPU (csrc/bgzf_gpu.hip): the file's compressed bytes
+ * are what crosses PCIe - staged through pinned memory chunk by chunk (chunk_blocks BGZF blocks, <= 0: 16384), chunk
+ * j + 1 uploaded while chunk j inflates (one wave per block).  For files in htslib's block layout, where every BGZF
+ * block begins with a record (samtools, bwa | samtools, this library's writer).  Returns BESST_ERR_UNSUPPORTED - context
+ * and reader unchanged - for any other layout (a record that straddles blocks) and for a block the device does not
+ * inflate: call besst_ctx_push_bam then.  The blocks' gzip CRC32 is not checked (nor does the host form check it). */
+int besst_ctx_push_bam_device(besst_ctx* ctx, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
+                              int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
+
+/* Test hook of the device inflate: the BGZF blocks of `bgzf` (n_bytes, host) inflated on `device`, their output
+ * concatenated in out (capacity out_cap, length in *out_len).  BESST_ERR_UNSUPPORTED when a block does not inflate
+ * (its index and status in besst_last_error()). */
+int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void* out, size_t out_cap, size_t* out_len);
 
 /* libmetrics sampling (replaces the three `for read in bam_file` scans, libmetrics.py:63,257,293).
  * top_mask[tid] != 0 marks the 1000 longest references.  orientation/min_mapq/read_len as in

@@ -1,0 +1,258 @@
+"""BAM ingest on the GPU (csrc/bgzf_gpu.hip): the device inflate against zlib byte for byte, the device record decode
+against the host reader column by column, and the hand-over to the host form for layouts the device form does not take."""
+import os
+import random
+import struct
+import tempfile
+import zlib
+
+import numpy as np
+import pytest
+
+from besst_amd import _lib, bamio, synth
+from tests import bam_writer
+
+pytestmark = pytest.mark.gpu
+
+COLS = ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen')
+
+
+def _bgzf(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra=b''):
+    """One BGZF block (a gzip member whose first extra subfield is BC); `extra`: further subfields behind it."""
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    payload = comp.compress(data) + comp.flush()
+    bsize = len(payload) + 25 + len(extra)           # BSIZE: the block's size minus one
+    assert bsize <= 65535
+    head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6 + len(extra), ord('B'), ord('C'), 2, bsize)
+    return head + extra + payload + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def _payloads():
+    rnd = random.Random(11)
+    out = {'empty': b'', 'one': b'x', 'zeros': bytes(65280), 'random': os.urandom(40000),
+           'acgt': bytes(rnd.choice(b'ACGT') for _ in range(65280)),
+           'period3': b'abc' * 20000, 'period70': bytes(range(70)) * 900}
+    words = [os.urandom(rnd.randint(1, 14)) for _ in range(400)]
+    out['words'] = b''.join(rnd.choice(words) for _ in range(12000))[:65280]
+    out['skewed'] = bytes(int(rnd.expovariate(0.03)) & 255 for _ in range(50000))   # long Huffman codes
+    far = os.urandom(2000)
+    out['far_matches'] = (far + os.urandom(30700) + far + os.urandom(29000) + far)[:65280]   # distances near 32768
+    out['bamlike'] = b''.join(struct.pack('<IiiBBHHHIiii', 180, 7, 1000 + 13 * i, 8, 60, 4680, 1, 99, 100, 7, 1400 + 13 * i, 500) +
+                              (b'read%03d\0' % (i % 1000)) + struct.pack('<I', 100 << 4) + bytes([0x12, 0x48] * 25) + b'I' * 100
+                              for i in range(330))[:65280]
+    return out
+
+
+@pytest.mark.parametrize('level,strategy', [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                            (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE),
+                                            (9, zlib.Z_FILTERED)])
+def test_inflate_equals_zlib(level, strategy):
+    """Stored, fixed and dynamic blocks, codes longer than the primary table, overlapping and far matches, the empty block,
+    blocks at every payload alignment (extra subfields of 0..3 bytes shift the DEFLATE stream)."""
+    pay = _payloads()
+    data = b''
+    want = b''
+    for k, (name, raw) in enumerate(sorted(pay.items())):
+        if level == 0 and len(raw) > 65000:
+            raw = raw[:65000]                   # (stored blocks add 5 bytes per 65535)
+        extra = struct.pack('<BBH', ord('X'), ord('Y'), k % 4) + bytes(k % 4)
+        data += _bgzf(raw, level, strategy, extra if k % 2 else b'')
+        want += raw
+    got = bamio.inflate_bgzf_device(data, out_cap=len(want) + 16)
+    assert len(got) == len(want)
+    assert got == want
+
+
+def test_inflate_many_blocks():
+    """More blocks than waves fit the chip, in one call and across the hook's chunks."""
+    rnd = random.Random(3)
+    base = os.urandom(3000)
+    blocks, want = [], []
+    for i in range(5000):
+        n = rnd.randint(0, 9000)
+        raw = (base * 4)[rnd.randint(0, 2000):][:n] + bytes(rnd.randint(0, 50))
+        blocks.append(_bgzf(raw, rnd.choice((1, 6))))
+        want.append(raw)
+    got = bamio.inflate_bgzf_device(b''.join(blocks), out_cap=sum(map(len, want)) + 16)
+    assert got == b''.join(want)
+
+
+def test_inflate_reports_a_corrupt_block():
+    raw = os.urandom(500) * 20
+    good = _bgzf(raw)
+    bad = bytearray(_bgzf(raw))
+    for i in range(40, 60):
+        bad[i] ^= 0x5a
+    with pytest.raises(_lib.BesstDeviceError) as e:
+        bamio.inflate_bgzf_device(good + bytes(bad) + good, out_cap=3 * len(raw) + 16)
+    assert 'block 1' in str(e.value)
+
+
+def _library(n_pairs=9000, seed=32):
+    asm = synth.make_assembly(120, 1500, seed - 1)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('rf', 1500.0, 150.0, contam_frac=0.2), n_pairs, seed)
+    batch.rlen[::9] = 0
+    return batch
+
+
+def _check_against_host(path, bam, host):
+    got = bam.ctx.fetch_records()
+    assert len(bam) == len(host)
+    for col in COLS:
+        assert np.array_equal(got[col], getattr(host, col)), col
+    k = min(1000, len(host))
+    assert np.array_equal(bam.rlen, host.rlen[:k]) and np.array_equal(bam.alen, host.alen[:k])
+    assert np.array_equal(bam.qlen, host.qlen[:k])
+    assert list(bam.references) == list(host.references) and list(bam.lengths) == list(host.lengths)
+
+
+@pytest.mark.parametrize('writer,level,block_bytes,chunk_blocks', [('native', 1, 0, 0), ('native', 6, 0, 64), ('python', 6, 60000, 64),
+                                                                   ('python', 6, 3000, 100), ('python', 6, 700, 0)])
+def test_device_ingest_equals_host_reader(writer, level, block_bytes, chunk_blocks):
+    """htslib's layout (every block begins with a record): the device form's columns, head arrays and counts equal the
+    host reader's; several chunks (64 blocks each), blocks of a few records, one chunk."""
+    batch = _library(30000 if writer == 'native' else 6000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        if writer == 'native':
+            bamio.write_bam(path, batch, threads=4, level=level)
+        else:
+            bam_writer.write_bam(path, batch, block_bytes=block_bytes, align_records=True)
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=3, mode='device', chunk_blocks=chunk_blocks)
+        try:
+            assert bam.ingest.on_device == 1 and bam.ingest.blocks > 0
+            assert bam.ingest.bytes_h2d <= os.path.getsize(path)
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+    for col in COLS:
+        assert np.array_equal(getattr(host, col), getattr(batch, col)), col
+
+
+def test_straddling_records_take_the_host_form():
+    """Blocks cut at arbitrary bytes: the device form answers BESST_ERR_UNSUPPORTED and changes nothing, 'auto' then runs
+    the host form on the same reader."""
+    batch = _library(4000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=5000, align_records=False)
+        host = bamio.read_bam(path, threads=2)
+        with pytest.raises(_lib.BesstDeviceError) as e:
+            bamio.ResidentBam(path, threads=2, mode='device')
+        assert 'status 5' in str(e.value)
+        bam = bamio.ResidentBam(path, threads=2, mode='auto')
+        try:
+            assert bam.ingest.on_device == 0
+            assert 'straddles' in bam.ctx.ingest_fallback
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+
+
+@pytest.mark.parametrize('name', ['handmade_a.bam', 'handmade_b.bam'])
+def test_hand_assembled_bam(name):
+    """The fixtures of tests/golden/bam (every CIGAR operation, records without CIGAR / sequence, straddling records, an
+    empty block, no EOF marker) through 'auto': whichever form runs, the columns are the host reader's."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bam')
+    path = os.path.join(here, name)
+    host = bamio.read_bam(path, threads=2)
+    bam = bamio.ResidentBam(path, threads=2, mode='auto')
+    try:
+        _check_against_host(path, bam, host)
+    finally:
+        bam.close()
+
+
+def test_every_cigar_operation_on_the_device():
+    """The hand-made records re-packed into htslib's layout, so that the DEVICE decode sees them: CIGAR I/D/N/S/H/P/=/X,
+    no CIGAR, no sequence, the CG:B,I placeholder, long and short names, auxiliary fields."""
+    import gzip
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bam')
+    with gzip.open(os.path.join(here, 'handmade_a.bam'), 'rb') as fh:
+        raw = fh.read()
+    l_text = struct.unpack_from('<I', raw, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from('<I', raw, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 8 + struct.unpack_from('<I', raw, at)[0]
+    header, recs = raw[:at], []
+    while at < len(raw):
+        size = struct.unpack_from('<I', raw, at)[0]
+        recs.append(raw[at:at + 4 + size])
+        at += 4 + size
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'aligned.bam')
+        with open(path, 'wb') as fh:
+            fh.write(_bgzf(header))
+            for i in range(0, len(recs), 3):                 # three records per block
+                fh.write(_bgzf(b''.join(recs[i:i + 3]), level=(1, 6, 9)[i % 3]))
+            fh.write(_bgzf(b''))
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=2, mode='device')
+        try:
+            assert bam.ingest.on_device == 1 and len(bam) == len(recs)
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+
+
+def test_header_and_records_share_a_block():
+    """The first record begins in the middle of the header's block (in-block offset of the reader's position)."""
+    batch = _library(800)
+    with tempfile.TemporaryDirectory() as tmp:
+        a, path = os.path.join(tmp, 'a.bam'), os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(a, batch, block_bytes=60000, align_records=True)
+        import gzip
+        with gzip.open(a, 'rb') as fh:
+            raw = fh.read()
+        l_text = struct.unpack_from('<I', raw, 4)[0]
+        at = 8 + l_text
+        n_ref = struct.unpack_from('<I', raw, at)[0]
+        at += 4
+        for _ in range(n_ref):
+            at += 8 + struct.unpack_from('<I', raw, at)[0]
+        cuts = [0]
+        pos = at
+        while pos < len(raw):                                # header + the first records in one block, then record-aligned blocks
+            size = struct.unpack_from('<I', raw, pos)[0]
+            if pos + 4 + size - cuts[-1] > 30000:
+                cuts.append(pos)
+            pos += 4 + size
+        cuts.append(len(raw))
+        with open(path, 'wb') as fh:
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                fh.write(_bgzf(raw[lo:hi]))
+            fh.write(_bgzf(b''))
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=2, mode='device')
+        try:
+            assert bam.ingest.on_device == 1
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+
+
+def test_second_library_appends():
+    """push_bam on a context that already holds records: the new ones follow them."""
+    from besst_amd import device
+    batch = _library(3000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bamio.write_bam(path, batch, threads=2, level=1)
+        lib = _lib.load()
+        with device.GraphContext(0) as ctx:
+            zeros = [0] * len(batch.references)
+            ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
+            for _ in range(2):
+                handle, _, _ = bamio._open(lib, path, 2)
+                try:
+                    stats, _, _, _ = ctx.push_bam(handle, mode='device', chunk_blocks=64)
+                    assert stats.on_device == 1 and stats.records == len(batch)
+                finally:
+                    lib.besst_bam_close(handle)
+            got = ctx.fetch_records()
+    for col in COLS:
+        want = np.concatenate([getattr(batch, col), getattr(batch, col)])
+        assert np.array_equal(got[col], want), col
