@@ -306,10 +306,12 @@ struct besst_bam {
     }
 
     // make at least n undecoded bytes available; false at clean EOF or on error
+    size_t batch_blocks = 16;        // blocks per fill(): a few while the header is parsed (a device ingest inflates nothing
+                                     // else on the host), kBatchBlocks from the first record on
     bool need(size_t n) {
         while (inflated.size() - cursor < n) {
             if (eof) return false;
-            if (!fill(kBatchBlocks)) return false;
+            if (!fill(batch_blocks)) return false;
         }
         return true;
     }
@@ -357,6 +359,7 @@ besst_bam* besst_bam_open(const char* path, int n_threads) {
         b->ref_lengths.push_back((int32_t)le32(b->inflated.data() + b->cursor + 4 + l_name));
         b->cursor += 8 + l_name;
     }
+    b->batch_blocks = kBatchBlocks;
     return b;
 }
 

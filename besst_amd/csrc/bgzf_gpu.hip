@@ -28,6 +28,9 @@
 //                         into the record columns at the block's place in the stream
 //
 // Not checked: the gzip CRC32 of a block (the host path does not check it either: both inflate raw DEFLATE).
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace besst {
@@ -35,7 +38,6 @@ namespace besst {
 namespace {
 
 constexpr int kRing = 32768;
-constexpr uint32_t kRingMask = kRing - 1;
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
 constexpr int kClBits = 7;
@@ -51,8 +53,9 @@ struct CanonLds {               // per code: count / first code / offset per len
     uint16_t cnt[16], first[16], offs[16];
 };
 
+template <int kRingBytes>
 struct InflateLds {
-    __attribute__((aligned(16))) uint8_t ring[kRing];
+    __attribute__((aligned(16))) uint8_t ring[kRingBytes ? kRingBytes : 16];
     uint16_t lit_tab[kTabSize];
     uint16_t dist_tab[kTabSize];
     uint16_t cl_tab[1 << kClBits];
@@ -196,10 +199,14 @@ struct BitReader {
 
 }  // namespace
 
+// kRingBytes = kRing: the window is an LDS ring (38 KB of LDS: four waves per CU); 0: the window is the block's own output
+// in HBM / L2 (6 KB of LDS: the registers allow six waves per SIMD).
+template <int kRingBytes>
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
-                                                          uint32_t n_blocks, uint8_t* __restrict__ dst,
-                                                          uint32_t* __restrict__ status) {
-    __shared__ InflateLds s;
+                                                          uint32_t n_blocks, uint8_t* dst, uint32_t* __restrict__ status) {
+    __shared__ InflateLds<kRingBytes> s;
+    constexpr bool kLds = kRingBytes != 0;
+    constexpr uint32_t kRingMask = kLds ? (uint32_t)kRingBytes - 1u : 0u;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -220,7 +227,19 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     const uint32_t in_base = (uint32_t)((uintptr_t)(src + src_off) & 3u);
     uint32_t pos = 0, flushed = 0;
     uint32_t err = kInfOk;
+    // ---- the window.  LDS form: bytes go to the ring and leave for HBM in granules.  Global form: bytes go straight to the
+    // block's output and a match reads its source there: a wave's vector memory instructions are processed in order, a
+    // load behind a store of the same wave to the same address returns the stored byte (the loads skip the CU's L1).
+    auto put_byte = [&](uint32_t at, uint32_t v) {
+        if constexpr (kLds) s.ring[at & kRingMask] = (uint8_t)v;
+        else out[at] = (uint8_t)v;
+    };
+    auto get_byte = [&](uint32_t at) -> uint32_t {
+        if constexpr (kLds) return s.ring[at & kRingMask];
+        else return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     auto flush_granules = [&]() {
+        if constexpr (!kLds) return;
         while (pos - flushed >= kFlushGranule) {             // uniform
 #pragma unroll
             for (int k = 0; k < (int)(kFlushGranule / 1024u); ++k) {
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             const uint8_t* from = reinterpret_cast<const uint8_t*>(br.words) + at;
             for (uint32_t i0 = 0; i0 < len; i0 += 2048u) {   // uniform; a granule's worth at a time
                 const uint32_t part = len - i0 < 2048u ? len - i0 : 2048u;
-                for (uint32_t i = (uint32_t)lane; i < part; i += 64u) s.ring[(pos + i) & kRingMask] = from[i0 + i];
+                for (uint32_t i = (uint32_t)lane; i < part; i += 64u) put_byte(pos + i, from[i0 + i]);
                 pos += part;
                 __builtin_amdgcn_wave_barrier();
                 flush_granules();
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 uint32_t sym = e >> 4;
                 if (sym < 256u) {
                     if (pos >= dst_len) { err = kInfOutputOverrun; break; }
-                    s.ring[pos & kRingMask] = (uint8_t)sym;
+                    put_byte(pos, sym);
                     ++pos;
                     if ((pos & (kFlushGranule - 1u)) == 0u) flush_granules();
                     continue;
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 if (dist >= length || dist >= 64u) {
                     // every source byte of a round of 64 is finished output (rounds complete in order)
                     for (uint32_t i = (uint32_t)lane; i < length; i += 64u)
-                        s.ring[(pos + i) & kRingMask] = s.ring[(pos + i - dist) & kRingMask];
+                        put_byte(pos + i, get_byte(pos + i - dist));
                 } else {
                     // an overlapping match repeats its last `dist` bytes: byte i is byte i mod dist of them
                     const float rcp = __frcp_rn((float)dist);
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                         int r = (int)i - q * (int)dist;
                         if (r < 0) r += (int)dist;
                         else if (r >= (int)dist) r -= (int)dist;
-                        s.ring[(pos + i) & kRingMask] = s.ring[(pos - dist + (uint32_t)r) & kRingMask];
+                        put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
                     }
                 }
                 pos += length;
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         if (pos != dst_len) err = kInfSizeMismatch;
         else if (br.byte_pos() - in_base > src_len + 8u) err = kInfInputOverrun;   // (the bit buffer reads ahead of its use)
     }
-    if (!err) {
+    if (!err && kLds) {
         // what is left in the ring: whole 16-byte units, then bytes
         __builtin_amdgcn_wave_barrier();
         const uint32_t rest = pos - flushed;
@@ -569,7 +588,10 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
                         uint32_t* status) {
     if (n_blocks == 0) return BESST_OK;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    // BESST_BGZF_WINDOW=lds: the LDS-ring form (A/B runs)
+    static const bool lds_ring = [] { const char* e = getenv("BESST_BGZF_WINDOW"); return e && strcmp(e, "lds") == 0; }();
+    if (lds_ring) hipLaunchKernelGGL((bgzf_inflate_kernel<kRing>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    else hipLaunchKernelGGL((bgzf_inflate_kernel<0>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }
