@@ -233,8 +233,9 @@ def dropin_timing(device, config, pairs=None, contigs=None):
 def bam_to_graph_timing(device, config, pairs=None):
     """BAM bytes -> scored graphs, everything included (SURVEY 8(f) rank 1 + the path): the config's stream is written as
     a BAM file (native writer, untimed scaffolding; /dev/shm when there is one), then timed: bamio.ResidentBam - the
-    library's reader inflating and decoding on host threads into pinned staging, chunk k's copies under chunk k + 1's
-    decode - followed by libmetrics.get_metrics and CreateGraph.PE on the resident records."""
+    compressed file uploaded chunk by chunk, BGZF inflate + record decode on the GPU (csrc/bgzf_gpu.hip) - followed by
+    libmetrics.get_metrics and CreateGraph.PE on the resident records.  The host form of the ingest (reader threads +
+    pinned staging) is timed on the same file beside it, and the records the two leave in HBM are compared."""
     import io
     import shutil
     import tempfile
@@ -269,14 +270,33 @@ def bam_to_graph_timing(device, config, pairs=None):
         G, Gp = CreateGraph.PE({}, {}, p.information_file, C_dict, p, {}, {}, bam)
         t3 = time.perf_counter()
         st = bam.ingest
+        out = {'records': n_rec, 'pairs_of_the_config': 'all' if pairs is None else '%d (a slice)' % pairs, 'bam_bytes': size,
+               'reader_threads': threads, 'usable_cpus': cores, 'machine_cpus': os.cpu_count(),
+               'write_bam_s_untimed': round(write_s, 2),
+               'ingest_form': 'device: BGZF inflate + record decode on the GPU (besst_ctx_push_bam_device)' if st.on_device else
+                              'host: reader threads + pinned staging (besst_ctx_push_bam)',
+               'ingest_s': round(t1 - t0, 3), 'ingest_records_per_s': n_rec / (t1 - t0),
+               'ingest_compressed_GBps': round(size / (t1 - t0) / 1e9, 2),
+               'ingest_staging_s' if st.on_device else 'ingest_decode_s': round(st.decode_seconds, 3),
+               'ingest_wait_s': round(st.copy_wait_seconds, 3), 'ingest_chunks': int(st.chunks), 'h2d_bytes': int(st.bytes_h2d),
+               'inflated_bytes': int(st.inflated_bytes), 'bgzf_blocks': int(st.blocks),
+               'get_metrics_s': round(t2 - t1, 3), 'PE_s': round(t3 - t2, 3), 'total_s': round(t3 - t0, 3),
+               'pairs_per_s': (n_rec // 2) / (t3 - t0), 'edges_G': G.number_of_edges(), 'edges_G_prime': Gp.number_of_edges()}
+        # the other ingest form on the same file (ingest only), and whether the two leave the same records in HBM
+        t0 = time.perf_counter()
+        other = bamio.ResidentBam(path, threads=threads, chunk_records=4 << 20, mode='host' if st.on_device else 'device')
+        t1 = time.perf_counter()
+        agree = len(other) == len(bam)
+        step = 16 << 20
+        for lo in range(0, len(bam) if agree else 0, step):
+            a, b = bam.ctx.fetch_records(lo, min(step, len(bam) - lo)), other.ctx.fetch_records(lo, min(step, len(bam) - lo))
+            agree = agree and all(np.array_equal(a[k], b[k]) for k in a)
+        out['ingest_other_form'] = {'form': 'device' if other.ingest.on_device else 'host', 'ingest_s': round(t1 - t0, 3),
+                                    'ingest_records_per_s': n_rec / (t1 - t0), 'h2d_bytes': int(other.ingest.bytes_h2d)}
+        out['ingest_forms_agree'] = bool(agree)
+        other.close()
         session.close_session(bam)
-        return {'records': n_rec, 'pairs_of_the_config': 'all' if pairs is None else '%d (a slice)' % pairs, 'bam_bytes': size, 'reader_threads': threads, 'usable_cpus': cores, 'machine_cpus': os.cpu_count(),
-                'write_bam_s_untimed': round(write_s, 2), 'ingest_s': round(t1 - t0, 3),
-                'ingest_records_per_s': n_rec / (t1 - t0), 'ingest_compressed_GBps': round(size / (t1 - t0) / 1e9, 2),
-                'ingest_decode_s': round(st.decode_seconds, 3), 'ingest_copy_wait_s': round(st.copy_wait_seconds, 3),
-                'ingest_chunks': int(st.chunks), 'h2d_bytes': int(st.bytes_h2d),
-                'get_metrics_s': round(t2 - t1, 3), 'PE_s': round(t3 - t2, 3), 'total_s': round(t3 - t0, 3),
-                'pairs_per_s': (n_rec // 2) / (t3 - t0), 'edges_G': G.number_of_edges(), 'edges_G_prime': Gp.number_of_edges()}
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

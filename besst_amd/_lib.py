@@ -122,6 +122,7 @@ _SIGNATURES = {
     'besst_bam_n_references': (C.c_int64, [_P]),
     'besst_bam_clamped_records': (C.c_int64, [_P]),
     'besst_bam_reference_name': (C.c_char_p, [_P, C.c_int64]),
+    'besst_bam_reference_names': (C.c_int64, [_P, _P, C.c_int64]),
     'besst_bam_reference_lengths': (C.c_int, [_P, _P]),
     'besst_bam_read_records': (C.c_int64, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_bam_write_records': (C.c_int, [C.c_char_p, C.c_int64, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -22,11 +22,20 @@ def _open(lib, path, threads):
     handle = lib.besst_bam_open(os.fsencode(path), int(threads))
     if not handle:
         raise IOError('cannot read BAM %s: %s' % (path, _lib.last_error()))
+    names, lengths = _header(lib, handle)
+    return handle, names, lengths
+
+
+def _header(lib, handle):
+    """(reference names, lengths) of an open reader; the names in one call (a C5 header has 2 M of them)."""
     n_ref = lib.besst_bam_n_references(handle)
-    names = [lib.besst_bam_reference_name(handle, i).decode() for i in range(n_ref)]
+    need = lib.besst_bam_reference_names(handle, None, 0)
+    buf = np.zeros(max(int(need), 1), dtype=np.uint8)
+    lib.besst_bam_reference_names(handle, _lib.ptr(buf), int(need))
+    names = buf[:need].tobytes().decode().split('\0')[:n_ref] if n_ref else []
     lengths = np.zeros(max(n_ref, 1), dtype=np.int32)
     _lib.check(lib.besst_bam_reference_lengths(handle, _lib.ptr(lengths)), 'bam_reference_lengths')
-    return handle, names, lengths[:n_ref].tolist()
+    return names, lengths[:n_ref].tolist()
 
 
 class ResidentBam(object):
@@ -46,7 +55,7 @@ class ResidentBam(object):
         self.path = path
         self.ctx = device.GraphContext(device_index)
         try:
-            zeros = [0] * len(self.references)
+            zeros = np.zeros(len(self.references), dtype=np.int32)
             self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
             self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records, mode=mode, chunk_blocks=chunk_blocks)
             clamped = lib.besst_bam_clamped_records(handle)
@@ -101,10 +110,7 @@ def read_bam(path, threads=None, chunk_records=8_000_000):
     if not handle:
         raise IOError('cannot read BAM %s: %s' % (path, _lib.last_error()))
     try:
-        n_ref = lib.besst_bam_n_references(handle)
-        names = [lib.besst_bam_reference_name(handle, i).decode() for i in range(n_ref)]
-        lengths = np.zeros(max(n_ref, 1), dtype=np.int32)
-        _lib.check(lib.besst_bam_reference_lengths(handle, _lib.ptr(lengths)), 'bam_reference_lengths')
+        names, lengths = _header(lib, handle)
         spec = (('tid', np.int32), ('mtid', np.int32), ('pos', np.int32), ('mpos', np.int32), ('tlen', np.int32),
                 ('flag', np.uint16), ('mapq', np.uint8), ('qlen', np.uint16), ('rlen', np.int32), ('alen', np.int32))
         parts = {k: [] for k, _ in spec}
@@ -125,4 +131,4 @@ def read_bam(path, threads=None, chunk_records=8_000_000):
                           'CreateGraph.py:138-139) is stored as 65535' % (path, clamped))
     finally:
         lib.besst_bam_close(handle)
-    return RecordBatch(names, lengths[:n_ref].tolist(), **cols)
+    return RecordBatch(names, lengths, **cols)

@@ -530,7 +530,7 @@ namespace {
 // inflated places 256-byte aligned.  Stops at max_blocks, at comp_cap compressed bytes, or at the end of the file.
 // false: not a BGZF block where one should be.
 bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t max_blocks, size_t comp_cap, BgzfBlock* out,
-                     uint32_t* n_out, size_t* comp_bytes, size_t* inflated_bytes) {
+                     uint32_t* n_out, size_t* comp_bytes, size_t* inflated_bytes, bool more_follows = false) {
     auto le16 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); };
     auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
     const size_t begin = *fpos;
@@ -538,11 +538,19 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
     uint32_t n = 0;
     while (n < max_blocks && at < map_len) {
         const uint8_t* hdr = map + at;
-        if (map_len - at < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return false;
+        if (map_len - at < 18) {                             // `map` is a window of the file: the block continues behind it
+            if (more_follows) break;
+            return false;
+        }
+        if (hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return false;
         const uint32_t xlen = le16(hdr + 10);
         if (xlen < 6 || hdr[12] != 'B' || hdr[13] != 'C' || le16(hdr + 14) != 2) return false;
         const size_t bsize = (size_t)le16(hdr + 16) + 1;
-        if (bsize < 18 || map_len - at < bsize) return false;
+        if (bsize < 18) return false;
+        if (map_len - at < bsize) {
+            if (more_follows) break;
+            return false;
+        }
         const size_t rest = bsize - 18, extra_left = xlen - 6;
         if (rest < extra_left + 8) return false;
         if (at + bsize - begin > comp_cap) {
@@ -593,7 +601,6 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         set_error("push_bam_device: the reader is inside a record that straddles two batches");
         return BESST_ERR_UNSUPPORTED;
     }
-    const uint8_t* map = bam_file_map(bam);
     const size_t map_len = (size_t)bam_file_bytes(bam);
     const size_t nb = (size_t)chunk_blocks;
     const size_t comp_cap = std::max<size_t>((size_t)128 << 20, nb * 8192);
@@ -638,6 +645,7 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
          hipMalloc((void**)&heads, head_n * 10) == hipSuccess &&
          hipHostMalloc((void**)&summ_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
          hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
+    const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (!ok) {
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
@@ -653,6 +661,7 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
     double stage_s = 0.0, wait_s = 0.0;
     int64_t pushed = 0, chunks = 0, comp_total = 0, inflated_total = 0, blocks_total = 0;
     size_t fpos = (size_t)f0;
+    double bytes_per_block = 0.0;
     Chunk ck[2];
     rc = BESST_OK;
     auto hip_fail = [&](hipError_t e) { set_error("push_bam_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; };
@@ -669,15 +678,31 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         const size_t begin = fpos;
         Chunk& q = ck[k];
         q = Chunk();
-        if (!scan_bgzf_chunk(map, map_len, &fpos, nb, comp_cap, reinterpret_cast<BgzfBlock*>(pin[k]), &q.n_blocks, &q.comp, &q.inflated)) {
-            set_error("push_bam_device: not a BGZF block at file offset %zu", fpos);
+        q.first_off = j == 0 ? u0 : 0u;
+        if (begin >= map_len) return true;
+        // A window of the file is READ into the pinned slot by the reader's threads (pread: no page faults, unlike a copy
+        // off the mapping, where the header walk alone touched every page) and the block headers are walked there; the
+        // window is sized from the blocks seen so far, the block it cuts is read again with the next chunk.
+        size_t want = map_len - begin < comp_cap ? map_len - begin : comp_cap;
+        if (bytes_per_block > 0.0) {
+            const size_t guess = (size_t)((double)nb * bytes_per_block * 1.08) + 65536;
+            if (guess < want) want = guess;
+        }
+        if (!bam_parallel_read(bam, pin[k] + desc_bytes, (int64_t)begin, want)) {
+            set_error("push_bam_device: reading the file failed at offset %zu", begin);
+            rc = BESST_ERR_ARG;
+            return false;
+        }
+        size_t used = 0;
+        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(pin[k] + desc_bytes), want, &used, nb, comp_cap,
+                             reinterpret_cast<BgzfBlock*>(pin[k]), &q.n_blocks, &q.comp, &q.inflated, begin + want < map_len) ||
+            (q.n_blocks == 0 && want > 0)) {
+            set_error("push_bam_device: not a BGZF block at file offset %zu", begin + used);
             rc = BESST_ERR_UNSUPPORTED;
             return false;
         }
-        q.first_off = j == 0 ? u0 : 0u;
-        if (q.n_blocks == 0) return true;
-        bam_parallel_copy(bam, pin[k] + desc_bytes, map + begin, q.comp);
-        memset(pin[k] + desc_bytes + q.comp, 0, 1024);
+        fpos = begin + q.comp;
+        bytes_per_block = (double)q.comp / (double)q.n_blocks;
         stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         hipError_t e = hipSuccess;
         if (j >= 2) e = hipStreamWaitEvent(copy_stream, slot_free[k], 0);   // the kernels that last read this device slot
@@ -780,7 +805,12 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         rc = BESST_ERR_ARG;
     }
     const uint32_t saturated = rc == BESST_OK ? summ_host[9] : 0u;
+    const auto t_rel = std::chrono::steady_clock::now();
     release();
+    if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
+        fprintf(stderr, "[push_bam_device] alloc %.3f s  staging %.3f s  waiting %.3f s  release %.3f s  total %.3f s\n", alloc_s, stage_s,
+                wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     if (rc) return rc;
     c->n_records += pushed;
     c->built = false;

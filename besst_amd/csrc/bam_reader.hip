@@ -380,6 +380,20 @@ const char* besst_bam_reference_name(const besst_bam* b, int64_t i) {
     return (b && i >= 0 && (size_t)i < b->ref_names.size()) ? b->ref_names[(size_t)i].c_str() : "";
 }
 
+int64_t besst_bam_reference_names(const besst_bam* b, char* buf, int64_t cap) {
+    if (!b) return -1;
+    int64_t need = 0;
+    for (const std::string& n : b->ref_names) need += (int64_t)n.size() + 1;
+    if (buf && cap >= need) {
+        char* p = buf;
+        for (const std::string& n : b->ref_names) {
+            memcpy(p, n.c_str(), n.size() + 1);
+            p += n.size() + 1;
+        }
+    }
+    return need;
+}
+
 int besst_bam_reference_lengths(const besst_bam* b, int32_t* out) {
     BESST_REQUIRE(b && out, "bam_reference_lengths: null pointer");
     for (size_t i = 0; i < b->ref_lengths.size(); ++i) out[i] = b->ref_lengths[i];
@@ -675,17 +689,27 @@ bool bam_record_position(besst_bam* b, int64_t* block_file_off, uint32_t* in_blo
     return true;
 }
 
-void bam_parallel_copy(besst_bam* b, void* dst, const void* src, size_t bytes) {
+// `bytes` of the file from file_off into dst, read (pread) by the pool's threads in 4 MiB pieces
+bool bam_parallel_read(besst_bam* b, void* dst, int64_t file_off, size_t bytes) {
+    if (!b || b->fd < 0) return false;
     constexpr size_t kPiece = (size_t)4 << 20;
     const size_t pieces = (bytes + kPiece - 1) / kPiece;
-    if (!b || !b->pool || pieces <= 1) {
-        memcpy(dst, src, bytes);
-        return;
+    std::atomic<bool> ok(true);
+    auto piece = [&](size_t i, int) {
+        size_t o = i * kPiece;
+        const size_t end = o + kPiece < bytes ? o + kPiece : bytes;
+        while (o < end) {
+            const ssize_t got = pread(b->fd, static_cast<char*>(dst) + o, end - o, (off_t)(file_off + (int64_t)o));
+            if (got <= 0) { ok = false; return; }
+            o += (size_t)got;
+        }
+    };
+    if (!b->pool || pieces <= 1) {
+        for (size_t i = 0; i < pieces; ++i) piece(i, 0);
+    } else {
+        b->pool->parallel_for(pieces, piece);
     }
-    b->pool->parallel_for(pieces, [&](size_t i, int) {
-        const size_t o = i * kPiece;
-        memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, bytes - o < kPiece ? bytes - o : kPiece);
-    });
+    return ok.load();
 }
 
 void bam_mark_consumed(besst_bam* b, int64_t saturated_qlen) {

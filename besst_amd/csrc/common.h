@@ -39,7 +39,7 @@ int64_t bam_file_position(besst_bam* b);
 // its BGZF block + offset inside the inflated block), a parallel copy on the reader's pool, and "read to the end"
 const uint8_t* bam_file_map(besst_bam* b);
 bool bam_record_position(besst_bam* b, int64_t* block_file_off, uint32_t* in_block_off);
-void bam_parallel_copy(besst_bam* b, void* dst, const void* src, size_t bytes);
+bool bam_parallel_read(besst_bam* b, void* dst, int64_t file_off, size_t bytes);
 void bam_mark_consumed(besst_bam* b, int64_t saturated_qlen);
 
 // ---- BAM ingest on the GPU (bgzf_gpu.hip) ---------------------------------------------------------------

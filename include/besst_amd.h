@@ -255,6 +255,9 @@ besst_bam* besst_bam_open(const char* path, int n_threads);
 void besst_bam_close(besst_bam* bam);
 int64_t besst_bam_n_references(const besst_bam* bam);
 const char* besst_bam_reference_name(const besst_bam* bam, int64_t index);
+/* All names at once, NUL-terminated and back to back (a header of 2 M contigs is 2 M calls otherwise): returns the bytes
+ * needed; buf is filled when cap is at least that. */
+int64_t besst_bam_reference_names(const besst_bam* bam, char* buf, int64_t cap);
 int besst_bam_reference_lengths(const besst_bam* bam, int32_t* out);
 /* Returns the number of records decoded (0 at end of file) or a negative status.  qlen is a 16-bit column: an aligned
  * query longer than 65535 bases (no paired short read is) is stored as 65535 and counted. */
