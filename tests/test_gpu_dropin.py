@@ -1,5 +1,6 @@
 """GPU parity of the drop-in entry points (get_metrics + PE) against the golden vectors of the real reference."""
 import io
+import os
 import tempfile
 
 import pytest
@@ -146,18 +147,24 @@ def test_dropin_from_bam_file(name, tmp_path):
     assert edge_rows(G_prime, False) == [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in fin['G_prime']]
 
 
+@pytest.mark.parametrize('mode', ['device', 'host'])
 @pytest.mark.parametrize('name,chunk', [('fr_infer', 4096), ('rf_contam', 1024), ('fr_edgecases', 1 << 22)])
-def test_dropin_from_streamed_bam(name, chunk, tmp_path):
-    """BAM file -> besst_ctx_push_bam (decode on host threads, pinned staging, copies under the next chunk's decode; small
-    chunks: many of them, the columns grow on the way) -> get_metrics + PE on the resident records: metrics, graphs and
-    object dicts as the reference's goldens, no host record columns anywhere."""
+def test_dropin_from_streamed_bam(name, chunk, mode, tmp_path):
+    """BAM file -> resident records - besst_ctx_push_bam_device (the compressed file uploaded, inflate + record decode on the
+    GPU) or besst_ctx_push_bam (decode on host threads, pinned staging, copies under the next chunk's decode; small chunks:
+    many of them, the columns grow on the way) -> get_metrics + PE on the resident records: metrics, graphs and object
+    dicts as the reference's goldens, no host record columns anywhere."""
     from besst_amd import bamio
     doc, batch = GU.load(name)
     path = str(tmp_path / 'mapped.bam')
     bamio.write_bam(path, batch, threads=3)
-    bam = bamio.ResidentBam(path, threads=4, chunk_records=chunk)
-    assert len(bam) == len(batch) and bam.ingest.chunks == -(-len(batch) // max(1024, chunk))
-    assert bam.ingest.bytes_h2d == 25 * len(batch)
+    bam = bamio.ResidentBam(path, threads=4, chunk_records=chunk, mode=mode, chunk_blocks=64)
+    assert len(bam) == len(batch)
+    if mode == 'host':
+        assert bam.ingest.on_device == 0 and bam.ingest.chunks == -(-len(batch) // max(1024, chunk))
+        assert bam.ingest.bytes_h2d == 25 * len(batch)
+    else:
+        assert bam.ingest.on_device == 1 and bam.ingest.bytes_h2d <= os.path.getsize(path)
     param = make_param(doc['overrides'])
     info = param.information_file
     libmetrics.get_metrics(bam, param, info)
