@@ -88,8 +88,11 @@ def inflate_bgzf_device(data, device_index=0, out_cap=None):
     return out[:n.value].tobytes()
 
 
-def write_bam(path, batch, threads=None, level=1):
-    """Test / bench scaffolding (besst_bam_write_records): the batch as a BAM file in htslib's block layout."""
+def write_bam(path, batch, threads=None, level=1, realistic=False):
+    """Test / bench scaffolding (besst_bam_write_records): the batch as a BAM file in htslib's block layout.  realistic:
+    pseudo-random bases and slowly changing qualities instead of constant bytes (the file compresses ~3 x, not ~13 x)."""
+    if realistic:
+        level = int(level) | 16
     import ctypes as C
     lib = _lib.load()
     names = (C.c_char_p * len(batch.references))(*[n.encode() for n in batch.references])

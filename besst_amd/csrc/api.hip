@@ -578,12 +578,13 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
 
 }  // namespace
 
-// BAM file -> resident records with the inflate and the record decode on the GPU: the file's COMPRESSED bytes are staged
-// through pinned memory (copied off the mapping by the reader's threads) and uploaded chunk by chunk; per chunk one wave
-// per BGZF block inflates, one lane per block walks its records, a scan places them and a thread per record fills the
-// columns.  Chunk j + 1 is staged and uploaded while chunk j inflates.  For files in htslib's layout (every block begins
-// with a record); anything else - and any block the device cannot inflate - returns BESST_ERR_UNSUPPORTED with context and
-// reader untouched, and the caller takes besst_ctx_push_bam.
+// BAM file -> resident records with the inflate and the record decode on the GPU: the file's COMPRESSED bytes are read into
+// pinned memory by the reader's threads and uploaded chunk by chunk; per chunk one wave per BGZF block inflates, one lane per
+// block walks its records, a scan places them and a thread per record fills the columns.  Two slots, each with its own
+// staging, scratch and stream: chunk j + 1 is read, uploaded and ALREADY INFLATING while the host waits for chunk j's record
+// count (the columns may have to grow before its decode) - the tail of one chunk's waves and the head of the next share the
+// chip.  For files in htslib's layout (every block begins with a record); anything else - and any block the device cannot
+// inflate - returns BESST_ERR_UNSUPPORTED with context and reader untouched, and the caller takes besst_ctx_push_bam.
 int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
     BESST_REQUIRE(c && bam, "push_bam_device: null context or reader");
@@ -603,82 +604,85 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
     }
     const size_t map_len = (size_t)bam_file_bytes(bam);
     const size_t nb = (size_t)chunk_blocks;
-    const size_t comp_cap = std::max<size_t>((size_t)128 << 20, nb * 8192);
+    // a chunk: nb blocks or comp_cap compressed bytes, whichever comes first (a sequencer's blocks are ~18 KB: 8 K of them)
+    size_t comp_cap = std::max<size_t>((size_t)160 << 20, nb * 8192);
+    if (comp_cap > map_len + 65536) comp_cap = align_up(map_len + 65536, 4096);
     const size_t desc_bytes = align_up(nb * sizeof(BgzfBlock), 4096);
     const size_t slot_bytes = desc_bytes + comp_cap + 4096;      // (the bit reader's windows run up to 512 bytes past a payload)
     struct Chunk { uint32_t n_blocks = 0, first_off = 0; size_t comp = 0, inflated = 0; };
-    char* pin[2] = {nullptr, nullptr};
-    char* dev[2] = {nullptr, nullptr};
-    uint8_t* inflated = nullptr;
-    uint16_t* offs = nullptr;
-    uint32_t* words = nullptr;       // status | count | closed | rec_base (nb each), then 2 x 4 summary words, then 2 flag words
+    struct Slot {
+        char* pin = nullptr;         // pinned: descriptors, then the chunk's bytes as they lie in the file
+        char* dev = nullptr;         // the same on the device
+        uint8_t* inflated = nullptr;
+        uint16_t* offs = nullptr;
+        uint32_t* words = nullptr;   // status | count | closed | rec_base (nb each), then 4 summary words
+        hipStream_t work = nullptr;
+        hipEvent_t h2d_done = nullptr, slot_free = nullptr, summ_done = nullptr;
+        Chunk ck;
+    } sl[2];
     char* heads = nullptr;           // head_rlen | head_alen | head_qlen on the device
+    uint32_t* d_flags = nullptr;     // corrupt-record bit, saturated-qlen count
     uint32_t* summ_host = nullptr;   // pinned: 2 x 4 summary words + 2 flag words
     hipStream_t copy_stream = nullptr;
-    hipEvent_t h2d_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr}, summ_done[2] = {nullptr, nullptr};
     const size_t inflated_cap = nb * 65536 + nb * 256 + 4096;
     auto release = [&]() {
-        for (int k = 0; k < 2; ++k) {
-            if (pin[k]) (void)hipHostFree(pin[k]);
-            if (dev[k]) (void)hipFree(dev[k]);
-            if (h2d_done[k]) (void)hipEventDestroy(h2d_done[k]);
-            if (slot_free[k]) (void)hipEventDestroy(slot_free[k]);
-            if (summ_done[k]) (void)hipEventDestroy(summ_done[k]);
+        for (Slot& q : sl) {
+            if (q.pin) (void)hipHostFree(q.pin);
+            if (q.dev) (void)hipFree(q.dev);
+            if (q.inflated) (void)hipFree(q.inflated);
+            if (q.offs) (void)hipFree(q.offs);
+            if (q.words) (void)hipFree(q.words);
+            if (q.h2d_done) (void)hipEventDestroy(q.h2d_done);
+            if (q.slot_free) (void)hipEventDestroy(q.slot_free);
+            if (q.summ_done) (void)hipEventDestroy(q.summ_done);
+            if (q.work) (void)hipStreamDestroy(q.work);
+            q = Slot();
         }
-        if (inflated) (void)hipFree(inflated);
-        if (offs) (void)hipFree(offs);
-        if (words) (void)hipFree(words);
         if (heads) (void)hipFree(heads);
+        if (d_flags) (void)hipFree(d_flags);
         if (summ_host) (void)hipHostFree(summ_host);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
     bool ok = true;
-    for (int k = 0; k < 2 && ok; ++k)
-        ok = hipHostMalloc((void**)&pin[k], slot_bytes, hipHostMallocDefault) == hipSuccess &&
-             hipMalloc((void**)&dev[k], slot_bytes) == hipSuccess && hipEventCreateWithFlags(&h2d_done[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&slot_free[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&summ_done[k], hipEventDisableTiming) == hipSuccess;
+    for (Slot& q : sl)
+        ok = ok && hipHostMalloc((void**)&q.pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
+             hipMalloc((void**)&q.offs, nb * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
+             hipMalloc((void**)&q.words, (nb * 4 + 4) * sizeof(uint32_t)) == hipSuccess &&
+             hipStreamCreateWithFlags(&q.work, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess;
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
-    ok = ok && hipMalloc((void**)&inflated, inflated_cap) == hipSuccess &&
-         hipMalloc((void**)&offs, nb * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
-         hipMalloc((void**)&words, (nb * 4 + 16) * sizeof(uint32_t)) == hipSuccess &&
-         hipMalloc((void**)&heads, head_n * 10) == hipSuccess &&
+    ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
          hipHostMalloc((void**)&summ_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
          hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
     const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (!ok) {
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
-                  (2 * slot_bytes) >> 20, (2 * slot_bytes + inflated_cap) >> 20);
+                  (2 * slot_bytes) >> 20, (2 * (slot_bytes + inflated_cap)) >> 20);
         return BESST_ERR_NOMEM;
     }
-    uint32_t* d_status = words;
-    uint32_t* d_count = words + nb;
-    uint32_t* d_closed = words + 2 * nb;
-    uint32_t* d_base = words + 3 * nb;
-    uint32_t* d_summ = words + 4 * nb;          // [slot][4]
-    uint32_t* d_flags = words + 4 * nb + 8;     // corrupt-record bit, saturated-qlen count
     double stage_s = 0.0, wait_s = 0.0;
     int64_t pushed = 0, chunks = 0, comp_total = 0, inflated_total = 0, blocks_total = 0;
     size_t fpos = (size_t)f0;
     double bytes_per_block = 0.0;
-    Chunk ck[2];
     rc = BESST_OK;
     auto hip_fail = [&](hipError_t e) { set_error("push_bam_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; };
-    // stage chunk j (the next blocks of the file) into slot j & 1 and start its upload
+    // read chunk j (the next blocks of the file) into slot j & 1 and start its upload
     auto stage = [&](int64_t j) -> bool {
-        const int k = (int)(j & 1);
+        Slot& q = sl[j & 1];
         if (j >= 2) {                                        // the upload that last read this pinned slot
             const auto t0 = std::chrono::steady_clock::now();
-            const hipError_t e = hipEventSynchronize(h2d_done[k]);
+            const hipError_t e = hipEventSynchronize(q.h2d_done);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); return false; }
         }
         const auto t0 = std::chrono::steady_clock::now();
         const size_t begin = fpos;
-        Chunk& q = ck[k];
-        q = Chunk();
-        q.first_off = j == 0 ? u0 : 0u;
+        q.ck = Chunk();
+        q.ck.first_off = j == 0 ? u0 : 0u;
         if (begin >= map_len) return true;
         // A window of the file is READ into the pinned slot by the reader's threads (pread: no page faults, unlike a copy
         // off the mapping, where the header walk alone touched every page) and the block headers are walked there; the
@@ -688,47 +692,48 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
             const size_t guess = (size_t)((double)nb * bytes_per_block * 1.08) + 65536;
             if (guess < want) want = guess;
         }
-        if (!bam_parallel_read(bam, pin[k] + desc_bytes, (int64_t)begin, want)) {
+        if (!bam_parallel_read(bam, q.pin + desc_bytes, (int64_t)begin, want)) {
             set_error("push_bam_device: reading the file failed at offset %zu", begin);
             rc = BESST_ERR_ARG;
             return false;
         }
         size_t used = 0;
-        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(pin[k] + desc_bytes), want, &used, nb, comp_cap,
-                             reinterpret_cast<BgzfBlock*>(pin[k]), &q.n_blocks, &q.comp, &q.inflated, begin + want < map_len) ||
-            (q.n_blocks == 0 && want > 0)) {
+        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(q.pin + desc_bytes), want, &used, nb, comp_cap,
+                             reinterpret_cast<BgzfBlock*>(q.pin), &q.ck.n_blocks, &q.ck.comp, &q.ck.inflated, begin + want < map_len) ||
+            (q.ck.n_blocks == 0 && want > 0)) {
             set_error("push_bam_device: not a BGZF block at file offset %zu", begin + used);
             rc = BESST_ERR_UNSUPPORTED;
             return false;
         }
-        fpos = begin + q.comp;
-        bytes_per_block = (double)q.comp / (double)q.n_blocks;
+        fpos = begin + q.ck.comp;
+        bytes_per_block = (double)q.ck.comp / (double)q.ck.n_blocks;
         stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         hipError_t e = hipSuccess;
-        if (j >= 2) e = hipStreamWaitEvent(copy_stream, slot_free[k], 0);   // the kernels that last read this device slot
-        if (e == hipSuccess) e = hipMemcpyAsync(dev[k], pin[k], (size_t)q.n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dev[k] + desc_bytes, pin[k] + desc_bytes, q.comp + 1024, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(h2d_done[k], copy_stream);
+        if (j >= 2) e = hipStreamWaitEvent(copy_stream, q.slot_free, 0);    // the kernels that last read this device slot
+        if (e == hipSuccess) e = hipMemcpyAsync(q.dev, q.pin, (size_t)q.ck.n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(q.dev + desc_bytes, q.pin + desc_bytes, q.ck.comp + 1024, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(q.h2d_done, copy_stream);
         if (e != hipSuccess) { hip_fail(e); return false; }
-        comp_total += (int64_t)q.comp;
-        inflated_total += (int64_t)q.inflated;
-        blocks_total += q.n_blocks;
+        comp_total += (int64_t)q.ck.comp;
+        inflated_total += (int64_t)q.ck.inflated;
+        blocks_total += q.ck.n_blocks;
         return true;
     };
-    // inflate + walk + scan of the chunk in slot k, its summary on the way to the host
+    // inflate + walk + scan of the chunk in slot k on the slot's stream, its summary on the way to the host
     auto enqueue_inflate = [&](int k) -> bool {
-        const Chunk& q = ck[k];
-        const BgzfBlock* d_blocks = reinterpret_cast<const BgzfBlock*>(dev[k]);
-        hipError_t e = hipStreamWaitEvent(c->stream, h2d_done[k], 0);
+        Slot& q = sl[k];
+        const BgzfBlock* d_blocks = reinterpret_cast<const BgzfBlock*>(q.dev);
+        uint32_t* w = q.words;
+        hipError_t e = hipStreamWaitEvent(q.work, q.h2d_done, 0);
         if (e != hipSuccess) { hip_fail(e); return false; }
-        if (launch_bgzf_inflate(c->stream, reinterpret_cast<const uint8_t*>(dev[k] + desc_bytes), d_blocks, q.n_blocks, inflated, d_status) ||
-            launch_bam_walk_scan(c->stream, inflated, d_blocks, q.n_blocks, q.first_off, d_status, offs, d_count, d_closed, d_base,
-                                 d_summ + 4 * k)) {
+        if (launch_bgzf_inflate(q.work, reinterpret_cast<const uint8_t*>(q.dev + desc_bytes), d_blocks, q.ck.n_blocks, q.inflated, w) ||
+            launch_bam_walk_scan(q.work, q.inflated, d_blocks, q.ck.n_blocks, q.ck.first_off, w, q.offs, w + nb, w + 2 * nb, w + 3 * nb,
+                                 w + 4 * nb)) {
             rc = BESST_ERR_HIP;
             return false;
         }
-        e = hipMemcpyAsync(summ_host + 4 * k, d_summ + 4 * k, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(summ_done[k], c->stream);
+        e = hipMemcpyAsync(summ_host + 4 * k, w + 4 * nb, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, q.work);
+        if (e == hipSuccess) e = hipEventRecord(q.summ_done, q.work);
         if (e != hipSuccess) { hip_fail(e); return false; }
         return true;
     };
@@ -739,19 +744,23 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
     {
         hipError_t e = hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(heads, 0, head_n * 10, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the slots' streams start behind these
         if (e != hipSuccess) hip_fail(e);
     }
-    if (rc == BESST_OK && stage(0) && ck[0].n_blocks) enqueue_inflate(0);
-    for (int64_t j = 0; rc == BESST_OK && ck[j & 1].n_blocks; ++j) {
-        const int k = (int)(j & 1);
-        if (!stage(j + 1)) break;                            // while chunk j inflates
+    if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks) enqueue_inflate(0);
+    for (int64_t j = 0; rc == BESST_OK && sl[j & 1].ck.n_blocks; ++j) {
+        Slot& q = sl[j & 1];
+        Slot& nx = sl[(j + 1) & 1];
+        // chunk j + 1: read, uploaded and inflating while chunk j's count is on its way
+        if (!stage(j + 1)) break;
+        if (nx.ck.n_blocks && !enqueue_inflate((int)((j + 1) & 1))) break;
         {
             const auto t0 = std::chrono::steady_clock::now();
-            const hipError_t e = hipEventSynchronize(summ_done[k]);
+            const hipError_t e = hipEventSynchronize(q.summ_done);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); break; }
         }
-        const uint32_t* sm = summ_host + 4 * k;
+        const uint32_t* sm = summ_host + 4 * (j & 1);
         if (!sm[1]) {
             if (sm[3]) set_error("push_bam_device: block %u of chunk %lld did not inflate on the device (status %u)", sm[2], (long long)j, sm[3]);
             else set_error("push_bam_device: a record straddles BGZF blocks (block %u of chunk %lld): not htslib's layout", sm[2], (long long)j);
@@ -762,13 +771,18 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         const int64_t have = c->n_records + pushed;
         if (have + got >= ((int64_t)1 << 32)) { set_error("more than 2^32-1 records in one context"); rc = BESST_ERR_ARG; break; }
         if ((size_t)(have + got) > c->tid.cap) {
-            // room for the whole file at the rate of the bytes read so far (+ 6 %), at least for this chunk
+            // room for the whole file at the rate of the bytes read so far (+ 6 %), at least for this chunk; the decode of
+            // the chunk before may still be writing the columns that are about to move
             int64_t want = have + got;
-            const size_t at = fpos - ck[(j + 1) & 1].comp;   // end of chunk j in the file
+            const size_t at = fpos - nx.ck.comp;             // end of chunk j in the file
             if (at > (size_t)f0 && at < map_len)
                 want = c->n_records + (int64_t)((double)(pushed + got) * ((double)(map_len - (size_t)f0) / (double)(at - (size_t)f0)) * 1.06) + 4096;
             if (want < have + got) want = have + got;
             if (want >= ((int64_t)1 << 32)) want = ((int64_t)1 << 32) - 1;
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t e = hipStreamSynchronize(nx.work);
+            wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (e != hipSuccess) { hip_fail(e); break; }
             const int64_t keep = c->n_records;
             c->n_records = have;
             rc = reserve_records(c, want);
@@ -777,14 +791,17 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         }
         col.tid = c->tid.p; col.mtid = c->mtid.p; col.pos = c->pos.p; col.mpos = c->mpos.p; col.tlen = c->tlen.p;
         col.flag = c->flag.p; col.qlen = c->qlen.p; col.mapq = c->mapq.p;
-        if (launch_bam_decode(c->stream, inflated, reinterpret_cast<const BgzfBlock*>(dev[k]), ck[k].n_blocks, offs, d_count, d_base, col,
-                              have, pushed, head_records, d_flags)) { rc = BESST_ERR_HIP; break; }
-        const hipError_t e = hipEventRecord(slot_free[k], c->stream);
+        if (launch_bam_decode(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks, q.offs, q.words + nb,
+                              q.words + 3 * nb, col, have, pushed, head_records, d_flags)) { rc = BESST_ERR_HIP; break; }
+        const hipError_t e = hipEventRecord(q.slot_free, q.work);
         if (e != hipSuccess) { hip_fail(e); break; }
         pushed += got;
         ++chunks;
-        if (ck[(j + 1) & 1].n_blocks && !enqueue_inflate((int)((j + 1) & 1))) break;
     }
+    const auto tw = std::chrono::steady_clock::now();
+    const hipError_t e0 = hipStreamSynchronize(sl[0].work), e1 = hipStreamSynchronize(sl[1].work);
+    const hipError_t ec = hipStreamSynchronize(copy_stream);
+    if (rc == BESST_OK && (e0 != hipSuccess || e1 != hipSuccess || ec != hipSuccess)) hip_fail(e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : ec);
     if (rc == BESST_OK) {
         hipError_t e = hipMemcpyAsync(summ_host + 8, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         const int64_t hn = pushed < head_records ? pushed : head_records;
@@ -793,13 +810,10 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
             if (e == hipSuccess) e = hipMemcpyAsync(head_alen, col.head_alen, (size_t)hn * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(head_qlen, col.head_qlen, (size_t)hn * 2, hipMemcpyDeviceToHost, c->stream);
         }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) hip_fail(e);
     }
-    const auto tw = std::chrono::steady_clock::now();
-    const hipError_t es = hipStreamSynchronize(c->stream);
-    const hipError_t ec = hipStreamSynchronize(copy_stream);
     wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-    if (rc == BESST_OK && (es != hipSuccess || ec != hipSuccess)) hip_fail(es != hipSuccess ? es : ec);
     if (rc == BESST_OK && (summ_host[8] & 1u)) {
         set_error("push_bam_device: corrupt record (its name and CIGAR do not fit its length)");
         rc = BESST_ERR_ARG;

@@ -546,7 +546,8 @@ int64_t besst_bam_read_records(besst_bam* b, int64_t max_records, int32_t* tid, 
  * Test / bench scaffolding: write record columns as a BAM file with htslib's block layout (a block is flushed before a
  * record that would not fit, so every block starts with a record).  Per record: name "r<index>", CIGAR [clip S] qlen M
  * with clip = rlen - qlen, rlen bases and qualities - qlen / rlen / alen round-trip through besst_bam_read_records.
- * Blocks are built and deflated by n_threads workers.  Nothing in the graph path calls this.
+ * Blocks are built and deflated by n_threads workers.  level: zlib's 0..9, + 16 for sequencer-like bases and qualities
+ * (see below) instead of constant bytes.  Nothing in the graph path calls this.
  * --------------------------------------------------------------------------------------------------------------- */
 int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* ref_names, const int32_t* ref_lengths,
                             int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos, const int32_t* mpos,
@@ -560,7 +561,7 @@ int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* 
     auto bgzf = [&](const uint8_t* data, size_t len, std::vector<uint8_t>& out) {
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        if (deflateInit2(&zs, level & 15, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
         std::vector<uint8_t> payload(deflateBound(&zs, (uLong)len) + 16);
         zs.next_in = const_cast<Bytef*>(data);
         zs.avail_in = (uInt)len;
@@ -647,8 +648,27 @@ int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* 
                 raw.insert(raw.end(), nm, nm + nl);
                 if (clip) put32(raw, (clip << 4) | 4u);
                 if (q) put32(raw, (q << 4) | 0u);
-                raw.insert(raw.end(), (sl + 1) / 2, (uint8_t)0x11);
-                raw.insert(raw.end(), sl, (uint8_t)0xff);
+                if (!(level & 16)) {
+                    raw.insert(raw.end(), (sl + 1) / 2, (uint8_t)0x11);
+                    raw.insert(raw.end(), sl, (uint8_t)0xff);
+                } else {
+                    // level | 16: bases and qualities that compress like a sequencer's (pseudo-random bases: 4 bits each;
+                    // qualities from a few values that change slowly along the read) instead of constant bytes
+                    uint64_t x = 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1);
+                    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+                    static const uint8_t kBase[4] = {1, 2, 4, 8};
+                    for (uint32_t k = 0; k < (sl + 1) / 2; ++k) {
+                        const uint64_t r = next();
+                        raw.push_back((uint8_t)((kBase[r & 3] << 4) | kBase[(r >> 2) & 3]));
+                    }
+                    static const uint8_t kQual[8] = {37, 37, 37, 32, 37, 25, 37, 11};
+                    uint8_t q8 = 37;
+                    for (uint32_t k = 0; k < sl; ++k) {
+                        const uint64_t r = next();
+                        if ((r & 7) == 0) q8 = kQual[(r >> 3) & 7];
+                        raw.push_back(q8);
+                    }
+                }
             }
             if (!bgzf(raw.data(), raw.size(), outs[k])) good = false;
         });

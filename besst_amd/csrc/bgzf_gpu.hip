@@ -42,6 +42,7 @@ constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
 constexpr int kClBits = 7;
 constexpr uint32_t kFlushGranule = 8192;
+constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is no short code: length nibble 0, and not below 0x1000 (a literal)
 
 // status of a block (0 = inflated)
 enum : uint32_t {
@@ -70,8 +71,8 @@ struct InflateLds {
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // Canonical code of `n` symbols with lengths lens[0..n) (0 = unused): per-length counts, first codes and offsets into
-// `sorted` (symbols by length, then by value), then the primary table of 2^bits entries (symbol << 4 | length; 0: the
-// code is longer than the table, or the pattern is not a code).  Returns false when the lengths oversubscribe the
+// `sorted` (symbols by length, then by value), then the primary table of 2^bits entries (symbol << 4 | length; kNoEntry:
+// the code is longer than the table, or the pattern is not a code).  Returns false when the lengths oversubscribe the
 // code space.  All lanes take part; everything returned in LDS.
 __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits, uint16_t* tab, uint16_t* sorted, CanonLds* c, int lane) {
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -126,12 +127,12 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
     __builtin_amdgcn_wave_barrier();
     for (int slot = lane; slot < (1 << bits); slot += 64) {
         const uint32_t r = __brev((uint32_t)slot) >> (32 - bits);          // the slot's bits as an MSB-first code prefix
-        uint32_t e = 0;
+        uint32_t e = kNoEntry;
 #pragma unroll
         for (int L = 1; L <= kTabBits; ++L) {
             if (L <= bits) {
                 const uint32_t d = (r >> (bits - L)) - first[L];
-                if (e == 0 && d < cnt[L]) e = ((uint32_t)sorted[offs[L] + d] << 4) | (uint32_t)L;
+                if (e == kNoEntry && d < cnt[L]) e = ((uint32_t)sorted[offs[L] + d] << 4) | (uint32_t)L;
             }
         }
         tab[slot] = (uint16_t)e;
@@ -337,24 +338,46 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             __builtin_amdgcn_wave_barrier();
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kTabBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
-            // ---- the symbols
+            // ---- the symbols.  Literals are not stored one by one: literal k of a run goes into lane k of a register
+            // (a compare and a select) and the run leaves with ONE store in front of the next match, at 64 literals or at
+            // the end of the block - a literal costs the table look-up, two shifts and that select (a sequencer's
+            // qualities and bases are literals: five symbols of six in such a file).
+            uint32_t lit_v = 0, run = 0;                     // (run: uniform)
+            auto flush_run = [&]() -> bool {                 // false: the output would overrun
+                if (run == 0u) return true;
+                if (pos + run > dst_len) return false;
+                if ((uint32_t)lane < run) put_byte(pos + (uint32_t)lane, lit_v);
+                pos = uni(pos + run);                        // (kept scalar by force: without it the compiler turns this
+                run = 0;                                     // branch into selects and the whole symbol loop into vector code)
+                if (pos - flushed >= kFlushGranule) flush_granules();
+                return true;
+            };
             for (;;) {
                 br.refill();
                 uint32_t e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
+                while (e < 0x1000u) {                        // a literal whose code fits the table (other entries are >= 0x1000)
+                    br.take(e & 15u);
+                    lit_v = (uint32_t)lane == run ? e >> 4 : lit_v;
+                    if (++run == 64u && !flush_run()) break;
+                    br.refill();
+                    e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
+                }
+                if (run == 64u) { err = kInfOutputOverrun; break; }          // (the inner loop left on a failed flush)
                 if ((e & 15u) == 0u) {
                     e = uni(slow_code(&s.lit_c, s.lit_sorted, (uint32_t)br.bb & 0x7fffu, kTabBits));
                     if (e == 0u) { err = kInfBadCode; break; }
                 }
                 br.take(e & 15u);
                 uint32_t sym = e >> 4;
-                if (sym < 256u) {
-                    if (pos >= dst_len) { err = kInfOutputOverrun; break; }
-                    put_byte(pos, sym);
-                    ++pos;
-                    if ((pos & (kFlushGranule - 1u)) == 0u) flush_granules();
+                if (sym < 256u) {                            // a literal with a long code
+                    lit_v = (uint32_t)lane == run ? sym : lit_v;
+                    if (++run == 64u && !flush_run()) { err = kInfOutputOverrun; break; }
                     continue;
                 }
-                if (sym == 256u) break;
+                if (sym == 256u) {
+                    if (!flush_run()) err = kInfOutputOverrun;
+                    break;
+                }
                 sym -= 257u;
                 if (sym >= 29u) { err = kInfBadCode; break; }
                 uint32_t length;
@@ -379,9 +402,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     const uint32_t ex = (dsym - 2u) >> 1;
                     dist = 1u + ((2u + (dsym & 1u)) << ex) + br.take(ex);
                 }
+                if (!flush_run()) { err = kInfOutputOverrun; break; }       // the match may read the run
                 if (dist > pos) { err = kInfBadDistance; break; }
                 if (pos + length > dst_len) { err = kInfOutputOverrun; break; }
-                if (dist >= length || dist >= 64u) {
+                if (length <= 64u && dist >= length) {
+                    if ((uint32_t)lane < length) put_byte(pos + (uint32_t)lane, get_byte(pos + (uint32_t)lane - dist));
+                } else if (dist >= length || dist >= 64u) {
                     // every source byte of a round of 64 is finished output (rounds complete in order)
                     for (uint32_t i = (uint32_t)lane; i < length; i += 64u)
                         put_byte(pos + i, get_byte(pos + i - dist));

@@ -266,7 +266,9 @@ int64_t besst_bam_read_records(besst_bam* bam, int64_t max_records, int32_t* tid
                                int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen,
                                int32_t* rlen, int32_t* alen);
 /* Test / bench scaffolding, not part of the graph path: the columns as a BAM file in htslib's block layout (name
- * "r<index>", CIGAR [clip S] qlen M, rlen bases) - what tests and bench.py read back through the reader above. */
+ * "r<index>", CIGAR [clip S] qlen M, rlen bases) - what tests and bench.py read back through the reader above.
+ * level: zlib's 0..9; + 16: pseudo-random bases and slowly changing qualities (a file that compresses like a sequencer's,
+ * ~3 x) instead of constant bytes (~13 x). */
 int besst_bam_write_records(const char* path, int64_t n_ref, const char* const* ref_names, const int32_t* ref_lengths,
                             int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* pos, const int32_t* mpos,
                             const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq, const uint16_t* qlen,

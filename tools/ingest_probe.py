@@ -10,7 +10,7 @@ from besst_amd import _lib, bamio, workload
 config = sys.argv[1] if len(sys.argv) > 1 else 'C2'
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None
 where = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != '-' else ('/dev/shm' if os.path.isdir('/dev/shm') else tempfile.mkdtemp())
-level = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+level = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # + 16: sequencer-like bases and qualities
 dev = torch.device('cuda', 0)
 wl = workload.make_device(dev, config, 0, pairs=pairs)
 batch = wl['batch']
