@@ -301,6 +301,58 @@ def bam_to_graph_timing(device, config, pairs=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def bam_ingest_timing(device, config, pairs):
+    """Ingest only, both forms, on a file whose bases and qualities compress like a sequencer's (~3.3 x: pseudo-random
+    bases, slowly changing qualities - five DEFLATE symbols of six are literals) instead of the constant bytes the other
+    BAM stages write (~13 x, long matches): the inflate kernel's other regime."""
+    import shutil
+    import tempfile
+    from besst_amd import _lib, bamio, workload
+    wl = workload.make_device(device, config, 0, pairs=pairs)
+    batch = wl['batch']
+    del wl['cols']
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > 128 * len(batch) else None
+    tmp = tempfile.mkdtemp(prefix='besst_amd_bam_', dir=base)
+    path = os.path.join(tmp, 'lib.bam')
+    try:
+        t0 = time.perf_counter()
+        bamio.write_bam(path, batch, level=1, realistic=True)
+        write_s = time.perf_counter() - t0
+        n_rec, size = len(batch), os.path.getsize(path)
+        del batch, wl
+        out = {'records': n_rec, 'bam_bytes': size, 'bytes_per_record_compressed': round(size / n_rec, 1),
+               'write_bam_s_untimed': round(write_s, 2), 'usable_cpus': _lib.effective_cpus()}
+        held = []
+        for mode in ('device', 'host'):
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                bam = bamio.ResidentBam(path, mode=mode)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    if best is not None:
+                        best[1].close()
+                    best = (dt, bam)
+                else:
+                    bam.close()
+            dt, bam = best
+            out[mode] = {'ingest_s': round(dt, 3), 'records_per_s': n_rec / dt, 'compressed_GBps': round(size / dt / 1e9, 2),
+                         'on_device': int(bam.ingest.on_device), 'h2d_bytes': int(bam.ingest.bytes_h2d),
+                         'inflated_bytes': int(bam.ingest.inflated_bytes)}
+            held.append(bam)
+        agree = len(held[0]) == len(held[1])
+        step = 16 << 20
+        for lo in range(0, n_rec if agree else 0, step):
+            a, b = held[0].ctx.fetch_records(lo, min(step, n_rec - lo)), held[1].ctx.fetch_records(lo, min(step, n_rec - lo))
+            agree = agree and all(np.array_equal(a[k], b[k]) for k in a)
+        out['forms_agree'] = bool(agree)
+        for bam in held:
+            bam.close()
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 class _SeqLen(object):                                   # PE only takes len() of a contig's sequence and stores it
     __slots__ = ('n',)
 
@@ -740,6 +792,8 @@ def main_single(args, device, result_fd):
                 try:
                     out['stages']['bam_to_graph_' + cfg_name.lower()] = bam_to_graph_timing(
                         device, cfg_name, pairs=50_000_000 if big else None)
+                    if big:
+                        out['stages']['bam_ingest_sequencer_like'] = bam_ingest_timing(device, cfg_name, pairs=20_000_000)
                 except Exception as e:                       # noqa: BLE001 - the bench line must still be printed
                     out['stages']['bam_to_graph_' + cfg_name.lower()] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
     if args.also and args.also != args.config and args.pairs is None:

@@ -221,11 +221,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     BitReader br;
     br.lane = lane;
     {
-        const uintptr_t a = (uintptr_t)(src + src_off);
-        br.words = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-        br.seek((uint32_t)(a & 3u));
+        // (src is 4-byte aligned; no detour through an integer, so that the window loads are global loads - a flat load
+        // also counts as an LDS operation, and every table look-up behind one would wait for it)
+        br.words = reinterpret_cast<const uint32_t*>(src + (src_off & ~3u));
+        br.seek(src_off & 3u);
     }
-    const uint32_t in_base = (uint32_t)((uintptr_t)(src + src_off) & 3u);
+    const uint32_t in_base = src_off & 3u;
     uint32_t pos = 0, flushed = 0;
     uint32_t err = kInfOk;
     // ---- the window.  LDS form: bytes go to the ring and leave for HBM in granules.  Global form: bytes go straight to the
