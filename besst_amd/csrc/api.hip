@@ -363,6 +363,14 @@ int besst_ctx_record_count(besst_ctx* c, int64_t* n) {
     return BESST_OK;
 }
 
+int besst_ctx_record_pointers(besst_ctx* c, int64_t* n, uint64_t* ptrs) {
+    BESST_REQUIRE(c && n && ptrs, "null pointer");
+    *n = c->n_records;
+    const void* p[8] = {c->tid.p, c->mtid.p, c->pos.p, c->mpos.p, c->tlen.p, c->flag.p, c->mapq.p, c->qlen.p};
+    for (int k = 0; k < 8; ++k) ptrs[k] = (uint64_t)(uintptr_t)p[k];
+    return BESST_OK;
+}
+
 int besst_ctx_fetch_records(besst_ctx* c, int64_t first, int64_t n, int32_t* tid, int32_t* mtid, int32_t* pos, int32_t* mpos,
                             int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen) {
     BESST_REQUIRE(c, "null context");
@@ -576,6 +584,30 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
     return true;
 }
 
+// First BGZF block boundary at or behind `from`: the gzip magic with the BC subfield, a plausible BSIZE, and two further
+// blocks (or the end of the file) chained behind it - payload bytes that happen to spell a header do not survive that.
+size_t find_bgzf_boundary(const uint8_t* map, size_t map_len, size_t from) {
+    auto le16 = [](const uint8_t* p) { return (size_t)p[0] | ((size_t)p[1] << 8); };
+    auto block_at = [&](size_t at, size_t* bsize) {
+        if (map_len - at < 28) return false;
+        const uint8_t* h = map + at;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || le16(h + 10) < 6 || h[12] != 'B' || h[13] != 'C' || le16(h + 14) != 2)
+            return false;
+        *bsize = le16(h + 16) + 1;
+        return *bsize >= 28 && *bsize <= map_len - at;
+    };
+    for (size_t at = from; at + 28 <= map_len; ++at) {
+        size_t b0 = 0, b1 = 0, b2 = 0;
+        if (!block_at(at, &b0)) continue;
+        const size_t n1 = at + b0;
+        if (n1 == map_len) return at;
+        if (!block_at(n1, &b1)) continue;
+        const size_t n2 = n1 + b1;
+        if (n2 == map_len || block_at(n2, &b2)) return at;
+    }
+    return map_len;
+}
+
 }  // namespace
 
 // BAM file -> resident records with the inflate and the record decode on the GPU: the file's COMPRESSED bytes are read into
@@ -587,7 +619,17 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
 // inflate - returns BESST_ERR_UNSUPPORTED with context and reader untouched, and the caller takes besst_ctx_push_bam.
 int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
+    return besst_ctx_push_bam_device_part(c, bam, 0, 1, chunk_blocks, head_records, head_rlen, head_alen, head_qlen, stats);
+}
+
+// The same for ONE PART of the file's records (multi-GPU ingest: rank r of W takes part r of W and holds the r-th slice of
+// the stream, which is what phase 1 of the sharded build works on): the file is cut at the BGZF block boundaries nearest
+// to part / parts of its bytes - in htslib's layout every block begins with a record, so every boundary is a valid place
+// to start, and every rank finds the same boundaries on its own.
+int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks, int64_t head_records,
+                                   int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
     BESST_REQUIRE(c && bam, "push_bam_device: null context or reader");
+    BESST_REQUIRE(parts >= 1 && part >= 0 && part < parts, "push_bam_device: part must be in [0, parts)");
     BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)),
                   "push_bam_device: head buffers missing");
     if (chunk_blocks <= 0) chunk_blocks = 16384;
@@ -602,7 +644,22 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
         set_error("push_bam_device: the reader is inside a record that straddles two batches");
         return BESST_ERR_UNSUPPORTED;
     }
-    const size_t map_len = (size_t)bam_file_bytes(bam);
+    size_t map_len = (size_t)bam_file_bytes(bam);        // (from here on: the end of this call's part of the file)
+    if (parts > 1) {
+        const uint8_t* map = bam_file_map(bam);
+        const size_t file_len = map_len;
+        auto cut = [&](int32_t k) -> size_t {
+            if (k <= 0) return (size_t)f0;
+            if (k >= parts) return file_len;
+            const size_t at = find_bgzf_boundary(map, file_len, (size_t)((double)file_len * (double)k / (double)parts));
+            return at < (size_t)f0 ? (size_t)f0 : at;
+        };
+        const size_t begin = cut(part);
+        map_len = cut(part + 1);
+        if (begin != (size_t)f0) u0 = 0;
+        f0 = (int64_t)begin;
+        if (map_len < begin) map_len = begin;
+    }
     const size_t nb = (size_t)chunk_blocks;
     // a chunk: nb blocks or comp_cap compressed bytes, whichever comes first (a sequencer's blocks are ~18 KB: 8 K of them)
     size_t comp_cap = std::max<size_t>((size_t)160 << 20, nb * 8192);

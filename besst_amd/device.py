@@ -61,12 +61,21 @@ def _timed(fn):
     return wrapper
 
 
+class _DeviceView(object):
+    """__cuda_array_interface__ over a span of a context's HBM (keeps the context alive)."""
+
+    def __init__(self, owner, ptr, n, typestr):
+        self.owner = owner
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (ptr, False), 'version': 2, 'strides': None}
+
+
 class GraphContext(object):
     def __init__(self, device=0):
         self._lib = _lib.load()
         self._ctx = self._lib.besst_ctx_create(int(device))
         if not self._ctx:
             raise BesstDeviceError('besst_ctx_create(%d) failed: %s' % (device, _lib.last_error()))
+        self.device = int(device)
         self.n_contigs = 0
 
     def close(self):
@@ -119,12 +128,13 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
 
     @_timed
-    def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0):
+    def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0, part=None):
         """Stream an open besst_bam (bamio) into the context.  mode 'device': BGZF inflate + record decode on the GPU, the
         compressed file crosses PCIe (besst_ctx_push_bam_device; files in htslib's block layout); 'host': inflate + decode
         on the reader's host threads into pinned staging, copies under the next chunk's decode (besst_ctx_push_bam, any
         layout); 'auto' (default; BESST_INGEST overrides): the device form, and the host form when the library answers
-        BESST_ERR_UNSUPPORTED (``stats.on_device`` tells which one ran).
+        BESST_ERR_UNSUPPORTED (``stats.on_device`` tells which one ran).  part = (r, W): only the r-th of W parts of the
+        file's records (cut at BGZF block boundaries; multi-GPU ingest: rank r's slice of the stream) - device form only.
         -> (IngestStats, head rlen, head alen, head qlen)."""
         import os
         from ._lib import IngestStats
@@ -136,9 +146,16 @@ class GraphContext(object):
         alen = np.zeros(head_records, dtype=np.int32)
         qlen = np.zeros(head_records, dtype=np.uint16)
         done = False
+        if part is not None:
+            r, w = int(part[0]), int(part[1])
+            if mode == 'host':
+                raise ValueError('push_bam: a part of a file is read by the device form only')
+            mode = 'device'
+        else:
+            r, w = 0, 1
         if mode in ('auto', 'device'):
-            rc = self._lib.besst_ctx_push_bam_device(self._ctx, handle, int(chunk_blocks), int(head_records), _lib.ptr(rlen),
-                                                     _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
+            rc = self._lib.besst_ctx_push_bam_device_part(self._ctx, handle, r, w, int(chunk_blocks), int(head_records),
+                                                          _lib.ptr(rlen), _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
             if rc == 0:
                 done = True
             elif rc != _lib.ERR_UNSUPPORTED or mode == 'device':
@@ -150,6 +167,24 @@ class GraphContext(object):
                                                     _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats)), 'push_bam')
         k = min(head_records, stats.records)
         return stats, rlen[:k], alen[:k], qlen[:k]
+
+    def record_tensors(self):
+        """The resident columns as torch tensors that VIEW the context's memory (no copy; valid while the context lives and
+        its records do not change) - what pipeline.DeviceRecords.from_columns and the sharded build take."""
+        import torch
+        n = C.c_int64(0)
+        ptrs = np.zeros(8, dtype=np.uint64)
+        _lib.check(self._lib.besst_ctx_record_pointers(self._ctx, C.byref(n), _lib.ptr(ptrs)), 'record_pointers')
+        spec = (('tid', '<i4'), ('mtid', '<i4'), ('pos', '<i4'), ('mpos', '<i4'), ('tlen', '<i4'), ('flag', '<u2'), ('mapq', '|u1'),
+                ('qlen', '<u2'))
+        out = {}
+        for (name, typestr), ptr in zip(spec, ptrs.tolist()):
+            view = _DeviceView(self, int(ptr), int(n.value), typestr)
+            t = torch.as_tensor(view, device=torch.device('cuda', self.device))
+            if name in ('flag', 'qlen') and t.dtype != torch.uint16:
+                t = t.view(torch.uint16)
+            out[name] = t
+        return out
 
     def fetch_records(self, first=0, n=None):
         """The resident records as host columns (dict of numpy arrays)."""

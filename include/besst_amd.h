@@ -154,6 +154,10 @@ int besst_ctx_push_records(besst_ctx* ctx, int64_t n, const int32_t* tid, const 
 /* The resident records back on the host (any column pointer may be NULL): what a caller that ingested a file straight
  * into HBM (below) needs to look at the records themselves; also how the tests compare the two ingest forms. */
 int besst_ctx_record_count(besst_ctx* ctx, int64_t* n_records);
+/* The resident columns where they lie: eight HBM pointers (tid mtid pos mpos tlen flag mapq qlen) for the besst_dev_*
+ * layer - a rank of the sharded build works on the slice its besst_ctx_push_bam_device_part left here, no copy.  Valid
+ * until the context's records change or the context is destroyed. */
+int besst_ctx_record_pointers(besst_ctx* ctx, int64_t* n_records, uint64_t* ptrs);
 int besst_ctx_fetch_records(besst_ctx* ctx, int64_t first, int64_t n, int32_t* tid, int32_t* mtid, int32_t* pos,
                             int32_t* mpos, int32_t* tlen, uint16_t* flag, uint8_t* mapq, uint16_t* qlen);
 
@@ -188,6 +192,14 @@ int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, in
  * inflate: call besst_ctx_push_bam then.  The blocks' gzip CRC32 is not checked (nor does the host form check it). */
 int besst_ctx_push_bam_device(besst_ctx* ctx, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
+
+/* The same for one PART of the file's records - multi-GPU ingest: rank r of W calls it with (r, W) and holds the r-th
+ * contiguous slice of the stream, the slice phase 1 of the sharded graph build works on.  The file is
+ * cut at the BGZF block boundaries nearest to part / parts of its bytes; every caller finds the same boundaries on its own
+ * (gzip magic + BC subfield + two chained blocks behind it).  The head_* arrays describe the part's first records. */
+int besst_ctx_push_bam_device_part(besst_ctx* ctx, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks,
+                                   int64_t head_records, int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen,
+                                   besst_ingest_stats* stats);
 
 /* Test hook of the device inflate: the BGZF blocks of `bgzf` (n_bytes, host) inflated on `device`, their output
  * concatenated in out (capacity out_cap, length in *out_len).  BESST_ERR_UNSUPPORTED when a block does not inflate

@@ -482,3 +482,67 @@ def test_empty_and_linkless_slices_in_the_middle(heads):
         if k & 1:
             r['s'] = r['s2'] = 0
     assert merged == want_rows
+
+
+@pytest.mark.parametrize('world', [3, 8])
+def test_simulated_ranks_ingest_their_part_of_a_bam_file(world, tmp_path):
+    """The whole multi-GPU path from the file: rank r ingests part (r, W) of the BAM on the GPU (besst_ctx_push_bam_device_part:
+    its slice of the stream, cut at BGZF block boundaries), the sharded build runs on the context's columns where they lie
+    (besst_ctx_record_pointers, no copy), and the merged edge tables equal the single-process oracle's on the whole file."""
+    import torch
+    from besst_amd import bamio, distributed, workload
+    wl = workload.make('C3', 0, pairs=150000, nc=300)
+    path = str(tmp_path / 'lib.bam')
+    bamio.write_bam(path, wl['batch'], threads=3, level=1, realistic=True)
+    dev = torch.device('cuda', 0)
+    pair_cap = 16384
+    backends, bams, total = [], [], 0
+    for r in range(world):
+        bam = bamio.ResidentBam(path, threads=2, part=(r, world), chunk_blocks=64)
+        assert bam.ingest.on_device == 1
+        bams.append(bam)
+        total += len(bam)
+        sub = {k: v for k, v in wl.items() if k not in ('batch', 'cols', '_rec')}
+        sub['cols'] = bam.ctx.record_tensors()
+        assert int(sub['cols']['tid'].shape[0]) == len(bam)
+        backends.append(distributed.HipBackend(dev, sub, r, world, pair_cap))
+    assert total == len(wl['batch'])
+    tails = []
+    for b in backends:
+        b.reset()
+        b.classify_scan()
+        tails.append(b.classify_tail().clone())
+    sends = []
+    for b in backends:
+        b.classify_emit_speculative()
+        sends.append(b.partition().clone())
+    if not backends[0].sums_ride_exchange:
+        tot = sum(b.pack_for_allreduce().clone() for b in backends)
+        for b in backends:
+            b.pack_for_allreduce().copy_(tot)
+    region = backends[0].region
+    for r, b in enumerate(backends):
+        b.unpack(torch.cat([sends[s][r * region:(r + 1) * region] for s in range(world)]))
+        b.reduce()
+    torch.cuda.synchronize()
+    assert not any(b.overflowed() for b in backends)
+    want_rows, want = DU.expected_rows(wl['batch'], wl['table'], wl['lib'], wl['node_bits'])
+    assert backends[0].aligned.cpu().tolist() == want.aligned
+    assert backends[0].counter_words.cpu().tolist()[:8] == [want.count, want.non_unique, want.non_unique_for_scaf, want.nr_of_duplicates,
+                                                            want.too_long, want.fishy_reads, len(want.tuples), want.n_reach]
+    merged = {}
+    for r, b in enumerate(backends):
+        rows = DU.rows_from_table(b.local_table())
+        for k in rows:
+            if k & 1:
+                rows[k]['lo'] = [0] * rows[k]['n']
+                rows[k]['hi'] = [0] * rows[k]['n']
+        assert not set(rows) & set(merged)
+        merged.update(rows)
+    for k, r in want_rows.items():
+        if k & 1:
+            r['s'] = r['s2'] = 0
+    assert merged == want_rows
+    del backends
+    for bam in bams:
+        bam.close()

@@ -256,3 +256,71 @@ def test_second_library_appends():
     for col in COLS:
         want = np.concatenate([getattr(batch, col), getattr(batch, col)])
         assert np.array_equal(got[col], want), col
+
+
+def _ingest_parts(path, parts, **kw):
+    got, counts = {c: [] for c in COLS}, []
+    for r in range(parts):
+        bam = bamio.ResidentBam(path, threads=2, part=(r, parts), **kw)
+        try:
+            assert bam.ingest.on_device == 1
+            cols = bam.ctx.fetch_records()
+            counts.append(len(bam))
+            for c in COLS:
+                got[c].append(cols[c])
+        finally:
+            bam.close()
+    return {c: np.concatenate(v) for c, v in got.items()}, counts
+
+
+@pytest.mark.parametrize('parts', [2, 3, 8])
+def test_parts_of_a_file_tile_its_records(parts):
+    """Multi-GPU ingest: rank r of W takes part (r, W) - the parts, cut at BGZF block boundaries every rank finds on its
+    own, are contiguous slices of the stream and together the whole of it."""
+    batch = _library(20000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bamio.write_bam(path, batch, threads=3, level=1, realistic=True)
+        whole, counts = _ingest_parts(path, parts, chunk_blocks=64)
+    assert sum(counts) == len(batch) and min(counts) > 0
+    assert max(counts) < 2 * len(batch) / parts            # (cut by bytes: about equal)
+    for c in COLS:
+        assert np.array_equal(whole[c], getattr(batch, c)), c
+
+
+def test_parts_of_a_small_file_and_a_false_block_header():
+    """More parts than blocks (most parts are empty), and payload bytes that spell a BGZF header (a stored block whose
+    record carries them in an auxiliary field): a boundary is only where blocks chain behind it."""
+    import gzip
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bam')
+    with gzip.open(os.path.join(here, 'handmade_a.bam'), 'rb') as fh:
+        raw = fh.read()
+    l_text = struct.unpack_from('<I', raw, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from('<I', raw, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        at += 8 + struct.unpack_from('<I', raw, at)[0]
+    header, recs = raw[:at], []
+    while at < len(raw):
+        size = struct.unpack_from('<I', raw, at)[0]
+        recs.append(raw[at:at + 4 + size])
+        at += 4 + size
+    fake = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, 99) + bytes(range(60))
+    body = recs[0][4:] + b'ZZB' + b'C' + struct.pack('<I', len(fake)) + fake       # an auxiliary B:C array holding it
+    liar = struct.pack('<I', len(body)) + body
+    recs = recs[:2] + [liar] * 40 + recs[2:]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'aligned.bam')
+        with open(path, 'wb') as fh:
+            fh.write(_bgzf(header))
+            for i in range(0, len(recs), 2):
+                fh.write(_bgzf(b''.join(recs[i:i + 2]), level=0 if i % 4 == 0 else 6))
+            fh.write(_bgzf(b''))
+        host = bamio.read_bam(path, threads=2)
+        assert len(host) == len(recs)
+        for parts in (2, 5, 64):
+            whole, counts = _ingest_parts(path, parts)
+            assert sum(counts) == len(recs), (parts, counts)
+            for c in COLS:
+                assert np.array_equal(whole[c], getattr(host, c)), (parts, c)
