@@ -1,0 +1,42 @@
+"""The scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder (tools/inflate_model.py: the table construction, the arithmetic
+form of the length / distance codes and the long-code path the kernel mirrors) against zlib - the part of the device
+inflate that can be checked without a GPU."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+
+
+def test_model_equals_zlib(capsys):
+    import inflate_model
+    inflate_model.main()
+    assert 'equal to zlib' in capsys.readouterr().out
+
+
+def test_length_and_distance_codes_in_closed_form():
+    """RFC 1951's tables against the shifts the kernel computes them with."""
+    lb = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    le = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+    db = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+          8193, 12289, 16385, 24577]
+    de = [0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13]
+    for s in range(29):
+        if s < 8:
+            b, e = 3 + s, 0
+        elif s == 28:
+            b, e = 258, 0
+        else:
+            e = (s - 4) >> 2
+            b = 3 + ((4 + (s & 3)) << e)
+        assert (b, e) == (lb[s], le[s])
+    for s in range(30):
+        if s < 4:
+            b, e = 1 + s, 0
+        else:
+            e = (s - 2) >> 1
+            b = 1 + ((2 + (s & 1)) << e)
+        assert (b, e) == (db[s], de[s])
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    for i in range(19):
+        got = 16 + i if i < 3 else 0 if i == 3 else 8 - ((i - 3) >> 1) if i & 1 else 8 + ((i - 4) >> 1)
+        assert got == order[i]
