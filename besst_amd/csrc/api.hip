@@ -632,7 +632,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     BESST_REQUIRE(parts >= 1 && part >= 0 && part < parts, "push_bam_device: part must be in [0, parts)");
     BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)),
                   "push_bam_device: head buffers missing");
-    if (chunk_blocks <= 0) chunk_blocks = 16384;
+    if (chunk_blocks <= 0) chunk_blocks = 8192;              // (a little more than one full chip of waves: 7168)
     if (chunk_blocks < 64) chunk_blocks = 64;
     if (chunk_blocks > 65536) chunk_blocks = 65536;
     int rc = use_device(c);
@@ -661,9 +661,24 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (map_len < begin) map_len = begin;
     }
     const size_t nb = (size_t)chunk_blocks;
-    // a chunk: nb blocks or comp_cap compressed bytes, whichever comes first (a sequencer's blocks are ~18 KB: 8 K of them)
-    size_t comp_cap = std::max<size_t>((size_t)160 << 20, nb * 8192);
-    if (comp_cap > map_len + 65536) comp_cap = align_up(map_len + 65536, 4096);
+    // a chunk: nb blocks or comp_cap compressed bytes, whichever comes first.  The staging slots are pinned (~70 us per
+    // MB to allocate and release), so they are sized from the file's first blocks - ~5 KB each in a file of constant
+    // qualities, ~18 KB in a sequencer's - with a third in hand; denser blocks further on just make a chunk hold fewer.
+    size_t comp_cap = (size_t)160 << 20;
+    {
+        const uint8_t* map = bam_file_map(bam);
+        size_t at = (size_t)f0, seen = 0;
+        while (seen < 256 && at + 18 <= map_len && map[at] == 31 && map[at + 1] == 139) {
+            at += ((size_t)map[at + 16] | ((size_t)map[at + 17] << 8)) + 1;
+            ++seen;
+        }
+        if (seen >= 16 && at <= map_len) {
+            const size_t guess = align_up((size_t)((double)(at - (size_t)f0) / (double)seen * (double)nb * 1.35) + ((size_t)4 << 20), 4096);
+            if (guess < comp_cap) comp_cap = guess;
+        }
+    }
+    if (comp_cap > map_len - (size_t)f0 + 65536) comp_cap = align_up(map_len - (size_t)f0 + 65536, 4096);
+    if (comp_cap < ((size_t)1 << 20)) comp_cap = (size_t)1 << 20;
     const size_t desc_bytes = align_up(nb * sizeof(BgzfBlock), 4096);
     const size_t slot_bytes = desc_bytes + comp_cap + 4096;      // (the bit reader's windows run up to 512 bytes past a payload)
     struct Chunk { uint32_t n_blocks = 0, first_off = 0; size_t comp = 0, inflated = 0; };

@@ -185,7 +185,7 @@ int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, in
                        int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
 
 /* The same with BGZF inflate, record walk and record decode ON THE GPU (csrc/bgzf_gpu.hip): the file's compressed bytes
- * are what crosses PCIe - staged through pinned memory chunk by chunk (chunk_blocks BGZF blocks, <= 0: 16384), chunk
+ * are what crosses PCIe - staged through pinned memory chunk by chunk (chunk_blocks BGZF blocks, <= 0: 8192), chunk
  * j + 1 uploaded while chunk j inflates (one wave per block).  For files in htslib's block layout, where every BGZF
  * block begins with a record (samtools, bwa | samtools, this library's writer).  Returns BESST_ERR_UNSUPPORTED - context
  * and reader unchanged - for any other layout (a record that straddles blocks) and for a block the device does not
