@@ -339,31 +339,44 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             __builtin_amdgcn_wave_barrier();
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kTabBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
-            // ---- the symbols.  Literals are not stored one by one: literal k of a run goes into lane k of a register
-            // (a compare and a select) and the run leaves with ONE store in front of the next match, at 64 literals or at
-            // the end of the block - a literal costs the table look-up, two shifts and that select (a sequencer's
-            // qualities and bases are literals: five symbols of six in such a file).
-            uint32_t lit_v = 0, run = 0;                     // (run: uniform)
-            auto flush_run = [&]() -> bool {                 // false: the output would overrun
-                if (run == 0u) return true;
-                if (pos + run > dst_len) return false;
-                if ((uint32_t)lane < run) put_byte(pos + (uint32_t)lane, lit_v);
-                pos = uni(pos + run);                        // (kept scalar by force: without it the compiler turns this
-                run = 0;                                     // branch into selects and the whole symbol loop into vector code)
-                if (pos - flushed >= kFlushGranule) flush_granules();
-                return true;
+            // ---- the symbols.  Output leaves in GROUPS of up to 64 bytes: lane k of the group stands for the byte at
+            // pos + k and holds either a literal (value in g_val, its bit in g_lit) or the place its byte is copied from
+            // (g_src); a literal is a compare and a select, a match two compares and a select per piece.  A full group -
+            // or a match whose source reaches into the group, or the end of the block - flushes it: ONE gather of the
+            // lanes that copy, ONE contiguous store.  The memory round trip of a match (~1 us with the window in HBM / L2,
+            // and a wave has nothing else to do meanwhile) is paid once per 64 bytes of output instead of once per match
+            // (a sequencer's file: 5241 matches of 9.7 bytes and 8865 literals in a block of 60 KB).
+            uint32_t g_val = 0, g_src = 0;
+            unsigned long long g_lit = 0;                    // uniform: the literal lanes
+            uint32_t filled = 0;                             // uniform: lanes of the group in use
+            auto flush_group = [&]() {
+                if (filled != 0u) {
+                    if ((uint32_t)lane < filled) {
+                        uint32_t v = g_val;
+                        if (!((g_lit >> lane) & 1ull)) v = get_byte(g_src);
+                        put_byte(pos + (uint32_t)lane, v);
+                    }
+                    pos = uni(pos + filled);                 // (kept scalar by force: without it the compiler turns this
+                    filled = 0;                              // branch into selects and the whole symbol loop into vector code)
+                    g_lit = 0;
+                    if (kLds && pos - flushed >= kFlushGranule) flush_granules();
+                }
             };
             for (;;) {
                 br.refill();
                 uint32_t e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
                 while (e < 0x1000u) {                        // a literal whose code fits the table (other entries are >= 0x1000)
                     br.take(e & 15u);
-                    lit_v = (uint32_t)lane == run ? e >> 4 : lit_v;
-                    if (++run == 64u && !flush_run()) break;
+                    g_val = (uint32_t)lane == filled ? e >> 4 : g_val;
+                    g_lit |= 1ull << filled;
+                    if (++filled == 64u) {
+                        if (pos + 64u > dst_len) break;
+                        flush_group();
+                    }
                     br.refill();
                     e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
                 }
-                if (run == 64u) { err = kInfOutputOverrun; break; }          // (the inner loop left on a failed flush)
+                if (filled == 64u) { err = kInfOutputOverrun; break; }       // (the inner loop left on an overrun)
                 if ((e & 15u) == 0u) {
                     e = uni(slow_code(&s.lit_c, s.lit_sorted, (uint32_t)br.bb & 0x7fffu, kTabBits));
                     if (e == 0u) { err = kInfBadCode; break; }
@@ -371,12 +384,17 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 br.take(e & 15u);
                 uint32_t sym = e >> 4;
                 if (sym < 256u) {                            // a literal with a long code
-                    lit_v = (uint32_t)lane == run ? sym : lit_v;
-                    if (++run == 64u && !flush_run()) { err = kInfOutputOverrun; break; }
+                    g_val = (uint32_t)lane == filled ? sym : g_val;
+                    g_lit |= 1ull << filled;
+                    if (++filled == 64u) {
+                        if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
+                        flush_group();
+                    }
                     continue;
                 }
                 if (sym == 256u) {
-                    if (!flush_run()) err = kInfOutputOverrun;
+                    if (pos + filled > dst_len) err = kInfOutputOverrun;
+                    else flush_group();
                     break;
                 }
                 sym -= 257u;
@@ -403,28 +421,42 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     const uint32_t ex = (dsym - 2u) >> 1;
                     dist = 1u + ((2u + (dsym & 1u)) << ex) + br.take(ex);
                 }
-                if (!flush_run()) { err = kInfOutputOverrun; break; }       // the match may read the run
-                if (dist > pos) { err = kInfBadDistance; break; }
-                if (pos + length > dst_len) { err = kInfOutputOverrun; break; }
-                if (length <= 64u && dist >= length) {
-                    if ((uint32_t)lane < length) put_byte(pos + (uint32_t)lane, get_byte(pos + (uint32_t)lane - dist));
-                } else if (dist >= length || dist >= 64u) {
-                    // every source byte of a round of 64 is finished output (rounds complete in order)
-                    for (uint32_t i = (uint32_t)lane; i < length; i += 64u)
-                        put_byte(pos + i, get_byte(pos + i - dist));
+                const uint32_t at = pos + filled;            // where the match begins
+                if (dist > at) { err = kInfBadDistance; break; }
+                if (at + length > dst_len) { err = kInfOutputOverrun; break; }
+                if (dist >= length) {
+                    // every byte's source is finished output - once the group is out of the way where the source reaches
+                    // into it.  The match joins the group piece by piece: the byte at position P comes from P - dist.
+                    if (at - dist + length > pos) flush_group();
+                    uint32_t left = length;
+                    while (left != 0u) {                     // uniform
+                        const uint32_t room = 64u - filled;
+                        const uint32_t take = left < room ? left : room;
+                        const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
+                        g_src = in ? pos + (uint32_t)lane - dist : g_src;
+                        filled = uni(filled + take);
+                        left -= take;
+                        if (filled == 64u) flush_group();
+                    }
                 } else {
                     // an overlapping match repeats its last `dist` bytes: byte i is byte i mod dist of them
-                    const float rcp = __frcp_rn((float)dist);
-                    for (uint32_t i = (uint32_t)lane; i < length; i += 64u) {
-                        int q = (int)((float)i * rcp);
-                        int r = (int)i - q * (int)dist;
-                        if (r < 0) r += (int)dist;
-                        else if (r >= (int)dist) r -= (int)dist;
-                        put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
+                    flush_group();
+                    if (dist >= 64u) {
+                        for (uint32_t i = (uint32_t)lane; i < length; i += 64u)     // (rounds complete in order)
+                            put_byte(pos + i, get_byte(pos + i - dist));
+                    } else {
+                        const float rcp = __frcp_rn((float)dist);
+                        for (uint32_t i = (uint32_t)lane; i < length; i += 64u) {
+                            int q = (int)((float)i * rcp);
+                            int r = (int)i - q * (int)dist;
+                            if (r < 0) r += (int)dist;
+                            else if (r >= (int)dist) r -= (int)dist;
+                            put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
+                        }
                     }
+                    pos += length;
+                    if (kLds && pos - flushed >= kFlushGranule) flush_granules();
                 }
-                pos += length;
-                if (pos - flushed >= kFlushGranule) flush_granules();
             }
             if (err) break;
         } else {
