@@ -151,15 +151,21 @@ __device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t*
     return 0u;
 }
 
+// The bit buffer is wave-uniform but lives in VECTOR registers (an empty asm with a "+v" operand pins it there): a CU has
+// ONE scalar ALU for all its waves, and with the whole symbol loop in scalar code that unit was the kernel's limit
+// (4.9 G scalar against 1.1 G vector instructions per launch by the counters, 43 + 10 per symbol).  The buffer's shifts,
+// masks and table indexes cost the vector units - idle otherwise - the same single issue; what steers control flow comes
+// back to a scalar register with v_readfirstlane.
 struct BitReader {
     const uint32_t* words;      // 4-byte aligned start of the block's payload (uniform)
     uint32_t in, in_next;       // the current and the next window of 64 dwords: one per lane
     uint32_t widx;              // next dword of the current window (uniform)
     uint32_t wcount;            // dwords handed to the bit buffer so far, counted from `words` (uniform)
-    uint64_t bb;                // bit buffer (uniform)
+    uint64_t bb;                // bit buffer (the same in every lane)
     uint32_t bc;                // valid bits in it (uniform)
     int lane;
 
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(bb)); }
     __device__ __forceinline__ void seek(uint32_t byte_pos) {
         wcount = byte_pos >> 2;
         in = words[wcount + (uint32_t)lane];
@@ -167,6 +173,7 @@ struct BitReader {
         widx = 0;
         bb = 0;
         bc = 0;
+        pin();
         refill();
         const uint32_t skip = (byte_pos & 3u) * 8u;
         bb >>= skip;
@@ -178,6 +185,7 @@ struct BitReader {
         if (bc <= 32u) {                                     // uniform
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)in, (int)widx);
             bb |= (uint64_t)w << bc;
+            pin();
             bc += 32u;
             ++wcount;
             ++widx;
@@ -188,8 +196,14 @@ struct BitReader {
             }
         }
     }
-    __device__ __forceinline__ uint32_t take(uint32_t n) {
-        const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+    // the low bits of the buffer, not consumed (table indexes)
+    __device__ __forceinline__ uint32_t peek(uint32_t mask) const { return (uint32_t)bb & mask; }
+    __device__ __forceinline__ void drop(uint32_t n) {
+        bb >>= n;
+        bc -= n;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {   // (the value back in a scalar register)
+        const uint32_t v = uni((uint32_t)bb & ((1u << n) - 1u));
         bb >>= n;
         bc -= n;
         return v;
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         const uint32_t type = br.take(2);
         if (type == 0u) {
             // ---- stored: LEN bytes straight from the input
-            br.take(br.bc & 7u);
+            br.drop(br.bc & 7u);
             br.refill();
             const uint32_t len = br.take(16), nlen = br.take(16);
             if (len != (~nlen & 0xffffu)) { err = kInfBadStored; break; }
@@ -298,10 +312,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 bool bad = false;
                 while (have < total) {                        // uniform
                     br.refill();
-                    const uint32_t e = uni(s.cl_tab[(uint32_t)br.bb & ((1u << kClBits) - 1u)]);
+                    const uint32_t e = uni(s.cl_tab[br.peek((1u << kClBits) - 1u)]);
                     const uint32_t l = e & 15u, sym = e >> 4;
                     if (l == 0u) { bad = true; break; }
-                    br.take(l);
+                    br.drop(l);
                     if (sym < 16u) {
                         s.lens[have++] = (uint8_t)sym;
                         prev = sym;
@@ -364,9 +378,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             };
             for (;;) {
                 br.refill();
-                uint32_t e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
+                uint32_t e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 while (e < 0x1000u) {                        // a literal whose code fits the table (other entries are >= 0x1000)
-                    br.take(e & 15u);
+                    br.drop(e & 15u);
                     g_val = (uint32_t)lane == filled ? e >> 4 : g_val;
                     g_lit |= 1ull << filled;
                     if (++filled == 64u) {
@@ -374,14 +388,14 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                         flush_group();
                     }
                     br.refill();
-                    e = uni(s.lit_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
+                    e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 }
                 if (filled == 64u) { err = kInfOutputOverrun; break; }       // (the inner loop left on an overrun)
                 if ((e & 15u) == 0u) {
-                    e = uni(slow_code(&s.lit_c, s.lit_sorted, (uint32_t)br.bb & 0x7fffu, kTabBits));
+                    e = uni(slow_code(&s.lit_c, s.lit_sorted, uni(br.peek(0x7fffu)), kTabBits));
                     if (e == 0u) { err = kInfBadCode; break; }
                 }
-                br.take(e & 15u);
+                br.drop(e & 15u);
                 uint32_t sym = e >> 4;
                 if (sym < 256u) {                            // a literal with a long code
                     g_val = (uint32_t)lane == filled ? sym : g_val;
@@ -407,12 +421,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     length = 3u + ((4u + (sym & 3u)) << ex) + br.take(ex);
                 }
                 br.refill();
-                uint32_t d = uni(s.dist_tab[(uint32_t)br.bb & (uint32_t)(kTabSize - 1)]);
+                uint32_t d = uni(s.dist_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 if ((d & 15u) == 0u) {
-                    d = uni(slow_code(&s.dist_c, s.dist_sorted, (uint32_t)br.bb & 0x7fffu, kTabBits));
+                    d = uni(slow_code(&s.dist_c, s.dist_sorted, uni(br.peek(0x7fffu)), kTabBits));
                     if (d == 0u) { err = kInfBadCode; break; }
                 }
-                br.take(d & 15u);
+                br.drop(d & 15u);
                 const uint32_t dsym = d >> 4;
                 if (dsym >= 30u) { err = kInfBadCode; break; }
                 uint32_t dist;
