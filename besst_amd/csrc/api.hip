@@ -1067,6 +1067,10 @@ static void presort_to_spec(const besst_presort* h, PresortSpec& ps) {
     if (!h || !h->table) return;
     ps.table = h->table; ps.rows = h->rows; ps.shift = h->shift; ps.key_base = h->key_base; ps.cap = h->capacity;
     ps.segmented = h->segmented; ps.in_record_loop = h->in_record_loop;
+    // the run-grouped stage 2 (what a stream with this description takes unless the flag says otherwise) has no use for
+    // the digit histograms: the record loop then does not count them
+    static const int always = [] { const char* e = getenv("BESST_PRESORT_COUNT"); return e ? atoi(e) : 0; }();   // A/B runs
+    ps.count = (!always && runs_enabled((int64_t)h->capacity) && !(h->flags & BESST_REDUCE_NO_RUNS)) ? 0 : 1;
     ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out,
                        h->seg_chunk_first};
 }
@@ -1125,6 +1129,11 @@ int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n
     BESST_REQUIRE(!seg || (ps.seg.seg_keys && ps.seg.seg_payload && ps.seg.offsets && ps.seg.skip &&
                            ps.seg.payload_out == payload && ps.seg.tile > 0),
                   "reduce_presorted: incomplete segment description");
+    if (h_presort->in_record_loop == 2 && (h_presort->flags & BESST_REDUCE_NO_RUNS)) {
+        set_error("reduce_presorted: the classify call behind this description did not count the sort's digits (its flags "
+                  "asked for the run-grouped form): repeat it with BESST_REDUCE_NO_RUNS in `flags`");
+        return BESST_ERR_STATE;
+    }
     return launch_sort_reduce(static_cast<hipStream_t>(stream), capacity, n_tuples, key_bits, keys, payload, row_key,
                               row_mask, row_n, row_sum, row_sum_sq, row_first, row_offset, obs_lo, obs_hi, n_rows,
                               workspace, workspace_bytes, first_map, key_base, true, seg ? &ps.seg : nullptr,

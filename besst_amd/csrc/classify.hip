@@ -1608,7 +1608,7 @@ __global__ __launch_bounds__(256) void presort_fixup_kernel(const uint64_t* __re
         for (uint32_t c = (lo + (uint32_t)kRunChunk - 1u) / (uint32_t)kRunChunk; (uint64_t)c * kRunChunk < hi; ++c) chunk_first[c] = b;
     }
     const uint32_t skip = skip_slot[b];
-    if (skip == kNoSlot) return;
+    if (skip == kNoSlot || !ps.count) return;
     const uint64_t k = seg_keys[(size_t)b * kClsTile + skip] - ps.key_base;
     atomicSub(&ps.table[(uint32_t)(k >> ps.shift) & 255u], 1u);
     atomicSub(&ps.table[256u + ((uint32_t)(k >> (ps.shift + 8)) & 255u)], 1u);
@@ -1933,11 +1933,12 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
         pre = *presort;
         static const int knob = [] { const char* e = getenv("BESST_PRESORT_IN_LOOP"); return e ? atoi(e) : 1; }();
         pre.in_record_loop = knob && a.record_path == 1 && a.n > 0;
-        if (pre.in_record_loop) {
+        if (pre.in_record_loop && pre.count) {
             BESST_REQUIRE(pre.rows > 0 && (pre.rows & (pre.rows - 1)) == 0, "classify: bad presort description");
             BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
             b.ps_table = pre.table; b.ps_rows = pre.rows; b.ps_shift = pre.shift; b.ps_base = pre.key_base;
         }
+        // (a stage 2 that groups runs never reads the histograms: the loop hands its segments over and counts nothing)
     }
     int rc = launch_classify_scan(s, b, aligned, counters, ws, ws_bytes);
     if (rc) return rc;
@@ -1946,7 +1947,7 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
     rc = launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
                               a.n_contigs, aligned, nullptr, 0, nullptr, pre.table ? &pre : nullptr);
     if (presort) {
-        presort->in_record_loop = pre.in_record_loop;
+        presort->in_record_loop = pre.in_record_loop ? (pre.count ? 1 : 2) : 0;
         presort->segmented = pre.table ? pre.segmented : 0;
         presort->seg = pre.seg;
     }

@@ -269,7 +269,9 @@ struct PresortSpec {
     uint64_t key_base;
     uint32_t cap;
     int in_record_loop;      // the fused record loop counts while it emits (the head tuples the stitch drops are taken
-                             // out again); else compact_kernel counts
+                             // out again); else compact_kernel counts.  Out: 2 = the loop handed its segments over
+                             // WITHOUT counting (`count` was 0)
+    int count;               // in: stage 2 will want the digit histograms (0: it groups runs and never reads them)
     int segmented;           // in: the sort can read block segments; out: it has to (compact_kernel did not run, `seg`)
     SegSource seg;
 };

@@ -112,6 +112,7 @@ class DeviceGraphBuilder(object):
         self.key_base, self.key_bits = 0, 2 * self.node_bits + 1
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
         self._presorted = False
+        self._last_rec = None
         self.keys_valid = False                              # self.keys / self.payload hold the last pass's dense tuple stream
         self.candidate_share = None
         # BESST_REDUCE_* flags of this builder's stage-2 calls.  A large stream is first reduced in the run-grouped form;
@@ -177,6 +178,8 @@ class DeviceGraphBuilder(object):
         return path
 
     def classify(self, rec, presort=False):
+        import weakref
+        self._last_rec = weakref.ref(rec)
         self.params.record_path = self.record_path(rec)
         # argument lists are marshalled once per record set (every buffer is allocated once)
         args = self._rec_args.get(rec)
@@ -225,6 +228,15 @@ class DeviceGraphBuilder(object):
 
                 def again():
                     spec.flags = self.sort_flags
+                    if spec.in_record_loop == 2 and (spec.flags & REDUCE_NO_RUNS):
+                        # the record loop handed its segments over without the sort's digit counts (stage 2 was going to
+                        # group runs): the pass is repeated from its start, counting this time
+                        rec = self._last_rec() if self._last_rec is not None else None
+                        if rec is None:
+                            raise _lib.BesstDeviceError('reduce: the record set of the pass to repeat is gone')
+                        self.reset()
+                        self.classify(rec, presort=True)
+                        self._presorted = False
                     st = torch.cuda.current_stream(self.device).cuda_stream
                     _lib.check(self.lib.besst_dev_reduce_presorted(C.c_void_p(st), *args, C.byref(spec)), 'dev_reduce')
             else:

@@ -387,8 +387,10 @@ typedef struct besst_presort {
      * ordered by the block offsets of the stitch - when stage 2's first stream pass can read it that way:
      * besst_dev_reduce_presort sets `segmented` to say so, besst_dev_classify_presort leaves it 1 (and fills the seg_*
      * fields) when it did NOT write the dense keys / payload, and besst_dev_reduce_presorted then reads the segments and
-     * writes the dense payload (the `payload` argument of both calls) itself.  in_record_loop (out): the record loop
-     * counted the digits while it emitted. */
+     * writes the dense payload (the `payload` argument of both calls) itself.  in_record_loop (out): 1 = the record loop
+     * counted the digits while it emitted; 2 = it handed its segments over without counting, because `flags` did not carry
+     * BESST_REDUCE_NO_RUNS and stage 2 then groups runs and reads no histogram - a repeat of besst_dev_reduce_presorted
+     * WITH that flag (after BESST_ROWS_RUN_OVERFLOW) needs a repeat of the classify call with it first. */
     int32_t segmented;
     int32_t in_record_loop;
     const uint64_t* seg_keys;
