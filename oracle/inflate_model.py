@@ -1,8 +1,11 @@
-"""Scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder (same table construction, same arithmetic for the
-length / distance codes, same slow path for codes longer than the primary table), checked against zlib.
-A development aid: the kernel mirrors this step by step, so a logic error shows up here, without a GPU.
+"""TEST INFRASTRUCTURE (not part of the product path): scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder - the same
+table construction (canonical counts / first codes / offsets, primary table filled by decoding every slot's bit pattern),
+the same closed forms for RFC 1951's length / distance codes, the same path for codes longer than the primary table -
+checked against zlib (the published algorithm's reference implementation; BGZF blocks are raw DEFLATE streams, SAM spec
+section 4.1).  The kernel mirrors this step by step, so a logic error shows up here, without a GPU
+(tests/test_inflate_model.py); on the GPU the kernel itself is compared with zlib byte for byte (tests/test_gpu_ingest.py).
 
-    python tools/inflate_model.py
+    python oracle/inflate_model.py
 """
 import os
 import random

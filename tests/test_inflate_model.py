@@ -1,14 +1,10 @@
-"""The scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder (tools/inflate_model.py: the table construction, the arithmetic
+"""The scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder (oracle/inflate_model.py: the table construction, the arithmetic
 form of the length / distance codes and the long-code path the kernel mirrors) against zlib - the part of the device
 inflate that can be checked without a GPU."""
-import os
-import sys
-
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
 
 
 def test_model_equals_zlib(capsys):
-    import inflate_model
+    from oracle import inflate_model
     inflate_model.main()
     assert 'equal to zlib' in capsys.readouterr().out
 
