@@ -110,7 +110,8 @@ def main(argv=None):
         param.read_len = _per_lib(args.readlen, i)
         print('\nPASS ' + str(i + 1) + '\n\n', file=Information)
         t0 = time()
-        records = bamio.read_bam(bam, threads=args.threads)
+        # straight to HBM: inflate + record decode on the GPU (files in htslib's block layout; others through the host reader)
+        records = bamio.ResidentBam(bam, threads=args.threads)
         print('Time elapsed reading %s (%d records): %s' % (bam, len(records), time() - t0), file=Information)
         param.contig_index = dict(enumerate(records.references))
         t0 = time()
