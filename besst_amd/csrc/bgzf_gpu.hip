@@ -42,6 +42,7 @@ constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
 constexpr int kClBits = 7;
 constexpr uint32_t kFlushGranule = 8192;
+constexpr uint32_t kGroupLit = 0x80000000u;   // output group: the lane holds a literal (else a source position, < 2^31)
 constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is no short code: length nibble 0, and not below 0x1000 (a literal)
 
 // status of a block (0 = inflated)
@@ -354,43 +355,43 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kTabBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
             // ---- the symbols.  Output leaves in GROUPS of up to 64 bytes: lane k of the group stands for the byte at
-            // pos + k and holds either a literal (value in g_val, its bit in g_lit) or the place its byte is copied from
-            // (g_src); a literal is a compare and a select, a match two compares and a select per piece.  A full group -
+            // pos + k and holds either a literal (flagged by the top bit) or the place its byte is copied from; a literal
+            // is a compare and a select, a match two compares and a select per piece.  A full group -
             // or a match whose source reaches into the group, or the end of the block - flushes it: ONE gather of the
             // lanes that copy, ONE contiguous store.  The memory round trip of a match (~1 us with the window in HBM / L2,
             // and a wave has nothing else to do meanwhile) is paid once per 64 bytes of output instead of once per match
             // (a sequencer's file: 5241 matches of 9.7 bytes and 8865 literals in a block of 60 KB).
-            uint32_t g_val = 0, g_src = 0;
-            unsigned long long g_lit = 0;                    // uniform: the literal lanes
+            uint32_t g = 0;                                  // lane k: kGroupLit | its literal, or where its byte is copied from
             uint32_t filled = 0;                             // uniform: lanes of the group in use
             auto flush_group = [&]() {
                 if (filled != 0u) {
                     if ((uint32_t)lane < filled) {
-                        uint32_t v = g_val;
-                        if (!((g_lit >> lane) & 1ull)) v = get_byte(g_src);
+                        uint32_t v = g;
+                        if (!(g & kGroupLit)) v = get_byte(g);
                         put_byte(pos + (uint32_t)lane, v);
                     }
                     pos = uni(pos + filled);                 // (kept scalar by force: without it the compiler turns this
                     filled = 0;                              // branch into selects and the whole symbol loop into vector code)
-                    g_lit = 0;
                     if (kLds && pos - flushed >= kFlushGranule) flush_granules();
                 }
             };
             for (;;) {
                 br.refill();
                 uint32_t e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
-                while (e < 0x1000u) {                        // a literal whose code fits the table (other entries are >= 0x1000)
+                // literals whose code fits the table (other entries are >= 0x1000), until the group is full: ONE way out
+                // of this loop - a second exit costs every iteration the flag registers the compiler threads through it
+                while (((e >> 12) | (filled >> 6)) == 0u) {    // e < 0x1000 (a literal) and filled < 64, as one test
                     br.drop(e & 15u);
-                    g_val = (uint32_t)lane == filled ? e >> 4 : g_val;
-                    g_lit |= 1ull << filled;
-                    if (++filled == 64u) {
-                        if (pos + 64u > dst_len) break;
-                        flush_group();
-                    }
+                    g = (uint32_t)lane == filled ? kGroupLit | (e >> 4) : g;
+                    ++filled;
                     br.refill();
                     e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 }
-                if (filled == 64u) { err = kInfOutputOverrun; break; }       // (the inner loop left on an overrun)
+                if (filled == 64u) {
+                    if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
+                    flush_group();
+                    if (e < 0x1000u) continue;               // (the entry is looked up again: nothing of it was consumed)
+                }
                 if ((e & 15u) == 0u) {
                     e = uni(slow_code(&s.lit_c, s.lit_sorted, uni(br.peek(0x7fffu)), kTabBits));
                     if (e == 0u) { err = kInfBadCode; break; }
@@ -398,8 +399,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 br.drop(e & 15u);
                 uint32_t sym = e >> 4;
                 if (sym < 256u) {                            // a literal with a long code
-                    g_val = (uint32_t)lane == filled ? sym : g_val;
-                    g_lit |= 1ull << filled;
+                    g = (uint32_t)lane == filled ? kGroupLit | sym : g;
                     if (++filled == 64u) {
                         if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
                         flush_group();
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                         const uint32_t room = 64u - filled;
                         const uint32_t take = left < room ? left : room;
                         const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
-                        g_src = in ? pos + (uint32_t)lane - dist : g_src;
+                        g = in ? pos + (uint32_t)lane - dist : g;
                         filled = uni(filled + take);
                         left -= take;
                         if (filled == 64u) flush_group();
