@@ -242,6 +242,26 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         br.seek(src_off & 3u);
     }
     const uint32_t in_base = src_off & 3u;
+    // RFC 1951's length and distance codes in closed form, one code per lane: base | extra bits << 9 (<< 16)
+    uint32_t len_info, dist_info;
+    {
+        const uint32_t k = (uint32_t)lane;
+        uint32_t base, extra = 0;
+        if (k < 8u) base = 3u + k;
+        else if (k == 28u) base = 258u;
+        else {
+            extra = (k - 4u) >> 2;
+            base = 3u + ((4u + (k & 3u)) << extra);
+        }
+        len_info = k < 29u ? base | (extra << 9) : 0u;
+        extra = 0;
+        if (k < 4u) base = 1u + k;
+        else {
+            extra = (k - 2u) >> 1;
+            base = 1u + ((2u + (k & 1u)) << extra);
+        }
+        dist_info = k < 30u ? base | (extra << 16) : 0u;
+    }
     uint32_t pos = 0, flushed = 0;
     uint32_t err = kInfOk;
     // ---- the window.  LDS form: bytes go to the ring and leave for HBM in granules.  Global form: bytes go straight to the
@@ -411,15 +431,13 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     else flush_group();
                     break;
                 }
+                // base and extra-bit count of the length / distance code: lane k of two registers holds them for code k
+                // (filled in once per wave), a v_readlane fetches them - the arithmetic on the symbol and its three
+                // branches were a fifth of a match's scalar instructions
                 sym -= 257u;
                 if (sym >= 29u) { err = kInfBadCode; break; }
-                uint32_t length;
-                if (sym < 8u) length = 3u + sym;
-                else if (sym == 28u) length = 258u;
-                else {
-                    const uint32_t ex = (sym - 4u) >> 2;
-                    length = 3u + ((4u + (sym & 3u)) << ex) + br.take(ex);
-                }
+                const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)len_info, (int)sym);
+                const uint32_t length = (li & 0x1ffu) + br.take(li >> 9);
                 br.refill();
                 uint32_t d = uni(s.dist_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 if ((d & 15u) == 0u) {
@@ -429,12 +447,8 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 br.drop(d & 15u);
                 const uint32_t dsym = d >> 4;
                 if (dsym >= 30u) { err = kInfBadCode; break; }
-                uint32_t dist;
-                if (dsym < 4u) dist = 1u + dsym;
-                else {
-                    const uint32_t ex = (dsym - 2u) >> 1;
-                    dist = 1u + ((2u + (dsym & 1u)) << ex) + br.take(ex);
-                }
+                const uint32_t di = (uint32_t)__builtin_amdgcn_readlane((int)dist_info, (int)dsym);
+                const uint32_t dist = (di & 0xffffu) + br.take(di >> 16);
                 const uint32_t at = pos + filled;            // where the match begins
                 if (dist > at) { err = kInfBadDistance; break; }
                 if (at + length > dst_len) { err = kInfOutputOverrun; break; }
