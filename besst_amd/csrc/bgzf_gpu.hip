@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t*
 // back to a scalar register with v_readfirstlane.
 struct BitReader {
     const uint32_t* words;      // 4-byte aligned start of the block's payload (uniform)
-    uint32_t in, in_next;       // the current and the next window of 64 dwords: one per lane
+    uint32_t in;                // the current window of 64 dwords of input: one per lane
     uint32_t widx;              // next dword of the current window (uniform)
     uint32_t wcount;            // dwords handed to the bit buffer so far, counted from `words` (uniform)
     uint64_t bb;                // bit buffer (the same in every lane)
@@ -170,7 +170,6 @@ struct BitReader {
     __device__ __forceinline__ void seek(uint32_t byte_pos) {
         wcount = byte_pos >> 2;
         in = words[wcount + (uint32_t)lane];
-        in_next = words[wcount + 64u + (uint32_t)lane];
         widx = 0;
         bb = 0;
         bc = 0;
@@ -190,9 +189,11 @@ struct BitReader {
             bc += 32u;
             ++wcount;
             ++widx;
+            // (the next window is loaded when this one is used up, not ahead: a second register handed on at every
+            // refill site made the compiler wait for ALL outstanding memory operations - the group's stores - at each
+            // of them; the six other waves of the SIMD cover the load)
             if (widx == 64u) {                               // uniform
-                in = in_next;
-                in_next = words[wcount + 64u + (uint32_t)lane];
+                in = words[wcount + (uint32_t)lane];
                 widx = 0;
             }
         }
