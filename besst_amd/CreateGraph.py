@@ -19,6 +19,7 @@ from __future__ import print_function
 
 import gc
 import math
+import operator
 import os
 import sys
 from itertools import repeat
@@ -464,7 +465,7 @@ def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime,
 
 
 def _column(objects, attribute, dtype):
-    return np.fromiter((getattr(o, attribute) for o in objects), dtype=dtype, count=len(objects))
+    return np.fromiter(map(operator.attrgetter(attribute), objects), dtype=dtype, count=len(objects))
 
 
 def CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_scaffolds):
