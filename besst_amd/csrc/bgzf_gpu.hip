@@ -289,6 +289,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         }
     };
     for (;;) {
+        // (a DEFLATE block may be empty: without this test a payload of nothing but empty blocks - corrupt, but every bit of
+        // it valid - would be followed out of the chunk's buffer)
+        if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
         br.refill();
         const uint32_t final_block = br.take(1);
         const uint32_t type = br.take(2);

@@ -324,3 +324,20 @@ def test_parts_of_a_small_file_and_a_false_block_header():
             assert sum(counts) == len(recs), (parts, counts)
             for c in COLS:
                 assert np.array_equal(whole[c], getattr(host, c)), (parts, c)
+
+
+def test_endless_empty_blocks_end_at_the_payload():
+    """A payload of empty fixed-Huffman blocks that never sets BFINAL - every bit valid, no output, no end: the kernel stops
+    at the end of the payload instead of following the stream out of its buffer."""
+    bits = '010' + '0000000'                                 # BFINAL 0, BTYPE 01 (LSB first: 1, 0), end-of-block code
+    stream = ''.join(bits for _ in range(400))
+    stream += '0' * (-len(stream) % 8)
+    payload = bytes(int(stream[i:i + 8][::-1], 2) for i in range(0, len(stream), 8))
+    assert zlib.decompressobj(-15).decompress(payload) == b''        # zlib agrees: valid so far, nothing produced
+    bsize = len(payload) + 25
+    head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, bsize)
+    block = head + payload + struct.pack('<II', 0, 77)       # ISIZE claims 77 bytes
+    good = _bgzf(b'abc' * 100)
+    with pytest.raises(_lib.BesstDeviceError) as e:
+        bamio.inflate_bgzf_device(good + block + good * 200, out_cap=1 << 20)
+    assert 'block 1' in str(e.value)
