@@ -400,6 +400,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 }
             };
             for (;;) {
+                // (at least once per 64 literals: a corrupt stream is not followed more than a few hundred bytes past its
+                // payload - the chunk's buffer has 4 KB behind its last block)
+                if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
                 br.refill();
                 uint32_t e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
                 // literals whose code fits the table (other entries are >= 0x1000), until the group is full: ONE way out

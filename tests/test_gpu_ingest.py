@@ -341,3 +341,34 @@ def test_endless_empty_blocks_end_at_the_payload():
     with pytest.raises(_lib.BesstDeviceError) as e:
         bamio.inflate_bgzf_device(good + block + good * 200, out_cap=1 << 20)
     assert 'block 1' in str(e.value)
+
+
+def test_corrupt_payloads_are_refused_not_followed():
+    """Random damage to the DEFLATE payloads of 300 blocks (bytes flipped, payloads cut short with ISIZE kept): the call
+    reports the first block that does not inflate - or, where the damage happens to decode, still returns ISIZE bytes per
+    block - and the device is fine afterwards."""
+    rnd = random.Random(17)
+    src = _payloads()['bamlike']
+    blocks = []
+    for i in range(300):
+        raw = src[rnd.randint(0, 2000):][:rnd.randint(200, 60000)]
+        b = bytearray(_bgzf(raw, rnd.choice((1, 6, 9))))
+        kind = i % 3
+        if kind == 0:                                        # a few flipped bytes inside the payload
+            for _ in range(rnd.randint(1, 6)):
+                b[rnd.randint(18, len(b) - 9)] ^= rnd.randint(1, 255)
+        elif kind == 1:                                      # the payload's tail replaced by zeros
+            cut = rnd.randint(18, len(b) - 9)
+            b[cut:len(b) - 8] = bytes(len(b) - 8 - cut)
+        else:                                                # garbage from some point on
+            cut = rnd.randint(18, len(b) - 9)
+            b[cut:len(b) - 8] = os.urandom(len(b) - 8 - cut)
+        blocks.append(bytes(b))
+    total = sum(struct.unpack('<I', b[-4:])[0] for b in blocks)
+    try:
+        out = bamio.inflate_bgzf_device(b''.join(blocks), out_cap=total + 16)
+        assert len(out) == total                             # (every damaged stream happened to decode to its ISIZE)
+    except _lib.BesstDeviceError as e:
+        assert 'did not inflate' in str(e)
+    good = _bgzf(src[:50000])
+    assert bamio.inflate_bgzf_device(good * 3, out_cap=150016) == src[:50000] * 3
