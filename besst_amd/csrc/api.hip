@@ -573,7 +573,7 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
         b.dst_off_lo = (uint32_t)dst;
         b.dst_off_hi = (uint32_t)((uint64_t)dst >> 32);
         b.dst_len = isize;
-        b.pad = 0;
+        b.crc = le32(hdr + bsize - 8);
         dst += align_up((size_t)isize, 256);
         at += bsize;
     }

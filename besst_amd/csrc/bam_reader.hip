@@ -44,16 +44,19 @@ namespace {
 typedef void* (*ld_alloc_t)(void);
 typedef int (*ld_decomp_t)(void*, const void*, size_t, void*, size_t, size_t*);
 typedef void (*ld_free_t)(void*);
+typedef uint32_t (*ld_crc32_t)(uint32_t, const void*, size_t);
 struct LibDeflate {
     ld_alloc_t alloc = nullptr;
     ld_decomp_t decompress = nullptr;
     ld_free_t free_ = nullptr;
+    ld_crc32_t crc32_ = nullptr;
     LibDeflate() {
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc = (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor");
         decompress = (ld_decomp_t)dlsym(h, "libdeflate_deflate_decompress");
         free_ = (ld_free_t)dlsym(h, "libdeflate_free_decompressor");
+        crc32_ = (ld_crc32_t)dlsym(h, "libdeflate_crc32");
         if (!alloc || !decompress || !free_) alloc = nullptr;
     }
     bool ok() const { return alloc != nullptr; }
@@ -197,7 +200,14 @@ struct BlockRecs {
 struct Block {
     size_t src_off, src_len;   // deflate payload inside the batch buffer
     size_t dst_off, dst_len;   // position inside the inflated buffer
+    uint32_t crc;              // CRC-32 of the inflated bytes (gzip trailer)
 };
+
+// the block's CRC-32 as htslib checks it (bgzf.c): a payload that inflates to the right size with the wrong bytes is an error
+uint32_t crc32_of(const uint8_t* p, size_t n) {
+    if (libdeflate().crc32_) return libdeflate().crc32_(0, p, n);
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
 
 uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -219,6 +229,7 @@ struct besst_bam {
     Pool* pool = nullptr;
     double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0;   // seconds per phase (BESST_BAM_PROFILE=1 prints them)
     std::vector<void*> ld_ctx;       // one libdeflate decompressor per worker
+    bool check_crc = [] { const char* e = getenv("BESST_BGZF_CRC"); return !(e && atoi(e) == 0); }();   // (=0: timing runs)
     std::vector<BlockRecs> brecs;    // speculative per-block walks of the current batch, in stream order
     std::vector<size_t> brec_file_off;   // where each of those blocks begins in the file
     std::vector<uint32_t> blk_offs;
@@ -263,7 +274,7 @@ struct besst_bam {
             if (rest < extra_left + 8) { error = "corrupt BGZF block"; return false; }
             const size_t payload = rest - extra_left - 8;
             const uint32_t isize = le32(hdr + bsize - 4);
-            blocks.push_back(Block{file_off + 18 + extra_left, payload, dst_total, isize});
+            blocks.push_back(Block{file_off + 18 + extra_left, payload, dst_total, isize, le32(hdr + bsize - 8)});
             brec_file_off.push_back(file_off);
             dst_total += isize;
             file_off += bsize;
@@ -282,7 +293,8 @@ struct besst_bam {
             br.count = 0;
             if (k.dst_len == 0) return;           // the empty EOF marker block
             if (!inflate_raw(map + k.src_off, k.src_len, inflated.data() + k.dst_off, k.dst_len,
-                             ld_ctx.empty() ? nullptr : ld_ctx[(size_t)worker])) {
+                             ld_ctx.empty() ? nullptr : ld_ctx[(size_t)worker]) ||
+                (check_crc && crc32_of(inflated.data() + k.dst_off, k.dst_len) != k.crc)) {
                 ok = false;
                 return;
             }
@@ -301,7 +313,7 @@ struct besst_bam {
         const auto tp2 = std::chrono::steady_clock::now();
         t_read += std::chrono::duration<double>(tp1 - tp0).count();
         t_inflate += std::chrono::duration<double>(tp2 - tp1).count();
-        if (!ok.load()) { error = "inflate failed (corrupt BGZF payload)"; return false; }
+        if (!ok.load()) { error = "inflate failed (corrupt BGZF payload or CRC-32 mismatch)"; return false; }
         return true;
     }
 

@@ -27,7 +27,7 @@
 //                         CIGAR walk of pysam 0.8.4's qlen / alen (bam_reader.hip has the semantics), coalesced stores
 //                         into the record columns at the block's place in the stream
 //
-// Not checked: the gzip CRC32 of a block (the host path does not check it either: both inflate raw DEFLATE).
+//   bgzf_crc_kernel       the CRC-32 of every block's inflated bytes against the block's gzip trailer (what htslib checks)
 #include <stdlib.h>
 #include <string.h>
 
@@ -48,7 +48,7 @@ constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is n
 // status of a block (0 = inflated)
 enum : uint32_t {
     kInfOk = 0, kInfBadBlockType, kInfBadStored, kInfBadLengths, kInfOversubscribed, kInfBadCode, kInfBadDistance,
-    kInfOutputOverrun, kInfInputOverrun, kInfSizeMismatch
+    kInfOutputOverrun, kInfInputOverrun, kInfSizeMismatch, kInfCrcMismatch
 };
 
 struct CanonLds {               // per code: count / first code / offset per length, symbols sorted by (length, symbol)
@@ -519,6 +519,105 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     if (lane == 0) status[b] = err;
 }
 
+// ---- the blocks' CRC32 ---------------------------------------------------------------------------------------------------
+// BGZF stores the CRC-32 of every block's inflated bytes (the gzip trailer); htslib - what the reference reads its files
+// through - checks it, and so does this path: a damaged payload that still decodes, or a byte the window logic got wrong,
+// is a refused block, not a wrong record.  One workgroup per block, a thread per slice of <= 256 bytes: nibble-table CRC
+// of the slice, then the slice's CRC is carried over the bytes behind it - multiplication by x^(8n) modulo the CRC polynomial, zlib's
+// crc32_combine - and the 256 values are XORed.
+namespace {
+
+constexpr uint32_t kCrcPoly = 0xedb88320u;
+__device__ const uint32_t kCrcX2n[32] = {           // x^(2^k) mod the polynomial, reflected (zlib's x2n_table)
+    0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u,
+    0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu,
+    0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
+    0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
+__device__ const uint32_t kCrcNibble[16] = {
+    0x00000000u, 0x1db71064u, 0x3b6e20c8u, 0x26d930acu, 0x76dc4190u, 0x6b6b51f4u, 0x4db26158u, 0x5005713cu,
+    0xedb88320u, 0xf00f9344u, 0xd6d6a3e8u, 0xcb61b38cu, 0x9b64c2b0u, 0x86d3d2d4u, 0xa00ae278u, 0xbdbdf21cu};
+
+// a(x) * b(x) modulo the polynomial (both reflected: bit 31 is x^0); `a` is the same in every lane
+__device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (uint32_t m = 1u << 31; m; m >>= 1) {                // uniform
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
+                                                       uint32_t n_blocks, uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_nib[16], s_part[4];
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t len = blocks[b].dst_len;
+    if (len == 0u || status[b] != kInfOk) return;            // uniform
+    if (t < 16u) s_nib[t] = kCrcNibble[t];
+    __syncthreads();
+    const uint8_t* base = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
+    // slice t = [t S, (t + 1) S) cut at len; S a multiple of 16, so that every slice is read as aligned 16-byte words
+    // (the next word is requested before the current one's 32 table look-ups - a byte at a time the loads alone, each
+    // waited for, took longer than the inflate)
+    const uint32_t S = (((len + 255u) >> 8) + 15u) & ~15u;
+    const uint32_t lo = t * S < len ? t * S : len;
+    const uint32_t hi = lo + S < len ? lo + S : len;
+    const uint32_t n_slice = hi - lo;
+    const uint4* src = reinterpret_cast<const uint4*>(base + lo);
+    uint32_t crc = 0xffffffffu;
+    auto eat = [&](uint32_t w, uint32_t count) {             // the low `count` bytes of a word
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (k < count) {
+                crc ^= (w >> (8u * k)) & 0xffu;
+                crc = s_nib[crc & 15u] ^ (crc >> 4);
+                crc = s_nib[crc & 15u] ^ (crc >> 4);
+            }
+        }
+    };
+    uint4 cur = n_slice ? src[0] : make_uint4(0, 0, 0, 0);
+    for (uint32_t q = 0; q * 16u < n_slice; ++q) {
+        const uint4 next = (q + 1u) * 16u < n_slice ? src[q + 1u] : make_uint4(0, 0, 0, 0);
+        const uint32_t rem = n_slice - q * 16u;
+        if (rem >= 16u) {
+            eat(cur.x, 4); eat(cur.y, 4); eat(cur.z, 4); eat(cur.w, 4);
+        } else {
+            eat(cur.x, rem); eat(cur.y, rem > 4u ? rem - 4u : 0u); eat(cur.z, rem > 8u ? rem - 8u : 0u);
+            eat(cur.w, rem > 12u ? rem - 12u : 0u);
+        }
+        cur = next;
+    }
+    crc = n_slice ? ~crc : 0u;
+    // carry it over the bytes behind the slice: multiply by x^(8 n)
+    uint32_t n = len - hi;
+    uint32_t p = 1u << 31;                                   // x^0
+    for (uint32_t k = 3; n; n >>= 1, ++k)
+        if (n & 1u) p = crc_mul(kCrcX2n[k & 31u], p);
+    // (p differs per lane: crc_mul's first argument must be uniform, so the product is formed bit by bit of `crc`... the
+    // multiplication is commutative: run it with the per-lane operands swapped into its lane-wise form)
+    uint32_t prod = 0;
+    {
+        uint32_t a = crc, bb = p;
+        for (int j = 0; j < 32; ++j) {
+            if (a & (1u << 31)) prod ^= bb;
+            a <<= 1;
+            bb = (bb & 1u) ? (bb >> 1) ^ kCrcPoly : bb >> 1;
+        }
+    }
+    uint32_t x = prod;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d, 64);
+    if ((t & 63u) == 0u) s_part[t >> 6] = x;
+    __syncthreads();
+    if (t == 0u) {
+        const uint32_t got = s_part[0] ^ s_part[1] ^ s_part[2] ^ s_part[3];
+        if (got != blocks[b].crc) status[b] = kInfCrcMismatch;
+    }
+}
+
 namespace {
 
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {     // little-endian dword at any alignment
@@ -686,6 +785,9 @@ int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* bloc
     static const bool lds_ring = [] { const char* e = getenv("BESST_BGZF_WINDOW"); return e && strcmp(e, "lds") == 0; }();
     if (lds_ring) hipLaunchKernelGGL((bgzf_inflate_kernel<kRing>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
     else hipLaunchKernelGGL((bgzf_inflate_kernel<0>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    // BESST_BGZF_CRC=0: skip the check (timing runs)
+    static const bool check_crc = [] { const char* e = getenv("BESST_BGZF_CRC"); return !(e && atoi(e) == 0); }();
+    if (check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(256), 0, s, dst, blocks, n_blocks, status);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

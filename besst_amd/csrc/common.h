@@ -46,7 +46,7 @@ void bam_mark_consumed(besst_bam* b, int64_t saturated_qlen);
 struct BgzfBlock {             // one BGZF block of a chunk: its DEFLATE payload in the chunk's compressed bytes, its place in
     uint32_t src_off, src_len; // the chunk's inflated scratch (256-byte aligned) and ISIZE
     uint32_t dst_off_lo, dst_off_hi;
-    uint32_t dst_len, pad;
+    uint32_t dst_len, crc;     // and the CRC-32 of the inflated bytes from the gzip trailer
 };
 constexpr int kBamBlockRecs = 2048;   // a 64 KiB block holds < 65536 / 36 records
 struct BamColumns {

@@ -189,7 +189,8 @@ int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, in
  * j + 1 uploaded while chunk j inflates (one wave per block).  For files in htslib's block layout, where every BGZF
  * block begins with a record (samtools, bwa | samtools, this library's writer).  Returns BESST_ERR_UNSUPPORTED - context
  * and reader unchanged - for any other layout (a record that straddles blocks) and for a block the device does not
- * inflate: call besst_ctx_push_bam then.  The blocks' gzip CRC32 is not checked (nor does the host form check it). */
+ * inflate or whose CRC-32 does not match its gzip trailer: call besst_ctx_push_bam then (which checks the CRC-32 too and
+ * reports the file as corrupt, as htslib would). */
 int besst_ctx_push_bam_device(besst_ctx* ctx, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
 

@@ -79,3 +79,25 @@ def test_native_writer_agrees_with_the_python_writer(threads):
         got = bamio.read_bam(a, threads=3, chunk_records=1000)
     for col in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen', 'rlen'):
         assert np.array_equal(getattr(got, col), getattr(batch, col)), col
+
+
+def test_a_wrong_block_crc_is_an_error():
+    """BGZF keeps the CRC-32 of every block's inflated bytes; htslib (what the reference reads through) checks it, and so
+    does the reader: a file whose stored CRC does not match is refused, not decoded."""
+    asm = synth.make_assembly(40, 1500, 5)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 500.0, 50.0), 3000, 6)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=20000, align_records=True)
+        assert len(bamio.read_bam(path, threads=2)) == len(batch)
+        raw = bytearray(open(path, 'rb').read())
+        # the third block's trailer: walk the BSIZE fields
+        at = 0
+        for _ in range(2):
+            at += (raw[at + 16] | (raw[at + 17] << 8)) + 1
+        end = at + (raw[at + 16] | (raw[at + 17] << 8)) + 1
+        raw[end - 8] ^= 0x01                                 # one bit of its CRC-32
+        with open(path, 'wb') as fh:
+            fh.write(raw)
+        with pytest.raises(IOError):
+            bamio.read_bam(path, threads=2)

@@ -372,3 +372,34 @@ def test_corrupt_payloads_are_refused_not_followed():
         assert 'did not inflate' in str(e)
     good = _bgzf(src[:50000])
     assert bamio.inflate_bgzf_device(good * 3, out_cap=150016) == src[:50000] * 3
+
+
+def test_a_wrong_block_crc_is_refused_by_both_forms():
+    """The device checks every block's CRC-32 (bgzf_crc_kernel) against its gzip trailer: a payload that inflates to ISIZE
+    bytes under a CRC that does not match is a refused block (status 10), in a file the device form answers
+    BESST_ERR_UNSUPPORTED, and the host form - which checks too - refuses the file as well."""
+    raw = _payloads()['bamlike'][:40000]
+    good = _bgzf(raw)
+    bad = bytearray(good)
+    bad[-8] ^= 0x10
+    assert bamio.inflate_bgzf_device(good * 2, out_cap=80016) == raw * 2
+    with pytest.raises(_lib.BesstDeviceError) as e:
+        bamio.inflate_bgzf_device(good + bytes(bad) + good, out_cap=120016)
+    assert 'block 1' in str(e.value) and 'status 10' in str(e.value)
+    batch = _library(30000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bamio.write_bam(path, batch, threads=2, level=1)
+        data = bytearray(open(path, 'rb').read())
+        at = 0
+        for _ in range(60):                                  # (a block the reader does not touch when it opens the file)
+            at += (data[at + 16] | (data[at + 17] << 8)) + 1
+        end = at + (data[at + 16] | (data[at + 17] << 8)) + 1
+        data[end - 7] ^= 0x80
+        with open(path, 'wb') as fh:
+            fh.write(data)
+        with pytest.raises(_lib.BesstDeviceError) as e:
+            bamio.ResidentBam(path, threads=2, mode='device')
+        assert 'status 5' in str(e.value)
+        with pytest.raises((_lib.BesstDeviceError, IOError)):
+            bamio.ResidentBam(path, threads=2, mode='auto')
