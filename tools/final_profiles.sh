@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box: the round's profile set from ONE box - kernel stats + PMC traffic of C3 and C2, the default bench line,
+# the ingest kernels - under gpurun_out/final/.
+cd "$(dirname "$0")/.."
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
+tools/profile_round.sh C3 400000000 > /dev/null 2>&1
+tools/profile_round.sh C2 20000000 > /dev/null 2>&1
+cp gpurun_out/prof_c3/kernel_stats.csv $O/c3_kernel_stats.csv; cp gpurun_out/prof_c3/pmc_traffic.json $O/c3_pmc_traffic.json
+cp gpurun_out/prof_c2/kernel_stats.csv $O/c2_kernel_stats.csv; cp gpurun_out/prof_c2/pmc_traffic.json $O/c2_pmc_traffic.json
+cp $O/c3_pmc_traffic.json profiles/r03_c3_pmc_traffic.json; cp $O/c2_pmc_traffic.json profiles/r03_c2_pmc_traffic.json
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench.err
+tools/ingest_prof.sh C3 50000000 > $O/ingest_prof.txt 2>&1
+cp gpurun_out/ingest_prof/kernel_stats.csv $O/ingest_kernel_stats.csv
+python - <<PY
+import json
+d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["verified_vs_c_oracle"], d["c2"]["ms_per_step"], d["roofline"]["record_loop_kernel"]["avg_launch_ms"], d["overlapped"]["ms_per_step"], d["roofline"]["measured_d2d_copy_GBps"])
+PY
