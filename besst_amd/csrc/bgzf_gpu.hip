@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
 // ---- the blocks' CRC32 ---------------------------------------------------------------------------------------------------
 // BGZF stores the CRC-32 of every block's inflated bytes (the gzip trailer); htslib - what the reference reads its files
 // through - checks it, and so does this path: a damaged payload that still decodes, or a byte the window logic got wrong,
-// is a refused block, not a wrong record.  One workgroup per block, a thread per slice of <= 256 bytes: nibble-table CRC
+// is a refused block, not a wrong record.  One workgroup per block, a thread per slice of <= 256 bytes: byte-table CRC
 // of the slice, then the slice's CRC is carried over the bytes behind it - multiplication by x^(8n) modulo the CRC polynomial, zlib's
 // crc32_combine - and the 256 values are XORed.
 namespace {
@@ -533,9 +533,6 @@ __device__ const uint32_t kCrcX2n[32] = {           // x^(2^k) mod the polynomia
     0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu,
     0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
     0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
-__device__ const uint32_t kCrcNibble[16] = {
-    0x00000000u, 0x1db71064u, 0x3b6e20c8u, 0x26d930acu, 0x76dc4190u, 0x6b6b51f4u, 0x4db26158u, 0x5005713cu,
-    0xedb88320u, 0xf00f9344u, 0xd6d6a3e8u, 0xcb61b38cu, 0x9b64c2b0u, 0x86d3d2d4u, 0xa00ae278u, 0xbdbdf21cu};
 
 // a(x) * b(x) modulo the polynomial (both reflected: bit 31 is x^0); `a` is the same in every lane
 __device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
@@ -551,12 +548,17 @@ __device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
 
 __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
                                                        uint32_t n_blocks, uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_nib[16], s_part[4];
+    __shared__ uint32_t s_tab[256], s_part[4];
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     if (b >= n_blocks) return;
     const uint32_t len = blocks[b].dst_len;
     if (len == 0u || status[b] != kInfOk) return;            // uniform
-    if (t < 16u) s_nib[t] = kCrcNibble[t];
+    {   // the byte table: entry t is t carried through eight steps of the polynomial division
+        uint32_t c = t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+        s_tab[t] = c;
+    }
     __syncthreads();
     const uint8_t* base = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
     // slice t = [t S, (t + 1) S) cut at len; S a multiple of 16, so that every slice is read as aligned 16-byte words
@@ -572,9 +574,7 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             if (k < count) {
-                crc ^= (w >> (8u * k)) & 0xffu;
-                crc = s_nib[crc & 15u] ^ (crc >> 4);
-                crc = s_nib[crc & 15u] ^ (crc >> 4);
+                crc = s_tab[(crc ^ (w >> (8u * k))) & 0xffu] ^ (crc >> 8);
             }
         }
     };
