@@ -1197,7 +1197,9 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         };
         auto load_c = [&](int st, const ColsA& v) {
             const bool need = v.tid.x != v.mtid.x || v.tid.y != v.mtid.y || v.tid.z != v.mtid.z || v.tid.w != v.mtid.w;
-            const int64_t i0 = block_base + (int64_t)st * kFwSub + (need ? (int64_t)lane * 4 : 0);
+            // (a lane without a candidate reads the columns' first 16 bytes - one sector per column for the whole launch,
+            // always in cache - and not its sub-tile's first sector, which nobody else may want: 0.3 GB less from HBM, -3 %)
+            const int64_t i0 = need ? block_base + (int64_t)st * kFwSub + (int64_t)lane * 4 : 0;
             ColsC c;
             c.pos = *reinterpret_cast<const int4*>(a.pos + i0);
             c.mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
