@@ -2,23 +2,28 @@
 // (the device form of bam_reader.hip's host path - `pysam.Samfile` iteration, runBESST:162,
 // CreateGraph.py:111, libmetrics.py:63,257,293 - for files in htslib's block layout, where no record straddles a block.)
 //
-// A BGZF block is an independent DEFLATE stream of at most 64 KiB of output, and a BAM of C3's size holds a million of
-// them: the parallelism is across blocks, so a block belongs to ONE WAVE and everything about the stream that is
-// sequential - bit buffer, Huffman state, output position - is wave-uniform (scalar registers, scalar branches), while
-// everything that is data parallel uses the wave's 64 lanes:
+// A BGZF block is an independent DEFLATE stream of at most 64 KiB of output, and a BAM of C3's size holds 1.3 million of
+// them: the parallelism is across blocks, so a block belongs to ONE WAVE; what is sequential about the stream - Huffman
+// state, output position, control flow - is wave-uniform, what is data parallel uses the wave's 64 lanes:
 //
 //   bgzf_inflate_kernel   one single-wave workgroup per block.
-//       input    256 compressed bytes per coalesced load (one dword per lane, the next window in flight), handed to
-//                the 64-bit bit buffer with v_readlane;
+//       input    256 compressed bytes per coalesced load, a dword per lane, handed to the 64-bit bit buffer with
+//                v_readlane; the buffer itself lives in vector registers (the CU's one scalar ALU is this kernel's limit);
 //       tables   canonical Huffman codes from the code lengths: symbols ranked by (length, symbol) with one ballot per
 //                length and 64 symbols, then every lane fills the primary-table slots it owns by DECODING the slot's bit
 //                pattern canonically (first code / count / offset per length) - balanced, no replication loops; codes
-//                longer than the 10-bit primary table (rare) are decoded the same way on the spot;
-//       window   a 32 KiB ring in LDS (DEFLATE's maximum distance): a literal is one LDS byte store, a match one LDS
-//                load + store per 64 bytes over the lanes (overlapping matches - distance < length - read
-//                pos - dist + i mod dist, which lies in finished output), LDS operations of a wave complete in order;
-//       output   the ring leaves for HBM in 8 KiB granules of 16-byte stores as they complete.
-//       38 KB of LDS per wave: four waves per CU, one per SIMD, 1024 blocks in flight on the chip.
+//                longer than the 10-bit primary table (rare) are decoded the same way on the spot; base and extra-bit
+//                count of a length / distance code come from two per-lane registers (v_readlane);
+//       window   the block's own output in HBM / L2 (default; 6 KB of LDS, seven waves per SIMD) - a wave's vector memory
+//                instructions are processed in order, a load behind a store of the same wave returns the stored byte -
+//                or a 32 KiB ring in LDS that leaves for HBM in 8 KiB granules (BESST_BGZF_WINDOW=lds; 38 KB of LDS, one
+//                wave per SIMD: 2.3 x slower, kept for A/B runs);
+//       output   in groups of 64 bytes: lane k of a group holds a literal or the place its byte is copied from; a full
+//                group, a match that reads from the group, or the end of the block flushes it with one gather and one
+//                store (an overlapping match - distance < length - is written directly: byte i is byte i mod dist of its
+//                last dist bytes).
+//   bgzf_crc_kernel       the CRC-32 of every block's inflated bytes against the block's gzip trailer (what htslib checks):
+//                         a thread per slice, the slices' values combined as zlib's crc32_combine does
 //   bam_walk_kernel       one lane per block: follows the records' length prefixes from the block's first byte
 //                         (u16 offsets per record, count, and whether the walk ended exactly at the block's end)
 //   bam_scan_kernel       exclusive scan of the blocks' record counts + the chunk's verdict (all blocks inflated, all walks
@@ -26,8 +31,7 @@
 //   bam_decode_kernel     one workgroup per block, a thread per record: the 36 fixed bytes as ten aligned dwords, the
 //                         CIGAR walk of pysam 0.8.4's qlen / alen (bam_reader.hip has the semantics), coalesced stores
 //                         into the record columns at the block's place in the stream
-//
-//   bgzf_crc_kernel       the CRC-32 of every block's inflated bytes against the block's gzip trailer (what htslib checks)
+// DESIGN.md section 8 has the measurements that led here.
 #include <stdlib.h>
 #include <string.h>
 
