@@ -121,6 +121,18 @@ def device_records(wl, device):
     return rec
 
 
+def ingest_slice(path, rank, world, device_index=None, threads=None):
+    """Rank ``rank``'s slice of a BAM file for the sharded build: part (rank, world) of the file - cut at BGZF block
+    boundaries every rank finds on its own - is inflated and decoded on the rank's GPU (besst_ctx_push_bam_device_part), and the
+    resident columns are handed on where they lie (besst_ctx_record_pointers).  -> (bamio.ResidentBam, column dict for
+    ``wl['cols']`` / pipeline.DeviceRecords.from_columns).  The ResidentBam owns the memory: keep it while the columns are
+    in use, close() it afterwards."""
+    from . import bamio
+    bam = bamio.ResidentBam(path, device_index=rank if device_index is None else device_index, threads=threads,
+                            part=(int(rank), int(world)))
+    return bam, bam.ctx.record_tensors()
+
+
 class HipBackend(object):
     """Kernel stages of one rank on its GPU."""
 

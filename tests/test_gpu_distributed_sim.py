@@ -498,12 +498,12 @@ def test_simulated_ranks_ingest_their_part_of_a_bam_file(world, tmp_path):
     pair_cap = 16384
     backends, bams, total = [], [], 0
     for r in range(world):
-        bam = bamio.ResidentBam(path, threads=2, part=(r, world), chunk_blocks=64)
+        bam, cols = distributed.ingest_slice(path, r, world, device_index=0, threads=2)
         assert bam.ingest.on_device == 1
         bams.append(bam)
         total += len(bam)
         sub = {k: v for k, v in wl.items() if k not in ('batch', 'cols', '_rec')}
-        sub['cols'] = bam.ctx.record_tensors()
+        sub['cols'] = cols
         assert int(sub['cols']['tid'].shape[0]) == len(bam)
         backends.append(distributed.HipBackend(dev, sub, r, world, pair_cap))
     assert total == len(wl['batch'])
