@@ -72,7 +72,7 @@ enum ProfSlot {
     kProfStream = 0, kProfFused, kProfFusedWave, kProfOrdered, kProfStitch, kProfFixup, kProfCompact,
     kProfRadixHist, kProfRadixScan, kProfRadixScatter, kProfBucketSort, kProfBucketReduce, kProfRowHeads, kProfRowScan, kProfRowReduce,
     kProfOsHist, kProfOsOffsets, kProfOsScatter, kProfOsBucket, kProfOsBucketRows, kProfOsReduce, kProfOsFixup,
-    kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfSlots
+    kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfMsdPartition, kProfSlots
 };
 static_assert(kProfSlots <= 32, "besst_prof_enable takes a 32-bit slot mask");
 struct ProfScope {

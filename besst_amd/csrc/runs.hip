@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void rg_rows_kernel(const uint32_t* __restrict
         return;
     }
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= *n_rows) return;
+    const uint32_t nr = *n_rows;
+    if (nr >= BESST_ROWS_RUN_OVERFLOW || r >= nr) return;    // (the sort of the runs gave up: its word travels on)
     const uint32_t j0 = r_first_run[r], c = r_runs[r];
     uint32_t nn = 0, first = 0, mask = 0;
     unsigned long long s = 0, q = 0;
@@ -463,13 +464,13 @@ __global__ __launch_bounds__(256) void rg_rows_kernel(const uint32_t* __restrict
 __global__ __launch_bounds__(256) void rg_copy_kernel(const uint32_t* __restrict__ n_runs, const int32_t* __restrict__ run_len,
                                                       const int32_t* __restrict__ run_at, const uint32_t* __restrict__ run_dst,
                                                       const uint64_t* __restrict__ grouped, int32_t* __restrict__ obs_lo,
-                                                      int32_t* __restrict__ obs_hi) {
+                                                      int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ n_rows) {
     constexpr int G = kRgCopyRuns;
     const int lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = *n_runs;
     const uint32_t j = w * (uint32_t)G + (uint32_t)lane;
-    if (w * (uint32_t)G >= n) return;                        // uniform
+    if (w * (uint32_t)G >= n || *n_rows >= BESST_ROWS_RUN_OVERFLOW) return;   // uniform (no rows: the runs' places are not valid)
     const bool live = lane < G && j < n;
     const uint32_t len = live ? (uint32_t)run_len[j] : 0u;
     const uint32_t at = live ? (uint32_t)run_at[j] : 0u;
@@ -630,7 +631,7 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         ProfScope ps(s, kProfRunCopy);
         const uint32_t waves = (w.run_cap + kRgCopyRuns - 1) / kRgCopyRuns;
         hipLaunchKernelGGL(rg_copy_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, w.n_runs, w.run_len, w.run_at, w.run_dst,
-                           grouped, obs_lo, obs_hi);
+                           grouped, obs_lo, obs_hi, n_rows);
     }
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;

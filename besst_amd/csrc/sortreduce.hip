@@ -17,6 +17,10 @@
 //
 // All sizes are read from device memory (n_tuples), so the whole stage is enqueued without a host
 // round trip; grids are sized by the caller's capacity bound and surplus workgroups exit at once.
+#include <unistd.h>
+
+#include <atomic>
+#include <random>
 #include <type_traits>
 
 #include "common.h"
@@ -342,6 +346,165 @@ constexpr int kBucketLds = BESST_BUCKET_LDS;
 #endif
 constexpr int kBucketThreads = BESST_BUCKET_THREADS;
 
+// The partition of the packed words in ONE launch (histogram + scatter were two, with a scan launch between them
+// beyond 64 tiles): the partition need not be stable, so a tile's share of a bucket can begin wherever the tile's
+// count ARRIVES - one returning atomic per (tile, digit) on the digit totals replaces the per-tile table, its scan
+// and the scatter's walk over the rows of the tiles before it.  The bucket starts need the final totals, i.e. every
+// tile's counts: the tiles wait for each other inside the launch.  That is safe because a launch of this path has at
+// most kMsdMaxBlocks workgroups (16 KB of LDS, 256 threads: all of them fit on the chip at once, and what else runs
+// on it finishes without waiting for anything here), and bounded all the same: a tile that gives up leaves the
+// call's nonce in the status word, the bucket kernels then do nothing and *n_rows reads BESST_ROWS_SORT_FAILED.
+// No state is assumed in the workspace: workgroup 0 clears the totals and says so, flags carry the call's 64-bit
+// nonce (a random base per process + a counter), which no stale word equals.
+//   flags[0] = totals cleared, flags[1] = a tile gave up, flags[2 + b] = tile b's counts are in
+typedef __attribute__((address_space(1))) unsigned long long msd_gu64;
+typedef __attribute__((address_space(1))) uint32_t msd_gu32;
+#define BESST_MSD_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr uint32_t kMsdSpinLimit = 1u << 22;
+static uint32_t msd_spin_limit() {      // BESST_MSD_SPIN_LIMIT (tests): 0 = the first unanswered poll gives up
+    static const uint32_t v = [] { const char* e = getenv("BESST_MSD_SPIN_LIMIT"); return e ? (uint32_t)strtoul(e, nullptr, 10) : kMsdSpinLimit; }();
+    return v;
+}
+static int msd_one_launch() {           // BESST_MSD_ONE_LAUNCH=0: the histogram / (scan) / scatter launches
+    static const int v = [] { const char* e = getenv("BESST_MSD_ONE_LAUNCH"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static unsigned long long msd_next_nonce() {
+    static std::atomic<unsigned long long> ctr{[] {
+        std::random_device rd;
+        return (((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ ((unsigned long long)getpid() << 20)) | 1ull;
+    }()};
+    return ctr.fetch_add(0x9E3779B97F4A7C15ull) | 1ull;   // (odd: never 0, the value of a zero-filled workspace)
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds,
+    uint32_t* total, unsigned long long* flags, unsigned long long nonce, uint32_t spin_limit,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ bucket_start, int packed_bits,
+    uint32_t* __restrict__ zero_n, unsigned long long* __restrict__ zero_sum,
+    unsigned long long* __restrict__ zero_sum_sq) {
+    constexpr int BITS = kMsdBits;
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / kSortThreads;
+    __shared__ uint32_t s_hist[RADIX];
+    __shared__ uint32_t s_base[RADIX];
+    __shared__ uint32_t s_w[4];
+    __shared__ int s_fail;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t wbase = b * (kSortThreads * ITEMS) + wave * (ITEMS * 64);
+    uint64_t key[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        key[r] = i < cap ? keys_in[i] : ~0ull;
+    }
+    uint32_t n = *n_ptr;
+    n = n < cap ? n : cap;
+    const uint32_t nb = nblocks_of(n, (kSortThreads * ITEMS));
+    if (b == 0) {
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) __hip_atomic_store((msd_gu32*)&total[q * kSortThreads + t], 0u, BESST_MSD_RLX);
+        __threadfence();                                     // the clears have landed ...
+        __syncthreads();
+        if (t == 0) __hip_atomic_store((msd_gu64*)&flags[0], nonce, BESST_MSD_RLX);   // ... before anyone is told
+    }
+    if (b >= nb) return;
+    if (t == 0) s_fail = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) s_hist[q * kSortThreads + t] = 0;
+    __syncthreads();
+    const uint64_t low_mask = ds.shift > 0 ? ((1ull << ds.shift) - 1ull) : 0ull;
+    uint32_t dig_rank[ITEMS];                                // digit | rank inside the tile's share of it << BITS
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        dig_rank[r] = 0;
+        if (i < n) {
+            const uint32_t d = digit_of(key[r], ds);
+            dig_rank[r] = d | (atomicAdd(&s_hist[d], 1u) << BITS);
+        }
+    }
+    if (b != 0 && t == 0) {                                  // the totals are clear (workgroup 0 starts first: long done)
+        uint32_t spins = 0;
+        while (__hip_atomic_load((msd_gu64*)&flags[0], BESST_MSD_RLX) != nonce) {
+            if (spins++ >= spin_limit) { s_fail = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (s_fail) {                                            // uniform
+        if (t == 0) __hip_atomic_store((msd_gu64*)&flags[1], nonce, BESST_MSD_RLX);
+        return;
+    }
+    // where the tile's share of every digit begins inside the digit's bucket: arrival order
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        const int d = q * kSortThreads + t;                  // (a wave's 64 lanes on 64 consecutive counters)
+        const uint32_t c = s_hist[d];
+        s_base[d] = c ? __hip_atomic_fetch_add((msd_gu32*)&total[d], c, BESST_MSD_RLX) : 0u;
+    }
+    __syncthreads();                                         // every returning atomic of the tile has returned
+    if (t == 0) __hip_atomic_store((msd_gu64*)&flags[2 + b], nonce, BESST_MSD_RLX);
+    if (wave == 0) {                                         // wait for the counts of all tiles
+        uint32_t spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (uint32_t j = lane; j < nb; j += 64)
+                ok = ok && __hip_atomic_load((msd_gu64*)&flags[2 + j], BESST_MSD_RLX) == nonce;
+            if (__all(ok)) break;
+            if (__hip_atomic_load((msd_gu64*)&flags[1], BESST_MSD_RLX) == nonce || spins++ >= spin_limit) {
+                if (lane == 0) s_fail = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (t == 0) __hip_atomic_store((msd_gu64*)&flags[1], nonce, BESST_MSD_RLX);
+        return;
+    }
+    {   // bucket starts: exclusive scan of the totals (thread t: digits t * DPT ..)
+        uint32_t tot[DPT];
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            tot[q] = __hip_atomic_load((msd_gu32*)&total[t * DPT + q], BESST_MSD_RLX);
+            run += tot[q];
+        }
+        uint32_t x = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(x, d, 64);
+            if (lane >= d) x += o;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t start = x - run;
+        for (int w = 0; w < wave; ++w) start += s_w[w];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            s_base[t * DPT + q] += start;
+            if (b == 0) bucket_start[t * DPT + q] = start;
+            start += tot[q];
+        }
+        if (b == 0 && t == kSortThreads - 1) bucket_start[RADIX] = start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < n) {
+            const uint32_t dst = s_base[dig_rank[r] & (RADIX - 1)] + (dig_rank[r] >> BITS);
+            // only the key bits below the digit travel in the word (bucket_reduce_kernel puts the digit back)
+            keys_out[dst] = (((key[r] - ds.base) & low_mask) << packed_bits) | i;
+            if (zero_n) { zero_n[i] = 0; zero_sum[i] = 0; zero_sum_sq[i] = 0; }   // rows <= tuples: the accumulators
+        }
+    }
+}
+
 __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
     return ka < kb || (ka == kb && ia < ib);
 }
@@ -399,7 +562,9 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
                                                           uint64_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ big_idx,
                                                           uint32_t* __restrict__ bucket_rows, int packed_bits,
-                                                          int sub_bits /* key bits below the MSD digit */) {
+                                                          int sub_bits /* key bits below the MSD digit */,
+                                                          const unsigned long long* __restrict__ msd_flags,
+                                                          unsigned long long nonce) {
     constexpr int kRank = kCap <= 512 ? kCap : 256;     // largest bucket the plain rank sort takes
     static_assert(kPacked || kCap <= 512, "unpacked pairs are only sorted in the small-stream configuration");
     static_assert(kBucketThreads == 256 || kCap <= 512, "the group scan of the two-level sort uses one thread per group");
@@ -412,6 +577,7 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_sort_kernel(uint64_t* _
     // the three loads are issued together (one memory round trip); bucket_start is stale when nothing was partitioned
     const uint32_t n_all = *n_ptr;
     const uint32_t s0 = bucket_start[blockIdx.x], e0 = bucket_start[blockIdx.x + 1];
+    if (msd_flags && msd_flags[1] == nonce) return;   // the partition gave up: bucket_start is not this call's
     const int n = n_all == 0 ? 0 : (int)(e0 - s0);
     if (n <= 1) {                     // nothing to sort; a single tuple is a single edge row
         if (kPacked && threadIdx.x == 0) bucket_rows[blockIdx.x] = (uint32_t)n;
@@ -554,13 +720,17 @@ __global__ __launch_bounds__(256) void bucket_reduce_kernel(
     uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
     unsigned long long* __restrict__ row_sum_sq, uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset,
     int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi, const uint32_t* __restrict__ first_map,
-    uint64_t key_base) {
+    uint64_t key_base, const unsigned long long* __restrict__ msd_flags, unsigned long long nonce) {
     __shared__ uint32_t s_part[4];
     __shared__ int s_wheads[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n_all = *n_ptr;
     const uint32_t s0 = bucket_start[b], e0 = bucket_start[b + 1];
+    if (msd_flags && msd_flags[1] == nonce) {         // the partition gave up: say so instead of a row count
+        if (b == 0 && t == 0) *n_rows = BESST_ROWS_SORT_FAILED;
+        return;
+    }
     if (n_all == 0) {
         if (b == 0 && t == 0) *n_rows = 0;
         return;
@@ -862,6 +1032,7 @@ struct RedWorkspace {
     uint32_t* blk_base;
     uint32_t* bucket_start;
     uint32_t* bucket_rows;
+    unsigned long long* msd_flags;   // one-launch partition: cleared / failed / per-tile arrival words
     uint64_t* big_keys;
     uint32_t* big_idx;
     uint32_t stride;
@@ -925,6 +1096,7 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up((kMaxRadix + 1) * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
+    w.msd_flags = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)(2 + kMsdMaxBlocks) * 8, 256);
     // in-place scratch of the bucket sort (only streams that take the MSD path can use it)
     const size_t big = nb_sort <= (size_t)kMsdMaxBlocks ? 2 * (size_t)cap + 8 : 8;
     w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
@@ -1028,7 +1200,15 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         const int shift = key_bits > kMsdBits ? key_bits - kMsdBits : 0;
         const DigitSel ds{0, shift, 0, 1u, kMsdBits, key_base};
         packed_bits = packable ? cap_idx_bits : 0;    // key and stream index in one word (always, in practice)
-        if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
+        const bool one_launch = packed_bits != 0 && msd_one_launch() != 0 && nb_sort <= (uint32_t)kMsdMaxBlocks;
+        const unsigned long long nonce = one_launch ? msd_next_nonce() : 0ull;
+        const unsigned long long* mflags = one_launch ? w.msd_flags : nullptr;
+        if (one_launch) {
+            ProfScope ps(s, kProfMsdPartition);
+            hipLaunchKernelGGL((msd_partition_kernel<kSortItems>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples,
+                               (uint32_t)cap, ds, w.row_total, w.msd_flags, nonce, msd_spin_limit(), w.keys[0],
+                               w.bucket_start, packed_bits, row_n, zsum, zsq);
+        } else if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
             // few sort tiles leave most of the chip idle: half-size tiles (and the row scan they then need)
             const uint32_t nb_small = (uint32_t)((cap + kSortThreads * kMsdSmallItems - 1) / (kSortThreads * kMsdSmallItems));
             launch_pass<kMsdBits, kMsdSmallItems>(s, w, nb_small, (uint32_t)cap, n_tuples, ds, true, keys, nullptr,
@@ -1042,17 +1222,17 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             const dim3 grid(1u << kMsdBits), block(kBucketThreads);
             if (!packed_bits)
                 hipLaunchKernelGGL((bucket_sort_kernel<false, kBucketLds>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0, shift);
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, 0, shift, mflags, nonce);
             else
                 hipLaunchKernelGGL((bucket_sort_kernel<true, 4096>), grid, block, 0, s, w.keys[0], w.idx[0],
-                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift);
+                                   w.bucket_start, n_tuples, w.big_keys, w.big_idx, w.bucket_rows, packed_bits, shift, mflags, nonce);
         }
         if (packed_bits) {
             // rows are local to a bucket: one launch instead of head counts + tile-based reduction
             ProfScope ps(s, kProfBucketReduce);
             hipLaunchKernelGGL(bucket_reduce_kernel, dim3(1u << kMsdBits), dim3(256), 0, s, w.keys[0], payload, n_tuples,
                                w.bucket_start, w.bucket_rows, packed_bits, shift, n_rows, row_key, row_mask, row_n, zsum, zsq,
-                               row_first, row_offset, obs_lo, obs_hi, first_map, key_base);
+                               row_first, row_offset, obs_lo, obs_hi, first_map, key_base, mflags, nonce);
             BESST_HIP_TRY(hipGetLastError());
             return BESST_OK;
         }

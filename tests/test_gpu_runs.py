@@ -163,6 +163,65 @@ def test_look_back_that_gives_up_is_reported():
     assert 'RAISED' in out.stdout and 'look-back gave up' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
+_MSD_SPIN_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+import numpy as np
+sys.path.insert(0, %(tests)r)
+import test_gpu_runs as T
+from besst_amd import pipeline, _lib
+rng = np.random.default_rng(6)
+n, node_bits = %(n)d, 18
+pair = rng.integers(0, %(pairs)d, n, dtype=np.int64)
+keys = (np.sort(pair) << 1).astype(np.uint64) if %(clustered)d else (pair << 1).astype(np.uint64)
+payload = rng.integers(26, 5000, n).astype(np.uint64) | (rng.integers(26, 5000, n).astype(np.uint64) << np.uint64(32))
+try:
+    T.run_reduce(keys, payload, node_bits)
+except _lib.BesstDeviceError as e:
+    print('RAISED', e)
+else:
+    print('NO ERROR')
+"""
+
+
+@pytest.mark.parametrize('n,pairs,clustered', [(300_000, 1 << 30, 0), (6_000_000, 40_000, 1)])
+def test_partition_tile_that_gives_up_is_reported(n, pairs, clustered):
+    """BESST_MSD_SPIN_LIMIT=0: a tile of the one-launch partition (small streams, and the runs of a large one) that
+    finds the other tiles' counts missing gives up at once.  The bucket kernels behind it must not touch the stale
+    bucket table, the run-grouped form's copy must not move anything, and the call reports BESST_ROWS_SORT_FAILED."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BESST_MSD_SPIN_LIMIT='0')
+    script = _MSD_SPIN_SCRIPT % dict(repo=os.path.dirname(here), tests=here, n=n, pairs=pairs, clustered=clustered)
+    out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=600)
+    assert 'RAISED' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize('one_launch', ['0', '1'])
+def test_partition_forms_agree(one_launch):
+    """The one-launch partition (tiles wait for each other's counts) and the histogram / scan / scatter launches it
+    replaces leave the same edge table (BESST_MSD_ONE_LAUNCH is read once per process, hence the subprocess)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BESST_MSD_ONE_LAUNCH=one_launch)
+    script = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+import numpy as np
+sys.path.insert(0, %(tests)r)
+import test_gpu_runs as T
+rng = np.random.default_rng(8)
+for n, pairs in ((1, 5), (4097, 300), (140_000, 9_000), (700_000, 1 << 34), (3_000_000, 200_000)):
+    node_bits = 18
+    keys = (rng.integers(0, pairs, n, dtype=np.int64) << 1).astype(np.uint64)
+    payload = rng.integers(26, 5000, n).astype(np.uint64) | (rng.integers(26, 5000, n).astype(np.uint64) << np.uint64(32))
+    for rep in range(2):
+        gb, n_rows = T.run_reduce(keys, payload, node_bits)
+        T.assert_rows(gb, n_rows, keys, payload)
+print('ALL EQUAL')
+""" % dict(repo=os.path.dirname(here), tests=here)
+    out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=900)
+    assert 'ALL EQUAL' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 def test_sparse_segments_chunks_spanning_many_blocks(monkeypatch):
     """The fused record loop hands its block segments over; a capacity beyond 4 M tuples picks the run-grouped form
     whatever the stream holds.  Long contigs and short inserts leave a dozen tuples per 16 384-record block, so a

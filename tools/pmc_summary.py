@@ -18,7 +18,7 @@ STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kerne
                 'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel', 'os_bucket_start_kernel', 'os_bucket_wave_kernel',
                 'os_bucket_sort_kernel', 'os_bucket_rows_kernel', 'os_bucket_wave_lds_kernel', 'os_seg_tiles_kernel',
                 'stitch_spans_kernel', 'presort_fixup_kernel', 'fused_wave_kernel', 'rg_group_kernel', 'rg_compact_kernel',
-                'rg_tile_sums_kernel', 'rg_dst_kernel', 'rg_rows_kernel', 'rg_copy_kernel')
+                'rg_tile_sums_kernel', 'rg_dst_kernel', 'rg_rows_kernel', 'rg_copy_kernel', 'msd_partition_kernel')
 
 
 def source_hash():
@@ -56,7 +56,7 @@ def main():
         # dispatches per step: relative to a kernel that runs exactly once per record loop / once per sort
         classify = k in ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'fused_wave_kernel', 'stitch_kernel', 'compact_kernel',
                         'stitch_spans_kernel', 'presort_fixup_kernel')
-        sort_anchor = next((a for a in ('rg_compact_kernel', 'os_offsets_kernel', 'radix_hist_kernel') if a in f), 'stitch_kernel')
+        sort_anchor = next((a for a in ('rg_compact_kernel', 'os_offsets_kernel', 'msd_partition_kernel', 'radix_hist_kernel') if a in f), 'stitch_kernel')
         anchor = 'stitch_kernel' if classify else sort_anchor
         per_step = len(f[k]) / float(max(1, len(f.get(anchor, []))))
         if per_step < 0.5:          # not a kernel of the step (compact_kernel of the capacity probe, when the sort reads segments)
