@@ -361,6 +361,12 @@ typedef __attribute__((address_space(1))) unsigned long long msd_gu64;
 typedef __attribute__((address_space(1))) uint32_t msd_gu32;
 #define BESST_MSD_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr uint32_t kMsdSpinLimit = 1u << 22;
+// keys per thread of a partition tile (build knob).  Without a per-tile table smaller tiles cost nothing but atomics:
+// 16 / 8 / 4 keys per thread = C2's step 100.1 / 97.7 / 97.9 us, the partition of C3's 0.5 M runs 22.5 / 21.6 / 23.8 us
+#ifndef BESST_MSD_ITEMS
+#define BESST_MSD_ITEMS 8
+#endif
+constexpr int kMsdItems = BESST_MSD_ITEMS;
 static uint32_t msd_spin_limit() {      // BESST_MSD_SPIN_LIMIT (tests): 0 = the first unanswered poll gives up
     static const uint32_t v = [] { const char* e = getenv("BESST_MSD_SPIN_LIMIT"); return e ? (uint32_t)strtoul(e, nullptr, 10) : kMsdSpinLimit; }();
     return v;
@@ -1096,7 +1102,7 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.blk_base = reinterpret_cast<uint32_t*>(p + off); off += align_up(nb_red * 4, 256);
     w.bucket_start = reinterpret_cast<uint32_t*>(p + off); off += align_up((kMaxRadix + 1) * 4, 256);
     w.bucket_rows = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
-    w.msd_flags = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)(2 + kMsdMaxBlocks) * 8, 256);
+    w.msd_flags = reinterpret_cast<unsigned long long*>(p + off); off += align_up((size_t)(2 + kMsdMaxBlocks * (kSortItems / kMsdItems)) * 8, 256);
     // in-place scratch of the bucket sort (only streams that take the MSD path can use it)
     const size_t big = nb_sort <= (size_t)kMsdMaxBlocks ? 2 * (size_t)cap + 8 : 8;
     w.big_keys = reinterpret_cast<uint64_t*>(p + off); off += align_up(big * 8, 256);
@@ -1205,7 +1211,8 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         const unsigned long long* mflags = one_launch ? w.msd_flags : nullptr;
         if (one_launch) {
             ProfScope ps(s, kProfMsdPartition);
-            hipLaunchKernelGGL((msd_partition_kernel<kSortItems>), dim3(nb_sort), dim3(kSortThreads), 0, s, keys, n_tuples,
+            const uint32_t nb_part = (uint32_t)((cap + kSortThreads * kMsdItems - 1) / (kSortThreads * kMsdItems));
+            hipLaunchKernelGGL((msd_partition_kernel<kMsdItems>), dim3(nb_part), dim3(kSortThreads), 0, s, keys, n_tuples,
                                (uint32_t)cap, ds, w.row_total, w.msd_flags, nonce, msd_spin_limit(), w.keys[0],
                                w.bucket_start, packed_bits, row_n, zsum, zsq);
         } else if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
