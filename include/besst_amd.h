@@ -48,7 +48,8 @@ extern "C" {
 /* Stage 2 (besst_dev_reduce*) reports a table it could not build in the size word the caller reads anyway: *n_rows is
  * one of these instead of a row count, and no other output of the call is valid.  (The besst_ctx_* layer turns the first
  * into BESST_ERR_HIP and handles the second itself.) */
-#define BESST_ROWS_SORT_FAILED 0xFFFFFFFFu  /* a chained-scan look-back gave up waiting for its predecessor tile        */
+#define BESST_ROWS_SORT_FAILED 0xFFFFFFFFu  /* a wait between workgroups inside a sort launch gave up (chained-scan look-back
+                                             * for the predecessor tile; small streams: a partition tile for the others' counts) */
 #define BESST_ROWS_RUN_OVERFLOW 0xFFFFFFFEu /* run-grouped form: more runs of equal keys than its buffers hold (a stream
                                              * whose keys do not cluster); repeat the call with BESST_REDUCE_NO_RUNS   */
 /* flags of besst_dev_reduce_flags / besst_presort.flags */
