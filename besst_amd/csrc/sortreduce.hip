@@ -350,9 +350,16 @@ constexpr int kBucketThreads = BESST_BUCKET_THREADS;
 // beyond 64 tiles): the partition need not be stable, so a tile's share of a bucket can begin wherever the tile's
 // count ARRIVES - one returning atomic per (tile, digit) on the digit totals replaces the per-tile table, its scan
 // and the scatter's walk over the rows of the tiles before it.  The bucket starts need the final totals, i.e. every
-// tile's counts: the tiles wait for each other inside the launch.  That is safe because a launch of this path has at
-// most kMsdMaxBlocks workgroups (16 KB of LDS, 256 threads: all of them fit on the chip at once, and what else runs
-// on it finishes without waiting for anything here), and bounded all the same: a tile that gives up leaves the
+// tile's counts: the tiles wait for each other inside the launch.  Two forms:
+//   * up to kMsdMutualTiles tiles, every workgroup does both halves and they wait for EACH OTHER - safe only because
+//     that few workgroups (16 KB of LDS, 256 threads) are on the chip together whatever else runs there, even a
+//     dozen launches of this kind on other streams (what else runs finishes without waiting for anything here);
+//   * beyond that (kSplit), a tile is served by two workgroups: one of the first half of the grid counts, leaves the
+//     tile's shares in a table row (written and read once, by row - no walk) and ends; one of the second half waits
+//     for the counting workgroups - all of them started before it, so the wait cannot deadlock however little of
+//     the grid fits on the chip (three streams sorting 1.8 M tuples each would otherwise hold each other's slots) -
+//     ranks its keys again and scatters.
+// The waits are bounded all the same: a tile that gives up leaves the
 // call's nonce in the status word, the bucket kernels then do nothing and *n_rows reads BESST_ROWS_SORT_FAILED.
 // No state is assumed in the workspace: workgroup 0 clears the totals and says so, flags carry the call's 64-bit
 // nonce (a random base per process + a counter), which no stale word equals.
@@ -383,13 +390,18 @@ static unsigned long long msd_next_nonce() {
     return ctr.fetch_add(0x9E3779B97F4A7C15ull) | 1ull;   // (odd: never 0, the value of a zero-filled workspace)
 }
 
-template <int ITEMS>
+#ifndef BESST_MSD_MUTUAL_TILES
+#define BESST_MSD_MUTUAL_TILES 128
+#endif
+constexpr uint32_t kMsdMutualTiles = BESST_MSD_MUTUAL_TILES;
+
+template <int ITEMS, bool kSplit>
 __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ n_ptr, uint32_t cap, DigitSel ds,
     uint32_t* total, unsigned long long* flags, unsigned long long nonce, uint32_t spin_limit,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ bucket_start, int packed_bits,
     uint32_t* __restrict__ zero_n, unsigned long long* __restrict__ zero_sum,
-    unsigned long long* __restrict__ zero_sum_sq) {
+    unsigned long long* __restrict__ zero_sum_sq, uint32_t* table) {
     constexpr int BITS = kMsdBits;
     constexpr int RADIX = 1 << BITS;
     constexpr int DPT = RADIX / kSortThreads;
@@ -398,7 +410,10 @@ __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
     __shared__ uint32_t s_w[4];
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t b = blockIdx.x;
+    // kSplit: the first half of the grid counts, the second half scatters; else every workgroup does both
+    const uint32_t tiles = kSplit ? gridDim.x / 2u : gridDim.x;
+    const bool counts = !kSplit || blockIdx.x < tiles, scatters = !kSplit || blockIdx.x >= tiles;
+    const uint32_t b = blockIdx.x < tiles ? blockIdx.x : blockIdx.x - tiles;
     const uint32_t wbase = b * (kSortThreads * ITEMS) + wave * (ITEMS * 64);
     uint64_t key[ITEMS];
 #pragma unroll
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
     uint32_t n = *n_ptr;
     n = n < cap ? n : cap;
     const uint32_t nb = nblocks_of(n, (kSortThreads * ITEMS));
-    if (b == 0) {
+    if (b == 0 && counts) {
 #pragma unroll
         for (int q = 0; q < DPT; ++q) __hip_atomic_store((msd_gu32*)&total[q * kSortThreads + t], 0u, BESST_MSD_RLX);
         __threadfence();                                     // the clears have landed ...
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
             dig_rank[r] = d | (atomicAdd(&s_hist[d], 1u) << BITS);
         }
     }
-    if (b != 0 && t == 0) {                                  // the totals are clear (workgroup 0 starts first: long done)
+    if (b != 0 && counts && t == 0) {                        // the totals are clear (workgroup 0 starts first: long done)
         uint32_t spins = 0;
         while (__hip_atomic_load((msd_gu64*)&flags[0], BESST_MSD_RLX) != nonce) {
             if (spins++ >= spin_limit) { s_fail = 1; break; }
@@ -445,14 +460,20 @@ __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
         return;
     }
     // where the tile's share of every digit begins inside the digit's bucket: arrival order
+    if (counts) {
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-        const int d = q * kSortThreads + t;                  // (a wave's 64 lanes on 64 consecutive counters)
-        const uint32_t c = s_hist[d];
-        s_base[d] = c ? __hip_atomic_fetch_add((msd_gu32*)&total[d], c, BESST_MSD_RLX) : 0u;
+        for (int q = 0; q < DPT; ++q) {
+            const int d = q * kSortThreads + t;              // (a wave's 64 lanes on 64 consecutive counters)
+            const uint32_t c = s_hist[d];
+            const uint32_t base = c ? __hip_atomic_fetch_add((msd_gu32*)&total[d], c, BESST_MSD_RLX) : 0u;
+            if (kSplit) __hip_atomic_store((msd_gu32*)&table[(size_t)b * RADIX + d], base, BESST_MSD_RLX);
+            else s_base[d] = base;
+        }
+        if (kSplit) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the row is written through: the stores themselves)
+        __syncthreads();                                     // every returning atomic of the tile has returned
+        if (t == 0) __hip_atomic_store((msd_gu64*)&flags[2 + b], nonce, BESST_MSD_RLX);
+        if (!scatters) return;
     }
-    __syncthreads();                                         // every returning atomic of the tile has returned
-    if (t == 0) __hip_atomic_store((msd_gu64*)&flags[2 + b], nonce, BESST_MSD_RLX);
     if (wave == 0) {                                         // wait for the counts of all tiles
         uint32_t spins = 0;
         for (;;) {
@@ -492,7 +513,8 @@ __global__ __launch_bounds__(kSortThreads) void msd_partition_kernel(
         for (int w = 0; w < wave; ++w) start += s_w[w];
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
-            s_base[t * DPT + q] += start;
+            if (kSplit) s_base[t * DPT + q] = start + __hip_atomic_load((msd_gu32*)&table[(size_t)b * RADIX + t * DPT + q], BESST_MSD_RLX);
+            else s_base[t * DPT + q] += start;
             if (b == 0) bucket_start[t * DPT + q] = start;
             start += tot[q];
         }
@@ -1092,9 +1114,11 @@ RedWorkspace carve(void* ws, int64_t cap) {
     w.stride = (uint32_t)nb_sort;
     // the wide-digit path is only taken for small streams, the 8-bit path for any size
     const size_t wide_max = (size_t)(kWideDigitMaxBlocks > kMsdMaxBlocks ? kWideDigitMaxBlocks : kMsdMaxBlocks);
+    // (rows: the tiles of the MSD pass, which may be smaller than a sort tile - kMsdSmallItems or kMsdItems keys per thread)
+    constexpr size_t kRowsPerSortTile = kSortItems / (kMsdSmallItems < kMsdItems ? kMsdSmallItems : kMsdItems);
     const size_t table_entries = nb_sort <= wide_max
-                                     ? (nb_sort * (kSortItems / kMsdSmallItems) > (size_t)kScanFreeMaxBlocks
-                                            ? nb_sort * (kSortItems / kMsdSmallItems) : (size_t)kScanFreeMaxBlocks) * kMaxRadix
+                                     ? (nb_sort * kRowsPerSortTile > (size_t)kScanFreeMaxBlocks
+                                            ? nb_sort * kRowsPerSortTile : (size_t)kScanFreeMaxBlocks) * kMaxRadix
                                      : nb_sort * (size_t)(1 << kLsdBits);
     w.table = reinterpret_cast<uint32_t*>(p + off); off += align_up(table_entries * 4, 256);
     w.row_total = reinterpret_cast<uint32_t*>(p + off); off += align_up(kMaxRadix * 4, 256);
@@ -1212,9 +1236,14 @@ int launch_sort_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         if (one_launch) {
             ProfScope ps(s, kProfMsdPartition);
             const uint32_t nb_part = (uint32_t)((cap + kSortThreads * kMsdItems - 1) / (kSortThreads * kMsdItems));
-            hipLaunchKernelGGL((msd_partition_kernel<kMsdItems>), dim3(nb_part), dim3(kSortThreads), 0, s, keys, n_tuples,
-                               (uint32_t)cap, ds, w.row_total, w.msd_flags, nonce, msd_spin_limit(), w.keys[0],
-                               w.bucket_start, packed_bits, row_n, zsum, zsq);
+            if (nb_part <= kMsdMutualTiles)
+                hipLaunchKernelGGL((msd_partition_kernel<kMsdItems, false>), dim3(nb_part), dim3(kSortThreads), 0, s, keys,
+                                   n_tuples, (uint32_t)cap, ds, w.row_total, w.msd_flags, nonce, msd_spin_limit(), w.keys[0],
+                                   w.bucket_start, packed_bits, row_n, zsum, zsq, w.table);
+            else
+                hipLaunchKernelGGL((msd_partition_kernel<kMsdItems, true>), dim3(2u * nb_part), dim3(kSortThreads), 0, s, keys,
+                                   n_tuples, (uint32_t)cap, ds, w.row_total, w.msd_flags, nonce, msd_spin_limit(), w.keys[0],
+                                   w.bucket_start, packed_bits, row_n, zsum, zsq, w.table);
         } else if (nb_sort <= (uint32_t)kMsdSmallMaxBlocks) {
             // few sort tiles leave most of the chip idle: half-size tiles (and the row scan they then need)
             const uint32_t nb_small = (uint32_t)((cap + kSortThreads * kMsdSmallItems - 1) / (kSortThreads * kMsdSmallItems));

@@ -222,6 +222,41 @@ print('ALL EQUAL')
     assert 'ALL EQUAL' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
 
 
+def test_partitions_on_several_streams_do_not_wait_for_each_other():
+    """Four streams partition ~1.9 M tuples each at the same time: ~930 tiles per launch, more workgroups together
+    than the chip holds.  A form in which the tiles of a launch wait for EACH OTHER could then hold the slots another
+    launch's missing tiles need; the split form (scattering workgroups wait only for counting workgroups started before
+    them) cannot.  Every stream's table is checked."""
+    import torch
+    from besst_amd import pipeline
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(21)
+    node_bits, streams, jobs = 18, [torch.cuda.Stream(device=dev) for _ in range(4)], []
+    for j in range(4):
+        n = 1_900_000 + 1000 * j
+        keys = (rng.integers(0, 60_000 + 7 * j, n, dtype=np.int64) << 1).astype(np.uint64)
+        payload = rng.integers(26, 5000, n).astype(np.uint64) | (rng.integers(26, 5000, n).astype(np.uint64) << np.uint64(32))
+        gb = pipeline.DeviceGraphBuilder(dev, 4, node_bits, LIB, 1, n)
+        dk = torch.from_numpy(keys.view(np.int64)).to(dev)
+        dp = torch.from_numpy(payload.view(np.int64)).to(dev)
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        jobs.append((gb, keys, payload, dk, dp, cnt, n))
+    torch.cuda.synchronize()
+    for st in streams:                                       # hold the four queues back so that they start together
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(200_000_000)
+    for rep in range(3):
+        for st, (gb, keys, payload, dk, dp, cnt, n) in zip(streams, jobs):
+            with torch.cuda.stream(st):
+                gb.reduce(keys=dk, payload=dp, n_tuples_ptr=C.c_void_p(cnt.data_ptr()), capacity=n)
+    torch.cuda.synchronize()
+    for st, (gb, keys, payload, dk, dp, cnt, n) in zip(streams, jobs):
+        with torch.cuda.stream(st):
+            n_rows = gb.read_sizes()[1]
+        assert gb.sort_flags == 0
+        assert_rows(gb, n_rows, keys, payload)
+
+
 def test_sparse_segments_chunks_spanning_many_blocks(monkeypatch):
     """The fused record loop hands its block segments over; a capacity beyond 4 M tuples picks the run-grouped form
     whatever the stream holds.  Long contigs and short inserts leave a dozen tuples per 16 384-record block, so a
