@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbesst_amd.so')
+# BESST_AMD_LIB: another build of the same library (A/B runs of kernel variants, tools/variant.sh)
+LIB_PATH = os.environ.get('BESST_AMD_LIB') or os.path.join(_HERE, 'libbesst_amd.so')
 
 
 class BesstDeviceError(RuntimeError):
@@ -32,7 +33,8 @@ class Presort(C.Structure):          # include/besst_amd.h: besst_presort
                 ('capacity', C.c_uint32), ('flags', C.c_uint32), ('segmented', C.c_int32), ('in_record_loop', C.c_int32),
                 ('seg_keys', C.c_void_p), ('seg_payload', C.c_void_p), ('seg_offsets', C.c_void_p), ('seg_skip', C.c_void_p),
                 ('seg_blocks', C.c_uint32), ('seg_tile', C.c_uint32), ('payload_out', C.c_void_p),
-                ('seg_chunk_first', C.c_void_p)]
+                ('seg_chunk_first', C.c_void_p), ('seg_run_offsets', C.c_void_p), ('seg_summ', C.c_void_p),
+                ('seg_summ_stride', C.c_uint32), ('seg_run_status', C.c_void_p)]
 
 
 class Counters(C.Structure):

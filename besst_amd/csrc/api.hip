@@ -178,7 +178,8 @@ const char* besst_prof_slot_name(int slot) {
         "os_bucket_start_kernel+os_bucket_wave_kernel+os_bucket_wave_lds_kernel+os_bucket_sort_kernel", "os_bucket_rows_kernel",
         "os_reduce_kernel", "os_fixup_kernel",
         "metrics_kernels", "score_kernels", "rg_group_kernel", "rg_compact_kernel",
-        "rg_tile_sums_kernel+rg_dst_kernel+rg_rows_kernel", "rg_copy_kernel", "msd_partition_kernel"};
+        "rg_tile_sums_kernel+rg_dst_kernel+rg_rows_kernel", "rg_copy_kernel", "msd_partition_kernel",
+        "rl_list_kernel", "rl_place_kernel"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
 }
 
@@ -1072,7 +1073,7 @@ static void presort_to_spec(const besst_presort* h, PresortSpec& ps) {
     static const int always = [] { const char* e = getenv("BESST_PRESORT_COUNT"); return e ? atoi(e) : 0; }();   // A/B runs
     ps.count = (!always && runs_enabled((int64_t)h->capacity) && !(h->flags & BESST_REDUCE_NO_RUNS)) ? 0 : 1;
     ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out,
-                       h->seg_chunk_first};
+                       h->seg_chunk_first, h->seg_run_offsets, h->seg_summ, h->seg_summ_stride, h->seg_run_status};
 }
 
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
@@ -1108,6 +1109,8 @@ int besst_dev_classify_presort(void* stream, int64_t n, const int32_t* tid, cons
         h_presort->seg_offsets = ps.seg.offsets; h_presort->seg_skip = ps.seg.skip;
         h_presort->seg_blocks = ps.seg.nblocks; h_presort->seg_tile = ps.seg.tile; h_presort->payload_out = ps.seg.payload_out;
         h_presort->seg_chunk_first = ps.seg.chunk_first;
+        h_presort->seg_run_offsets = ps.seg.run_offsets; h_presort->seg_summ = ps.seg.summ;
+        h_presort->seg_summ_stride = ps.seg.summ_stride; h_presort->seg_run_status = ps.seg.run_status;
     }
     return rc;
 }
@@ -1129,7 +1132,9 @@ int besst_dev_reduce_presorted(void* stream, int64_t capacity, const uint32_t* n
     BESST_REQUIRE(!seg || (ps.seg.seg_keys && ps.seg.seg_payload && ps.seg.offsets && ps.seg.skip &&
                            ps.seg.payload_out == payload && ps.seg.tile > 0),
                   "reduce_presorted: incomplete segment description");
-    if (h_presort->in_record_loop == 2 && (h_presort->flags & BESST_REDUCE_NO_RUNS)) {
+    BESST_REQUIRE(h_presort->in_record_loop != 3 || (seg && ps.seg.run_offsets && ps.seg.summ && ps.seg.run_status),
+                  "reduce_presorted: incomplete description of the record loop's runs");
+    if (h_presort->in_record_loop >= 2 && (h_presort->flags & BESST_REDUCE_NO_RUNS)) {
         set_error("reduce_presorted: the classify call behind this description did not count the sort's digits (its flags "
                   "asked for the run-grouped form): repeat it with BESST_REDUCE_NO_RUNS in `flags`");
         return BESST_ERR_STATE;

@@ -936,22 +936,66 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {     // the sum in every lan
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// kRuns (round 4): the wave also GROUPS what it emits (RunLayout, common.h) - stage 2 then reads neither keys nor tuples
+// back to find the runs of equal keys (rg_group_kernel: 0.68 GB read + 0.34 GB written per C3 step), it gets a run byte per
+// tuple and one table entry per run.  Per evaluation round the distinct keys among the <= 64 emitted tuples (two or three in
+// a coordinate-sorted stream) are peeled off - first emitting lane's key, one compare + ballot for the round's tuples, one
+// for the open runs the lanes hold - so the cost is per distinct key and round, not per tuple; no LDS, three registers.
+template <bool kRuns>
 __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
-    uint64_t* __restrict__ seg_payload, SummView summ) {
+    uint64_t* __restrict__ seg_payload, SummView summ, uint32_t* __restrict__ run_status) {
     __shared__ uint32_t s_buf[5][kFwRing];                // tid, mtid, pos, mpos, flag | mapq << 16 of the queued candidates
     __shared__ unsigned short s_qlen[kFwRing];
-    __shared__ uint32_t s_ph[256];                        // the sort's two digit histograms, 16 bits per counter (<= 16 384 tuples)
+    __shared__ uint32_t s_ph[kRuns ? 1 : 256];            // the sort's two digit histograms, 16 bits per counter (<= 16 384 tuples)
     const int lane = threadIdx.x;
     const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // (lanes below this one in a ballot: v_mbcnt_lo/hi on the mask - a (1 << lane) - 1 kept in registers for the whole
+    // block cost two of the 128 a wave has at four per SIMD, and this loop spills)
+    auto below_cnt = [](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
     const uint32_t thr_u32 = ins_thr_u32(a);
     const bool all_present = a.cls8[a.n_contigs] != 0;    // (uniform: the byte behind the class bytes, besst_dev_pack_contigs)
-    if (a.ps_table) {                                     // uniform
+    if (!kRuns && a.ps_table) {                           // uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q) s_ph[q * 64 + lane] = 0;
     }
-    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
+    // ---- kRuns: the open chunk (uniform: its first slot, its tuples, its runs; s_rk: the keys of its runs, a hash table
+    // whose slot number IS the run's name inside the chunk) and the block's totals
+    __shared__ unsigned long long s_rk[kRuns ? kRlSlots : 1];
+    char* const rl_region = reinterpret_cast<char*>(seg_keys + block_base);
+    int rl_start = 0, rl_n = 0, rl_k = 0, rl_chunks = 0, rl_runs = 0, rl_over = 0;
+    if constexpr (kRuns) {
+#pragma unroll
+        for (int q = 0; q < kRlSlots / 64; ++q) s_rk[q * 64 + lane] = kRlEmpty;
+    }
+    auto close_chunk = [&]() {
+        if (rl_n == 0) return;                               // uniform
+#pragma unroll
+        for (int q = 0; q < kRlSlots / 64; ++q) {
+            const unsigned long long k = s_rk[q * 64 + lane];
+            if (k != kRlEmpty && rl_chunks < kRlMaxChunks)
+                reinterpret_cast<unsigned long long*>(rl_region + kRlKeys)[rl_chunks * kRlSlots + q * 64 + lane] = k;
+            s_rk[q * 64 + lane] = kRlEmpty;
+        }
+        if (rl_chunks < kRlMaxChunks) {
+            if (lane == 0)
+                reinterpret_cast<uint64_t*>(rl_region + kRlHdr)[rl_chunks] =
+                    (uint64_t)(uint32_t)rl_start | ((uint64_t)(uint32_t)rl_n << 16) | ((uint64_t)(uint32_t)rl_k << 32);
+        } else {
+            rl_over = 1;
+        }
+        ++rl_chunks;
+        rl_runs += rl_k;
+        rl_start += rl_n;
+        rl_n = 0;
+        rl_k = 0;
+    };
+    // the block's share of the counters, two per register (a lane sees at most 257 rounds and 64 sub-tiles: < 2^16 each);
+    // the records that reached CreateEdge are counted from the ballot the chain needs anyway
+    uint32_t c_count_nus = 0, c_dup_long = 0, c_nonuniq_fishy = 0;
+    int c_reach_u = 0;
     int32_t run_tid = -1;                                 // the wave's running coverage (uniform)
     int run_sum = 0;
     int q_head = 0, q_count = 0;                          // the queue of candidates not yet evaluated (uniform)
@@ -959,6 +1003,13 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     // and the block's first reaching record (the one stitch_kernel resolves against the blocks before)
     int st_known = 0, st_p1 = 0, st_p2 = 0, st_emit = 0;
     int hd_present = 0, hd_o1 = 0, hd_o2 = 0, hd_info = 0, hd_slot = (int)kNoSlot;
+    // a rare coverage correction: the index is taken inside the branch (an empty asm hides it from the scheduler) - hoisted
+    // above it, its sign-extended 64-bit form was kept alive for every record of a sub-tile and spilled to scratch, whose
+    // stores then sat in the same in-order queue as the loop's prefetches
+    auto cov_add = [&](int32_t t, unsigned long long v) {
+        asm volatile("" : "+v"(t));
+        atomicAdd(&aligned[t], v);
+    };
     // An evaluation round in two halves: round_fetch takes up to 64 candidates off the queue into registers and issues
     // the gathers of their two contig rows; round_finish does the rest once the rows are there.  In the pipelined loop
     // below the gathers of a round travel with the column loads of the sub-tiles ahead and are waited for together
@@ -1000,16 +1051,22 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         const Eval e = eval_record(a, in_range, r.c1, r.c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
         // (see fused_kernel: the coverage credited with the streamed records is taken back when a contig is not in the table)
         if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
-            atomicAdd(&aligned[tid], 0ull - (unsigned long long)qlen);
+            cov_add(tid, 0ull - (unsigned long long)qlen);
         const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
         const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
         const bool dbl = (e.bits & EV_DOUBLE) != 0;
-        c_nonuniq += (live && (e.bits & EV_NONUNIQ)) ? 1 : 0;
-        c_fishy += fishy ? 1 : 0;
-        c_reach += reach ? 1 : 0;
+        c_nonuniq_fishy += ((live && (e.bits & EV_NONUNIQ)) ? 1u : 0u) | (fishy ? 0x10000u : 0u);
         const int32_t o1 = e.o1, o2 = e.o2;
         const unsigned long long has_mask = __ballot(reach);
-        const unsigned long long below = has_mask & lt_mask;
+        c_reach_u += __popcll(has_mask);
+        unsigned long long below;
+        {
+            int l = lane;
+            asm volatile("" : "+v"(l));                      // (not hoisted: the mask is rebuilt where it is needed)
+            const uint32_t lo_m = l < 32 ? (1u << l) - 1u : 0xffffffffu;
+            const uint32_t hi_m = l < 32 ? 0u : (1u << (l - 32)) - 1u;
+            below = has_mask & (((unsigned long long)hi_m << 32) | lo_m);
+        }
         // "previous record that reached CreateEdge" [:835-838, 869-870]: the nearest reaching lane below, else the state
         bool pk = below != 0ull;
         int32_t p1, p2;
@@ -1027,19 +1084,53 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                 emit = accept;
             } else {
                 const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
-                c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
+                c_count_nus += (uint32_t)d.count | ((uint32_t)d.nus << 16);
+                c_dup_long += (uint32_t)d.dup | ((uint32_t)d.too_long << 16);
                 emit = d.keep;
             }
         }
         const unsigned long long emit_mask = __ballot(emit);
-        const int slot = st_emit + __popcll(emit_mask & lt_mask);
-        if (emit) {
-            const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
-            const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
-            const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
-            const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
-            const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
-            const uint64_t key = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+        const int slot = st_emit + below_cnt(emit_mask);
+        const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
+        const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
+        const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
+        const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
+        const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
+        const uint64_t key = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
+        if constexpr (kRuns) {
+            if (emit_mask) {                                 // uniform
+                const int n_emit = __popcll(emit_mask);
+                if (rl_k >= kRlCloseRuns || rl_n + n_emit > kRlChunkTuples) close_chunk();
+                // every emitting lane looks its key up in the chunk's table - linear probing from a slot the two node
+                // numbers pick; partners of one scaffold end are neighbours, so a chunk's handful of keys rarely collide -
+                // and the first lane to bring a key claims a slot for it.  (Peeling the round's distinct keys off one by
+                // one - first lane's key, compare + ballot against the round and against the open runs - cost 35
+                // instructions per distinct key and round, all on the wave's critical path: +0.27 ms on full C3.)
+                uint32_t my_run = kRlNoRun;                  // (the block's head: in no run, the stitch may still drop it)
+                bool pending = emit && !is_head, fresh = false;
+                uint32_t h = (e.n_max + 5u * e.n_min + (fishy ? 64u : 0u)) & (uint32_t)(kRlSlots - 1);
+                while (__ballot(pending) != 0ull) {          // one turn unless keys collide
+                    if (pending) {
+                        const unsigned long long cur = s_rk[h];
+                        bool hit = cur == key;
+                        if (cur == kRlEmpty) {
+                            const unsigned long long old = atomicCAS(&s_rk[h], kRlEmpty, (unsigned long long)key);
+                            fresh = old == kRlEmpty;
+                            hit = fresh || old == key;
+                        }
+                        if (hit) { my_run = h; pending = false; }
+                        else h = (h + 1u) & (uint32_t)(kRlSlots - 1);
+                    }
+                }
+                rl_k += __popcll(__ballot(fresh));
+                if (emit) {
+                    seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
+                    reinterpret_cast<uint8_t*>(rl_region + kRlRid)[slot] = (uint8_t)my_run;
+                    if (is_head) *reinterpret_cast<uint64_t*>(rl_region + kRlHeadKey) = key;
+                }
+                rl_n += n_emit;
+            }
+        } else if (emit) {
             seg_keys[block_base + slot] = key;
             seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
             if (a.ps_table) {                                // uniform
@@ -1051,7 +1142,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                     const unsigned long long m = __ballot(d == f);
                     uint32_t add = 0, at = d;
                     if (d != f) add = 1u;
-                    else if ((m & lt_mask) == 0ull) { add = (uint32_t)__popcll(m); at = f; }
+                    else if (below_cnt(m) == 0) { add = (uint32_t)__popcll(m); at = f; }
                     if (add) atomicAdd(&s_ph[128 * q + (at >> 1)], add << (16 * (at & 1u)));
                 }
             }
@@ -1114,7 +1205,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                                  (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs);
                 if (!act) continue;
                 if (lane_uni) val += (int)r_qlen[k];
-                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
+                else cov_add(r_tid[k], (unsigned long long)r_qlen[k]);
             }
             if (lane_uni) key = r_tid[0];
             wave_add_runs(aligned, key, val, lane);
@@ -1136,9 +1227,9 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             if (cand[k] && !full[k] && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs && (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs) {
                 bool present = true;
                 if (!all_present) present = a.cls8[r_tid[k]] != BESST_CLS_ABSENT && a.cls8[r_mtid[k]] != BESST_CLS_ABSENT;
-                if (present) c_nonuniq += r_mapq[k] == 0 ? 1 : 0;
+                if (present) c_nonuniq_fishy += r_mapq[k] == 0 ? 1u : 0u;
                 else if ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0)
-                    atomicAdd(&aligned[r_tid[k]], 0ull - (unsigned long long)r_qlen[k]);
+                    cov_add(r_tid[k], 0ull - (unsigned long long)r_qlen[k]);
             }
         }
         // ---- candidates -> the wave's ring, in record order (record = 4 * lane + k)
@@ -1146,7 +1237,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         const unsigned long long b2 = __ballot(full[2]), b3 = __ballot(full[3]);
         const int total = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         if (total == 0) return;                              // uniform
-        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask);
+        int slot = below_cnt(b0) + below_cnt(b1) + below_cnt(b2) + below_cnt(b3);
         slot += q_head + q_count;                            // behind the queued ones (at most 63 + 256 entries in all)
         slot = slot >= kFwRing ? slot - kFwRing : slot;
         slot = slot >= kFwRing ? slot - kFwRing : slot;
@@ -1177,41 +1268,54 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         // iteration.  (Issued at the END of an iteration the same loads are needed at once: 1.53 -> 1.71 ms.)  The candidate columns are
         // loaded by every lane - a lane without a candidate reads the sub-tile's first sector again - so that the
         // number of outstanding loads is the same on every path and the waits the compiler places are exact.
-        struct ColsA { int4 tid, mtid; uchar4 mapq; ushort4 qlen; };
-        struct ColsC { int4 pos, mpos; ushort4 flag; };
+        // (the byte and halfword columns stay packed as they were loaded - one and two registers - until process() takes
+        // them apart: three sub-tiles of columns are live at once)
+        struct ColsA { int4 tid, mtid; uint32_t mapq; uint2 qlen; };
+        struct ColsC { int4 pos, mpos; uint2 flag; };
+        // Addresses: the block's first record of every column is a uniform pointer (a scalar register pair), a lane adds
+        // a 32-bit offset to it (the saddr + voffset form of the load) - as 64-bit pointers per lane and column the seven
+        // columns held fourteen vector registers through the loop, and the loop spilled.
+        const int32_t* const b_tid = a.tid + block_base;
+        const int32_t* const b_mtid = a.mtid + block_base;
+        const int32_t* const b_pos = a.pos + block_base;
+        const int32_t* const b_mpos = a.mpos + block_base;
+        const uint16_t* const b_flag = a.flag + block_base;
+        const uint8_t* const b_mapq = a.mapq + block_base;
+        const uint16_t* const b_qlen = a.qlen + block_base;
+        typedef int v4i __attribute__((ext_vector_type(4)));
         auto load_a = [&](int st) {
-            const int64_t i0 = block_base + (int64_t)st * kFwSub + (int64_t)lane * 4;
+            const uint32_t li = (uint32_t)st * (uint32_t)(kFwSub / 4) + (uint32_t)lane;   // the lane's group of four records
             ColsA v;
 #ifndef BESST_FW_PLAIN_LOADS
             // (non-temporal: every record is read once - marking these four streams so took 2.3 % off the kernel; the same
             // mark on the candidate columns, where idle lanes re-read one sector, or on the segment stores made it slower)
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            typedef unsigned short v4h __attribute__((ext_vector_type(4)));
-            const v4i t4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a.tid + i0));
-            const v4i m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a.mtid + i0));
-            const uint32_t q1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.mapq + i0));
-            const v4h q4 = __builtin_nontemporal_load(reinterpret_cast<const v4h*>(a.qlen + i0));
+            const v4i t4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_tid) + li);
+            const v4i m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_mtid) + li);
+            const uint32_t q1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(b_mapq) + li);
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            const v2u q4 = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(b_qlen) + li);
             v.tid = make_int4(t4.x, t4.y, t4.z, t4.w);
             v.mtid = make_int4(m4.x, m4.y, m4.z, m4.w);
-            v.mapq = make_uchar4(q1 & 255u, (q1 >> 8) & 255u, (q1 >> 16) & 255u, q1 >> 24);
-            v.qlen = make_ushort4(q4.x, q4.y, q4.z, q4.w);
+            v.mapq = q1;
+            v.qlen = make_uint2(q4.x, q4.y);
 #else
-            v.tid = *reinterpret_cast<const int4*>(a.tid + i0);
-            v.mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
-            v.mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            v.qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            v.tid = reinterpret_cast<const int4*>(b_tid)[li];
+            v.mtid = reinterpret_cast<const int4*>(b_mtid)[li];
+            v.mapq = reinterpret_cast<const uint32_t*>(b_mapq)[li];
+            v.qlen = reinterpret_cast<const uint2*>(b_qlen)[li];
 #endif
             return v;
         };
         auto load_c = [&](int st, const ColsA& v) {
             const bool need = v.tid.x != v.mtid.x || v.tid.y != v.mtid.y || v.tid.z != v.mtid.z || v.tid.w != v.mtid.w;
-            // (a lane without a candidate reads the columns' first 16 bytes - one sector per column for the whole launch,
-            // always in cache - and not its sub-tile's first sector, which nobody else may want: 0.3 GB less from HBM, -3 %)
-            const int64_t i0 = need ? block_base + (int64_t)st * kFwSub + (int64_t)lane * 4 : 0;
+            // (a lane without a candidate reads the first 16 bytes of the BLOCK's columns - one sector per column and block,
+            // in cache after its first use - and not its sub-tile's first sector, which nobody else may want: 0.3 GB less
+            // from HBM, -3 %)
+            const uint32_t li = need ? (uint32_t)st * (uint32_t)(kFwSub / 4) + (uint32_t)lane : 0u;
             ColsC c;
-            c.pos = *reinterpret_cast<const int4*>(a.pos + i0);
-            c.mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
-            c.flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
+            c.pos = reinterpret_cast<const int4*>(b_pos)[li];
+            c.mpos = reinterpret_cast<const int4*>(b_mpos)[li];
+            c.flag = reinterpret_cast<const uint2*>(b_flag)[li];
             return c;
         };
         constexpr int kSubs = kClsTile / kFwSub;
@@ -1235,9 +1339,9 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                 const int32_t r_mtid[4] = {a0.mtid.x, a0.mtid.y, a0.mtid.z, a0.mtid.w};
                 const int32_t r_pos[4] = {c0.pos.x, c0.pos.y, c0.pos.z, c0.pos.w};
                 const int32_t r_mpos[4] = {c0.mpos.x, c0.mpos.y, c0.mpos.z, c0.mpos.w};
-                const uint32_t r_flag[4] = {c0.flag.x, c0.flag.y, c0.flag.z, c0.flag.w};
-                const uint32_t r_mapq[4] = {a0.mapq.x, a0.mapq.y, a0.mapq.z, a0.mapq.w};
-                const uint32_t r_qlen[4] = {a0.qlen.x, a0.qlen.y, a0.qlen.z, a0.qlen.w};
+                const uint32_t r_flag[4] = {c0.flag.x & 0xffffu, c0.flag.x >> 16, c0.flag.y & 0xffffu, c0.flag.y >> 16};
+                const uint32_t r_mapq[4] = {a0.mapq & 255u, (a0.mapq >> 8) & 255u, (a0.mapq >> 16) & 255u, a0.mapq >> 24};
+                const uint32_t r_qlen[4] = {a0.qlen.x & 0xffffu, a0.qlen.x >> 16, a0.qlen.y & 0xffffu, a0.qlen.y >> 16};
                 process(r_tid, r_mtid, r_pos, r_mpos, r_flag, r_mapq, r_qlen);
             }
             a0 = a1; a1 = a2; c0 = c1;
@@ -1272,11 +1376,17 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
         atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
     // ---- block summary (same planes as fused_kernel / ordered_kernel)
-    const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
+    const int vals[7] = {(int)(c_count_nus & 0xffffu), (int)(c_nonuniq_fishy & 0xffffu), (int)(c_count_nus >> 16),
+                         (int)(c_dup_long & 0xffffu), (int)(c_dup_long >> 16), (int)(c_nonuniq_fishy >> 16), 0};
     int tot[7];
 #pragma unroll
-    for (int f = 0; f < 7; ++f) tot[f] = wave_sum_dpp(vals[f]);
-    if (a.ps_table) {
+    for (int f = 0; f < 6; ++f) tot[f] = wave_sum_dpp(vals[f]);
+    tot[6] = c_reach_u;
+    if constexpr (kRuns) {
+        close_chunk();
+        if (rl_over && lane == 0) atomicOr(run_status, 1u);
+    }
+    if (!kRuns && a.ps_table) {
         __builtin_amdgcn_wave_barrier();
         uint32_t* row = a.ps_table + (size_t)(blockIdx.x & (uint32_t)(a.ps_rows - 1)) * 512u;
 #pragma unroll
@@ -1298,6 +1408,10 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
 #pragma unroll
     for (int f = 0; f < 7; ++f)
         if (lane == kSumCtr0 + f) v = (uint32_t)tot[f];
+    if constexpr (kRuns) {
+        if (lane == kSumChunks) v = (uint32_t)rl_chunks;
+        if (lane == kSumRuns) v = (uint32_t)rl_runs + ((hd_present && hd_slot != (int)kNoSlot) ? 1u : 0u);
+    }
     if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
 }
 
@@ -1322,6 +1436,7 @@ struct StitchAgg {
     int32_t head_present, f1, f2;       // its first one: resolved against the spans before
     uint32_t head_info;
     uint32_t total;                     // tuples of the span, that head's provisional tuple included
+    uint32_t runs;                      // runs of the span (kSumRuns), that head's run of one included
 };
 
 __global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint32_t nblocks, uint32_t span, int detect,
@@ -1331,22 +1446,23 @@ __global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint3
     __shared__ int s_tab[64];
     __shared__ int s_total;
     __shared__ int32_t s_first[4];
-    __shared__ int s_sum[16];
+    __shared__ int s_sum[16], s_sum_runs[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t c0 = blockIdx.x * span;
     if (blockIdx.x == 0 && t == 0) { carry_in[0] = carry[0]; carry_in[1] = carry[1]; }   // stitch_kernel overwrites carry
     if (t == 0) { s_first[0] = -1; }
-    uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], has[kStitchRounds];
+    uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], has[kStitchRounds], n_runs[kStitchRounds];
     int32_t f1[kStitchRounds], f2[kStitchRounds], l1[kStitchRounds], l2[kStitchRounds];
 #pragma unroll
     for (int r = 0; r < kStitchRounds; ++r) {
         const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
-        n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0;
+        n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0; n_runs[r] = 0;
         if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
             n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
             f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
             l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
             head_info[r] = summ.at(kSumHeadInfo, b);
+            n_runs[r] = summ.at(kSumRuns, b);
         }
     }
     int incl[kStitchRounds];
@@ -1377,25 +1493,27 @@ __global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint3
     }
     __syncthreads();
     const int last_idx = s_total;
-    int mine = 0;
+    int mine = 0, mine_runs = 0;
 #pragma unroll
     for (int r = 0; r < kStitchRounds; ++r) {
         int ex = __shfl_up(incl[r], 1, 64);
         if (lane == 0) ex = -1;
         const int wpre = s_tab[r * 16 + wave];
         const int pi = ex > wpre ? ex : wpre;
-        int n_final = (int)n_emit[r];
+        int n_final = (int)n_emit[r], r_final = (int)n_runs[r];
         if (has[r] && pi < 0) {                              // the span's first reaching block (one thread at most)
             s_first[0] = 1; s_first[1] = f1[r]; s_first[2] = f2[r]; s_first[3] = (int32_t)head_info[r];
         } else if (has[r]) {
             const CEDelta d = create_edge(f1[r], f2[r], s_l1[pi], s_l2[pi], head_info[r] & 1u, head_info[r] & 2u,
                                           head_info[r] & 4u, detect != 0);
-            if ((head_info[r] & 8u) && !d.keep) n_final -= 1;
+            if ((head_info[r] & 8u) && !d.keep) { n_final -= 1; r_final -= r_final > 0 ? 1 : 0; }
         }
         mine += n_final;
+        mine_runs += r_final;
     }
     mine = wave_sum(mine);
-    if (lane == 0) s_sum[wave] = mine;
+    mine_runs = wave_sum(mine_runs);
+    if (lane == 0) { s_sum[wave] = mine; s_sum_runs[wave] = mine_runs; }
     __syncthreads();
     if (t == 0) {
         StitchAgg a;
@@ -1404,9 +1522,10 @@ __global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint3
         a.l2 = last_idx >= 0 ? s_l2[last_idx] : 0;
         a.head_present = s_first[0] > 0 ? 1 : 0;
         a.f1 = s_first[1]; a.f2 = s_first[2]; a.head_info = (uint32_t)s_first[3];
-        int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += s_sum[w];
+        int tot = 0, tot_runs = 0;
+        for (int w = 0; w < 16; ++w) { tot += s_sum[w]; tot_runs += s_sum_runs[w]; }
         a.total = (uint32_t)tot;
+        a.runs = (uint32_t)tot_runs;
         agg[blockIdx.x] = a;
     }
 }
@@ -1419,7 +1538,11 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                                                       const int32_t* __restrict__ tails, int rank,
                                                       int32_t* __restrict__ slice_info,
                                                       const StitchAgg* __restrict__ agg,
-                                                      const int32_t* __restrict__ carry_in, uint32_t span) {
+                                                      const int32_t* __restrict__ carry_in, uint32_t span,
+                                                      uint32_t* __restrict__ run_offsets) {
+    // run_offsets (a record loop that grouped its runs, kSumRuns): where each block's runs begin in the stream-ordered
+    // run list - the same scan as the tuple offsets, in the upper half of a 64-bit word; a head the stitch drops takes its
+    // run of one with it
     // slice_info != nullptr (sharded build without a tail exchange): the slice's FIRST reaching record is left
     // unresolved - its provisional tuple stays, its CreateEdge call is not counted - and described in slice_info
     // { any reaching, last obs1, last obs2, head present, head obs1, head obs2, head info, head tuple position },
@@ -1430,8 +1553,10 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
     __shared__ int32_t s_head[4];    // its obs1, obs2, info, slot
     __shared__ int s_tab[64];
     __shared__ int s_total;
+    __shared__ long long s_tab64[64];
+    __shared__ long long s_total64;
     __shared__ int32_t s_carry[2];
-    __shared__ int s_base;
+    __shared__ long long s_base;         // tuples | runs << 32 in front of this span
     __shared__ int s_redc[16][7];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool last_span = blockIdx.x == gridDim.x - 1;
@@ -1443,14 +1568,15 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
             for (int j = 0; j < rank; ++j)
                 if (tails[j * 4]) { p1 = tails[j * 4 + 1]; p2 = tails[j * 4 + 2]; }
         // the spans before this one: what their first reaching records resolve to, where their tuples end
-        int any = 0, base = 0;
+        int any = 0;
+        long long base = 0;
         for (uint32_t j = 0; j < blockIdx.x; ++j) {
             const StitchAgg a = agg[j];
-            int tot = (int)a.total;
+            long long tot = (long long)a.total | ((long long)a.runs << 32);
             if (a.head_present && !(slice_info && !any)) {   // (the slice head keeps its provisional tuple)
                 const CEDelta d = create_edge(a.f1, a.f2, p1, p2, a.head_info & 1u, a.head_info & 2u, a.head_info & 4u,
                                               detect != 0);
-                if ((a.head_info & 8u) && !d.keep) tot -= 1;
+                if ((a.head_info & 8u) && !d.keep) tot -= 1ll + (a.runs ? 1ll << 32 : 0ll);
             }
             base += tot;
             if (a.has_any) { p1 = a.l1; p2 = a.l2; any = 1; }
@@ -1463,12 +1589,15 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
     {
         const uint32_t c0 = blockIdx.x * span;
         uint32_t n_emit[kStitchRounds], head_info[kStitchRounds], head_slot[kStitchRounds], has[kStitchRounds];
+        uint32_t n_runs[kStitchRounds];
         int32_t f1[kStitchRounds], f2[kStitchRounds], l1[kStitchRounds], l2[kStitchRounds];
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
             const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
             n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0; head_slot[r] = kNoSlot;
+            n_runs[r] = 0;
             if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
+                n_runs[r] = run_offsets ? summ.at(kSumRuns, b) : 0u;
                 n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
                 f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
                 l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
@@ -1526,46 +1655,52 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                 const CEDelta d = create_edge(f1[r], f2[r], p1, p2, head_info[r] & 1u, head_info[r] & 2u,
                                               head_info[r] & 4u, detect != 0);
                 c_count += d.count; c_long += d.too_long; c_dup += d.dup; c_nus += d.nus;
-                if ((head_info[r] & 8u) && !d.keep) { n_final[r] -= 1; skip[r] = head_slot[r]; }
+                if ((head_info[r] & 8u) && !d.keep) {
+                    n_final[r] -= 1; skip[r] = head_slot[r];
+                    n_runs[r] -= n_runs[r] ? 1u : 0u;
+                }
             }
         }
-        __syncthreads();                                     // s_tab is reused for the sums
-        // ---- tuple offsets
-        int sincl[kStitchRounds];
+        __syncthreads();
+        // ---- tuple offsets (and run offsets: upper half of the word)
+        long long sincl[kStitchRounds];
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
-            int v = (int)n_final[r];
+            long long v = (long long)n_final[r] | ((long long)n_runs[r] << 32);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(v, d, 64);
+                const long long o = __shfl_up(v, d, 64);
                 if (lane >= d) v += o;
             }
             sincl[r] = v;
-            if (lane == 63) s_tab[r * 16 + wave] = v;
+            if (lane == 63) s_tab64[r * 16 + wave] = v;
         }
         __syncthreads();
         if (wave == 0) {
-            const int own = s_tab[lane];
-            int v = own;
+            const long long own = s_tab64[lane];
+            long long v = own;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(v, d, 64);
+                const long long o = __shfl_up(v, d, 64);
                 if (lane >= d) v += o;
             }
-            s_tab[lane] = v - own;
-            if (lane == 63) s_total = v;
+            s_tab64[lane] = v - own;
+            if (lane == 63) s_total64 = v;
         }
         __syncthreads();
-        const int base = s_base;
+        const long long base = s_base;
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
             const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
             if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
-                offsets[b] = (uint32_t)(base + s_tab[r * 16 + wave] + sincl[r] - (int)n_final[r]);
+                const long long ex = base + s_tab64[r * 16 + wave] + sincl[r] -
+                                     ((long long)n_final[r] | ((long long)n_runs[r] << 32));
+                offsets[b] = (uint32_t)ex;
                 skip_slot[b] = skip[r];
+                if (run_offsets) run_offsets[b] = (uint32_t)(ex >> 32);
             }
         }
-        const int span_total = s_total;
+        const long long span_total = s_total64;
         __syncthreads();
         if (t == 0) {
             s_base = base + span_total;
@@ -1599,7 +1734,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
             carry[0] = s_carry[0];
             carry[1] = s_carry[1];
             *n_out = (uint32_t)s_base;
-            atomicAdd(&counters[6], (unsigned long long)s_base);
+            atomicAdd(&counters[6], (unsigned long long)(uint32_t)s_base);
             if (slice_info) {
                 slice_info[0] = s_any; slice_info[1] = s_carry[0]; slice_info[2] = s_carry[1];
                 if (!s_any) {                                // no record of the slice reached CreateEdge: no head either
@@ -1701,6 +1836,8 @@ struct ClsWorkspace {
     uint32_t* offsets;
     uint32_t* skip;
     uint32_t* chunk_first;          // per chunk of kRunChunk tuples of the dense stream: its first block
+    uint32_t* run_offsets;          // per block: its first run in the stream-ordered run list (record loop that groups runs)
+    uint32_t* run_status;           // one word: a block's run tables overflowed
     struct StitchAgg* agg;          // one per span of blocks, + the prev_obs entering the stream (2 x int32) behind them
     uint32_t agg_spans;
     unsigned long long* bitmask;
@@ -1722,6 +1859,8 @@ ClsWorkspace carve(void* ws, int64_t n) {
     w.offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.skip = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
     w.chunk_first = reinterpret_cast<uint32_t*>(p + off); off += align_up(((size_t)n / kRunChunk + 2) * 4, 256);
+    w.run_offsets = reinterpret_cast<uint32_t*>(p + off); off += align_up((size_t)nblocks * 4, 256);
+    w.run_status = reinterpret_cast<uint32_t*>(p + off); off += 256;
     // (room for 4096 spans whatever the stream: the test knob BESST_STITCH_SPAN cuts small streams into many)
     const size_t spans = (size_t)((nblocks + kStitchSpan - 1) / kStitchSpan) + 4096;
     w.agg_spans = (uint32_t)spans;
@@ -1803,8 +1942,20 @@ __global__ void resolve_carry_kernel(const int32_t* __restrict__ tails, int rank
 
 }  // namespace
 
+// BESST_FUSED_FORM (A/B runs, tests): 0 = four waves per block with workgroup barriers, 1 = one wave per block
+static int fused_form() {
+    static const int form = [] { const char* e = getenv("BESST_FUSED_FORM"); return e ? atoi(e) : 1; }();
+    return form;
+}
+
+bool classify_can_group_runs(const ClassifyArgs& a) {
+    // BESST_LOOP_RUNS=0 (A/B runs, tests): the record loop writes keys and rg_group_kernel finds the runs
+    static const int knob = [] { const char* e = getenv("BESST_LOOP_RUNS"); return e ? atoi(e) : 1; }();
+    return knob != 0 && a.record_path == 1 && fused_form() == 1 && a.n > 0;
+}
+
 int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
-                         void* ws, size_t ws_bytes) {
+                         void* ws, size_t ws_bytes, bool group_runs) {
     if (a.n <= 0) return BESST_OK;
     BESST_REQUIRE(a.n < (int64_t)1 << 32, "classify: more than 2^32-1 records in one call");
     const ClsWorkspace w = carve(ws, a.n);
@@ -1815,13 +1966,17 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     // compacted and evaluated in LDS, chain by wave 0 - was built and measured on a C3 slice: correct, but 0.70 ms
     // against 0.16 + 0.42 ms for the two passes; at 135 VGPRs and a barrier-separated chain per 1024 records it is
     // latency bound at 3 waves per SIMD.  The split design below serves every library.)
+    BESST_REQUIRE(!group_runs || classify_can_group_runs(a), "classify: this record loop cannot group runs");
     if (a.record_path == 1) {
-        // BESST_FUSED_FORM (experiments): 0 = four waves per block with workgroup barriers, 1 = one wave per block
-        static const int form = [] { const char* e = getenv("BESST_FUSED_FORM"); return e ? atoi(e) : 1; }();
+        const int form = fused_form();
+        if (group_runs) BESST_HIP_TRY(hipMemsetAsync(w.run_status, 0, 4, s));
         ProfScope ps(s, form == 1 ? kProfFusedWave : kProfFused);
-        if (form == 1)
-            hipLaunchKernelGGL(fused_wave_kernel, dim3(nblocks), dim3(64), 0, s, a,
-                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
+        if (form == 1 && group_runs)
+            hipLaunchKernelGGL(fused_wave_kernel<true>, dim3(nblocks), dim3(64), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
+        else if (form == 1)
+            hipLaunchKernelGGL(fused_wave_kernel<false>, dim3(nblocks), dim3(64), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
         else
         hipLaunchKernelGGL(fused_kernel, dim3(nblocks), dim3(kFusedThreads), 0, s, a,
                            reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
@@ -1898,6 +2053,9 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
     BESST_REQUIRE(ws != nullptr && ws_bytes >= w.total, "classify: workspace too small");
     const uint32_t nblocks = (uint32_t)((n + kClsTile - 1) / kClsTile);
     auto* ctr = reinterpret_cast<unsigned long long*>(counters);
+    const bool grouped = pre.table && pre.in_record_loop == 3;   // the record loop left runs, not keys
+    BESST_REQUIRE(!grouped || (pre.segmented && !slice_info && !tails), "classify: grouped runs need the segmented hand-over");
+    uint32_t* run_offsets = grouped ? w.run_offsets : nullptr;
     // (Folding the stitch into compact_kernel - every workgroup working its own offset out from the summaries of the
     // blocks before it - was built three ways (scans, scan-free with a walk-back, batched plane loads) and always
     // landed at 15-17 us against 10 + 5 us for the two launches: 1221 workgroups re-reading the same 350 cache lines
@@ -1917,11 +2075,11 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
             hipLaunchKernelGGL(stitch_spans_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, span, detect_dup, carry,
                                w.agg, carry_in);
             hipLaunchKernelGGL(stitch_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
-                               w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span);
+                               w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span, run_offsets);
         } else {
             hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
                                w.skip, n_out, ctr, tails, rank, slice_info, (const StitchAgg*)nullptr,
-                               (const int32_t*)nullptr, span);
+                               (const int32_t*)nullptr, span, run_offsets);
         }
     }
     {
@@ -1931,12 +2089,13 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
             ProfScope ps(s, kProfFixup);
             hipLaunchKernelGGL(presort_fixup_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, w.seg_keys, w.skip, nblocks, pre,
                                segmented ? cls8 : nullptr, n_contigs, reinterpret_cast<unsigned long long*>(aligned),
-                               w.offsets, n_out, segmented ? w.chunk_first : nullptr);
+                               w.offsets, n_out, (segmented && !grouped) ? w.chunk_first : nullptr);
             in_compact.table = nullptr;
         }
         if (segmented) {                                     // the sort's first pass reads the segments: no dense copy
             presort->segmented = 1;
-            presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload, w.chunk_first};
+            presort->seg = SegSource{w.seg_keys, w.seg_payload, w.offsets, w.skip, nblocks, (uint32_t)kClsTile, payload, w.chunk_first,
+                                     grouped ? w.run_offsets : nullptr, w.summ.p, w.summ.stride, w.run_status};
         } else {
             if (presort) presort->segmented = 0;
             ProfScope ps(s, kProfCompact);
@@ -1963,16 +2122,19 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
             BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
             b.ps_table = pre.table; b.ps_rows = pre.rows; b.ps_shift = pre.shift; b.ps_base = pre.key_base;
         }
-        // (a stage 2 that groups runs never reads the histograms: the loop hands its segments over and counts nothing)
+        // (a stage 2 that groups runs never reads the histograms: the loop hands its segments over and counts nothing -
+        // and where it can, it finds the runs itself)
     }
-    int rc = launch_classify_scan(s, b, aligned, counters, ws, ws_bytes);
-    if (rc) return rc;
     static const int seg_knob = [] { const char* e = getenv("BESST_SEGMENTED"); return e ? atoi(e) : 1; }();
     pre.segmented = pre.segmented && seg_knob;
+    const bool group_runs = pre.table && pre.in_record_loop && !pre.count && pre.segmented && classify_can_group_runs(a);
+    int rc = launch_classify_scan(s, b, aligned, counters, ws, ws_bytes, group_runs);
+    if (rc) return rc;
+    if (pre.in_record_loop) pre.in_record_loop = pre.count ? 1 : (group_runs ? 3 : 2);
     rc = launch_classify_emit(s, a.n, a.detect_dup, carry, keys, payload, n_out, counters, ws, ws_bytes, a.cls8,
                               a.n_contigs, aligned, nullptr, 0, nullptr, pre.table ? &pre : nullptr);
     if (presort) {
-        presort->in_record_loop = pre.in_record_loop ? (pre.count ? 1 : 2) : 0;
+        presort->in_record_loop = pre.in_record_loop;
         presort->segmented = pre.table ? pre.segmented : 0;
         presort->seg = pre.seg;
     }

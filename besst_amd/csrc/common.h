@@ -72,7 +72,8 @@ enum ProfSlot {
     kProfStream = 0, kProfFused, kProfFusedWave, kProfOrdered, kProfStitch, kProfFixup, kProfCompact,
     kProfRadixHist, kProfRadixScan, kProfRadixScatter, kProfBucketSort, kProfBucketReduce, kProfRowHeads, kProfRowScan, kProfRowReduce,
     kProfOsHist, kProfOsOffsets, kProfOsScatter, kProfOsBucket, kProfOsBucketRows, kProfOsReduce, kProfOsFixup,
-    kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfMsdPartition, kProfSlots
+    kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfMsdPartition,
+    kProfRunList, kProfRunPlace, kProfSlots
 };
 static_assert(kProfSlots <= 32, "besst_prof_enable takes a 32-bit slot mask");
 struct ProfScope {
@@ -133,7 +134,9 @@ enum SummPlane {
     kSumHeadSlot,     // local slot of the head's tuple
     kSumCtr0,         // the block's share of besst_counters fields 0..5 and 7 (summed by stitch: thousands of
                       // workgroups hitting the same seven device-scope atomics were the slowest part of the kernel)
-    kSumPlanes = kSumCtr0 + 7
+    kSumChunks = kSumCtr0 + 7,   // record loop that groups runs while it emits (RunLayout): chunks it closed ...
+    kSumRuns,         // ... and runs in them, + 1 for the head's provisional tuple (a run of its own); else 0
+    kSumPlanes
 };
 struct SummView {
     uint32_t* p;
@@ -261,7 +264,43 @@ struct SegSource {
     uint32_t nblocks, tile;
     uint64_t* payload_out;
     const uint32_t* chunk_first;     // per chunk of kRunChunk dense positions: the block its first position lies in (or null)
+    // the record loop grouped the runs itself (RunLayout below; null: it wrote keys): where each block's runs begin in the
+    // stream-ordered run list (stitch), the block summaries, and a word that is non-zero when a block's tables overflowed
+    const uint32_t* run_offsets;
+    const uint32_t* summ;
+    uint32_t summ_stride;
+    const uint32_t* run_status;
 };
+
+// Runs of equal keys found by the record loop itself (fused_wave_kernel<true>): the wave that emits a block's tuples
+// keeps the distinct keys of the last few hundred of them in a small hash table in LDS - the open CHUNK's runs, a run's
+// name is its slot -, writes that name in one byte next to every tuple's payload, and no keys: nothing for a grouping
+// pass to read back.  A chunk is closed (its table written out and cleared) in front of an evaluation round that would
+// take it beyond kRlChunkTuples tuples or that finds kRlCloseRuns runs open - so a table never fills: at most
+// kRlCloseRuns - 1 + 64 < kRlSlots keys -; the block's first reaching record (the one the stitch may still drop) is in
+// no run (byte kRlNoRun) and becomes a run of its own if it stays.  What the wave leaves lies in the block's KEY segment
+// (kClsTile x 8 bytes, unused in this form):
+//   [kRlRid, + kClsTile)                   run byte per tuple slot
+//   [kRlHeadKey, + 8)                      key of the head's tuple
+//   [kRlHdr, + 8 kRlMaxChunks)             per chunk: first slot | tuples << 16 | runs << 32
+//   [kRlKeys, + 8 kRlSlots kRlMaxChunks)   per chunk: the table's keys (only the slots in use are written)
+//   [kRlOrd, + kRlSlots kRlMaxChunks)      per chunk, written by rl_list_kernel: the table slots of its runs in list order
+// More than kRlMaxChunks chunks in a block (keys that do not cluster: every round closes a chunk) set *run_status: stage 2
+// then reports BESST_ROWS_RUN_OVERFLOW as it does for its own run buffers, and the pass is repeated tuple by tuple.
+constexpr int kRlChunkTuples = 512;
+constexpr int kRlSlots = 128;
+constexpr int kRlCloseRuns = 64;
+constexpr int kRlMaxChunks = 96;
+constexpr uint32_t kRlNoRun = 255u;
+constexpr unsigned long long kRlEmpty = ~0ull;           // (a key is below 2^59)
+constexpr size_t kRlRid = 0;
+constexpr size_t kRlHeadKey = (size_t)kClsTile;
+constexpr size_t kRlHdr = kRlHeadKey + 64;
+constexpr size_t kRlKeys = kRlHdr + 8 * (size_t)kRlMaxChunks;
+constexpr size_t kRlOrd = kRlKeys + 8 * (size_t)kRlSlots * kRlMaxChunks;
+static_assert(kRlOrd + (size_t)kRlSlots * kRlMaxChunks <= (size_t)kClsTile * 8, "the run tables live in the block's key segment");
+static_assert(kClsTile <= 65536 && kRlChunkTuples < 65536 && kRlSlots <= (int)kRlNoRun, "slots, counts and run names are packed");
+static_assert(kRlCloseRuns - 1 + 64 < kRlSlots, "a chunk's table must never fill");
 
 struct PresortSpec {
     uint32_t* table;
@@ -270,7 +309,7 @@ struct PresortSpec {
     uint32_t cap;
     int in_record_loop;      // the fused record loop counts while it emits (the head tuples the stitch drops are taken
                              // out again); else compact_kernel counts.  Out: 2 = the loop handed its segments over
-                             // WITHOUT counting (`count` was 0)
+                             // WITHOUT counting (`count` was 0), 3 = it grouped the runs itself (seg.run_offsets)
     int count;               // in: stage 2 will want the digit histograms (0: it groups runs and never reads them)
     int segmented;           // in: the sort can read block segments; out: it has to (compact_kernel did not run, `seg`)
     SegSource seg;
@@ -283,7 +322,9 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
                     void* ws, size_t ws_bytes, PresortSpec* presort = nullptr);
 // the same split in three phases for the multi-GPU path (the duplicate chain crosses rank boundaries)
 int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
-                         void* ws, size_t ws_bytes);
+                         void* ws, size_t ws_bytes, bool group_runs = false);
+// true: launch_classify_scan(..., group_runs = true) on these arguments leaves runs (RunLayout) instead of keys
+bool classify_can_group_runs(const ClassifyArgs& a);
 int launch_candidate_density(hipStream_t s, int64_t n, const int32_t* tid, const int32_t* mtid, int64_t sample_records,
                              unsigned long long* counts);
 int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes);

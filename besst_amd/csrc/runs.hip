@@ -373,10 +373,13 @@ __global__ __launch_bounds__(kRsThreads) void rg_tile_sums_kernel(const int32_t*
     }
 }
 
+// (dst_of: also by the run's place in the stream-ordered list, for a consumer that walks the runs in that order)
 __global__ __launch_bounds__(kRsThreads) void rg_dst_kernel(const int32_t* __restrict__ run_len,
                                                            const uint32_t* __restrict__ n_runs,
                                                            const uint32_t* __restrict__ tile_sum,
-                                                           uint32_t* __restrict__ run_dst) {
+                                                           uint32_t* __restrict__ run_dst,
+                                                           const int32_t* __restrict__ run_at,
+                                                           uint32_t* __restrict__ dst_of) {
     __shared__ uint32_t s_w[kRsThreads / 64], s_b[kRsThreads / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t n = *n_runs;
@@ -412,7 +415,10 @@ __global__ __launch_bounds__(kRsThreads) void rg_dst_kernel(const int32_t* __res
 #pragma unroll
     for (int q = 0; q < kRsItems; ++q) {
         const uint32_t j = j0 + (uint32_t)(t * kRsItems + q);
-        if (j < n) run_dst[j] = off;
+        if (j < n) {
+            run_dst[j] = off;
+            if (dst_of) dst_of[(uint32_t)run_at[j]] = off;
+        }
         off += len[q];
     }
 }
@@ -452,6 +458,43 @@ __global__ __launch_bounds__(256) void rg_rows_kernel(const uint32_t* __restrict
     row_sum[r] = s;
     row_sum_sq[r] = q;
     row_first[r] = first;
+    row_offset[r] = run_dst[j0];
+}
+
+// 5'. the same over the run columns of the record loop's runs (their sums come from rl_place_kernel)
+__global__ __launch_bounds__(256) void rl_rows_kernel(const uint32_t* __restrict__ status, uint32_t* __restrict__ n_rows,
+                                                      const uint32_t* __restrict__ r_runs, const uint32_t* __restrict__ r_first_run,
+                                                      const int32_t* __restrict__ run_len, const int32_t* __restrict__ run_at,
+                                                      const uint32_t* __restrict__ run_dst, const uint32_t* __restrict__ c_first,
+                                                      const uint32_t* __restrict__ c_mask,
+                                                      const unsigned long long* __restrict__ c_sum,
+                                                      const unsigned long long* __restrict__ c_sq, uint32_t* __restrict__ row_mask,
+                                                      uint32_t* __restrict__ row_n, unsigned long long* __restrict__ row_sum,
+                                                      unsigned long long* __restrict__ row_sum_sq,
+                                                      uint32_t* __restrict__ row_first, uint32_t* __restrict__ row_offset) {
+    const uint32_t st_err = status[0], st_over = status[1];
+    if (st_err | st_over) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_rows = st_err ? BESST_ROWS_SORT_FAILED : BESST_ROWS_RUN_OVERFLOW;
+        return;
+    }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nr = *n_rows;
+    if (nr >= BESST_ROWS_RUN_OVERFLOW || r >= nr) return;
+    const uint32_t j0 = r_first_run[r], c = r_runs[r];
+    uint32_t nn = 0;
+    unsigned long long s = 0, q = 0;
+    for (uint32_t j = j0; j < j0 + c; ++j) {
+        const uint32_t at = (uint32_t)run_at[j];
+        nn += (uint32_t)run_len[j];
+        s += c_sum[at];
+        q += c_sq[at];
+    }
+    const uint32_t at0 = (uint32_t)run_at[j0];
+    row_mask[r] = c_mask[at0];
+    row_n[r] = nn;
+    row_sum[r] = s;
+    row_sum_sq[r] = q;
+    row_first[r] = c_first[at0];
     row_offset[r] = run_dst[j0];
 }
 
@@ -510,6 +553,253 @@ __global__ __launch_bounds__(256) void rg_copy_kernel(const uint32_t* __restrict
             if (p < total) {
                 obs_lo[to[u]] = (int32_t)(uint32_t)v[u];
                 obs_hi[to[u]] = (int32_t)((uint32_t)(v[u] >> 32) & 0x3fffffffu);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The runs as the record loop leaves them (fused_wave_kernel<true>, RunLayout in common.h): steps 1 and 2 shrink to a
+// listing pass over the blocks' run tables, and step 6 walks the blocks' chunks instead of the sorted runs.
+// ---------------------------------------------------------------------------------------------------
+struct RunCols {                                         // per run, by its place in the stream-ordered list
+    uint32_t* first;                                     // stream index of its first tuple
+    uint32_t* mask;                                      // graph mask of that tuple
+    unsigned long long* sum;                             // sums of its observations (place kernel)
+    unsigned long long* sq;
+    uint32_t* dst;                                       // where its observations go (rg_dst_kernel)
+};
+
+__device__ __forceinline__ uint32_t rl_summ(const SegSource& seg, int plane, uint32_t b) {
+    return seg.summ[(size_t)plane * seg.summ_stride + b];
+}
+
+// What a wave of the two kernels below knows about its block after ONE memory round trip: the summary words, the
+// stitch's offsets, and the headers of all its chunks (two per lane, loaded before the chunk count is known - the region is
+// there whatever it holds) with the exclusive scan of their run counts: chunk c's runs begin at run0 + ex(c) in the list.
+struct RlBlock {
+    uint32_t nch, off, skip, hslot, run0, head_idx;
+    bool head_kept;
+    uint64_t hdr[2];
+    uint32_t ex[2], total;
+    char* region;
+    const uint64_t* pl_p;
+    __device__ __forceinline__ uint64_t header(uint32_t c) const {
+        const int l = (int)(c & 63u);
+        const uint64_t h = c < 64u ? hdr[0] : hdr[1];
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(h >> 32), l) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)h, l);
+    }
+    __device__ __forceinline__ uint32_t first_run(uint32_t c) const {
+        return run0 + (uint32_t)__builtin_amdgcn_readlane((int)(c < 64u ? ex[0] : ex[1]), (int)(c & 63u));
+    }
+};
+__device__ __forceinline__ RlBlock rl_block(const SegSource& seg, uint32_t b, int lane) {
+    RlBlock k;
+    k.region = reinterpret_cast<char*>(const_cast<uint64_t*>(seg.seg_keys) + (size_t)b * seg.tile);
+    k.pl_p = seg.seg_payload + (size_t)b * seg.tile;
+    const uint64_t* hp = reinterpret_cast<const uint64_t*>(k.region + kRlHdr);
+    const uint64_t h0 = hp[lane], h1 = (uint32_t)(lane + 64) < (uint32_t)kRlMaxChunks ? hp[lane + 64] : 0ull;
+    const uint32_t nch = rl_summ(seg, kSumChunks, b), hinfo = rl_summ(seg, kSumHeadInfo, b);
+    k.hslot = rl_summ(seg, kSumHeadSlot, b);
+    k.off = seg.offsets[b];
+    k.skip = seg.skip[b];
+    k.head_idx = seg.run_offsets[b];
+    k.nch = nch < (uint32_t)kRlMaxChunks ? nch : (uint32_t)kRlMaxChunks;
+    k.head_kept = (hinfo & 8u) && k.hslot != kRgNoSlot && k.skip == kRgNoSlot;
+    k.run0 = k.head_idx + (k.head_kept ? 1u : 0u);
+    k.hdr[0] = (uint32_t)lane < k.nch ? h0 : 0ull;
+    k.hdr[1] = (uint32_t)(lane + 64) < k.nch ? h1 : 0ull;
+    uint32_t before = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t n = (uint32_t)(k.hdr[q] >> 32) & 0xffffu;
+        uint32_t x = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)x, d, 64);
+            if (lane >= d) x += v;
+        }
+        k.ex[q] = before + x - n;
+        before += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    }
+    k.total = before;
+    return k;
+}
+constexpr int kRlWaves = 4;                              // waves per block: wave w takes chunks w, w + 4, ...
+
+// 1'. the run list.  The record loop named every tuple's run (its slot in the chunk's key table) but counted nothing: a
+// wave reads a chunk's run bytes - 1 byte per tuple, eight per lane - and peels the distinct names off in order of first
+// occurrence (one compare + ballot per round of 64 and name: count and first slot come out as wave-uniform values;
+// per-slot LDS atomics instead took 0.26 ms on full C3 - hundreds of lanes on a handful of counters), then writes
+// (key, count | list index << 32) pairs for the sort, first stream index and mask per run, and the chunk's slots in list
+// order for rl_place_kernel.  Wave 0 of a block also lists the head's run of one (if the stitch kept the head); wave 0 of
+// the last block writes the run count - or the overflow word when the list does not fit or a block ran out of chunks.
+__global__ __launch_bounds__(kRlWaves * 64) void rl_list_kernel(SegSource seg, uint32_t run_cap, uint64_t* __restrict__ run_keys,
+                                                               uint64_t* __restrict__ run_payload, RunCols rc,
+                                                               uint32_t* __restrict__ n_runs, uint32_t* __restrict__ status) {
+    constexpr int R = kRlChunkTuples / 64, Q = kRlSlots / 64;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x;
+    const RlBlock k = rl_block(seg, b, lane);
+    const uint8_t* rid_p = reinterpret_cast<const uint8_t*>(k.region + kRlRid);
+    if (w == 0u) {                                           // uniform
+        if (k.head_kept && lane == 0 && k.head_idx < run_cap) {
+            run_keys[k.head_idx] = *reinterpret_cast<const uint64_t*>(k.region + kRlHeadKey);
+            run_payload[k.head_idx] = 1ull | ((uint64_t)k.head_idx << 32);
+            rc.first[k.head_idx] = k.off + k.hslot;
+            rc.mask[k.head_idx] = (uint32_t)(k.pl_p[k.hslot] >> 62);
+        }
+        if (b == seg.nblocks - 1u && lane == 0) {
+            const uint32_t all = k.run0 + k.total;
+            if (all > run_cap || *seg.run_status != 0u) {
+                status[1] = 1u;
+                status[2] = all;
+                *n_runs = 0u;
+            } else {
+                *n_runs = all;
+            }
+        }
+    }
+    for (uint32_t c = w; c < k.nch; c += (uint32_t)kRlWaves) {   // uniform
+        const uint64_t hdr = k.header(c);
+        const uint32_t start = (uint32_t)hdr & 0xffffu, cnt = (uint32_t)(hdr >> 16) & 0xffffu;
+        const uint32_t idx = k.first_run(c);
+        uint32_t rid[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t)(r * 64 + lane);
+            rid[r] = i < cnt ? (uint32_t)rid_p[start + i] : kRlNoRun;
+        }
+        uint32_t K = 0;
+        uint32_t my_slot[Q], my_n[Q], my_first[Q];           // lane l: runs l and 64 + l of the chunk, in order of first occurrence
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { my_slot[q] = 0; my_n[q] = 0; my_first[q] = 0; }
+#pragma unroll
+        for (int r0 = 0; r0 < R; ++r0) {
+            unsigned long long rest = __ballot(rid[r0] < (uint32_t)kRlSlots);
+            while (rest != 0ull) {                           // uniform
+                const int src = __ffsll((long long)rest) - 1;
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)rid[r0], src);
+                uint32_t n = 0;
+#pragma unroll
+                for (int r = r0; r < R; ++r) {
+                    const bool hit = rid[r] == sl;
+                    const unsigned long long mm = __ballot(hit);
+                    n += (uint32_t)__popcll(mm);
+                    if (hit) rid[r] = kRlNoRun;              // counted
+                    if (r == r0) rest &= ~mm;
+                }
+                const uint32_t first = (uint32_t)(r0 * 64 + src);
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if ((uint32_t)(q * 64 + lane) == K) { my_slot[q] = sl; my_n[q] = n; my_first[q] = first; }
+                ++K;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t kk = (uint32_t)(q * 64 + lane);
+            if (kk < K) {
+                const uint32_t j = idx + kk, fs = start + my_first[q];
+                reinterpret_cast<uint8_t*>(k.region + kRlOrd)[c * (uint32_t)kRlSlots + kk] = (uint8_t)my_slot[q];
+                if (j < run_cap) {
+                    run_keys[j] = reinterpret_cast<const uint64_t*>(k.region + kRlKeys)[c * (uint32_t)kRlSlots + my_slot[q]];
+                    run_payload[j] = (uint64_t)my_n[q] | ((uint64_t)j << 32);
+                    rc.first[j] = k.off + fs - (fs > k.skip ? 1u : 0u);
+                    rc.mask[j] = (uint32_t)(k.pl_p[fs] >> 62);
+                }
+            }
+        }
+    }
+}
+
+// 6'. the observations to their places.  A wave takes a chunk: the tuples' run bytes and payload (eight words per lane, as
+// rg_group_kernel held them), per run of the chunk one compare + ballot + mbcnt per round of 64 - rank inside the run -,
+// the observations stored at the run's sorted place + rank, the run's two sums left for the row kernel.  The payload is
+// read ONCE, where the record loop wrote it, and written once, where the table wants it.
+__global__ __launch_bounds__(kRlWaves * 64, 6) void rl_place_kernel(SegSource seg, const uint32_t* __restrict__ status,
+                                                                   const uint32_t* __restrict__ n_rows, RunCols rc,
+                                                                   int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi) {
+    constexpr int R = kRlChunkTuples / 64, Q = kRlSlots / 64;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = blockIdx.x;
+    if ((status[0] | status[1]) != 0u || *n_rows >= BESST_ROWS_RUN_OVERFLOW) return;   // uniform
+    const RlBlock k = rl_block(seg, b, lane);
+    const uint8_t* rid_p = reinterpret_cast<const uint8_t*>(k.region + kRlRid);
+    for (uint32_t c = w; c < k.nch; c += (uint32_t)kRlWaves) {   // uniform
+        const uint64_t hdr = k.header(c);
+        const uint32_t start = (uint32_t)hdr & 0xffffu, cnt = (uint32_t)(hdr >> 16) & 0xffffu, K = (uint32_t)(hdr >> 32) & 0xffffu;
+        const uint32_t idx = k.first_run(c);
+        uint32_t my_dst[Q], my_slot[Q];                      // lane l: runs l and 64 + l of the chunk (list order)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t kk = (uint32_t)(q * 64 + lane);
+            my_dst[q] = kk < K ? rc.dst[idx + kk] : 0u;
+            my_slot[q] = kk < K ? (uint32_t)reinterpret_cast<const uint8_t*>(k.region + kRlOrd)[c * (uint32_t)kRlSlots + kk] : kRlNoRun;
+        }
+        uint32_t rid[R], to[R];
+        uint64_t pl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t)(r * 64 + lane);
+            rid[r] = kRlNoRun + 1u;                          // padding: matches nothing
+            pl[r] = 0ull;
+            to[r] = 0u;
+            if ((uint32_t)(r * 64) < cnt) {                  // uniform
+                if (i < cnt) {
+                    rid[r] = rid_p[start + i];
+                    pl[r] = k.pl_p[start + i];
+                }
+            }
+        }
+        // the block's head lies in this chunk (uniform): its place comes with the chunk's other loads
+        const bool has_head = k.head_kept && k.hslot >= start && k.hslot < start + cnt;
+        const uint32_t head_dst = has_head ? rc.dst[k.head_idx] : 0u;
+        unsigned long long my_s[Q], my_q[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            my_s[q] = 0; my_q[q] = 0;
+            const uint32_t kq = K > (uint32_t)(q * 64) ? (K - (uint32_t)(q * 64) < 64u ? K - (uint32_t)(q * 64) : 64u) : 0u;
+            for (uint32_t kk = 0; kk < kq; ++kk) {           // uniform
+                uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)my_dst[q], (int)kk);
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)my_slot[q], (int)kk);
+                unsigned long long s2 = 0, q2 = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool hit = rid[r] == sl;
+                    const unsigned long long mm = __ballot(hit);
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, run));
+                    const uint32_t ol = hit ? (uint32_t)pl[r] : 0u;
+                    const uint32_t oh = (hit ? (uint32_t)(pl[r] >> 32) : 0u) & 0x3fffffffu;
+                    const unsigned long long o = (unsigned long long)(ol + oh);
+                    s2 += o;
+                    q2 += o * o;
+                    if (hit) to[r] = rk;
+                    run += (uint32_t)__popcll(mm);
+                }
+                s2 = rg_wave_sum64(s2);
+                q2 = rg_wave_sum64(q2);
+                if ((uint32_t)lane == kk) { my_s[q] = s2; my_q[q] = q2; }
+            }
+            if ((uint32_t)lane < kq) {
+                rc.sum[idx + (uint32_t)(q * 64 + lane)] = my_s[q];
+                rc.sq[idx + (uint32_t)(q * 64 + lane)] = my_q[q];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (rid[r] < kRlNoRun) {
+                obs_lo[to[r]] = (int32_t)(uint32_t)pl[r];
+                obs_hi[to[r]] = (int32_t)((uint32_t)(pl[r] >> 32) & 0x3fffffffu);
+            } else if (rid[r] == kRlNoRun && has_head) {     // the block's head: a run of one
+                const unsigned long long o = (unsigned long long)rg_obs(pl[r]);
+                obs_lo[head_dst] = (int32_t)(uint32_t)pl[r];
+                obs_hi[head_dst] = (int32_t)((uint32_t)(pl[r] >> 32) & 0x3fffffffu);
+                rc.sum[k.head_idx] = o;
+                rc.sq[k.head_idx] = o * o;
             }
         }
     }
@@ -597,6 +887,50 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
     const uint32_t nchunks = (uint32_t)((cap + kRgChunk - 1) / kRgChunk);
     const uint32_t grid1 = (nchunks + kRgWaves - 1) / kRgWaves;
     BESST_HIP_TRY(hipMemsetAsync(w.status, 0, 64, s));
+    if (seg && seg->run_offsets) {
+        // the record loop grouped the runs (RunLayout): list them, sort the list, place the observations block by block
+        BESST_REQUIRE(!first_map && seg->summ && seg->run_status, "reduce: incomplete description of the record loop's runs");
+        RunCols rc;                                          // (in the row staging of the chained-scan form: 40 bytes per tuple slot)
+        {
+            char* p = static_cast<char*>(staged_rows);
+            const size_t n = (size_t)w.run_cap;
+            rc.sum = reinterpret_cast<unsigned long long*>(p); p += n * 8;
+            rc.sq = reinterpret_cast<unsigned long long*>(p); p += n * 8;
+            rc.first = reinterpret_cast<uint32_t*>(p); p += n * 4;
+            rc.mask = reinterpret_cast<uint32_t*>(p); p += n * 4;
+            rc.dst = reinterpret_cast<uint32_t*>(p);
+        }
+        const uint32_t bgrid = seg->nblocks;                // one workgroup per block, a wave per chunk
+        {
+            ProfScope ps(s, kProfRunList);
+            hipLaunchKernelGGL(rl_list_kernel, dim3(bgrid), dim3(kRlWaves * 64), 0, s, *seg, w.run_cap, w.run_keys, w.run_payload, rc,
+                               w.n_runs, w.status);
+        }
+        const int rcode = launch_sort_reduce(s, (int64_t)w.run_cap, w.n_runs, key_bits, w.run_keys, w.run_payload, row_key, w.r_mask,
+                                             w.r_runs, w.r_sum, w.r_sq, w.r_first, w.r_first_run, w.run_len, w.run_at, n_rows,
+                                             w.nested, w.nested_bytes, nullptr, key_base, false, nullptr, BESST_REDUCE_NO_RUNS);
+        if (rcode) return rcode;
+        const uint32_t tiles = (w.run_cap + kRsTile - 1) / kRsTile;
+        {
+            ProfScope ps(s, kProfRunScan);
+            hipLaunchKernelGGL(rg_tile_sums_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum);
+            hipLaunchKernelGGL(rg_dst_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum, w.run_dst,
+                               w.run_at, rc.dst);
+        }
+        {
+            ProfScope ps(s, kProfRunPlace);
+            hipLaunchKernelGGL(rl_place_kernel, dim3(bgrid), dim3(kRlWaves * 64), 0, s, *seg, w.status, n_rows, rc, obs_lo, obs_hi);
+        }
+        {
+            ProfScope ps(s, kProfRunCopy);
+            hipLaunchKernelGGL(rl_rows_kernel, dim3((w.run_cap + 255) / 256), dim3(256), 0, s, w.status, n_rows, w.r_runs,
+                               w.r_first_run, w.run_len, w.run_at, w.run_dst, rc.first, rc.mask, rc.sum, rc.sq, row_mask, row_n,
+                               reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),
+                               row_first, row_offset);
+        }
+        BESST_HIP_TRY(hipGetLastError());
+        return BESST_OK;
+    }
     {
         ProfScope ps(s, kProfRunGroup);
         if (seg)
@@ -621,7 +955,8 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         ProfScope ps(s, kProfRunScan);
         const uint32_t tiles = (w.run_cap + kRsTile - 1) / kRsTile;
         hipLaunchKernelGGL(rg_tile_sums_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum);
-        hipLaunchKernelGGL(rg_dst_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum, w.run_dst);
+        hipLaunchKernelGGL(rg_dst_kernel, dim3(tiles), dim3(kRsThreads), 0, s, w.run_len, w.n_runs, w.tile_sum, w.run_dst,
+                           (const int32_t*)nullptr, (uint32_t*)nullptr);
         hipLaunchKernelGGL(rg_rows_kernel, dim3((w.run_cap + 255) / 256), dim3(256), 0, s, w.status, n_rows, w.r_runs,
                            w.r_first_run, w.run_at, w.run_dst, staged, row_mask, row_n,
                            reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),

@@ -210,6 +210,9 @@ class DeviceGraphBuilder(object):
         if not spec[1]:
             return None
         spec[0].segmented = 1                               # asked for anew on every pass (classify answers in place)
+        # the record loop has to know which form of stage 2 follows (with BESST_REDUCE_NO_RUNS it counts the sort's
+        # digits and writes keys; without, it groups the runs itself)
+        spec[0].flags = self.sort_flags
         return C.byref(spec[0])
 
     def reduce(self, keys=None, payload=None, n_tuples_ptr=None, capacity=None, first_map=None):
@@ -228,7 +231,7 @@ class DeviceGraphBuilder(object):
 
                 def again():
                     spec.flags = self.sort_flags
-                    if spec.in_record_loop == 2 and (spec.flags & REDUCE_NO_RUNS):
+                    if spec.in_record_loop >= 2 and (spec.flags & REDUCE_NO_RUNS):
                         # the record loop handed its segments over without the sort's digit counts (stage 2 was going to
                         # group runs): the pass is repeated from its start, counting this time
                         rec = self._last_rec() if self._last_rec is not None else None

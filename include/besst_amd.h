@@ -391,8 +391,11 @@ typedef struct besst_presort {
      * fields) when it did NOT write the dense keys / payload, and besst_dev_reduce_presorted then reads the segments and
      * writes the dense payload (the `payload` argument of both calls) itself.  in_record_loop (out): 1 = the record loop
      * counted the digits while it emitted; 2 = it handed its segments over without counting, because `flags` did not carry
-     * BESST_REDUCE_NO_RUNS and stage 2 then groups runs and reads no histogram - a repeat of besst_dev_reduce_presorted
-     * WITH that flag (after BESST_ROWS_RUN_OVERFLOW) needs a repeat of the classify call with it first. */
+     * BESST_REDUCE_NO_RUNS and stage 2 then groups runs and reads no histogram; 3 = as 2, and the record loop grouped the
+     * runs of equal keys itself while it emitted: the key segments then hold run tables and a run byte per tuple instead
+     * of keys (seg_run_* below), and stage 2 only sorts the list of runs and places the observations.  After 2 or 3 a
+     * repeat of besst_dev_reduce_presorted WITH that flag (after BESST_ROWS_RUN_OVERFLOW) needs a repeat of the classify
+     * call with it first. */
     int32_t segmented;
     int32_t in_record_loop;
     const uint64_t* seg_keys;
@@ -402,7 +405,13 @@ typedef struct besst_presort {
     uint32_t seg_blocks;
     uint32_t seg_tile;
     uint64_t* payload_out;
-    const uint32_t* seg_chunk_first; /* per 1024 positions of the ordered stream: the block the first of them lies in */
+    const uint32_t* seg_chunk_first; /* per 512 positions of the ordered stream: the block the first of them lies in */
+    /* in_record_loop == 3 only (else NULL / 0): per block the place of its first run in the stream-ordered run list, the
+     * record loop's block summaries (planes of seg_summ_stride words) and the word that says a block's run tables overflowed */
+    const uint32_t* seg_run_offsets;
+    const uint32_t* seg_summ;
+    uint32_t seg_summ_stride;
+    const uint32_t* seg_run_status;
 } besst_presort;
 int besst_dev_reduce_presort(int64_t capacity, int32_t key_bits, uint64_t key_base, void* workspace,
                              size_t workspace_bytes, besst_presort* h_out);
