@@ -964,20 +964,36 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     // ---- kRuns: the open chunk (uniform: its first slot, its tuples, its runs; s_rk: the keys of its runs, a hash table
     // whose slot number IS the run's name inside the chunk) and the block's totals
     __shared__ unsigned long long s_rk[kRuns ? kRlSlots : 1];
+    __shared__ uint32_t s_rn[kRuns ? kRlSlots : 1], s_rf[kRuns ? kRlSlots : 1];   // tuples and first slot of each run
     char* const rl_region = reinterpret_cast<char*>(seg_keys + block_base);
     int rl_start = 0, rl_n = 0, rl_k = 0, rl_chunks = 0, rl_runs = 0, rl_over = 0;
     if constexpr (kRuns) {
 #pragma unroll
-        for (int q = 0; q < kRlSlots / 64; ++q) s_rk[q * 64 + lane] = kRlEmpty;
+        for (int q = 0; q < kRlSlots / 64; ++q) {
+            s_rk[q * 64 + lane] = kRlEmpty;
+            s_rn[q * 64 + lane] = 0u;
+            s_rf[q * 64 + lane] = 0xffffu;
+        }
     }
     auto close_chunk = [&]() {
         if (rl_n == 0) return;                               // uniform
+        // the slots in use, in slot order, as a dense list of rl_k entries: key, tuples | first slot << 16, slot
+        int before = 0;
 #pragma unroll
         for (int q = 0; q < kRlSlots / 64; ++q) {
             const unsigned long long k = s_rk[q * 64 + lane];
-            if (k != kRlEmpty && rl_chunks < kRlMaxChunks)
-                reinterpret_cast<unsigned long long*>(rl_region + kRlKeys)[rl_chunks * kRlSlots + q * 64 + lane] = k;
+            const uint32_t meta = s_rn[q * 64 + lane] | (s_rf[q * 64 + lane] << 16);
+            const unsigned long long used = __ballot(k != kRlEmpty);
+            if (k != kRlEmpty && rl_chunks < kRlMaxChunks) {
+                const int e = rl_chunks * kRlSlots + before + below_cnt(used);
+                reinterpret_cast<unsigned long long*>(rl_region + kRlKeys)[e] = k;
+                reinterpret_cast<uint32_t*>(rl_region + kRlMeta)[e] = meta;
+                reinterpret_cast<uint8_t*>(rl_region + kRlOrd)[e] = (uint8_t)(q * 64 + lane);
+            }
+            before += __popcll(used);
             s_rk[q * 64 + lane] = kRlEmpty;
+            s_rn[q * 64 + lane] = 0u;
+            s_rf[q * 64 + lane] = 0xffffu;
         }
         if (rl_chunks < kRlMaxChunks) {
             if (lane == 0)
@@ -1107,7 +1123,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                 // one - first lane's key, compare + ballot against the round and against the open runs - cost 35
                 // instructions per distinct key and round, all on the wave's critical path: +0.27 ms on full C3.)
                 uint32_t my_run = kRlNoRun;                  // (the block's head: in no run, the stitch may still drop it)
-                bool pending = emit && !is_head, fresh = false;
+                bool pending = emit && !is_head, fresh = false, tried = false;
                 uint32_t h = (e.n_max + 5u * e.n_min + (fishy ? 64u : 0u)) & (uint32_t)(kRlSlots - 1);
                 while (__ballot(pending) != 0ull) {          // one turn unless keys collide
                     if (pending) {
@@ -1117,12 +1133,21 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
                             const unsigned long long old = atomicCAS(&s_rk[h], kRlEmpty, (unsigned long long)key);
                             fresh = old == kRlEmpty;
                             hit = fresh || old == key;
+                            tried = true;
                         }
                         if (hit) { my_run = h; pending = false; }
                         else h = (h + 1u) & (uint32_t)(kRlSlots - 1);
                     }
                 }
                 rl_k += __popcll(__ballot(fresh));
+                // the run's size and first slot for the listing pass (LDS atomics whose result nobody waits for: +0.04 ms on
+                // full C3 - what the listing pass saves by not reading the run bytes back -; lanes that share a key walk
+                // the same slots in step, so those that found their key's slot empty are exactly the tuples of a run that
+                // begins in this round)
+                if (my_run != kRlNoRun) {
+                    atomicAdd(&s_rn[my_run], 1u);
+                    if (tried) atomicMin(&s_rf[my_run], (uint32_t)(slot - rl_start));
+                }
                 if (emit) {
                     seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
                     reinterpret_cast<uint8_t*>(rl_region + kRlRid)[slot] = (uint8_t)my_run;

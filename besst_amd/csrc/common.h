@@ -283,21 +283,23 @@ struct SegSource {
 //   [kRlRid, + kClsTile)                   run byte per tuple slot
 //   [kRlHeadKey, + 8)                      key of the head's tuple
 //   [kRlHdr, + 8 kRlMaxChunks)             per chunk: first slot | tuples << 16 | runs << 32
-//   [kRlKeys, + 8 kRlSlots kRlMaxChunks)   per chunk: the table's keys (only the slots in use are written)
-//   [kRlOrd, + kRlSlots kRlMaxChunks)      per chunk, written by rl_list_kernel: the table slots of its runs in list order
+//   [kRlKeys, + 8 kRlSlots kRlMaxChunks)   per chunk: the keys of its runs, dense (the slots in use, in slot order) ...
+//   [kRlMeta, + 4 kRlSlots kRlMaxChunks)   ... their tuples | first slot (relative to the chunk's) << 16 ...
+//   [kRlOrd, + kRlSlots kRlMaxChunks)      ... and their slots, i.e. the names the run bytes use
 // More than kRlMaxChunks chunks in a block (keys that do not cluster: every round closes a chunk) set *run_status: stage 2
 // then reports BESST_ROWS_RUN_OVERFLOW as it does for its own run buffers, and the pass is repeated tuple by tuple.
 constexpr int kRlChunkTuples = 512;
 constexpr int kRlSlots = 128;
 constexpr int kRlCloseRuns = 64;
-constexpr int kRlMaxChunks = 96;
+constexpr int kRlMaxChunks = 64;
 constexpr uint32_t kRlNoRun = 255u;
 constexpr unsigned long long kRlEmpty = ~0ull;           // (a key is below 2^59)
 constexpr size_t kRlRid = 0;
 constexpr size_t kRlHeadKey = (size_t)kClsTile;
 constexpr size_t kRlHdr = kRlHeadKey + 64;
 constexpr size_t kRlKeys = kRlHdr + 8 * (size_t)kRlMaxChunks;
-constexpr size_t kRlOrd = kRlKeys + 8 * (size_t)kRlSlots * kRlMaxChunks;
+constexpr size_t kRlMeta = kRlKeys + 8 * (size_t)kRlSlots * kRlMaxChunks;
+constexpr size_t kRlOrd = kRlMeta + 4 * (size_t)kRlSlots * kRlMaxChunks;
 static_assert(kRlOrd + (size_t)kRlSlots * kRlMaxChunks <= (size_t)kClsTile * 8, "the run tables live in the block's key segment");
 static_assert(kClsTile <= 65536 && kRlChunkTuples < 65536 && kRlSlots <= (int)kRlNoRun, "slots, counts and run names are packed");
 static_assert(kRlCloseRuns - 1 + 64 < kRlSlots, "a chunk's table must never fill");

@@ -626,90 +626,69 @@ __device__ __forceinline__ RlBlock rl_block(const SegSource& seg, uint32_t b, in
     k.total = before;
     return k;
 }
+static_assert(kRlMaxChunks <= 64, "rl_list_kernel searches the chunk prefixes one wave holds");
 constexpr int kRlWaves = 4;                              // waves per block: wave w takes chunks w, w + 4, ...
 
-// 1'. the run list.  The record loop named every tuple's run (its slot in the chunk's key table) but counted nothing: a
-// wave reads a chunk's run bytes - 1 byte per tuple, eight per lane - and peels the distinct names off in order of first
-// occurrence (one compare + ballot per round of 64 and name: count and first slot come out as wave-uniform values;
-// per-slot LDS atomics instead took 0.26 ms on full C3 - hundreds of lanes on a handful of counters), then writes
-// (key, count | list index << 32) pairs for the sort, first stream index and mask per run, and the chunk's slots in list
-// order for rl_place_kernel.  Wave 0 of a block also lists the head's run of one (if the stitch kept the head); wave 0 of
-// the last block writes the run count - or the overflow word when the list does not fit or a block ran out of chunks.
-__global__ __launch_bounds__(kRlWaves * 64) void rl_list_kernel(SegSource seg, uint32_t run_cap, uint64_t* __restrict__ run_keys,
-                                                               uint64_t* __restrict__ run_payload, RunCols rc,
-                                                               uint32_t* __restrict__ n_runs, uint32_t* __restrict__ status) {
-    constexpr int R = kRlChunkTuples / 64, Q = kRlSlots / 64;
+// 1'. the run list.  The record loop left per chunk a dense list of its runs - key, tuples | first slot (counted in LDS while
+// it emitted), name - so listing is a copy: ONE WAVE per block walks the block's runs 64 at a time (run -> chunk by a
+// search over the chunks' prefix counts, which the lanes hold), and every run becomes a (key, count | list index << 32)
+// pair for the sort, a first stream index and a graph mask.  (Counting here instead - reading the run bytes back and
+// peeling the names off, or per-slot LDS atomics - took 0.08 / 0.26 ms on full C3, a wave per chunk 0.075: bound by the
+// number of short-lived waves, not by their work.)  The wave also lists the head's run of one (if the stitch kept the
+// head); the last block's wave writes the run count - or the overflow word when the list does not fit or a block ran out
+// of chunks.
+__global__ __launch_bounds__(256) void rl_list_kernel(SegSource seg, uint32_t run_cap, uint64_t* __restrict__ run_keys,
+                                                      uint64_t* __restrict__ run_payload, RunCols rc,
+                                                      uint32_t* __restrict__ n_runs, uint32_t* __restrict__ status) {
     const int lane = threadIdx.x & 63;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (b >= seg.nblocks) return;
+    // (chunk 0's first 64 runs travel with the block's words: one round trip for the loads of most blocks)
+    const char* region0 = reinterpret_cast<const char*>(seg.seg_keys + (size_t)b * seg.tile);
+    uint64_t key = reinterpret_cast<const uint64_t*>(region0 + kRlKeys)[lane];
+    uint32_t meta = reinterpret_cast<const uint32_t*>(region0 + kRlMeta)[lane];
     const RlBlock k = rl_block(seg, b, lane);
-    const uint8_t* rid_p = reinterpret_cast<const uint8_t*>(k.region + kRlRid);
-    if (w == 0u) {                                           // uniform
-        if (k.head_kept && lane == 0 && k.head_idx < run_cap) {
-            run_keys[k.head_idx] = *reinterpret_cast<const uint64_t*>(k.region + kRlHeadKey);
-            run_payload[k.head_idx] = 1ull | ((uint64_t)k.head_idx << 32);
-            rc.first[k.head_idx] = k.off + k.hslot;
-            rc.mask[k.head_idx] = (uint32_t)(k.pl_p[k.hslot] >> 62);
-        }
-        if (b == seg.nblocks - 1u && lane == 0) {
-            const uint32_t all = k.run0 + k.total;
-            if (all > run_cap || *seg.run_status != 0u) {
-                status[1] = 1u;
-                status[2] = all;
-                *n_runs = 0u;
-            } else {
-                *n_runs = all;
-            }
+    if (k.head_kept && lane == 0 && k.head_idx < run_cap) {
+        run_keys[k.head_idx] = *reinterpret_cast<const uint64_t*>(k.region + kRlHeadKey);
+        run_payload[k.head_idx] = 1ull | ((uint64_t)k.head_idx << 32);
+        rc.first[k.head_idx] = k.off + k.hslot;
+        rc.mask[k.head_idx] = (uint32_t)(k.pl_p[k.hslot] >> 62);
+    }
+    if (b == seg.nblocks - 1u && lane == 0) {
+        const uint32_t all = k.run0 + k.total;
+        if (all > run_cap || *seg.run_status != 0u) {
+            status[1] = 1u;
+            status[2] = all;
+            *n_runs = 0u;
+        } else {
+            *n_runs = all;
         }
     }
-    for (uint32_t c = w; c < k.nch; c += (uint32_t)kRlWaves) {   // uniform
-        const uint64_t hdr = k.header(c);
-        const uint32_t start = (uint32_t)hdr & 0xffffu, cnt = (uint32_t)(hdr >> 16) & 0xffffu;
-        const uint32_t idx = k.first_run(c);
-        uint32_t rid[R];
+    for (uint32_t r0 = 0; r0 < k.total; r0 += 64u) {         // uniform
+        const uint32_t r = r0 + (uint32_t)lane;              // the lane's run of the block
+        // its chunk: the last one whose exclusive prefix is <= r (chunks without runs share their successor's prefix and
+        // lose the search to it, as they must); six steps over the 64 prefixes the lanes hold
+        uint32_t c = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = (uint32_t)(r * 64 + lane);
-            rid[r] = i < cnt ? (uint32_t)rid_p[start + i] : kRlNoRun;
+        for (int step = 32; step > 0; step >>= 1) {
+            const uint32_t t = c + (uint32_t)step;
+            const uint32_t ex_t = (uint32_t)__shfl((int)k.ex[0], (int)(t & 63u), 64);
+            if (t < k.nch && ex_t <= r) c = t;
         }
-        uint32_t K = 0;
-        uint32_t my_slot[Q], my_n[Q], my_first[Q];           // lane l: runs l and 64 + l of the chunk, in order of first occurrence
-#pragma unroll
-        for (int q = 0; q < Q; ++q) { my_slot[q] = 0; my_n[q] = 0; my_first[q] = 0; }
-#pragma unroll
-        for (int r0 = 0; r0 < R; ++r0) {
-            unsigned long long rest = __ballot(rid[r0] < (uint32_t)kRlSlots);
-            while (rest != 0ull) {                           // uniform
-                const int src = __ffsll((long long)rest) - 1;
-                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)rid[r0], src);
-                uint32_t n = 0;
-#pragma unroll
-                for (int r = r0; r < R; ++r) {
-                    const bool hit = rid[r] == sl;
-                    const unsigned long long mm = __ballot(hit);
-                    n += (uint32_t)__popcll(mm);
-                    if (hit) rid[r] = kRlNoRun;              // counted
-                    if (r == r0) rest &= ~mm;
-                }
-                const uint32_t first = (uint32_t)(r0 * 64 + src);
-#pragma unroll
-                for (int q = 0; q < Q; ++q)
-                    if ((uint32_t)(q * 64 + lane) == K) { my_slot[q] = sl; my_n[q] = n; my_first[q] = first; }
-                ++K;
+        const uint32_t ex_c = (uint32_t)__shfl((int)k.ex[0], (int)c, 64);
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)k.hdr[0], (int)c, 64);
+        const uint32_t e = c * (uint32_t)kRlSlots + (r - ex_c);
+        if (r < k.total) {
+            if (!(r0 == 0u && c == 0u)) {                    // (not what came with the first round trip)
+                key = reinterpret_cast<const uint64_t*>(k.region + kRlKeys)[e];
+                meta = reinterpret_cast<const uint32_t*>(k.region + kRlMeta)[e];
             }
-        }
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const uint32_t kk = (uint32_t)(q * 64 + lane);
-            if (kk < K) {
-                const uint32_t j = idx + kk, fs = start + my_first[q];
-                reinterpret_cast<uint8_t*>(k.region + kRlOrd)[c * (uint32_t)kRlSlots + kk] = (uint8_t)my_slot[q];
-                if (j < run_cap) {
-                    run_keys[j] = reinterpret_cast<const uint64_t*>(k.region + kRlKeys)[c * (uint32_t)kRlSlots + my_slot[q]];
-                    run_payload[j] = (uint64_t)my_n[q] | ((uint64_t)j << 32);
-                    rc.first[j] = k.off + fs - (fs > k.skip ? 1u : 0u);
-                    rc.mask[j] = (uint32_t)(k.pl_p[fs] >> 62);
-                }
+            const uint32_t j = k.run0 + r, fs = (lo & 0xffffu) + (meta >> 16);
+            if (j < run_cap) {
+                run_keys[j] = key;
+                run_payload[j] = (uint64_t)(meta & 0xffffu) | ((uint64_t)j << 32);
+                rc.first[j] = k.off + fs - (fs > k.skip ? 1u : 0u);
+                rc.mask[j] = (uint32_t)(k.pl_p[fs] >> 62);
             }
         }
     }
@@ -903,7 +882,7 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
         const uint32_t bgrid = seg->nblocks;                // one workgroup per block, a wave per chunk
         {
             ProfScope ps(s, kProfRunList);
-            hipLaunchKernelGGL(rl_list_kernel, dim3(bgrid), dim3(kRlWaves * 64), 0, s, *seg, w.run_cap, w.run_keys, w.run_payload, rc,
+            hipLaunchKernelGGL(rl_list_kernel, dim3((bgrid + 3u) / 4u), dim3(256), 0, s, *seg, w.run_cap, w.run_keys, w.run_payload, rc,
                                w.n_runs, w.status);
         }
         const int rcode = launch_sort_reduce(s, (int64_t)w.run_cap, w.n_runs, key_bits, w.run_keys, w.run_payload, row_key, w.r_mask,
