@@ -170,7 +170,7 @@ int besst_prof_slots(void) { return kProfSlots; }
 
 const char* besst_prof_slot_name(int slot) {
     static const char* names[kProfSlots] = {
-        "stream_kernel", "fused_kernel", "fused_wave_kernel", "ordered_kernel", "stitch_spans_kernel+stitch_kernel",
+        "stream_kernel", "fused_wave_kernel", "ordered_kernel", "stitch_spans_kernel+stitch_kernel",
         "presort_fixup_kernel", "compact_kernel",
         "radix_hist_kernel", "radix_rowscan_kernel", "radix_scatter_kernel", "bucket_sort_kernel", "bucket_reduce_kernel",
         "row_heads_kernel", "row_scan_kernel", "row_reduce_kernel",
@@ -1070,8 +1070,7 @@ static void presort_to_spec(const besst_presort* h, PresortSpec& ps) {
     ps.segmented = h->segmented; ps.in_record_loop = h->in_record_loop;
     // the run-grouped stage 2 (what a stream with this description takes unless the flag says otherwise) has no use for
     // the digit histograms: the record loop then does not count them
-    static const int always = [] { const char* e = getenv("BESST_PRESORT_COUNT"); return e ? atoi(e) : 0; }();   // A/B runs
-    ps.count = (!always && runs_enabled((int64_t)h->capacity) && !(h->flags & BESST_REDUCE_NO_RUNS)) ? 0 : 1;
+    ps.count = (runs_enabled((int64_t)h->capacity) && !(h->flags & BESST_REDUCE_NO_RUNS)) ? 0 : 1;
     ps.seg = SegSource{h->seg_keys, h->seg_payload, h->seg_offsets, h->seg_skip, h->seg_blocks, h->seg_tile, h->payload_out,
                        h->seg_chunk_first, h->seg_run_offsets, h->seg_summ, h->seg_summ_stride, h->seg_run_status};
 }

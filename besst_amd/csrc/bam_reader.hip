@@ -229,7 +229,7 @@ struct besst_bam {
     Pool* pool = nullptr;
     double t_read = 0, t_inflate = 0, t_walk = 0, t_decode = 0;   // seconds per phase (BESST_BAM_PROFILE=1 prints them)
     std::vector<void*> ld_ctx;       // one libdeflate decompressor per worker
-    bool check_crc = [] { const char* e = getenv("BESST_BGZF_CRC"); return !(e && atoi(e) == 0); }();   // (=0: timing runs)
+    bool check_crc = true;           // every block's CRC-32 against its gzip trailer, as htslib does
     std::vector<BlockRecs> brecs;    // speculative per-block walks of the current batch, in stream order
     std::vector<size_t> brec_file_off;   // where each of those blocks begins in the file
     std::vector<uint32_t> blk_offs;

@@ -14,10 +14,14 @@
 //                pattern canonically (first code / count / offset per length) - balanced, no replication loops; codes
 //                longer than the 10-bit primary table (rare) are decoded the same way on the spot; base and extra-bit
 //                count of a length / distance code come from two per-lane registers (v_readlane);
-//       window   the block's own output in HBM / L2 (default; 6 KB of LDS, seven waves per SIMD) - a wave's vector memory
-//                instructions are processed in order, a load behind a store of the same wave returns the stored byte -
-//                or a 32 KiB ring in LDS that leaves for HBM in 8 KiB granules (BESST_BGZF_WINDOW=lds; 38 KB of LDS, one
-//                wave per SIMD: 2.3 x slower, kept for A/B runs);
+//       symbols  SEVERAL per turn of the loop: lane i decodes - speculatively - the literal / length symbol AND the distance
+//                symbol that would begin at bit i of the next 64 bits of input (two table look-ups, base and extra bits:
+//                vector work, the same for every lane), and the chain of symbols that really begin there is then walked
+//                with one v_readlane per symbol; what the walk cannot take (a code longer than the table, the end of a
+//                block, a window that has to be reloaded) is left to the one-symbol-at-a-time loop;
+//       window   the block's own output in HBM / L2 (6 KB of LDS, seven waves per SIMD) - a wave's vector memory
+//                instructions are processed in order, a load behind a store of the same wave returns the stored byte
+//                (round 3's other form, a 32 KiB ring in LDS at one wave per SIMD, was 2.3 x slower and is gone);
 //       output   in groups of 64 bytes: lane k of a group holds a literal or the place its byte is copied from; a full
 //                group, a match that reads from the group, or the end of the block flushes it with one gather and one
 //                store (an overlapping match - distance < length - is written directly: byte i is byte i mod dist of its
@@ -41,11 +45,9 @@ namespace besst {
 
 namespace {
 
-constexpr int kRing = 32768;
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
 constexpr int kClBits = 7;
-constexpr uint32_t kFlushGranule = 8192;
 constexpr uint32_t kGroupLit = 0x80000000u;   // output group: the lane holds a literal (else a source position, < 2^31)
 constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is no short code: length nibble 0, and not below 0x1000 (a literal)
 
@@ -59,9 +61,7 @@ struct CanonLds {               // per code: count / first code / offset per len
     uint16_t cnt[16], first[16], offs[16];
 };
 
-template <int kRingBytes>
 struct InflateLds {
-    __attribute__((aligned(16))) uint8_t ring[kRingBytes ? kRingBytes : 16];
     uint16_t lit_tab[kTabSize];
     uint16_t dist_tab[kTabSize];
     uint16_t cl_tab[1 << kClBits];
@@ -147,87 +147,88 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
 }
 
 // a code longer than the primary table: canonical decode of the next 15 bits (uniform); 0 = not a code
-__device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t* sorted, uint32_t low15, int bits) {
+// (z: an opaque zero the caller makes where the rare path begins - with addresses that depend on it the fifteen table
+// words are read THERE; hoisted, they were read and unpacked once per batch of symbols: ~60 instructions in front of ~5 symbols)
+__device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t* sorted, uint32_t low15, int bits, uint32_t z = 0u) {
     const uint32_t r = __brev(low15) >> 17;
     for (int L = bits + 1; L < 16; ++L) {
-        const uint32_t d = (r >> (15 - L)) - (uint32_t)c->first[L];
-        if (d < (uint32_t)c->cnt[L]) return ((uint32_t)sorted[(uint32_t)c->offs[L] + d] << 4) | (uint32_t)L;
+        const uint32_t d = (r >> (15 - L)) - (uint32_t)c->first[z + L];
+        if (d < (uint32_t)c->cnt[z + L]) return ((uint32_t)sorted[(uint32_t)c->offs[z + L] + d] << 4) | (uint32_t)L;
     }
     return 0u;
 }
+__device__ __forceinline__ uint32_t opaque_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 
-// The bit buffer is wave-uniform but lives in VECTOR registers (an empty asm with a "+v" operand pins it there): a CU has
-// ONE scalar ALU for all its waves, and with the whole symbol loop in scalar code that unit was the kernel's limit
-// (4.9 G scalar against 1.1 G vector instructions per launch by the counters, 43 + 10 per symbol).  The buffer's shifts,
-// masks and table indexes cost the vector units - idle otherwise - the same single issue; what steers control flow comes
-// back to a scalar register with v_readfirstlane.
+// The input as the symbol loop wants it: a POSITION in a window of 64 dwords that the lanes hold (a dword each), not a
+// bit buffer.  What a SIMD runs short of in this kernel is its scalar issue slot - one scalar instruction or branch per four
+// cycles for all its waves, ~90 % in use by the counters -, and a buffer that is shifted, topped up and tested after every
+// symbol spends that slot on bookkeeping: consuming bits is ONE addition here, and the window moves on by half its length
+// (two lane permutes and a load, every 1024 bits) so that the four dwords behind the position always lie in it.
 struct BitReader {
     const uint32_t* words;      // 4-byte aligned start of the block's payload (uniform)
-    uint32_t in;                // the current window of 64 dwords of input: one per lane
-    uint32_t widx;              // next dword of the current window (uniform)
-    uint32_t wcount;            // dwords handed to the bit buffer so far, counted from `words` (uniform)
-    uint64_t bb;                // bit buffer (the same in every lane)
-    uint32_t bc;                // valid bits in it (uniform)
+    uint32_t in0, in1;          // dwords [wbase, wbase + 64) and [wbase + 64, wbase + 128) of it, a dword per lane
+    uint32_t wbase;             // (uniform)
+    uint32_t bitpos;            // bits of in0 consumed (uniform; < 1024 + what is consumed between two calls of roll())
     int lane;
 
-    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(bb)); }
     __device__ __forceinline__ void seek(uint32_t byte_pos) {
-        wcount = byte_pos >> 2;
-        in = words[wcount + (uint32_t)lane];
-        widx = 0;
-        bb = 0;
-        bc = 0;
-        pin();
-        refill();
-        const uint32_t skip = (byte_pos & 3u) * 8u;
-        bb >>= skip;
-        bc -= skip;
-        refill();
+        wbase = byte_pos >> 2;
+        in0 = words[wbase + (uint32_t)lane];
+        in1 = words[wbase + 64u + (uint32_t)lane];
+        bitpos = (byte_pos & 3u) * 8u;
     }
-    // at least 32 valid bits afterwards
-    __device__ __forceinline__ void refill() {
-        if (bc <= 32u) {                                     // uniform
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)in, (int)widx);
-            bb |= (uint64_t)w << bc;
-            pin();
-            bc += 32u;
-            ++wcount;
-            ++widx;
-            // (the next window is loaded when this one is used up, not ahead: a second register handed on at every
-            // refill site made the compiler wait for ALL outstanding memory operations - the group's stores - at each
-            // of them; the six other waves of the SIMD cover the load)
-            if (widx == 64u) {                               // uniform
-                in = words[wcount + (uint32_t)lane];
-                widx = 0;
-            }
+    __device__ __forceinline__ void roll() {
+        if (bitpos >= 1024u) {                               // uniform
+            const uint32_t a = (uint32_t)__shfl((int)in0, lane + 32, 64), b = (uint32_t)__shfl((int)in1, lane - 32, 64);
+            in0 = lane < 32 ? a : b;
+            wbase += 32u;
+            in1 = words[wbase + 64u + (uint32_t)lane];
+            bitpos -= 1024u;
         }
     }
-    // the low bits of the buffer, not consumed (table indexes)
-    __device__ __forceinline__ uint32_t peek(uint32_t mask) const { return (uint32_t)bb & mask; }
-    __device__ __forceinline__ void drop(uint32_t n) {
-        bb >>= n;
-        bc -= n;
+    // the next 32 bits (uniform, in a scalar register)
+    __device__ __forceinline__ uint32_t peek32() const {
+        const uint32_t i = bitpos >> 5;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)i);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)i + 1);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (bitpos & 31u));
     }
-    __device__ __forceinline__ uint32_t take(uint32_t n) {   // (the value back in a scalar register)
-        const uint32_t v = uni((uint32_t)bb & ((1u << n) - 1u));
-        bb >>= n;
-        bc -= n;
+    __device__ __forceinline__ void drop(uint32_t n) {
+        bitpos += n;
+        roll();
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {
+        const uint32_t v = peek32() & ((1u << n) - 1u);
+        drop(n);
         return v;
     }
-    // bytes of input consumed so far (whole bytes: call on a byte boundary)
-    __device__ __forceinline__ uint32_t byte_pos() const { return wcount * 4u - (bc >> 3); }
+    __device__ __forceinline__ void align_to_byte() { bitpos = (bitpos + 7u) & ~7u; }
+    // the four dwords the next 64 bit positions read from (uniform), and the position's offset in the first
+    __device__ __forceinline__ uint32_t ahead(uint32_t (&v)[4]) const {
+        const uint32_t i = bitpos >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)i + j);
+        return bitpos & 31u;
+    }
+    // bytes of input consumed so far (rounded up)
+    __device__ __forceinline__ uint32_t byte_pos() const { return wbase * 4u + ((bitpos + 7u) >> 3); }
 };
 
 }  // namespace
 
-// kRingBytes = kRing: the window is an LDS ring (38 KB of LDS: four waves per CU); 0: the window is the block's own output
-// in HBM / L2 (6 KB of LDS: the registers allow six waves per SIMD).
-template <int kRingBytes>
-__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+// what lane i found at bit i of the window: the literal / length symbol (A) and the distance symbol (B) that would begin there
+//   A: bits | kind << 5 | literal or match length << 8     B: bits | kWalkLongDist | distance << 8
+// kWalkLong: the pattern is no code of the primary table - a longer code or none - and is decoded where the walk meets it
+constexpr uint32_t kWalkLit = 0u, kWalkLen = 1u, kWalkLong = 2u, kWalkEnd = 3u;
+constexpr uint32_t kWalkLongDist = 32u;
+
+__global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
                                                           uint32_t n_blocks, uint8_t* dst, uint32_t* __restrict__ status) {
-    __shared__ InflateLds<kRingBytes> s;
-    constexpr bool kLds = kRingBytes != 0;
-    constexpr uint32_t kRingMask = kLds ? (uint32_t)kRingBytes - 1u : 0u;
+    __shared__ InflateLds s;
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -267,55 +268,44 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         }
         dist_info = k < 30u ? base | (extra << 16) : 0u;
     }
-    uint32_t pos = 0, flushed = 0;
+    uint32_t pos = 0;
     uint32_t err = kInfOk;
-    // ---- the window.  LDS form: bytes go to the ring and leave for HBM in granules.  Global form: bytes go straight to the
-    // block's output and a match reads its source there: a wave's vector memory instructions are processed in order, a
-    // load behind a store of the same wave to the same address returns the stored byte (the loads skip the CU's L1).
-    auto put_byte = [&](uint32_t at, uint32_t v) {
-        if constexpr (kLds) s.ring[at & kRingMask] = (uint8_t)v;
-        else out[at] = (uint8_t)v;
-    };
+    // ---- the window: bytes go straight to the block's output and a match reads its source there: a wave's vector memory
+    // instructions are processed in order, a load behind a store of the same wave to the same address returns the stored
+    // byte (the loads skip the CU's L1).
+    auto put_byte = [&](uint32_t at, uint32_t v) { out[at] = (uint8_t)v; };
     auto get_byte = [&](uint32_t at) -> uint32_t {
-        if constexpr (kLds) return s.ring[at & kRingMask];
-        else return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto flush_granules = [&]() {
-        if constexpr (!kLds) return;
-        while (pos - flushed >= kFlushGranule) {             // uniform
-#pragma unroll
-            for (int k = 0; k < (int)(kFlushGranule / 1024u); ++k) {
-                const uint32_t o = flushed + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-                const uint4 v = *reinterpret_cast<const uint4*>(&s.ring[o & kRingMask]);
-                *reinterpret_cast<uint4*>(out + o) = v;
-            }
-            flushed += kFlushGranule;
+    // A group of output bytes whose gather is in flight: the memory round trip of a flush (~2.5 us with the window in HBM /
+    // L2; ~1500 of them per block of a sequencer's file were two thirds of a block's time) is waited for at the NEXT flush,
+    // with a group's worth of symbols decoded in between.  A group is stored before the gather of the next one is issued, so
+    // that gather - and every load behind it - sees its bytes.
+    uint32_t pend_n = 0, pend_pos = 0;                       // uniform: bytes of the pending group (0: none), where they go
+    uint32_t pend_g = 0, pend_v = 0;                         // lane k: kGroupLit | literal, or the byte the gather brought
+    auto retire = [&]() {
+        if (pend_n != 0u) {                                  // uniform
+            if ((uint32_t)lane < pend_n) put_byte(pend_pos + (uint32_t)lane, (pend_g & kGroupLit) ? pend_g : pend_v);
+            pend_n = 0;
         }
     };
     for (;;) {
         // (a DEFLATE block may be empty: without this test a payload of nothing but empty blocks - corrupt, but every bit of
         // it valid - would be followed out of the chunk's buffer)
         if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
-        br.refill();
         const uint32_t final_block = br.take(1);
         const uint32_t type = br.take(2);
         if (type == 0u) {
             // ---- stored: LEN bytes straight from the input
-            br.drop(br.bc & 7u);
-            br.refill();
+            br.align_to_byte();
             const uint32_t len = br.take(16), nlen = br.take(16);
             if (len != (~nlen & 0xffffu)) { err = kInfBadStored; break; }
             const uint32_t at = br.byte_pos();               // relative to br.words
             if (at - in_base + len > src_len) { err = kInfInputOverrun; break; }
             if (pos + len > dst_len) { err = kInfOutputOverrun; break; }
             const uint8_t* from = reinterpret_cast<const uint8_t*>(br.words) + at;
-            for (uint32_t i0 = 0; i0 < len; i0 += 2048u) {   // uniform; a granule's worth at a time
-                const uint32_t part = len - i0 < 2048u ? len - i0 : 2048u;
-                for (uint32_t i = (uint32_t)lane; i < part; i += 64u) put_byte(pos + i, from[i0 + i]);
-                pos += part;
-                __builtin_amdgcn_wave_barrier();
-                flush_granules();
-            }
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64u) put_byte(pos + i, from[i]);
+            pos += len;
             br.seek(at + len);
         } else if (type == 1u || type == 2u) {
             int n_lit = 288, n_dist = 30;
@@ -328,7 +318,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 if (lane < 32) s.cl_lens[lane] = 0;
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t i = 0; i < hclen; ++i) {       // uniform
-                    br.refill();
                     const uint32_t v = br.take(3);
                     // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                     const uint32_t order = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
@@ -340,8 +329,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 uint32_t have = 0, prev = 0;
                 bool bad = false;
                 while (have < total) {                        // uniform
-                    br.refill();
-                    const uint32_t e = uni(s.cl_tab[br.peek((1u << kClBits) - 1u)]);
+                    const uint32_t e = uni(s.cl_tab[br.peek32() & ((1u << kClBits) - 1u)]);
                     const uint32_t l = e & 15u, sym = e >> 4;
                     if (l == 0u) { bad = true; break; }
                     br.drop(l);
@@ -393,108 +381,165 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             uint32_t filled = 0;                             // uniform: lanes of the group in use
             auto flush_group = [&]() {
                 if (filled != 0u) {
-                    if ((uint32_t)lane < filled) {
-                        uint32_t v = g;
-                        if (!(g & kGroupLit)) v = get_byte(g);
-                        put_byte(pos + (uint32_t)lane, v);
-                    }
+                    retire();                                // (its bytes may be what this group copies from)
+                    // (every lane loads - one that copies nothing reads the block's first byte -, so that no branch stands
+                    // between the load and its use at the next flush: behind a branch the compiler waits for it at once)
+                    pend_v = get_byte(((uint32_t)lane < filled && !(g & kGroupLit)) ? g : 0u);
+                    pend_g = g;
+                    pend_pos = pos;
+                    pend_n = filled;
                     pos = uni(pos + filled);                 // (kept scalar by force: without it the compiler turns this
                     filled = 0;                              // branch into selects and the whole symbol loop into vector code)
-                    if (kLds && pos - flushed >= kFlushGranule) flush_granules();
                 }
             };
-            for (;;) {
-                // (at least once per 64 literals: a corrupt stream is not followed more than a few hundred bytes past its
-                // payload - the chunk's buffer has 4 KB behind its last block)
+            for (;;) {                                       // a batch of symbols per turn
+                // (once per turn: a corrupt stream is not followed more than a few hundred bytes past its payload - the
+                // chunk's buffer has 4 KB behind its last block)
                 if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
-                br.refill();
-                uint32_t e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
-                // literals whose code fits the table (other entries are >= 0x1000), until the group is full: ONE way out
-                // of this loop - a second exit costs every iteration the flag registers the compiler threads through it
-                while (((e >> 12) | (filled >> 6)) == 0u) {    // e < 0x1000 (a literal) and filled < 64, as one test
-                    br.drop(e & 15u);
-                    g = (uint32_t)lane == filled ? kGroupLit | (e >> 4) : g;
-                    ++filled;
-                    br.refill();
-                    e = uni(s.lit_tab[br.peek((uint32_t)(kTabSize - 1))]);
+                // ---- several symbols at once.  One symbol at a time cost ~49 scalar instructions and branches per symbol,
+                // and a SIMD issues one of those per four cycles for all its waves: that slot is what a sequencer's file
+                // (14 000 symbols per block, more than half of them matches of ~7 bytes) saturates.  The 64 lanes instead
+                // decode what WOULD begin at each of the next 64 bit positions - the table look-ups, base and extra bits of a
+                // symbol are the same vector instructions for one lane or for all -, and the symbols that really begin
+                // there are found by following the bit counts from position 0: a v_readlane per symbol, eleven scalar
+                // instructions per literal, about twenty-five per match.
+                uint32_t v[4];
+                const uint32_t t = br.ahead(v) + (uint32_t)lane;                   // the lane's bit, counted from v[0]
+                const uint32_t lo = t < 32u ? v[0] : t < 64u ? v[1] : v[2], hi = t < 32u ? v[1] : t < 64u ? v[2] : v[3];
+                const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, t & 31u);     // 32 bits of input from that bit on
+                const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
+                const uint32_t eb = s.dist_tab[x & (uint32_t)(kTabSize - 1)];
+                const uint32_t la = ea & 15u, sa = ea >> 4;
+                const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
+                const uint32_t xa = li >> 9;                 // (garbage unless sa is a length code: not used then)
+                const uint32_t mlen = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
+                uint32_t wa = kWalkLong << 5;                // a longer code, no code, or an invalid symbol (286, 287)
+                if (la != 0u) {
+                    if (sa < 256u) wa = la | (kWalkLit << 5) | (sa << 8);
+                    else if (sa == 256u) wa = la | (kWalkEnd << 5);
+                    else if (sa < 286u) wa = (la + xa) | (kWalkLen << 5) | (mlen << 8);
                 }
-                if (filled == 64u) {
-                    if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
-                    flush_group();
-                    if (e < 0x1000u) continue;               // (the entry is looked up again: nothing of it was consumed)
-                }
-                if ((e & 15u) == 0u) {
-                    e = uni(slow_code(&s.lit_c, s.lit_sorted, uni(br.peek(0x7fffu)), kTabBits));
-                    if (e == 0u) { err = kInfBadCode; break; }
-                }
-                br.drop(e & 15u);
-                uint32_t sym = e >> 4;
-                if (sym < 256u) {                            // a literal with a long code
-                    g = (uint32_t)lane == filled ? kGroupLit | sym : g;
-                    if (++filled == 64u) {
+                const uint32_t lb = eb & 15u, sb = eb >> 4;
+                const uint32_t di = (uint32_t)__shfl((int)dist_info, (int)sb, 64);
+                const uint32_t xb = di >> 16;
+                const uint32_t mdist = (di & 0xffffu) + ((x >> lb) & ((1u << xb) - 1u));
+                const uint32_t wb = (lb != 0u && sb < 30u) ? (lb + xb) | (mdist << 8) : kWalkLongDist;
+                uint32_t p = 0;                              // bits of the window the walk has consumed (uniform)
+                bool done = false;
+                uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wa, 0);
+                for (;;) {
+                    // literals with a code of the table, until the group is full or the window used up: ONE way out of this
+                    // loop (kind, filled and p in one test)
+                    while ((((a >> 5) & 3u) | (filled >> 6) | (p >> 6)) == 0u) {
+                        g = (uint32_t)lane == filled ? kGroupLit | (a >> 8) : g;
+                        ++filled;
+                        p += a & 31u;
+                        a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
+                    }
+                    if (filled == 64u) {
                         if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
                         flush_group();
+                        continue;                            // (`a` still stands for position p, if that is in the window)
                     }
-                    continue;
+                    if (p >= 64u) break;
+                    uint32_t kind = (a >> 5) & 3u;
+                    if (kind == kWalkLong) {
+                        // a code longer than the table (or no code): canonical decode of the 15 bits at p, on the spot
+                        const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)p);
+                        const uint32_t e = uni(slow_code(&s.lit_c, s.lit_sorted, xs & 0x7fffu, kTabBits, opaque_zero()));
+                        if (e == 0u) { err = kInfBadCode; break; }
+                        const uint32_t l = e & 15u, sym = e >> 4;
+                        if (sym < 256u) {
+                            g = (uint32_t)lane == filled ? kGroupLit | sym : g;
+                            ++filled;
+                            p += l;
+                            a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
+                            continue;
+                        }
+                        if (sym == 256u) {
+                            a = l | (kWalkEnd << 5);
+                            kind = kWalkEnd;
+                        } else {
+                            if (sym >= 286u) { err = kInfBadCode; break; }
+                            const uint32_t li2 = (uint32_t)__builtin_amdgcn_readlane((int)len_info, (int)(sym - 257u));
+                            const uint32_t x2 = li2 >> 9;
+                            a = (l + x2) | (kWalkLen << 5) | (((li2 & 0x1ffu) + ((xs >> l) & ((1u << x2) - 1u))) << 8);
+                            kind = kWalkLen;
+                        }
+                    }
+                    if (kind == kWalkEnd) {
+                        p += a & 31u;
+                        done = true;
+                        break;
+                    }
+                    // ---- a match: its distance symbol begins at q
+                    const uint32_t q = p + (a & 31u);
+                    if (q >= 64u) break;                     // beyond what the lanes looked at: the next batch begins with it
+                    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)wb, (int)q);
+                    if (d & kWalkLongDist) {
+                        const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q);
+                        const uint32_t e = uni(slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kTabBits, opaque_zero()));
+                        if (e == 0u || (e >> 4) >= 30u) { err = kInfBadCode; break; }
+                        const uint32_t l = e & 15u;
+                        const uint32_t di2 = (uint32_t)__builtin_amdgcn_readlane((int)dist_info, (int)(e >> 4));
+                        const uint32_t x2 = di2 >> 16;
+                        d = (l + x2) | (((di2 & 0xffffu) + ((xq >> l) & ((1u << x2) - 1u))) << 8);
+                    }
+                    const uint32_t length = a >> 8, dist = d >> 8;
+                    const uint32_t fl = filled + length, at = pos + filled;        // where the match begins
+                    // the common case in ONE test (four differences, their sign bits): the match fits the group's free lanes,
+                    // its source lies wholly in finished output in front of the group, not in front of the block, and the
+                    // output has room for it
+                    if ((int32_t)((64u - fl) | (dist - fl) | (at - dist) | (dst_len - pos - fl)) >= 0) {
+                        g = (uint32_t)lane - filled < length ? at - filled + (uint32_t)lane - dist : g;
+                        filled = fl;
+                        if (filled == 64u) flush_group();
+                    } else {
+                        if (dist > at) { err = kInfBadDistance; break; }
+                        if (at + length > dst_len) { err = kInfOutputOverrun; break; }
+                        if (dist >= length) {
+                            // every byte's source is finished output - once the group is out of the way where the source
+                            // reaches into it.  The match joins the group piece by piece: the byte at P comes from P - dist.
+                            if (at - dist + length > pos) flush_group();
+                            uint32_t left = length;
+                            while (left != 0u) {             // uniform
+                                const uint32_t room = 64u - filled;
+                                const uint32_t take = left < room ? left : room;
+                                const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
+                                g = in ? pos + (uint32_t)lane - dist : g;
+                                filled = uni(filled + take);
+                                left -= take;
+                                if (filled == 64u) flush_group();
+                            }
+                        } else {
+                            // an overlapping match repeats its last `dist` bytes: byte i is byte i mod dist of them
+                            flush_group();
+                            retire();
+                            if (dist >= 64u) {
+                                for (uint32_t i = (uint32_t)lane; i < length; i += 64u)     // (rounds complete in order)
+                                    put_byte(pos + i, get_byte(pos + i - dist));
+                            } else {
+                                const float rcp = __frcp_rn((float)dist);
+                                for (uint32_t i = (uint32_t)lane; i < length; i += 64u) {
+                                    int qq = (int)((float)i * rcp);
+                                    int r = (int)i - qq * (int)dist;
+                                    if (r < 0) r += (int)dist;
+                                    else if (r >= (int)dist) r -= (int)dist;
+                                    put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
+                                }
+                            }
+                            pos += length;
+                        }
+                    }
+                    p = q + (d & 31u);
+                    a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
                 }
-                if (sym == 256u) {
+                if (err) break;
+                br.drop(p);                                  // (p > 0: position 0 always yields a symbol or an error)
+                if (done) {
                     if (pos + filled > dst_len) err = kInfOutputOverrun;
                     else flush_group();
                     break;
-                }
-                // base and extra-bit count of the length / distance code: lane k of two registers holds them for code k
-                // (filled in once per wave), a v_readlane fetches them - the arithmetic on the symbol and its three
-                // branches were a fifth of a match's scalar instructions
-                sym -= 257u;
-                if (sym >= 29u) { err = kInfBadCode; break; }
-                const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)len_info, (int)sym);
-                const uint32_t length = (li & 0x1ffu) + br.take(li >> 9);
-                br.refill();
-                uint32_t d = uni(s.dist_tab[br.peek((uint32_t)(kTabSize - 1))]);
-                if ((d & 15u) == 0u) {
-                    d = uni(slow_code(&s.dist_c, s.dist_sorted, uni(br.peek(0x7fffu)), kTabBits));
-                    if (d == 0u) { err = kInfBadCode; break; }
-                }
-                br.drop(d & 15u);
-                const uint32_t dsym = d >> 4;
-                if (dsym >= 30u) { err = kInfBadCode; break; }
-                const uint32_t di = (uint32_t)__builtin_amdgcn_readlane((int)dist_info, (int)dsym);
-                const uint32_t dist = (di & 0xffffu) + br.take(di >> 16);
-                const uint32_t at = pos + filled;            // where the match begins
-                if (dist > at) { err = kInfBadDistance; break; }
-                if (at + length > dst_len) { err = kInfOutputOverrun; break; }
-                if (dist >= length) {
-                    // every byte's source is finished output - once the group is out of the way where the source reaches
-                    // into it.  The match joins the group piece by piece: the byte at position P comes from P - dist.
-                    if (at - dist + length > pos) flush_group();
-                    uint32_t left = length;
-                    while (left != 0u) {                     // uniform
-                        const uint32_t room = 64u - filled;
-                        const uint32_t take = left < room ? left : room;
-                        const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
-                        g = in ? pos + (uint32_t)lane - dist : g;
-                        filled = uni(filled + take);
-                        left -= take;
-                        if (filled == 64u) flush_group();
-                    }
-                } else {
-                    // an overlapping match repeats its last `dist` bytes: byte i is byte i mod dist of them
-                    flush_group();
-                    if (dist >= 64u) {
-                        for (uint32_t i = (uint32_t)lane; i < length; i += 64u)     // (rounds complete in order)
-                            put_byte(pos + i, get_byte(pos + i - dist));
-                    } else {
-                        const float rcp = __frcp_rn((float)dist);
-                        for (uint32_t i = (uint32_t)lane; i < length; i += 64u) {
-                            int q = (int)((float)i * rcp);
-                            int r = (int)i - q * (int)dist;
-                            if (r < 0) r += (int)dist;
-                            else if (r >= (int)dist) r -= (int)dist;
-                            put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
-                        }
-                    }
-                    pos += length;
-                    if (kLds && pos - flushed >= kFlushGranule) flush_granules();
                 }
             }
             if (err) break;
@@ -504,21 +549,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         }
         if (final_block) break;
     }
+    retire();
     if (!err) {
         if (pos != dst_len) err = kInfSizeMismatch;
-        else if (br.byte_pos() - in_base > src_len + 8u) err = kInfInputOverrun;   // (the bit buffer reads ahead of its use)
-    }
-    if (!err && kLds) {
-        // what is left in the ring: whole 16-byte units, then bytes
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t rest = pos - flushed;
-        const uint32_t n16 = rest >> 4;
-        for (uint32_t j = (uint32_t)lane; j < n16; j += 64u) {
-            const uint32_t o = flushed + j * 16u;
-            *reinterpret_cast<uint4*>(out + o) = *reinterpret_cast<const uint4*>(&s.ring[o & kRingMask]);
-        }
-        const uint32_t tail0 = flushed + n16 * 16u;
-        if (tail0 + (uint32_t)lane < pos) out[tail0 + (uint32_t)lane] = s.ring[(tail0 + (uint32_t)lane) & kRingMask];
+        else if (br.byte_pos() - in_base > src_len + 8u) err = kInfInputOverrun;
     }
     if (lane == 0) status[b] = err;
 }
@@ -785,13 +819,8 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
                         uint32_t* status) {
     if (n_blocks == 0) return BESST_OK;
-    // BESST_BGZF_WINDOW=lds: the LDS-ring form (A/B runs)
-    static const bool lds_ring = [] { const char* e = getenv("BESST_BGZF_WINDOW"); return e && strcmp(e, "lds") == 0; }();
-    if (lds_ring) hipLaunchKernelGGL((bgzf_inflate_kernel<kRing>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
-    else hipLaunchKernelGGL((bgzf_inflate_kernel<0>), dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
-    // BESST_BGZF_CRC=0: skip the check (timing runs)
-    static const bool check_crc = [] { const char* e = getenv("BESST_BGZF_CRC"); return !(e && atoi(e) == 0); }();
-    if (check_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(256), 0, s, dst, blocks, n_blocks, status);
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(256), 0, s, dst, blocks, n_blocks, status);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -568,355 +568,21 @@ __global__ __launch_bounds__(kOrdThreads, BESST_ORD_MIN_BLOCKS) void ordered_ker
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fused_kernel: the record loop of a candidate-DENSE library (mate pairs: a fifth of the records have their mate
-// on another contig) in ONE pass over the seven columns.  stream_kernel + ordered_kernel read such a library twice
-// (the candidates' seven scattered column reads touch every sector again: 12.4 GB instead of 8.4 GB on C3) and
-// ordered_kernel is bound by vector instructions there - 600 per candidate, most of them spent finding the r-th set
-// bit of a group mask.  Here a 256-thread workgroup walks its 16 384 records in 16 sub-tiles of 1024:
-//   all waves  coalesced loads of the seven columns; tid == mtid records only add coverage (a running (contig, sum)
-//              per wave, flushed with one atomic when the contig changes);
-//              candidates are compacted, in stream order, into LDS (ballot prefix; five words per record)
-//   all waves  thread j evaluates candidate j: two contig rows (L2), PosDirCalculator, link dispatch, then the
-//              order-dependent part (duplicate chain, acceptance, counters, ordered emission into the block's
-//              segment) for all 256 candidates of the round at once - ballots inside a wave, the waves' tails and
-//              counts through LDS; a single wave walking the entries 64 at a time, as ordered_kernel does, was the
-//              critical path of every sub-tile here
-// and publishes the same block summary, so stitch_kernel / compact_kernel and the sharded build's head / tail logic
-// are shared by both paths.  besst_lib_params.record_path selects the path (the host samples the candidate density).
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kFusedThreads = 256;
-constexpr int kFusedSub = kFusedThreads * 4;              // records per sub-tile
-constexpr int kFusedRing = kFusedSub + kFusedThreads;     // candidates in LDS: a sub-tile's worth + an unfinished round
-#ifndef BESST_FUSED_MIN_WAVES
-#define BESST_FUSED_MIN_WAVES 4
-#endif
-
-__global__ __launch_bounds__(kFusedThreads, BESST_FUSED_MIN_WAVES) void fused_kernel(
-    ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
-    uint64_t* __restrict__ seg_payload, SummView summ) {
-    // SoA over the sub-tile's candidates: words 0..4 = tid, mtid, pos, mpos, flag | mapq << 16 (qlen in word 5's
-    // place would make six; it travels in the top half of the flag word: flag bits above 0x100 are not read)
-    // ... a RING of kFusedRing entries: candidates queue up across sub-tiles and are evaluated 256 at a time, so the
-    // evaluation rounds run with every lane busy (C3: a median of 207 candidates per sub-tile but 621 at the ninth
-    // decile - one round per started 256 of a sub-tile left a quarter of the lanes idle)
-    __shared__ uint32_t s_buf[5][kFusedRing];
-    __shared__ uint32_t s_qlen[kFusedRing / 2];           // 16 bits per candidate
-    __shared__ int s_wcnt[2][4];                          // candidates per wave, double buffered by sub-tile
-    __shared__ int32_t s_tail[4][4];                      // per wave: {has, obs1, obs2} of its last reaching record
-    __shared__ int s_ecnt[4];                             // per wave: tuples emitted this round
-    // running state of the block, double buffered by round: {prev known, prev obs1, prev obs2, emit base, any reach}
-    __shared__ int32_t s_state[2][8];
-    __shared__ int32_t s_head[8];                         // the block's first reaching record {present, obs1, obs2, info, slot}
-    __shared__ int s_red[4][7];
-    __shared__ uint32_t s_ph[512];                        // the sort's two digit histograms of the block's tuples
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t block_base = (int64_t)blockIdx.x * kClsTile;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t thr_u32 = ins_thr_u32(a);
-    if (a.ps_table) { s_ph[t] = 0; s_ph[t + 256] = 0; }   // (uniform; ordered before the first use by the barriers below)
-    if (t < 8) { s_state[0][t] = 0; s_state[1][t] = 0; s_head[t] = 0; }   // visible after the first sub-tile's barriers
-    int round = 0;
-    int c_count = 0, c_nonuniq = 0, c_nus = 0, c_dup = 0, c_long = 0, c_fishy = 0, c_reach = 0;
-    int32_t run_tid = -1;                                   // the wave's running coverage (uniform)
-    int run_sum = 0;
-    int q_head = 0, q_count = 0;                            // the queue of candidates not yet evaluated (uniform)
-    // ---- evaluation + the order-dependent part of up to 256 queued candidates, thread j on candidate j.  The chain
-    // (Chain::step's semantics, CreateGraph.py:835-870) runs over all four waves at once: "previous record that
-    // reached CreateEdge" = nearest reaching lane below (ballot), else the tail of the nearest earlier wave that has
-    // one, else the block's running state; emission slots by ballot prefix + the waves' counts.  Two barriers per
-    // round, no serial wave.
-    auto run_round = [&](const int cnt) {
-        {
-            const bool live = t < cnt;
-            int32_t tid = -1, mtid = -1, pos = 0, mpos = 0;
-            uint32_t fm = 0, qlen = 0;
-            if (live) {
-                int j = q_head + t;
-                j = j >= kFusedRing ? j - kFusedRing : j;
-                tid = (int32_t)s_buf[0][j]; mtid = (int32_t)s_buf[1][j];
-                pos = (int32_t)s_buf[2][j]; mpos = (int32_t)s_buf[3][j];
-                fm = s_buf[4][j];
-                qlen = reinterpret_cast<const unsigned short*>(s_qlen)[j];
-            }
-            const bool in_range = live && (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs;
-            ContigRow c1, c2;
-            c1.w0 = c2.w0 = 0; c1.scaf_len = c2.scaf_len = 0; c1.ctg_pos = c2.ctg_pos = 0; c1.ctg_len = c2.ctg_len = 0;
-            if (in_range) {
-                c1 = a.table[tid];
-                c2 = a.table[mtid];
-            }
-            const Eval e = eval_record(a, in_range, c1, c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
-            // the candidate's coverage was credited with the streamed records (any in-range pair whose mapq qualifies);
-            // [:127-139] also wants both contigs in the table: taken back here when they are not
-            if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
-                atomicAdd(&aligned[tid], 0ull - (unsigned long long)qlen);
-            const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
-            const bool mapq0 = (e.bits & EV_MAPQ0) != 0, case_a = (e.bits & EV_CASEA) != 0;
-            const bool dbl = (e.bits & EV_DOUBLE) != 0;
-            c_nonuniq += (live && (e.bits & EV_NONUNIQ)) ? 1 : 0;
-            c_fishy += fishy ? 1 : 0;
-            c_reach += reach ? 1 : 0;
-            const int32_t o1 = e.o1, o2 = e.o2;
-            const unsigned long long has_mask = __ballot(reach);
-            const unsigned long long below = has_mask & lt_mask;
-            bool pk = below != 0ull;
-            int32_t p1, p2;
-            {
-                const int src = below ? 63 - __clzll((long long)below) : 0;
-                p1 = __shfl(o1, src, 64);
-                p2 = __shfl(o2, src, 64);
-            }
-            if (has_mask) {
-                if (lane == 63 - __clzll((long long)has_mask)) { s_tail[wave][0] = 1; s_tail[wave][1] = o1; s_tail[wave][2] = o2; }
-            } else if (lane == 0) {
-                s_tail[wave][0] = 0;
-            }
-            const int par = round & 1;
-            __syncthreads();                                 // A: the waves' tails; the state left by the round before
-            if (reach && !pk) {
-                pk = s_state[par][0] != 0; p1 = s_state[par][1]; p2 = s_state[par][2];
-#pragma unroll
-                for (int w = 0; w < 3; ++w)
-                    if (w < wave && s_tail[w][0]) { pk = true; p1 = s_tail[w][1]; p2 = s_tail[w][2]; }
-            }
-            // thread 0 also works out what the next round starts from; the tails must be read on this side of barrier B
-            // (a fast wave may already write the next round's tail behind it)
-            int nx_known = 0, nx_q1 = 0, nx_q2 = 0, nx_has = 0;
-            if (t == 0) {
-                nx_known = s_state[par][0]; nx_q1 = s_state[par][1]; nx_q2 = s_state[par][2]; nx_has = s_state[par][4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (s_tail[w][0]) { nx_known = 1; nx_has = 1; nx_q1 = s_tail[w][1]; nx_q2 = s_tail[w][2]; }
-            }
-            const bool accept = reach && o1 > 25 && o2 > 25 && ((uint32_t)o1 + (uint32_t)o2 < thr_u32);
-            bool emit = fishy, is_head = false;
-            if (reach) {
-                if (!pk) {
-                    is_head = true;                          // first reaching record of the workgroup: stitch_kernel's
-                    emit = accept;
-                } else {
-                    const CEDelta d = create_edge(o1, o2, p1, p2, accept, dbl, mapq0, a.detect_dup != 0);
-                    c_count += d.count; c_nus += d.nus; c_dup += d.dup; c_long += d.too_long;
-                    emit = d.keep;
-                }
-            }
-            const unsigned long long emit_mask = __ballot(emit);
-            if (lane == 0) s_ecnt[wave] = __popcll(emit_mask);
-            __syncthreads();                                 // B: the waves' emission counts
-            int slot = s_state[par][3] + __popcll(emit_mask & lt_mask);
-#pragma unroll
-            for (int w = 0; w < 3; ++w)
-                if (w < wave) slot += s_ecnt[w];
-            if (emit) {
-                const uint32_t mask_a = a.no_score ? BESST_MASK_GPRIME : (BESST_MASK_G | (a.extend_paths ? BESST_MASK_GPRIME : 0u));
-                const uint32_t mask = case_a ? mask_a : BESST_MASK_GPRIME;
-                const bool first_min = (e.bits & EV_FIRSTMIN) != 0;
-                const uint32_t lo = fishy ? 0u : (uint32_t)(first_min ? o1 : o2);
-                const uint32_t hi = fishy ? 0u : ((uint32_t)(first_min ? o2 : o1) | (mask << 30));
-                const uint64_t key = ((((uint64_t)e.n_min << a.node_bits) | e.n_max) << 1) | (fishy ? 1u : 0u);
-                seg_keys[block_base + slot] = key;
-                seg_payload[block_base + slot] = (uint64_t)lo | ((uint64_t)hi << 32);
-                if (a.ps_table) {                            // uniform
-                    // the emitting lanes that share the first one's digit add once, together (consecutive tuples of a
-                    // contig share their smaller node half of the time)
-                    const uint64_t k = key - a.ps_base;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const uint32_t d = (uint32_t)(k >> (a.ps_shift + 8 * q)) & 255u;
-                        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-                        const unsigned long long m = __ballot(d == f);
-                        if (d != f) atomicAdd(&s_ph[256 * q + d], 1u);
-                        else if ((m & lt_mask) == 0ull) atomicAdd(&s_ph[256 * q + f], (uint32_t)__popcll(m));
-                    }
-                }
-            }
-            if (is_head) {                                   // at most one thread of the whole block, once
-                s_head[0] = 1; s_head[1] = o1; s_head[2] = o2;
-                s_head[3] = (int32_t)((accept ? 9u : 0u) | (dbl ? 2u : 0u) | (mapq0 ? 4u : 0u));
-                s_head[4] = accept ? slot : (int32_t)kNoSlot;
-            }
-            if (t == 0) {                                    // the state the next round starts from (other buffer)
-                int eb = s_state[par][3];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) eb += s_ecnt[w];
-                s_state[par ^ 1][0] = nx_known; s_state[par ^ 1][1] = nx_q1; s_state[par ^ 1][2] = nx_q2;
-                s_state[par ^ 1][3] = eb; s_state[par ^ 1][4] = nx_has;
-            }
-            ++round;
-        }
-        q_head += kFusedThreads;
-        q_head = q_head >= kFusedRing ? q_head - kFusedRing : q_head;
-        q_count -= cnt;
-    };
-    for (int st = 0; st < kClsTile / kFusedSub; ++st) {
-        const int64_t sub_base = block_base + (int64_t)st * kFusedSub;
-        if (sub_base >= a.n) break;                         // uniform
-        const int64_t i0 = sub_base + (int64_t)t * 4;
-        int32_t r_tid[4], r_mtid[4], r_pos[4], r_mpos[4];
-        uint32_t r_flag[4], r_mapq[4], r_qlen[4];
-        if (sub_base + kFusedSub <= a.n) {
-            const int4 v_tid = *reinterpret_cast<const int4*>(a.tid + i0);
-            const int4 v_mtid = *reinterpret_cast<const int4*>(a.mtid + i0);
-            const uchar4 v_mapq = *reinterpret_cast<const uchar4*>(a.mapq + i0);
-            const ushort4 v_qlen = *reinterpret_cast<const ushort4*>(a.qlen + i0);
-            r_tid[0] = v_tid.x; r_tid[1] = v_tid.y; r_tid[2] = v_tid.z; r_tid[3] = v_tid.w;
-            r_mtid[0] = v_mtid.x; r_mtid[1] = v_mtid.y; r_mtid[2] = v_mtid.z; r_mtid[3] = v_mtid.w;
-            r_mapq[0] = v_mapq.x; r_mapq[1] = v_mapq.y; r_mapq[2] = v_mapq.z; r_mapq[3] = v_mapq.w;
-            r_qlen[0] = v_qlen.x; r_qlen[1] = v_qlen.y; r_qlen[2] = v_qlen.z; r_qlen[3] = v_qlen.w;
-            // pos, mpos and flag are only read for candidates, and candidates come in clusters (C3: a quarter of the
-            // records, but 49 % of the 32-byte sectors of a 4-byte column hold none): a lane without a candidate among
-            // its four records does not load them - 1.9 of the 7.6 GB of the record set stay in HBM.  The loads are
-            // issued here and first used when the candidates go to LDS, behind the coverage arithmetic and a barrier.
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r_pos[k] = 0; r_mpos[k] = 0; r_flag[k] = 0; }
-            if (v_tid.x != v_mtid.x || v_tid.y != v_mtid.y || v_tid.z != v_mtid.z || v_tid.w != v_mtid.w) {
-                const int4 v_pos = *reinterpret_cast<const int4*>(a.pos + i0);
-                const int4 v_mpos = *reinterpret_cast<const int4*>(a.mpos + i0);
-                const ushort4 v_flag = *reinterpret_cast<const ushort4*>(a.flag + i0);
-                r_pos[0] = v_pos.x; r_pos[1] = v_pos.y; r_pos[2] = v_pos.z; r_pos[3] = v_pos.w;
-                r_mpos[0] = v_mpos.x; r_mpos[1] = v_mpos.y; r_mpos[2] = v_mpos.z; r_mpos[3] = v_mpos.w;
-                r_flag[0] = v_flag.x; r_flag[1] = v_flag.y; r_flag[2] = v_flag.z; r_flag[3] = v_flag.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t i = i0 + k;
-                const bool in = i < a.n;
-                r_tid[k] = in ? a.tid[i] : -1;
-                r_mtid[k] = in ? a.mtid[i] : -1;           // tid == mtid == -1: no candidate, out of range: no coverage
-                r_pos[k] = in ? a.pos[i] : 0;
-                r_mpos[k] = in ? a.mpos[i] : 0;
-                r_flag[k] = in ? a.flag[i] : 0;
-                r_mapq[k] = in ? a.mapq[i] : 0;
-                r_qlen[k] = in ? a.qlen[i] : 0;
-            }
-        }
-        // ---- coverage of the tid == mtid records [:138-139]
-        const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
-        bool uni = true;
-        int mine = 0;
-        bool cand[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cand[k] = r_tid[k] != r_mtid[k];
-            uni = uni && (r_tid[k] == ref);
-            const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-            // a candidate's own coverage is credited here too, with its neighbours' (same contig, same reduction): all it
-            // takes beyond theirs is a mate on a contig of the header; the evaluation round takes it back in the rare case
-            // that one of the two contigs is not in the table (a reduction per round for it cost 0.1 ms on C3)
-            if (cov && (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs)) mine += (int)r_qlen[k];
-        }
-        if (__all(uni)) {
-            const int s = wave_sum(mine);
-            if (ref != run_tid) {
-                if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
-                    atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
-                run_tid = ref;
-                run_sum = 0;
-            }
-            run_sum += s;
-        } else {
-            // a contig boundary (or unsorted input) inside the wave: run-segmented reduction over the lanes, a lane
-            // that itself straddles a boundary adds its records directly (see stream_kernel)
-            const bool lane_uni = r_tid[0] == r_tid[1] && r_tid[0] == r_tid[2] && r_tid[0] == r_tid[3];
-            int32_t key = (int32_t)(0x80000000u | (uint32_t)lane);
-            int val = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
-                const bool act = cov && (uint32_t)r_tid[k] < (uint32_t)a.n_contigs &&
-                                 (!cand[k] || (uint32_t)r_mtid[k] < (uint32_t)a.n_contigs);
-                if (!act) continue;
-                if (lane_uni) val += (int)r_qlen[k];
-                else atomicAdd(&aligned[r_tid[k]], (unsigned long long)r_qlen[k]);
-            }
-            if (lane_uni) key = r_tid[0];
-            wave_add_runs(aligned, key, val, lane);
-        }
-        // ---- candidates -> LDS, in record order (record = 4 * lane + k inside the wave's 256)
-        const unsigned long long b0 = __ballot(cand[0]), b1 = __ballot(cand[1]);
-        const unsigned long long b2 = __ballot(cand[2]), b3 = __ballot(cand[3]);
-        const int wcount = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        int* wcnt = s_wcnt[st & 1];
-        if (lane == 0) wcnt[wave] = wcount;
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) before += wcnt[w];
-            total += wcnt[w];
-        }
-        total = __builtin_amdgcn_readfirstlane(total);
-        // uniform: a third of C3's sub-tiles hold no candidate at all (the counts are double buffered: the next sub-tile
-        // writes the other set, and nobody reaches the one after it before all have read this one)
-        if (total == 0) continue;
-        int slot = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask) + __popcll(b2 & lt_mask) + __popcll(b3 & lt_mask) + before;
-        slot += q_head + q_count;                           // behind the queued ones (at most 255 + 1024 entries in all)
-        slot = slot >= kFusedRing ? slot - kFusedRing : slot;
-        slot = slot >= kFusedRing ? slot - kFusedRing : slot;
-        if (wcount)                                         // uniform per wave
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (cand[k]) {
-                s_buf[0][slot] = (uint32_t)r_tid[k];
-                s_buf[1][slot] = (uint32_t)r_mtid[k];
-                s_buf[2][slot] = (uint32_t)r_pos[k];
-                s_buf[3][slot] = (uint32_t)r_mpos[k];
-                s_buf[4][slot] = (r_flag[k] & 0xffffu) | (r_mapq[k] << 16);
-                reinterpret_cast<unsigned short*>(s_qlen)[slot] = (unsigned short)r_qlen[k];
-                ++slot;
-                slot = slot == kFusedRing ? 0 : slot;
-            }
-        }
-        __syncthreads();
-        q_count += total;
-        while (q_count >= kFusedThreads) run_round(kFusedThreads);
-    }
-    if (q_count > 0) run_round(q_count);                    // the unfinished round (uniform)
-    if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
-        atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
-    // ---- block summary (same planes as ordered_kernel's Chain::publish)
-    {
-        const int vals[7] = {c_count, c_nonuniq, c_nus, c_dup, c_long, c_fishy, c_reach};
-#pragma unroll
-        for (int f = 0; f < 7; ++f) {
-            const int v = wave_sum(vals[f]);
-            if (lane == 0) s_red[wave][f] = v;
-        }
-    }
-    __syncthreads();
-    if (a.ps_table) {
-        uint32_t* row = a.ps_table + (size_t)(blockIdx.x & (uint32_t)(a.ps_rows - 1)) * 512u;
-        for (int d = t; d < 512; d += kFusedThreads) {
-            const uint32_t c = s_ph[d];
-            if (c) atomicAdd(&row[d], c);
-        }
-    }
-    if (wave != 0) return;
-    const int par = round & 1;
-    uint32_t v = 0;
-    if (lane == kSumEmit) v = (uint32_t)s_state[par][3];
-    if (lane == kSumHas) v = s_state[par][4] ? 1u : 0u;
-    if (lane == kSumFirst1) v = s_head[0] ? (uint32_t)s_head[1] : 0u;
-    if (lane == kSumFirst2) v = s_head[0] ? (uint32_t)s_head[2] : 0u;
-    if (lane == kSumLast1) v = (uint32_t)s_state[par][1];
-    if (lane == kSumLast2) v = (uint32_t)s_state[par][2];
-    if (lane == kSumHeadInfo) v = s_head[0] ? (uint32_t)s_head[3] : 0u;
-    if (lane == kSumHeadSlot) v = s_head[0] ? (uint32_t)s_head[4] : kNoSlot;
-    if (lane >= kSumCtr0 && lane < kSumCtr0 + 7)
-        v = (uint32_t)(s_red[0][lane - kSumCtr0] + s_red[1][lane - kSumCtr0] + s_red[2][lane - kSumCtr0] + s_red[3][lane - kSumCtr0]);
-    if (lane < kSumPlanes) summ.at(lane, blockIdx.x) = v;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// fused_wave_kernel: the same single pass with ONE WAVE per block and no workgroup barrier anywhere.
-// fused_kernel's four waves meet at ~65 barriers per block (three per sub-tile, two per evaluation round) and pass
-// the chain's state through LDS; whenever one wave waits for memory the other three wait with it.  Here a block of
-// 16 384 records belongs to a single-wave workgroup that walks it in 64 sub-tiles of 256 records: its candidates queue
-// up in the wave's own LDS ring and are evaluated 64 at a time, the duplicate chain / acceptance / ordered emission
-// are ballots and wave-uniform (scalar) state - prev_obs, emission base, head - and waves on a SIMD overlap freely.
-// Same loads (candidate-free lanes skip pos / mpos / flag), same coverage scheme, same block summary and segments as
-// fused_kernel, so everything behind the record loop is shared.
+// fused_wave_kernel: the record loop of a candidate-DENSE library (mate pairs: a fifth of the records have their mate
+// on another contig) in ONE pass over the seven columns.  stream_kernel + ordered_kernel read such a library twice - the
+// candidates' scattered column reads re-read the whole record set - and ordered_kernel spends most of its instructions
+// locating the r-th set bit of a group mask.  Here a block of 16 384 records belongs to ONE WAVE (a single-wave workgroup,
+// no barrier anywhere) that walks it in 64 sub-tiles of 256 records:
+//   coalesced loads of the seven columns; tid == mtid records only add coverage (a running (contig, sum), flushed with
+//   one atomic when the contig changes); candidates are compacted, in stream order, into the wave's own LDS ring and
+//   evaluated 64 at a time: lane j evaluates candidate j - two contig rows (L2), PosDirCalculator, link dispatch -, then
+//   the order-dependent part (duplicate chain, acceptance, counters, ordered emission into the block's segment) as
+//   ballots over wave-uniform (scalar) state: prev_obs, emission base, head.
+// It publishes the same block summary as ordered_kernel, so stitch_kernel / compact_kernel and the sharded build's head /
+// tail logic are shared by both paths.  besst_lib_params.record_path selects the path (the host samples the candidate
+// density).  (Round 2's form of this pass - four waves per block that met at ~65 workgroup barriers per block and passed
+// the chain's state through LDS: whenever one wave waited for memory the other three waited with it, 1.74 ms on full C3
+// against 1.45 here - was removed in round 4.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFwSub = 256;                              // records per sub-tile: four per lane
 constexpr int kFwRing = kFwSub + 64;                     // a sub-tile's worth of candidates + an unfinished round
@@ -1065,7 +731,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         const uint32_t fm = r.fm, qlen = r.qlen;
         const bool in_range = live && (uint32_t)tid < (uint32_t)a.n_contigs && (uint32_t)mtid < (uint32_t)a.n_contigs;
         const Eval e = eval_record(a, in_range, r.c1, r.c2, tid, mtid, pos, mpos, fm & 0xffffu, fm >> 16);
-        // (see fused_kernel: the coverage credited with the streamed records is taken back when a contig is not in the table)
+        // (the coverage credited with the streamed records is taken back when a contig is not in the table)
         if (in_range && !(e.bits & EV_COV) && ((int32_t)(fm >> 16) >= a.min_mapq || (fm >> 16) == 0u))
             cov_add(tid, 0ull - (unsigned long long)qlen);
         const bool reach = live && (e.bits & EV_REACH), fishy = live && (e.bits & EV_FISHY);
@@ -1198,7 +864,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     auto process = [&](const int32_t (&r_tid)[4], const int32_t (&r_mtid)[4], const int32_t (&r_pos)[4],
                        const int32_t (&r_mpos)[4], const uint32_t (&r_flag)[4], const uint32_t (&r_mapq)[4],
                        const uint32_t (&r_qlen)[4]) {
-        // ---- coverage [:138-139], candidates included on the cheap part of their condition (see fused_kernel)
+        // ---- coverage [:138-139], candidates included on the cheap part of their condition
         const int32_t ref = __builtin_amdgcn_readfirstlane(r_tid[0]);
         bool uni = true;
         int mine = 0;
@@ -1400,7 +1066,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     if (q_count > 0) run_round(q_count);                    // the unfinished round (uniform)
     if (lane == 0 && run_sum && (uint32_t)run_tid < (uint32_t)a.n_contigs)
         atomicAdd(&aligned[run_tid], (unsigned long long)run_sum);
-    // ---- block summary (same planes as fused_kernel / ordered_kernel)
+    // ---- block summary (same planes as ordered_kernel)
     const int vals[7] = {(int)(c_count_nus & 0xffffu), (int)(c_nonuniq_fishy & 0xffffu), (int)(c_count_nus >> 16),
                          (int)(c_dup_long & 0xffffu), (int)(c_dup_long >> 16), (int)(c_nonuniq_fishy >> 16), 0};
     int tot[7];
@@ -1967,16 +1633,10 @@ __global__ void resolve_carry_kernel(const int32_t* __restrict__ tails, int rank
 
 }  // namespace
 
-// BESST_FUSED_FORM (A/B runs, tests): 0 = four waves per block with workgroup barriers, 1 = one wave per block
-static int fused_form() {
-    static const int form = [] { const char* e = getenv("BESST_FUSED_FORM"); return e ? atoi(e) : 1; }();
-    return form;
-}
-
 bool classify_can_group_runs(const ClassifyArgs& a) {
     // BESST_LOOP_RUNS=0 (A/B runs, tests): the record loop writes keys and rg_group_kernel finds the runs
     static const int knob = [] { const char* e = getenv("BESST_LOOP_RUNS"); return e ? atoi(e) : 1; }();
-    return knob != 0 && a.record_path == 1 && fused_form() == 1 && a.n > 0;
+    return knob != 0 && a.record_path == 1 && a.n > 0;
 }
 
 int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned, besst_counters* counters,
@@ -1993,18 +1653,14 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     // latency bound at 3 waves per SIMD.  The split design below serves every library.)
     BESST_REQUIRE(!group_runs || classify_can_group_runs(a), "classify: this record loop cannot group runs");
     if (a.record_path == 1) {
-        const int form = fused_form();
         if (group_runs) BESST_HIP_TRY(hipMemsetAsync(w.run_status, 0, 4, s));
-        ProfScope ps(s, form == 1 ? kProfFusedWave : kProfFused);
-        if (form == 1 && group_runs)
+        ProfScope ps(s, kProfFusedWave);
+        if (group_runs)
             hipLaunchKernelGGL(fused_wave_kernel<true>, dim3(nblocks), dim3(64), 0, s, a,
                                reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
-        else if (form == 1)
+        else
             hipLaunchKernelGGL(fused_wave_kernel<false>, dim3(nblocks), dim3(64), 0, s, a,
                                reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
-        else
-        hipLaunchKernelGGL(fused_kernel, dim3(nblocks), dim3(kFusedThreads), 0, s, a,
-                           reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
         BESST_HIP_TRY(hipGetLastError());
         return BESST_OK;
     }
@@ -2140,8 +1796,7 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
     ClassifyArgs b = a;
     if (presort && presort->table) {
         pre = *presort;
-        static const int knob = [] { const char* e = getenv("BESST_PRESORT_IN_LOOP"); return e ? atoi(e) : 1; }();
-        pre.in_record_loop = knob && a.record_path == 1 && a.n > 0;
+        pre.in_record_loop = a.record_path == 1 && a.n > 0;
         if (pre.in_record_loop && pre.count) {
             BESST_REQUIRE(pre.rows > 0 && (pre.rows & (pre.rows - 1)) == 0, "classify: bad presort description");
             BESST_HIP_TRY(hipMemsetAsync(pre.table, 0, (size_t)pre.rows * 512 * sizeof(uint32_t), s));
@@ -2150,8 +1805,6 @@ int launch_classify(hipStream_t s, const ClassifyArgs& a, int32_t* carry, int64_
         // (a stage 2 that groups runs never reads the histograms: the loop hands its segments over and counts nothing -
         // and where it can, it finds the runs itself)
     }
-    static const int seg_knob = [] { const char* e = getenv("BESST_SEGMENTED"); return e ? atoi(e) : 1; }();
-    pre.segmented = pre.segmented && seg_knob;
     const bool group_runs = pre.table && pre.in_record_loop && !pre.count && pre.segmented && classify_can_group_runs(a);
     int rc = launch_classify_scan(s, b, aligned, counters, ws, ws_bytes, group_runs);
     if (rc) return rc;

@@ -69,7 +69,7 @@ int launch_bam_decode(hipStream_t s, const uint8_t* inflated, const BgzfBlock* b
 enum ProfSlot {
     // one slot per kernel (or per group of kernels that always run back to back): the names besst_prof_slot_name returns
     // are the kernels' own names, the ones a rocprofv3 trace of the same run shows
-    kProfStream = 0, kProfFused, kProfFusedWave, kProfOrdered, kProfStitch, kProfFixup, kProfCompact,
+    kProfStream = 0, kProfFusedWave, kProfOrdered, kProfStitch, kProfFixup, kProfCompact,
     kProfRadixHist, kProfRadixScan, kProfRadixScatter, kProfBucketSort, kProfBucketReduce, kProfRowHeads, kProfRowScan, kProfRowReduce,
     kProfOsHist, kProfOsOffsets, kProfOsScatter, kProfOsBucket, kProfOsBucketRows, kProfOsReduce, kProfOsFixup,
     kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfMsdPartition,
@@ -167,8 +167,8 @@ struct ClassifyArgs {
     int32_t detect_dup;
     int32_t extend_paths;
     int32_t no_score;
-    int32_t record_path;   // 0: stream_kernel + ordered_kernel (sparse candidates), 1: fused_kernel (dense)
-    // fused_kernel counts the sort's two stream-pass digits of every tuple it emits (PresortSpec; nullptr: off)
+    int32_t record_path;   // 0: stream_kernel + ordered_kernel (sparse candidates), 1: fused_wave_kernel (dense)
+    // fused_wave_kernel counts the sort's two stream-pass digits of every tuple it emits (PresortSpec; nullptr: off)
     uint32_t* ps_table;
     int32_t ps_rows, ps_shift;
     uint64_t ps_base;

@@ -1565,12 +1565,11 @@ static_assert(kOsPresortRows <= kOsHistBlocks, "the table is sized for kOsHistBl
 
 // the two-pass + buckets form (3b) serves packed keys of four digits or more
 static bool os_hybrid(int64_t cap, int key_bits) {
-    static const int hybrid_knob = [] { const char* e = getenv("BESST_SORT_HYBRID"); return e ? atoi(e) : 1; }();
     const int passes = (key_bits + kOsBits - 1) / kOsBits;
     int idx_bits = 1;
     while (((int64_t)1 << idx_bits) < cap) ++idx_bits;
     const bool packed = key_bits + idx_bits <= 64;
-    return hybrid_knob && packed && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31 && cap <= ((int64_t)1 << 30);
+    return packed && kOsBits == 8 && passes >= 4 && key_bits - 16 <= 31 && cap <= ((int64_t)1 << 30);
 }
 
 bool onesweep_presort_spec(int64_t cap, int key_bits, uint64_t key_base, void* ws, PresortSpec* out) {

@@ -850,8 +850,7 @@ size_t runs_workspace_bytes(int64_t cap) {
 }
 
 bool runs_enabled(int64_t cap) {
-    static const int knob = [] { const char* e = getenv("BESST_SORT_RUNS"); return e ? atoi(e) : 1; }();
-    return knob != 0 && cap >= 1 && cap <= ((int64_t)1 << 30);
+    return cap >= 1 && cap <= ((int64_t)1 << 30);
 }
 
 int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int key_bits, const uint64_t* keys,

@@ -403,3 +403,33 @@ def test_a_wrong_block_crc_is_refused_by_both_forms():
         assert 'status 5' in str(e.value)
         with pytest.raises((_lib.BesstDeviceError, IOError)):
             bamio.ResidentBam(path, threads=2, mode='auto')
+
+
+_PROFILE_SCRIPT = r'''
+import os, sys, tempfile
+sys.path.insert(0, %(repo)r)
+from besst_amd import bamio
+from tests import test_gpu_ingest as T
+batch = T._library(6000)
+with tempfile.TemporaryDirectory() as tmp:
+    path = os.path.join(tmp, 'x.bam')
+    bamio.write_bam(path, batch, threads=2, level=1)
+    for mode in ('device', 'host'):
+        bam = bamio.ResidentBam(path, threads=2, mode=mode)
+        assert len(bam) == len(batch)
+        bam.close()
+print('DONE')
+'''
+
+
+def test_profile_knobs_print_their_phase_times():
+    """BESST_INGEST_PROFILE=1 / BESST_BAM_PROFILE=1 (development aids of tools/ingest_probe.py and tools/bam_probe.py,
+    read by the native code at call time): a line of phase times per call on stderr, the ingest itself unchanged."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, BESST_INGEST_PROFILE='1', BESST_BAM_PROFILE='1')
+    out = subprocess.run([sys.executable, '-c', _PROFILE_SCRIPT % dict(repo=os.path.dirname(here))], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert 'DONE' in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
+    assert '[push_bam_device] alloc' in out.stderr and '[bam] read' in out.stderr, out.stderr[-2000:]
