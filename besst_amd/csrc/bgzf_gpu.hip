@@ -48,6 +48,7 @@ namespace {
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
 constexpr int kClBits = 7;
+constexpr int kLaneLongBits = 3;                 // literal / length codes of up to kTabBits + 3 bits are decoded by the lanes too
 constexpr uint32_t kGroupLit = 0x80000000u;   // output group: the lane holds a literal (else a source position, < 2^31)
 constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is no short code: length nibble 0, and not below 0x1000 (a literal)
 
@@ -59,6 +60,7 @@ enum : uint32_t {
 
 struct CanonLds {               // per code: count / first code / offset per length, symbols sorted by (length, symbol)
     uint16_t cnt[16], first[16], offs[16];
+    unsigned long long pk[16];  // the same, one word per length: first | cnt << 16 | offs << 32
 };
 
 struct InflateLds {
@@ -71,6 +73,7 @@ struct InflateLds {
     CanonLds lit_c, dist_c, cl_c;
     uint8_t lens[288 + 32 + 16];
     uint8_t cl_lens[32];
+    uint32_t mark[64];          // emission: which symbol of the batch begins at a lane of the output group
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -113,6 +116,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
         c->cnt[lane] = (uint16_t)cv;
         c->first[lane] = (uint16_t)fv;
         c->offs[lane] = (uint16_t)ov;
+        c->pk[lane] = (unsigned long long)fv | ((unsigned long long)cv << 16) | ((unsigned long long)ov << 32);
     }
     uint32_t run[16];
 #pragma unroll
@@ -147,20 +151,29 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
 }
 
 // a code longer than the primary table: canonical decode of the next 15 bits (uniform); 0 = not a code
-// (z: an opaque zero the caller makes where the rare path begins - with addresses that depend on it the fifteen table
-// words are read THERE; hoisted, they were read and unpacked once per batch of symbols: ~60 instructions in front of ~5 symbols)
-__device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t* sorted, uint32_t low15, int bits, uint32_t z = 0u) {
+__device__ __forceinline__ uint32_t slow_code(const CanonLds* c, const uint16_t* sorted, uint32_t low15, int bits) {
     const uint32_t r = __brev(low15) >> 17;
     for (int L = bits + 1; L < 16; ++L) {
-        const uint32_t d = (r >> (15 - L)) - (uint32_t)c->first[z + L];
-        if (d < (uint32_t)c->cnt[z + L]) return ((uint32_t)sorted[(uint32_t)c->offs[z + L] + d] << 4) | (uint32_t)L;
+        const uint32_t d = (r >> (15 - L)) - (uint32_t)c->first[L];
+        if (d < (uint32_t)c->cnt[L]) return ((uint32_t)sorted[(uint32_t)c->offs[L] + d] << 4) | (uint32_t)L;
     }
     return 0u;
 }
-__device__ __forceinline__ uint32_t opaque_zero() {
-    uint32_t z = 0;
-    asm volatile("" : "+s"(z));
-    return z;
+// inclusive scans over the wave (DPP row shifts inside the rows of 16, then row_bcast 15 and 31): sums and maxima of
+// values that are zero / non-negative where a lane takes no part
+__device__ __forceinline__ uint32_t scan_add(uint32_t v) {
+#define BESST_SCAN_STEP(ctrl, rows) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false);
+    BESST_SCAN_STEP(0x111, 0xf) BESST_SCAN_STEP(0x112, 0xf) BESST_SCAN_STEP(0x114, 0xf) BESST_SCAN_STEP(0x118, 0xf)
+    BESST_SCAN_STEP(0x142, 0xa) BESST_SCAN_STEP(0x143, 0xc)
+#undef BESST_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ uint32_t scan_max(uint32_t v) {
+#define BESST_SCAN_STEP(ctrl, rows) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false); v = o > v ? o : v; }
+    BESST_SCAN_STEP(0x111, 0xf) BESST_SCAN_STEP(0x112, 0xf) BESST_SCAN_STEP(0x114, 0xf) BESST_SCAN_STEP(0x118, 0xf)
+    BESST_SCAN_STEP(0x142, 0xa) BESST_SCAN_STEP(0x143, 0xc)
+#undef BESST_SCAN_STEP
+    return v;
 }
 
 // The input as the symbol loop wants it: a POSITION in a window of 64 dwords that the lanes hold (a dword each), not a
@@ -220,13 +233,13 @@ struct BitReader {
 
 }  // namespace
 
-// what lane i found at bit i of the window: the literal / length symbol (A) and the distance symbol (B) that would begin there
-//   A: bits | kind << 5 | literal or match length << 8     B: bits | kWalkLongDist | distance << 8
-// kWalkLong: the pattern is no code of the primary table - a longer code or none - and is decoded where the walk meets it
-constexpr uint32_t kWalkLit = 0u, kWalkLen = 1u, kWalkLong = 2u, kWalkEnd = 3u;
-constexpr uint32_t kWalkLongDist = 32u;
+// what lane i found at bit i of the window, as the walk reads it: the bits of the whole symbol that would begin there (a
+// literal, or a length with its distance), or kWalkStop where that is nothing the batch can take (the end of the block, a
+// code longer than the table, an invalid symbol, a match whose distance code begins beyond the 64 positions looked at)
+constexpr uint32_t kWalkStop = 0x40u;
+constexpr uint32_t kBadDist = 0x80u;                    // lane's distance symbol: bits | distance << 8, or this
 
-__global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+__global__ __launch_bounds__(64, 6) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
                                                           uint32_t n_blocks, uint8_t* dst, uint32_t* __restrict__ status) {
     __shared__ InflateLds s;
     const int lane = threadIdx.x;
@@ -277,16 +290,46 @@ __global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __re
     auto get_byte = [&](uint32_t at) -> uint32_t {
         return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    // A group of output bytes whose gather is in flight: the memory round trip of a flush (~2.5 us with the window in HBM /
-    // L2; ~1500 of them per block of a sequencer's file were two thirds of a block's time) is waited for at the NEXT flush,
-    // with a group's worth of symbols decoded in between.  A group is stored before the gather of the next one is issued, so
-    // that gather - and every load behind it - sees its bytes.
-    uint32_t pend_n = 0, pend_pos = 0;                       // uniform: bytes of the pending group (0: none), where they go
-    uint32_t pend_g = 0, pend_v = 0;                         // lane k: kGroupLit | literal, or the byte the gather brought
+    // ---- output leaves in GROUPS of up to 64 bytes: lane k of the group stands for the byte at pos + k and holds either a
+    // literal (flagged by the top bit) or the place its byte is copied from.  A full group (or the end of the block)
+    // flushes it: ONE gather of the lanes that copy from finished output, ONE contiguous store.  A lane that copies from a
+    // lane of its own group (a match close behind its source, or one that overlaps it) is resolved in registers: every
+    // lane follows its source to a lane that holds a byte (six doubling steps of a lane permute, only when there is such
+    // a lane).  The group's gather stays in flight while the next group is decoded: it is waited for, and the group
+    // stored, at the next flush - before that group's gather is issued, so that every load sees the bytes in front of it.
+    uint32_t g = 0;                                          // lane k: kGroupLit | its literal, or where its byte is copied from
+    uint32_t filled = 0;                                     // uniform: lanes of the group in use
+    uint32_t pend_n = 0, pend_pos = 0;                       // uniform: bytes of the group in flight (0: none), where they go
+    uint32_t pend_g = 0, pend_v = 0, pend_s = 0;             // its lanes: literal / the gather's byte / the lane to take the byte from
+    bool pend_res = false;                                   // uniform: some lane takes its byte from another lane
     auto retire = [&]() {
         if (pend_n != 0u) {                                  // uniform
-            if ((uint32_t)lane < pend_n) put_byte(pend_pos + (uint32_t)lane, (pend_g & kGroupLit) ? pend_g : pend_v);
+            uint32_t val = (pend_g & kGroupLit) ? pend_g : pend_v;
+            if (pend_res) val = (uint32_t)__shfl((int)val, (int)pend_s, 64);
+            if ((uint32_t)lane < pend_n) put_byte(pend_pos + (uint32_t)lane, val);
             pend_n = 0;
+        }
+    };
+    auto flush_group = [&]() {
+        if (filled != 0u) {                                  // uniform
+            retire();                                        // (its bytes may be what this group copies from)
+            const bool copy = (uint32_t)lane < filled && !(g & kGroupLit);
+            const bool own = copy && g >= pos;               // the source is a lane of this very group
+            // (every lane loads - one that copies nothing reads the block's first byte -, so that no branch stands between
+            // the load and its use at the next flush: behind a branch the compiler waits for it at once)
+            pend_v = get_byte((copy && !own) ? g : 0u);
+            uint32_t src = own ? g - pos : (uint32_t)lane;
+            pend_res = __ballot(own) != 0ull;
+            if (pend_res) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) src = (uint32_t)__shfl((int)src, (int)src, 64);
+            }
+            pend_s = src;
+            pend_g = g;
+            pend_pos = pos;
+            pend_n = filled;
+            pos = uni(pos + filled);
+            filled = 0;
         }
     };
     for (;;) {
@@ -304,6 +347,8 @@ __global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __re
             if (at - in_base + len > src_len) { err = kInfInputOverrun; break; }
             if (pos + len > dst_len) { err = kInfOutputOverrun; break; }
             const uint8_t* from = reinterpret_cast<const uint8_t*>(br.words) + at;
+            flush_group();                                   // (what a Huffman block in front of this one left)
+            retire();
             for (uint32_t i = (uint32_t)lane; i < len; i += 64u) put_byte(pos + i, from[i]);
             pos += len;
             br.seek(at + len);
@@ -370,177 +415,162 @@ __global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __re
             __builtin_amdgcn_wave_barrier();
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kTabBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
-            // ---- the symbols.  Output leaves in GROUPS of up to 64 bytes: lane k of the group stands for the byte at
-            // pos + k and holds either a literal (flagged by the top bit) or the place its byte is copied from; a literal
-            // is a compare and a select, a match two compares and a select per piece.  A full group -
-            // or a match whose source reaches into the group, or the end of the block - flushes it: ONE gather of the
-            // lanes that copy, ONE contiguous store.  The memory round trip of a match (~1 us with the window in HBM / L2,
-            // and a wave has nothing else to do meanwhile) is paid once per 64 bytes of output instead of once per match
-            // (a sequencer's file: 5241 matches of 9.7 bytes and 8865 literals in a block of 60 KB).
-            uint32_t g = 0;                                  // lane k: kGroupLit | its literal, or where its byte is copied from
-            uint32_t filled = 0;                             // uniform: lanes of the group in use
-            auto flush_group = [&]() {
-                if (filled != 0u) {
-                    retire();                                // (its bytes may be what this group copies from)
-                    // (every lane loads - one that copies nothing reads the block's first byte -, so that no branch stands
-                    // between the load and its use at the next flush: behind a branch the compiler waits for it at once)
-                    pend_v = get_byte(((uint32_t)lane < filled && !(g & kGroupLit)) ? g : 0u);
-                    pend_g = g;
-                    pend_pos = pos;
-                    pend_n = filled;
-                    pos = uni(pos + filled);                 // (kept scalar by force: without it the compiler turns this
-                    filled = 0;                              // branch into selects and the whole symbol loop into vector code)
-                }
-            };
-            for (;;) {                                       // a batch of symbols per turn
+            // ---- the symbols, a batch per turn.  One symbol at a time cost ~50 scalar instructions and branches per symbol,
+            // and a SIMD issues ONE of those per four cycles for all its waves: by the counters that slot was 90 % in use
+            // and the vector slot 30 % (a sequencer's file: 14 000 symbols per block, more than half of them matches of ~7
+            // bytes).  So the work is moved to the vector side:
+            //   1. the 64 lanes decode what WOULD begin at each of the next 64 bit positions - literal / length symbol, the
+            //      distance symbol a length would be followed by (fetched from the lane where it begins), bits and output
+            //      bytes of the whole symbol: the same vector instructions for one lane or for all;
+            //   2. the symbols that really begin there are found by following the bit counts from position 0 - a
+            //      v_readlane, a bit set and an addition per symbol, the only per-symbol scalar work left;
+            //   3. those symbols' bytes are laid into the output group by the lanes: an exclusive scan of their lengths says
+            //      where each begins, a marker per symbol and a max-scan say which symbol a byte belongs to, a lane permute
+            //      fetches its literal or distance.
+            // What a batch cannot take - the end of the block, a code longer than the table - is decoded on its own.
+            for (;;) {
                 // (once per turn: a corrupt stream is not followed more than a few hundred bytes past its payload - the
                 // chunk's buffer has 4 KB behind its last block)
                 if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
-                // ---- several symbols at once.  One symbol at a time cost ~49 scalar instructions and branches per symbol,
-                // and a SIMD issues one of those per four cycles for all its waves: that slot is what a sequencer's file
-                // (14 000 symbols per block, more than half of them matches of ~7 bytes) saturates.  The 64 lanes instead
-                // decode what WOULD begin at each of the next 64 bit positions - the table look-ups, base and extra bits of a
-                // symbol are the same vector instructions for one lane or for all -, and the symbols that really begin
-                // there are found by following the bit counts from position 0: a v_readlane per symbol, eleven scalar
-                // instructions per literal, about twenty-five per match.
                 uint32_t v[4];
                 const uint32_t t = br.ahead(v) + (uint32_t)lane;                   // the lane's bit, counted from v[0]
                 const uint32_t lo = t < 32u ? v[0] : t < 64u ? v[1] : v[2], hi = t < 32u ? v[1] : t < 64u ? v[2] : v[3];
                 const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, t & 31u);     // 32 bits of input from that bit on
                 const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
                 const uint32_t eb = s.dist_tab[x & (uint32_t)(kTabSize - 1)];
-                const uint32_t la = ea & 15u, sa = ea >> 4;
-                const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
-                const uint32_t xa = li >> 9;                 // (garbage unless sa is a length code: not used then)
-                const uint32_t mlen = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
-                uint32_t wa = kWalkLong << 5;                // a longer code, no code, or an invalid symbol (286, 287)
-                if (la != 0u) {
-                    if (sa < 256u) wa = la | (kWalkLit << 5) | (sa << 8);
-                    else if (sa == 256u) wa = la | (kWalkEnd << 5);
-                    else if (sa < 286u) wa = (la + xa) | (kWalkLen << 5) | (mlen << 8);
+                uint32_t la = ea & 15u, sa = ea >> 4;
+                {
+                    // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals), decoded
+                    // by the lanes as well: canonically, a table word per length (the same for every lane)
+                    const uint32_t r = __brev(x) >> 17;      // the next 15 bits, first bit on top
+                    uint32_t at = 0xffffffffu;
+#pragma unroll
+                    for (int L = kTabBits + 1; L <= kTabBits + kLaneLongBits; ++L) {
+                        const unsigned long long k = s.lit_c.pk[L];
+                        const uint32_t d = (r >> (15 - L)) - ((uint32_t)k & 0xffffu);
+                        if (la == 0u && d < ((uint32_t)(k >> 16) & 0xffffu)) {
+                            la = (uint32_t)L;
+                            at = (uint32_t)(k >> 32) + d;
+                        }
+                    }
+                    if (at != 0xffffffffu) sa = s.lit_sorted[at];
                 }
+                const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
+                const bool is_lit = la != 0u && sa < 256u, is_len = la != 0u && sa > 256u && sa < 286u;
+                const uint32_t xa = is_len ? li >> 9 : 0u;
+                const uint32_t mlen = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
                 const uint32_t lb = eb & 15u, sb = eb >> 4;
                 const uint32_t di = (uint32_t)__shfl((int)dist_info, (int)sb, 64);
                 const uint32_t xb = di >> 16;
                 const uint32_t mdist = (di & 0xffffu) + ((x >> lb) & ((1u << xb) - 1u));
-                const uint32_t wb = (lb != 0u && sb < 30u) ? (lb + xb) | (mdist << 8) : kWalkLongDist;
-                uint32_t p = 0;                              // bits of the window the walk has consumed (uniform)
-                bool done = false;
-                uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)wa, 0);
-                for (;;) {
-                    // literals with a code of the table, until the group is full or the window used up: ONE way out of this
-                    // loop (kind, filled and p in one test)
-                    while ((((a >> 5) & 3u) | (filled >> 6) | (p >> 6)) == 0u) {
-                        g = (uint32_t)lane == filled ? kGroupLit | (a >> 8) : g;
-                        ++filled;
-                        p += a & 31u;
-                        a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
-                    }
-                    if (filled == 64u) {
-                        if (pos + 64u > dst_len) { err = kInfOutputOverrun; break; }
-                        flush_group();
-                        continue;                            // (`a` still stands for position p, if that is in the window)
-                    }
-                    if (p >= 64u) break;
-                    uint32_t kind = (a >> 5) & 3u;
-                    if (kind == kWalkLong) {
-                        // a code longer than the table (or no code): canonical decode of the 15 bits at p, on the spot
-                        const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)p);
-                        const uint32_t e = uni(slow_code(&s.lit_c, s.lit_sorted, xs & 0x7fffu, kTabBits, opaque_zero()));
-                        if (e == 0u) { err = kInfBadCode; break; }
-                        const uint32_t l = e & 15u, sym = e >> 4;
-                        if (sym < 256u) {
-                            g = (uint32_t)lane == filled ? kGroupLit | sym : g;
-                            ++filled;
-                            p += l;
-                            a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
-                            continue;
-                        }
-                        if (sym == 256u) {
-                            a = l | (kWalkEnd << 5);
-                            kind = kWalkEnd;
-                        } else {
-                            if (sym >= 286u) { err = kInfBadCode; break; }
-                            const uint32_t li2 = (uint32_t)__builtin_amdgcn_readlane((int)len_info, (int)(sym - 257u));
-                            const uint32_t x2 = li2 >> 9;
-                            a = (l + x2) | (kWalkLen << 5) | (((li2 & 0x1ffu) + ((xs >> l) & ((1u << x2) - 1u))) << 8);
-                            kind = kWalkLen;
-                        }
-                    }
-                    if (kind == kWalkEnd) {
-                        p += a & 31u;
-                        done = true;
-                        break;
-                    }
-                    // ---- a match: its distance symbol begins at q
-                    const uint32_t q = p + (a & 31u);
-                    if (q >= 64u) break;                     // beyond what the lanes looked at: the next batch begins with it
-                    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)wb, (int)q);
-                    if (d & kWalkLongDist) {
-                        const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)q);
-                        const uint32_t e = uni(slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kTabBits, opaque_zero()));
-                        if (e == 0u || (e >> 4) >= 30u) { err = kInfBadCode; break; }
-                        const uint32_t l = e & 15u;
-                        const uint32_t di2 = (uint32_t)__builtin_amdgcn_readlane((int)dist_info, (int)(e >> 4));
-                        const uint32_t x2 = di2 >> 16;
-                        d = (l + x2) | (((di2 & 0xffffu) + ((xq >> l) & ((1u << x2) - 1u))) << 8);
-                    }
-                    const uint32_t length = a >> 8, dist = d >> 8;
-                    const uint32_t fl = filled + length, at = pos + filled;        // where the match begins
-                    // the common case in ONE test (four differences, their sign bits): the match fits the group's free lanes,
-                    // its source lies wholly in finished output in front of the group, not in front of the block, and the
-                    // output has room for it
-                    if ((int32_t)((64u - fl) | (dist - fl) | (at - dist) | (dst_len - pos - fl)) >= 0) {
-                        g = (uint32_t)lane - filled < length ? at - filled + (uint32_t)lane - dist : g;
-                        filled = fl;
-                        if (filled == 64u) flush_group();
-                    } else {
-                        if (dist > at) { err = kInfBadDistance; break; }
-                        if (at + length > dst_len) { err = kInfOutputOverrun; break; }
-                        if (dist >= length) {
-                            // every byte's source is finished output - once the group is out of the way where the source
-                            // reaches into it.  The match joins the group piece by piece: the byte at P comes from P - dist.
-                            if (at - dist + length > pos) flush_group();
-                            uint32_t left = length;
-                            while (left != 0u) {             // uniform
-                                const uint32_t room = 64u - filled;
-                                const uint32_t take = left < room ? left : room;
-                                const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
-                                g = in ? pos + (uint32_t)lane - dist : g;
-                                filled = uni(filled + take);
-                                left -= take;
-                                if (filled == 64u) flush_group();
-                            }
-                        } else {
-                            // an overlapping match repeats its last `dist` bytes: byte i is byte i mod dist of them
-                            flush_group();
-                            retire();
-                            if (dist >= 64u) {
-                                for (uint32_t i = (uint32_t)lane; i < length; i += 64u)     // (rounds complete in order)
-                                    put_byte(pos + i, get_byte(pos + i - dist));
-                            } else {
-                                const float rcp = __frcp_rn((float)dist);
-                                for (uint32_t i = (uint32_t)lane; i < length; i += 64u) {
-                                    int qq = (int)((float)i * rcp);
-                                    int r = (int)i - qq * (int)dist;
-                                    if (r < 0) r += (int)dist;
-                                    else if (r >= (int)dist) r -= (int)dist;
-                                    put_byte(pos + i, get_byte(pos - dist + (uint32_t)r));
-                                }
-                            }
-                            pos += length;
-                        }
-                    }
-                    p = q + (d & 31u);
-                    a = (uint32_t)__builtin_amdgcn_readlane((int)wa, (int)(p & 63u));
+                const uint32_t wb = (lb != 0u && sb < 30u) ? (lb + xb) | (mdist << 8) : kBadDist;
+                // a length's distance symbol begins la + xa bits on: what the lane there found
+                const uint32_t q = (uint32_t)lane + la + xa;
+                const uint32_t bq = (uint32_t)__shfl((int)wb, (int)q, 64);
+                const bool is_match = is_len && q < 64u && !(bq & kBadDist);
+                const uint32_t bits = is_lit ? la : is_match ? la + xa + (bq & 31u) : kWalkStop;
+                const uint32_t bytes = is_lit ? 1u : is_match ? mlen : 0u;
+                const uint32_t what = is_lit ? kGroupLit | sa : bq >> 8;           // the literal, or the match's distance
+                // ---- 2. the chain from position 0
+                // (a stop is worth 64 bits: the loop's one test ends on it, and what it added is taken back behind the loop -
+                // with a test of its own inside, the compiler turned the loop body into sixteen selects)
+                unsigned long long chain = 0ull;
+                uint32_t p = 0, w, from_p;
+                do {
+                    w = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)p);
+                    from_p = p;
+                    chain |= 1ull << p;
+                    p += w;
+                } while (p < 64u);
+                if (w & kWalkStop) {
+                    chain ^= 1ull << from_p;
+                    p = from_p;
                 }
-                if (err) break;
-                br.drop(p);                                  // (p > 0: position 0 always yields a symbol or an error)
-                if (done) {
-                    if (pos + filled > dst_len) err = kInfOutputOverrun;
-                    else flush_group();
+                if (chain != 0ull) {                         // uniform
+                    // ---- 3. the bytes of the chain's symbols
+                    const bool on = (chain >> lane) & 1ull;
+                    const uint32_t mine = on ? bytes : 0u;
+                    const uint32_t incl = scan_add(mine);
+                    const uint32_t begin = incl - mine;      // the symbol's first byte, counted from the batch's first
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (pos + filled + total > dst_len) { err = kInfOutputOverrun; break; }
+                    uint32_t done = 0;
+                    bool bad = false;
+                    while (done < total) {                   // uniform: once, unless the batch overflows the group
+                        const uint32_t room = 64u - filled;
+                        const uint32_t take = total - done < room ? total - done : room;
+                        // group lane filled + j takes byte done + j of the batch; the symbol that byte belongs to is the
+                        // last one beginning at or before it
+                        const unsigned long long before = __ballot(on && begin <= done);
+                        const uint32_t first = 64u - (uint32_t)__clzll((long long)before);   // (that symbol's lane + 1: never 0)
+                        // (the barriers: to the compiler a lane's LDS words are its own between synchronisation points)
+                        s.mark[lane] = 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        if (on && begin > done && begin < done + take) s.mark[filled + begin - done] = (uint32_t)lane + 1u;
+                        __builtin_amdgcn_wave_barrier();
+                        uint32_t m = s.mark[lane];
+                        if ((uint32_t)lane == filled) m = first;
+                        m = scan_max(m);
+                        const uint32_t from = (uint32_t)__shfl((int)what, (int)(m - 1u), 64);
+                        const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
+                        const uint32_t at = pos + (uint32_t)lane;
+                        bad = bad || (in && !(from & kGroupLit) && from > at);
+                        g = in ? ((from & kGroupLit) ? from : at - from) : g;
+                        filled = uni(filled + take);
+                        done += take;
+                        if (filled == 64u) flush_group();
+                    }
+                    if (__ballot(bad) != 0ull) { err = kInfBadDistance; break; }
+                    br.drop(p);
+                    continue;
+                }
+                // ---- one symbol on its own: the end of the block, a code longer than the table, an invalid symbol
+                const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane((int)x, 0);
+                uint32_t e = uni(s.lit_tab[xs & (uint32_t)(kTabSize - 1)]);
+                if ((e & 15u) == 0u) {
+                    e = uni(slow_code(&s.lit_c, s.lit_sorted, xs & 0x7fffu, kTabBits));
+                    if (e == 0u) { err = kInfBadCode; break; }
+                }
+                uint32_t used = e & 15u;
+                const uint32_t sym = e >> 4;
+                if (sym < 256u) {
+                    g = (uint32_t)lane == filled ? kGroupLit | sym : g;
+                    if (pos + filled + 1u > dst_len) { err = kInfOutputOverrun; break; }
+                    if (++filled == 64u) flush_group();
+                    br.drop(used);
+                    continue;
+                }
+                if (sym == 256u) {
+                    br.drop(used);
                     break;
                 }
+                if (sym >= 286u) { err = kInfBadCode; break; }
+                const uint32_t li2 = (uint32_t)__builtin_amdgcn_readlane((int)len_info, (int)(sym - 257u));
+                const uint32_t length = (li2 & 0x1ffu) + ((xs >> used) & ((1u << (li2 >> 9)) - 1u));
+                used += li2 >> 9;                            // <= 20: the distance symbol begins inside the window
+                const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)used);
+                uint32_t d = uni(s.dist_tab[xq & (uint32_t)(kTabSize - 1)]);
+                if ((d & 15u) == 0u) {
+                    d = uni(slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kTabBits));
+                    if (d == 0u) { err = kInfBadCode; break; }
+                }
+                if ((d >> 4) >= 30u) { err = kInfBadCode; break; }
+                const uint32_t di2 = (uint32_t)__builtin_amdgcn_readlane((int)dist_info, (int)(d >> 4));
+                const uint32_t dist = (di2 & 0xffffu) + ((xq >> (d & 15u)) & ((1u << (di2 >> 16)) - 1u));
+                used += (d & 15u) + (di2 >> 16);
+                if (dist > pos + filled) { err = kInfBadDistance; break; }
+                if (pos + filled + length > dst_len) { err = kInfOutputOverrun; break; }
+                uint32_t left = length;
+                while (left != 0u) {                         // uniform: the match joins the group piece by piece
+                    const uint32_t room = 64u - filled;
+                    const uint32_t take = left < room ? left : room;
+                    const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
+                    g = in ? pos + (uint32_t)lane - dist : g;
+                    filled = uni(filled + take);
+                    left -= take;
+                    if (filled == 64u) flush_group();
+                }
+                br.drop(used);
             }
             if (err) break;
         } else {
@@ -549,6 +579,7 @@ __global__ __launch_bounds__(64, 7) void bgzf_inflate_kernel(const uint8_t* __re
         }
         if (final_block) break;
     }
+    if (!err) flush_group();
     retire();
     if (!err) {
         if (pos != dst_len) err = kInfSizeMismatch;
@@ -586,7 +617,9 @@ __device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
 
 __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
                                                        uint32_t n_blocks, uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_tab[256], s_part[4];
+    // four tables (slicing by four): entry [j][t] is byte t carried over j further zero bytes, so that a dword of input costs
+    // four INDEPENDENT look-ups instead of a chain of four (a thread's 256-byte slice was a chain of 256 LDS round trips)
+    __shared__ uint32_t s_tab[4][256], s_part[4];
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     if (b >= n_blocks) return;
     const uint32_t len = blocks[b].dst_len;
@@ -595,7 +628,13 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
         uint32_t c = t;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
-        s_tab[t] = c;
+        s_tab[0][t] = c;
+        __syncthreads();
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            c = s_tab[0][c & 0xffu] ^ (c >> 8);
+            s_tab[j][t] = c;
+        }
     }
     __syncthreads();
     const uint8_t* base = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
@@ -609,10 +648,15 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
     const uint4* src = reinterpret_cast<const uint4*>(base + lo);
     uint32_t crc = 0xffffffffu;
     auto eat = [&](uint32_t w, uint32_t count) {             // the low `count` bytes of a word
+        if (count >= 4u) {
+            const uint32_t x = crc ^ w;
+            crc = s_tab[3][x & 0xffu] ^ s_tab[2][(x >> 8) & 0xffu] ^ s_tab[1][(x >> 16) & 0xffu] ^ s_tab[0][x >> 24];
+            return;
+        }
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
+        for (uint32_t k = 0; k < 3u; ++k) {
             if (k < count) {
-                crc = s_tab[(crc ^ (w >> (8u * k))) & 0xffu] ^ (crc >> 8);
+                crc = s_tab[0][(crc ^ (w >> (8u * k))) & 0xffu] ^ (crc >> 8);
             }
         }
     };
