@@ -168,6 +168,22 @@ def stage_timings(wl):
         out['metrics_scan_ms'] = (time.perf_counter() - t0) * 1e3
         out['metrics_kernels_ms'] = pipeline.prof_collect().get('metrics_kernels', (0.0, 0))[0]
         out['metrics_records_scanned'] = int(counts.records_scanned)
+
+        def roofline(records, ms):
+            # the library-metrics pass prices at 22 B/pair (15 B/record: tid mtid tlen flag mapq, read once)
+            gbps = records / 2 * 22 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {'records_scanned': int(records), 'kernel_ms': round(ms, 4), 'bytes_per_pair': 22,
+                    'achieved_GBps': round(gbps, 1), 'peak_GBps': 8000.0, 'frac': round(gbps / 8000.0, 4)}
+        out['metrics_roofline'] = roofline(counts.records_scanned, out['metrics_kernels_ms'])
+        # the same pass forced over the whole library: a top-1000 mask of three short contigs never fills the samples
+        # (libmetrics.py:293-303 then scans to the end of the file)
+        few = np.zeros(asm.nc, np.uint8)
+        few[np.argsort(asm.lengths, kind='stable')[:3]] = 1
+        ctx.metrics_sample(few, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+        pipeline.prof_collect()
+        _, _, counts_all = ctx.metrics_sample(few, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+        out['metrics_roofline_full_scan'] = roofline(counts_all.records_scanned,
+                                                     pipeline.prof_collect().get('metrics_kernels', (0.0, 0))[0])
         ctx.build_graph()
         t0 = time.perf_counter()
         table, _, _ = ctx.build_graph()

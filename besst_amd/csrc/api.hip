@@ -1434,11 +1434,17 @@ int besst_ctx_metrics_sample(besst_ctx* c, const uint8_t* top_mask, int32_t orie
     int rc = use_device(c);
     if (rc) return rc;
     constexpr int64_t kCap = 1000000;
-    constexpr int64_t kChunk = 4 << 20;
+    constexpr int64_t kChunk = 16 << 20;      // (most libraries fill their samples within it: one launch)
     if ((rc = c->top_mask.ensure((size_t)c->n_contigs))) return rc;
     if ((rc = c->sample_a.ensure((size_t)kCap))) return rc;
     if ((rc = c->sample_b.ensure((size_t)kCap))) return rc;
-    if ((rc = c->aux.ensure(metrics_workspace_bytes(kChunk) + 64))) return rc;
+    // Chunks: the reference stops each scan at its 1,000,000th qualifying record (libmetrics.py:83,302), the host learns the
+    // counts between chunks.  The first chunk is kChunk records; each later one is sized from the rate seen so far so that
+    // it should finish the scan (x 1.25, at most kChunkMax): a launch + a round trip to the host per 4 M records was most of
+    // the pass's time when the samples fill late (60 M records: 15 chunks, 1.1 ms for 0.18 ms worth of bytes).
+    constexpr int64_t kChunkMax = (int64_t)256 << 20;
+    const int64_t ws_records = c->n_records < kChunkMax ? (c->n_records > kChunk ? c->n_records : kChunk) : kChunkMax;
+    if ((rc = c->aux.ensure(metrics_workspace_bytes(ws_records) + 64))) return rc;
     BESST_HIP_TRY(hipMemcpyAsync(c->top_mask.p, top_mask, (size_t)c->n_contigs, hipMemcpyHostToDevice, c->stream));
     int64_t* state = reinterpret_cast<int64_t*>(c->aux.p);
     char* ws = c->aux.p + 64;
@@ -1452,15 +1458,23 @@ int besst_ctx_metrics_sample(besst_ctx* c, const uint8_t* top_mask, int32_t orie
     a.min_mapq = min_mapq;
     a.read_len = read_len;
     int64_t host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t start = 0; start < c->n_records; start += kChunk) {
-        const int64_t cnt = c->n_records - start < kChunk ? c->n_records - start : kChunk;
+    int64_t next = kChunk;
+    for (int64_t start = 0; start < c->n_records;) {
+        const int64_t cnt = c->n_records - start < next ? c->n_records - start : next;
         rc = launch_metrics(c->stream, a, start, cnt, want_isize ? c->sample_a.p : nullptr, c->sample_b.p, state, ws,
                             c->aux.cap - 64);
         if (rc) return rc;
         BESST_HIP_TRY(hipMemcpyAsync(host, state, 48, hipMemcpyDeviceToHost, c->stream));
         BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+        start += cnt;
         // the reference stops each scan once its 1,000,000-sample cut-off is reached (libmetrics.py:83,302)
         if ((!want_isize || host[0] >= kCap) && host[1] >= kCap) break;
+        // records still to scan at the rate of the slower of the two counts (none seen yet: as many as allowed)
+        const int64_t slow = (want_isize && host[0] < host[1]) ? host[0] : host[1];
+        double need = slow > 0 ? (double)(kCap - slow) * (double)start / (double)slow * 1.25 : (double)kChunkMax;
+        if (need > (double)kChunkMax) need = (double)kChunkMax;
+        next = ((int64_t)need + kChunk - 1) / kChunk * kChunk;   // (a multiple of 4: launch_metrics wants aligned starts)
+        if (next < kChunk) next = kChunk;
     }
     counts->n_isize = want_isize ? (host[0] < kCap ? host[0] : kCap) : 0;
     counts->sample_counter = host[1] < kCap ? host[1] : kCap;
