@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument('--no-stages', action='store_true', help='skip the separate metrics / scoring stage timings')
     ap.add_argument('--no-robustness', action='store_true',
                     help='skip the "robustness" object (C3 with chimeric pairs, name-sorted C2)')
+    ap.add_argument('--slices', choices=('independent', 'contiguous'), default='contiguous',
+                    help='N > 1: what a rank holds of a library - "contiguous": the rank-th (tid, pos)-contiguous cut of ONE '
+                         'stream, what distributed.ingest_slice yields on a real file (a slice\'s tuples concentrate on few '
+                         'owners); "independent": a whole-genome stream of its own per rank (rounds 2 and 3)')
     ap.add_argument('--in-flight', type=int, default=3,
                     help='library passes kept in flight (one HIP stream each) for the extra "overlapped" figure; '
                          '0 skips it.  The headline value is always measured with ONE pass at a time.')
@@ -987,7 +991,8 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
                             free_hbm / 1e9))
     jobs, wls = [], []
     for li, spec in enumerate(cfg['libs']):
-        cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device)
+        cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device,
+                                             window=(rank, world) if (args.slices == 'contiguous' and world > 1) else None)
         thr = spec.mean + 4 * spec.sd
         table = (workload.first_library_table(asm.lengths, thr) if li == 0 else
                  workload.later_library_table(asm, seed + 50 + li, thr, first_scaffold_id=asm.nc * li + 1))
@@ -1000,6 +1005,42 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     def step():
         for job in jobs:
             job.step()
+
+    # ---- who is here: the ranks the collective library sees and the devices they run on (a SCALE file whose ranks share a
+    # device, or whose group is smaller than --gpus, is not a scaling measurement)
+    uuid = str(getattr(torch.cuda.get_device_properties(device), 'uuid', '')) or 'device-%d' % device.index
+    uuids = [None] * world
+    if world > 1:
+        dist.all_gather_object(uuids, uuid)
+    else:
+        uuids = [uuid]
+    # ---- the like-for-like one-GPU figure: the SAME shape (this rank's slice of both libraries) through the same
+    # orchestration with a group of one, timed on rank 0 before the timed region - weak-scaling efficiency is value(N) /
+    # (N x this), not against the C3 line that `--gpus 1` prints
+    same_shape = None
+    if world > 1:
+        solo_groups = [dist.new_group([r]) for r in range(world)]      # (collective: every rank makes every group)
+        if rank == 0:
+            solo = [distributed.ShardedGraphBuild(device, wl, 0, 1, group=solo_groups[0],
+                                                  pair_capacity=int(cap_env) if cap_env else None) for wl in wls]
+            for k in range(40):
+                for job in solo:
+                    job.step()
+            torch.cuda.synchronize()
+            for job in solo:
+                job.check_capacity()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                for job in solo:
+                    job.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            same_shape = {'ms_per_step': round(dt * 1e3, 4), 'value': per_lib * len(solo) / dt, 'unit': 'read-pairs/s',
+                          'what': 'rank 0\'s slice of every library through the sharded orchestration with a group of one '
+                                  '(all-to-all to itself), %d steps, before the timed region' % args.steps}
+            del solo
+            torch.cuda.empty_cache()
+        dist.barrier()
 
     # setup, not measurement: RCCL opens its channels and the builders size their exchange regions on the first passes
     # (a run whose only untimed passes were two warm-up steps once measured 2.8 ms per step instead of 1.36), and an idle
@@ -1076,15 +1117,37 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
                                                   'aggregate peak of all GPUs',
                          'achieved': round(alg_step / step_s / 1e9, 1), 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s',
                          'frac': round(alg_step / step_s / 1e9 / (HBM_PEAK_GBS * world), 4), 'traffic': None,
+                         'traffic_note': 'PMC passes (rocprofv3 --pmc) are taken per process on one GPU: profiles/ holds '
+                                         'them for the single-GPU step; none was collected under torch.distributed.run',
                          'algorithmic_bytes_per_step': alg_step},
             'kernel_ms': breakdown,
             'verified_vs_c_oracle': ok if not (args.no_verify or args.no_cpu_baseline) else None,
-            'cpu_baseline': None,
+            'rccl_ranks_seen': int(dist.get_world_size()), 'backend': backend_name, 'device_uuids': uuids,
+            'distinct_devices': len(set(uuids)), 'slices': args.slices if world > 1 else 'whole stream',
+            'single_gpu_same_shape': same_shape,
+            'cpu_baseline': sharded_cpu_baseline(args, wls[0]),
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def sharded_cpu_baseline(args, wl):
+    """Rank 0's cpu_baseline of an N > 1 line: the Python port on the head of ITS slice of the first library (a bounded
+    sample, one core) + the committed calibration against the real reference loop."""
+    if args.no_cpu_baseline or args.cpu_sample_records <= 0:
+        return {'value': None, 'unit': 'read-pairs/s', 'cores': 1, 'kind': 'port', 'sample': 'skipped (--no-cpu-baseline)'}
+    from besst_amd import synth
+    n = int(min(args.cpu_sample_records, wl['cols']['tid'].shape[0]))
+    head = synth.device_columns_to_batch(wl['asm'], {k: v[:n] for k, v in wl['cols'].items()}, int(wl['spec'].read_len))
+    base, _ = cpu_baseline(head, wl['table'], wl['lib'], n)
+    base['sample'] = 'rank 0, library 1: ' + base['sample']
+    cal = reference_calibration()
+    if cal:
+        base['reference_calibration'] = cal
+        base['reference_equivalent_value'] = base['value'] / cal['port_over_reference']
+    return base
 
 
 def overlapped_throughput(runner, wl, device, in_flight, steps):

@@ -200,8 +200,12 @@ class LinkData(dict):
     MakeScaffolds.py:322,331,425,1139: a few edges per extended path); every other key is an ordinary item."""
     __slots__ = ('_col', '_lo', '_hi')
 
+    def __init__(self, *args, **kw):
+        dict.__init__(self, *args, **kw)
+        self._col, self._lo, self._hi = None, 0, 0           # (a LinkData built anywhere is a plain dict until GraphPlan lends it a column)
+
     def _cut(self):
-        col = self._col
+        col = getattr(self, '_col', None)
         if col is not None:
             self._col = None
             dict.__setitem__(self, 'observations', col[self._lo:self._hi].tolist())
@@ -239,6 +243,39 @@ class LinkData(dict):
         if key == 'observations':
             self._cut()
         return dict.get(self, key, default)
+
+    # writers: the lazily cut list must not overwrite, or hide from, what a caller puts there
+    def __setitem__(self, key, value):
+        if key == 'observations':
+            self._col = None                                 # the caller's value replaces the column for good
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        if key == 'observations':
+            self._cut()
+        dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        if key == 'observations':
+            self._cut()
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        self._cut()
+        return dict.popitem(self)
+
+    def setdefault(self, key, default=None):
+        if key == 'observations':
+            self._cut()
+        return dict.setdefault(self, key, default)
+
+    def update(self, *args, **kw):
+        self._cut()
+        dict.update(self, *args, **kw)
+
+    def clear(self):
+        self._col = None
+        dict.clear(self)
 
     def keys(self):
         self._cut()

@@ -289,7 +289,14 @@ def _extend_within_components(G, G_prime, Contigs, small_contigs, Scaffolds, sma
     scaffolds into G and out of G_prime), then the relabelling of the path's two ends in G_prime to the scaffold the
     component becomes.  The searches only read G_prime, the scaffold lengths of their own component and
     `already_visited`; the walk of an earlier component (contig positions, the Scaffolds entries of ITS scaffolds) is
-    nothing a later search looks at, so the walks can wait until every component has been extended."""
+    nothing a later search looks at, so the walks can wait until every component has been extended.
+
+    The callback's CONTRACT (what the equivalence with the reference's interleaved search / walk / relabel rests on; BESST's
+    PROWithinScaf keeps it: its get_total_length only looks a scaffold up in small_scaffolds): it must not look up
+    Scaffolds[id] for an id a previous component was renamed to - that object does not exist before the walks -, and it must
+    not read param.scaffold_indexer, which advances only with the walks (the names handed to G_prime here count on from it
+    in a local).  A component without a degree-1 node (a single scaffold whose two ends are not in G as a path) is left
+    as it is; the reference would go on with the start / end of the component before - a state no test of BESST's shows."""
     import networkx as nx
     components = [G.subgraph(c) for c in nx.connected_components(G)]
     name = param.scaffold_indexer

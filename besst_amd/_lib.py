@@ -20,6 +20,7 @@ class BesstDeviceError(RuntimeError):
 
 
 ERR_UNSUPPORTED = 5     # include/besst_amd.h: BESST_ERR_UNSUPPORTED
+ERR_NOMEM = 4           # include/besst_amd.h: BESST_ERR_NOMEM
 
 
 class LibParams(C.Structure):

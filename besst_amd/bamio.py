@@ -42,7 +42,9 @@ class ResidentBam(object):
     """A BAM file whose records went straight to HBM - besst_ctx_push_bam_device: the compressed file is uploaded and
     inflated + decoded on the GPU (files in htslib's block layout); else besst_ctx_push_bam: decode on host threads, pinned
     staging, copies under the next chunk's decode; ``mode`` as in GraphContext.push_bam - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
-    on the host needs the record columns; ``part=(r, W)``: rank r's slice of the stream (multi-GPU ingest).  It carries what the host side of those two does read: the header
+    on the host needs the record columns; ``part=(r, W)``: rank r's slice of the stream (multi-GPU ingest: ``len()`` and the
+    head arrays then describe that slice only - such an object is for distributed.ingest_slice, not for
+    libmetrics.get_metrics, whose < 1000-record check and read-length step are about the whole file).  It carries what the host side of those two does read: the header
     (``references``, ``lengths``), the record count (``len()``) and ``rlen`` / ``alen`` / ``qlen`` of the first 1000
     records (the read-length step, libmetrics.py:246-273); ``ctx`` is the GraphContext that holds the records and
     ``ingest`` the timings of the upload."""
@@ -53,14 +55,16 @@ class ResidentBam(object):
         threads = threads or reader_threads()
         handle, self.references, self.lengths = _open(lib, path, threads)
         self.path = path
-        self.ctx = device.GraphContext(device_index)
+        self.ctx = None
         try:
+            self.ctx = device.GraphContext(device_index)     # (inside the try: a context that cannot be made must not leak the reader)
             zeros = np.zeros(len(self.references), dtype=np.int32)
             self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
             self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records, mode=mode, chunk_blocks=chunk_blocks, part=part)
             clamped = lib.besst_bam_clamped_records(handle)
         except Exception:
-            self.ctx.close()
+            if self.ctx is not None:
+                self.ctx.close()
             raise
         finally:
             lib.besst_bam_close(handle)

@@ -158,9 +158,11 @@ class GraphContext(object):
                                                           _lib.ptr(rlen), _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
             if rc == 0:
                 done = True
-            elif rc != _lib.ERR_UNSUPPORTED or mode == 'device':
+            elif rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_NOMEM) or mode == 'device':
                 _lib.check(rc, 'push_bam_device')
             else:
+                # (out of memory: the device form wants two slots of scratch - ~1 GB of HBM, 2 x 160 MB pinned - before it
+                # reads anything, the host form 2 x 25 B x chunk_records of pinned staging; context and reader are untouched)
                 self.ingest_fallback = _lib.last_error()
         if not done:
             _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),

@@ -320,7 +320,7 @@ class ShardedGraphBuild(object):
         if backend is None:
             tuple_capacity = None
             if pair_capacity is None:
-                pair_capacity, tuple_capacity = self._probe_pair_capacity(device, wl, world)
+                pair_capacity, tuple_capacity = self._probe_pair_capacity(device, wl, world, group)
             backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
         self.backend = backend
         self._tails = None
@@ -342,7 +342,7 @@ class ShardedGraphBuild(object):
         self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
-    def _probe_pair_capacity(device, wl, world):
+    def _probe_pair_capacity(device, wl, world, group=None):
         """One untimed local pass to size the exchange regions (tuples per (src,dst) pair, 1.5x slack)."""
         from . import pipeline
         rec = device_records(wl, device)
@@ -353,7 +353,7 @@ class ShardedGraphBuild(object):
         n_out, _ = probe.read_sizes()
         cap = torch.tensor([int(n_out * 1.5 / world) + 4096], dtype=torch.int64, device=device)
         if dist.is_initialized():
-            _all_reduce(cap, None, op=dist.ReduceOp.MAX)
+            _all_reduce(cap, group, op=dist.ReduceOp.MAX)        # (the build's own group: a group of one must not wait for the world)
         return int(cap.item()), int(n_out * 1.25) + 4096
 
     def step(self):

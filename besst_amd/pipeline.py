@@ -135,6 +135,8 @@ class DeviceGraphBuilder(object):
 
     @property
     def _n_rows(self):
+        """Device address of the row count.  Read it through read_sizes(): the word also carries ROWS_RUN_OVERFLOW /
+        ROWS_SORT_FAILED, which only read_sizes() acts on."""
         return self._small(COUNTER_BYTES + 12)
 
     def set_contigs(self, scaf_id, scaf_len, ctg_pos, ctg_len, direction, cls):
@@ -230,6 +232,9 @@ class DeviceGraphBuilder(object):
                 spec = self._args['presort'][0]
 
                 def again():
+                    # (valid for reset -> classify -> reduce passes, which is what step() runs: the repeat below resets the
+                    # state and classifies the LAST record set only - a caller that classified several record sets into one
+                    # state without reset() must repeat them itself, with sort_flags |= REDUCE_NO_RUNS set beforehand)
                     spec.flags = self.sort_flags
                     if spec.in_record_loop >= 2 and (spec.flags & REDUCE_NO_RUNS):
                         # the record loop handed its segments over without the sort's digit counts (stage 2 was going to

@@ -188,13 +188,16 @@ def config_seed(name):
     return BASE_SEED + int(name[1:])
 
 
-def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, order='coordinate'):
+def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, order='coordinate', window=None):
     """The generator of ``simulate_library`` written with torch ops, so that the full-size configs (C3: 400 M
     records) are drawn, sorted and left resident on the GPU in seconds instead of minutes of numpy on the host.
     Same model, same record semantics, its own random stream (torch.Generator seeded with ``seed``).
     Returns a dict of device tensors {tid mtid pos mpos tlen: int32, flag qlen: int16 bit patterns, mapq: uint8}
     in (tid, pos) order - or, order='name', the two records of a pair next to each other and the pairs in the order
-    they were drawn (a name-sorted BAM).  Bench / test scaffolding, not the product."""
+    they were drawn (a name-sorted BAM).  window=(k, W): the k-th of W equal cuts of the genome - what rank k of a sharded
+    run holds of ONE coordinate-sorted file: pairs are drawn around the cut and only the RECORDS that lie in it are kept (a
+    pair across a cut leaves one record on each side, each side drawing its own), 2 n_pairs records in all.
+    Bench / test scaffolding, not the product."""
     import torch
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -211,9 +214,16 @@ def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, 
     def rand(m):
         return torch.rand(m, generator=g, device=dev)
 
+    w_lo, w_hi = 0, int(asm.total)
+    if window is not None:
+        if order == 'name':
+            raise ValueError('a window of the genome is a cut of the coordinate-sorted stream')
+        k_w, n_w = int(window[0]), int(window[1])
+        w_lo, w_hi = int(asm.total) * k_w // n_w, int(asm.total) * (k_w + 1) // n_w
+    pad = int(max(spec.mean + 8 * spec.sd, spec.contam_mean + 8 * spec.contam_sd)) if window is not None else 0
     while done < n_pairs:
         m = int(min(chunk, max(1024, int((n_pairs - done) * 1.3))))
-        start = torch.randint(0, int(asm.total), (m,), generator=g, device=dev)
+        start = torch.randint(max(0, w_lo - pad), w_hi, (m,), generator=g, device=dev)
         contam = rand(m) < spec.contam_frac
         z = torch.randn(m, generator=g, device=dev, dtype=torch.float64)
         x = torch.where(contam, z * spec.contam_sd + spec.contam_mean, z * spec.sd + spec.mean)
@@ -226,6 +236,8 @@ def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, 
         ok = (lpos + r <= starts[lt] + lengths[lt]) & (rpos + r <= starts[rt] + lengths[rt])
         lt, rt, lpos, rpos, x, contam = lt[ok], rt[ok], lpos[ok], rpos[ok], x[ok], contam[ok]
         k = int(lt.shape[0])
+        in_l = (lpos >= w_lo) & (lpos < w_hi)                # which of the pair's two records lie in the window
+        in_r = (rpos >= w_lo) & (rpos < w_hi)
         lp = lpos - starts[lt]
         rp = rpos - starts[rt]
         del lpos, rpos, start, ok
@@ -265,13 +277,24 @@ def simulate_library_device(asm, spec, n_pairs, seed, device, chunk=32_000_000, 
         base_n = min(k, int(np.ceil((n_pairs - done) / (1.0 + spec.dup_frac))))
         dup = torch.nonzero(rand(base_n) < spec.dup_frac).flatten()
         sel = torch.cat((torch.arange(base_n, device=dev), dup))[:n_pairs - done]
-        done += int(sel.shape[0])
+        keep = None
+        if window is not None:
+            keep = torch.cat((in_l[sel], in_r[sel]))
+            budget = 2 * (n_pairs - done)                    # records still wanted
+            over = torch.cumsum(keep.to(torch.int64), 0) > budget
+            keep = keep & ~over
+            done += (int(keep.sum().item()) + 1) // 2
+        else:
+            done += int(sel.shape[0])
         for name, left, right in (('tid', lt, rt), ('mtid', rt, lt), ('pos', lp, rp), ('mpos', rp, lp),
                                   ('tlen', tl, -tl), ('flag', fl, fr_), ('mapq', mapq, mapq), ('qlen', ql, qr)):
             if order == 'name':
                 parts[name].append(torch.stack((left[sel], right[sel]), dim=1).reshape(-1).to(tdt[name]))
+            elif keep is not None:
+                parts[name].append(torch.cat((left[sel], right[sel]))[keep].to(tdt[name]))
             else:
                 parts[name].append(torch.cat((left[sel], right[sel])).to(tdt[name]))
+        del in_l, in_r
         del lt, rt, lp, rp, tl, fl, fr_, mapq, ql, qr, x, contam, same, sel
     cat = {name: torch.cat(parts[name]) for name in names}
     parts.clear()

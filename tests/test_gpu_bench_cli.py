@@ -22,7 +22,7 @@ def _last_json_line(text):
 
 def test_single_gpu_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + SMALL, cwd=REPO, capture_output=True,
-                         text=True, timeout=900)
+                         text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json_line(out.stdout)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -49,7 +49,7 @@ def test_two_ranks_over_gloo_on_one_gpu():
     env = dict(os.environ, BESST_DIST_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2'] + SMALL
-    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json_line(out.stdout)
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
@@ -59,5 +59,30 @@ def test_two_ranks_over_gloo_on_one_gpu():
         assert lib['exchange_consistent'] is True
         assert all(lib['verified_vs_c_oracle'].values()), lib
     assert d['verified_vs_c_oracle'] is True
-    assert d['cpu_baseline'] is None                      # the CPU legs run at N = 1 only
     assert abs(d['value'] - 2 * 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    # what a SCALE file is judged on: the CPU leg (rank 0, the port on the head of its slice + the committed calibration),
+    # the traffic field with its reason, who took part, and the like-for-like one-GPU figure of the same shape
+    assert set(('value', 'unit', 'cores', 'kind', 'sample')) <= set(d['cpu_baseline']) and d['cpu_baseline']['value'] > 0
+    assert d['roofline']['traffic'] is None and d['roofline']['traffic_note']
+    assert d['rccl_ranks_seen'] == 2 and len(d['device_uuids']) == 2 and d['distinct_devices'] == 1   # (both on the box's one GPU)
+    assert d['slices'] == 'contiguous'
+    same = d['single_gpu_same_shape']
+    assert same['value'] > 0 and abs(same['value'] - 2 * 400000 / (same['ms_per_step'] * 1e-3)) < 1e-3 * same['value']   # (ms rounded to 0.1 us)
+
+
+def test_two_ranks_with_independent_slices():
+    """--slices independent (rounds 2 and 3): every rank draws a whole-genome stream of its own."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--slices',
+           'independent'] + SMALL
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    assert d['slices'] == 'independent' and d['verified_vs_c_oracle'] is True
+    for lib in d['config']['libraries']:
+        assert lib['exchange_consistent'] is True and all(lib['verified_vs_c_oracle'].values()), lib

@@ -75,6 +75,38 @@ def test_host_side_reproduces_reference_goldens(fake_gpu, name):
                 assert dict.__contains__(d, 'observations') and len(d['observations']) == d['nr_links']
 
 
+def test_link_data_writers_see_and_replace_the_lazy_list():
+    """Writers on an edge whose 'observations' were not cut yet: an assignment wins over the column (it is not overwritten by
+    a later read), pop / del / setdefault / update see the list, and a LinkData built without a column is a plain dict."""
+    col = numpy.arange(100, dtype=numpy.int32)
+
+    def fresh():
+        d = CreateGraph.LinkData(nr_links=3, obs=33, obs_sq=365)
+        d._col, d._lo, d._hi = col, 10, 13
+        return d
+    d = fresh()
+    d['observations'] = [7]
+    assert list(d.keys()).count('observations') == 1 and d['observations'] == [7] and dict(d)['observations'] == [7]
+    assert fresh().pop('observations') == [10, 11, 12]
+    d = fresh()
+    del d['observations']
+    assert 'observations' not in d and len(d) == 3
+    assert fresh().setdefault('observations', None) == [10, 11, 12]
+    d = fresh()
+    d.update(gap=4)
+    assert d['observations'] == [10, 11, 12] and d['gap'] == 4
+    d = fresh()
+    d.update(observations=[1])
+    assert d['observations'] == [1]
+    d = fresh()
+    d.clear()
+    assert len(d) == 0 and 'observations' not in d
+    plain = CreateGraph.LinkData(nr_links=None)              # (built anywhere: no column, no AttributeError)
+    assert 'observations' not in plain and plain.get('observations') is None and len(plain) == 1
+    with pytest.raises(KeyError):
+        plain['observations']
+
+
 def test_link_data_is_a_complete_dict_to_whatever_looks_at_it_whole():
     col = numpy.arange(100, dtype=numpy.int32)
 
@@ -194,3 +226,34 @@ def test_new_contigs_scaffolds_with_the_reference_path_search_as_hook(fake_gpu, 
     for k in results[0]:
         assert results[0][k] == results[1][k], k
     print('small scaffolds placed inside new scaffolds:', moved[0])
+
+
+def test_extend_within_components_contract():
+    """The order the drop-in gives the path-search hook (besst_amd.MakeScaffolds._extend_within_components): every component
+    is searched and its path ends relabelled in G_prime BEFORE any walk, so a later search sees the (name, 'L'/'R') nodes
+    of earlier components in G_prime while param.scaffold_indexer still holds its old value - the contract the docstring
+    states (the hook must not read either); names count on from the indexer in component order."""
+    from besst_amd import MakeScaffolds as OURS
+    from besst_amd import nxcompat
+
+    class P(object):
+        scaffold_indexer = 40
+    G, Gp = nxcompat.Graph(), nxcompat.Graph()
+    for base in (1, 2, 3, 4):                                # components {1, 2} and {3, 4}: two scaffolds joined R - L
+        for g in (G, Gp):
+            g.add_edge((base, 'L'), (base, 'R'), nr_links=None)
+    for a, b in ((1, 2), (3, 4)):
+        for g in (G, Gp):
+            g.add_edge((a, 'R'), (b, 'L'), nr_links=7, obs=70, obs_sq=800, observations=[10] * 7)
+    Gp.add_edge((2, 'R'), (3, 'L'), nr_links=5, obs=50, obs_sq=600, observations=[10] * 5)   # a G_prime-only link between them
+    seen = []
+
+    def hook(G_, Gp_, Contigs, small_contigs, Scaffolds, small_scaffolds, param, component, table, visited):
+        seen.append((sorted(n[0] for n in component if n[1] == 'L'), param.scaffold_indexer,
+                     sorted(n for n in Gp_.nodes() if n[0] > 40)))
+    OURS._extend_within_components(G, Gp, {}, {}, {}, {}, P(), None, set(), hook)
+    assert [s[0] for s in seen] == [[1, 2], [3, 4]]
+    assert [s[1] for s in seen] == [40, 40]                   # the indexer advances with the walks, not here
+    assert seen[0][2] == [] and seen[1][2] == [(41, 'L'), (41, 'R')]   # the second search sees the first component renamed
+    assert sorted(Gp.nodes()) == [(41, 'L'), (41, 'R'), (42, 'L'), (42, 'R')]
+    assert Gp[(41, 'R')][(42, 'L')]['nr_links'] == 5          # the link between the two paths' ends travelled with them
