@@ -48,7 +48,7 @@ class Counters(C.Structure):
 class IngestStats(C.Structure):      # include/besst_amd.h: besst_ingest_stats
     _fields_ = [('records', C.c_int64), ('chunks', C.c_int64), ('bytes_h2d', C.c_int64), ('seconds', C.c_double),
                 ('decode_seconds', C.c_double), ('copy_wait_seconds', C.c_double), ('inflated_bytes', C.c_int64),
-                ('blocks', C.c_int64), ('on_device', C.c_int32), ('reserved', C.c_int32)]
+                ('blocks', C.c_int64), ('on_device', C.c_int32), ('starts_repaired', C.c_int32)]
 
 
 class MetricsCounts(C.Structure):

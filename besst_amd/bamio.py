@@ -40,7 +40,7 @@ def _header(lib, handle):
 
 class ResidentBam(object):
     """A BAM file whose records went straight to HBM - besst_ctx_push_bam_device: the compressed file is uploaded and
-    inflated + decoded on the GPU (files in htslib's block layout); else besst_ctx_push_bam: decode on host threads, pinned
+    inflated + decoded on the GPU (any BGZF block layout); else besst_ctx_push_bam: decode on host threads, pinned
     staging, copies under the next chunk's decode; ``mode`` as in GraphContext.push_bam - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
     on the host needs the record columns; ``part=(r, W)``: rank r's slice of the stream (multi-GPU ingest: ``len()`` and the
     head arrays then describe that slice only - such an object is for distributed.ingest_slice, not for

@@ -538,12 +538,15 @@ namespace {
 // The BGZF blocks of [*fpos, ...) that fit one chunk: descriptors with offsets relative to the chunk's first byte,
 // inflated places 256-byte aligned.  Stops at max_blocks, at comp_cap compressed bytes, or at the end of the file.
 // false: not a BGZF block where one should be.
+// dst0 / back_to_back: where the first block's bytes go and whether the blocks follow each other without padding (the
+// ingest: a record may run on into the next block) or at 256-byte boundaries (the inflate test hook)
 bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t max_blocks, size_t comp_cap, BgzfBlock* out,
-                     uint32_t* n_out, size_t* comp_bytes, size_t* inflated_bytes, bool more_follows = false) {
+                     uint32_t* n_out, size_t* comp_bytes, size_t* inflated_bytes, bool more_follows = false, size_t dst0 = 0,
+                     bool back_to_back = false) {
     auto le16 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); };
     auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
     const size_t begin = *fpos;
-    size_t at = begin, dst = 0;
+    size_t at = begin, dst = dst0;
     uint32_t n = 0;
     while (n < max_blocks && at < map_len) {
         const uint8_t* hdr = map + at;
@@ -575,13 +578,13 @@ bool scan_bgzf_chunk(const uint8_t* map, size_t map_len, size_t* fpos, size_t ma
         b.dst_off_hi = (uint32_t)((uint64_t)dst >> 32);
         b.dst_len = isize;
         b.crc = le32(hdr + bsize - 8);
-        dst += align_up((size_t)isize, 256);
+        dst += back_to_back ? (size_t)isize : align_up((size_t)isize, 256);
         at += bsize;
     }
     *fpos = at;
     *n_out = n;
     *comp_bytes = at - begin;
-    *inflated_bytes = dst;
+    *inflated_bytes = dst - dst0;
     return true;
 }
 
@@ -613,11 +616,13 @@ size_t find_bgzf_boundary(const uint8_t* map, size_t map_len, size_t from) {
 
 // BAM file -> resident records with the inflate and the record decode on the GPU: the file's COMPRESSED bytes are read into
 // pinned memory by the reader's threads and uploaded chunk by chunk; per chunk one wave per BGZF block inflates, one lane per
-// block walks its records, a scan places them and a thread per record fills the columns.  Two slots, each with its own
-// staging, scratch and stream: chunk j + 1 is read, uploaded and ALREADY INFLATING while the host waits for chunk j's record
-// count (the columns may have to grow before its decode) - the tail of one chunk's waves and the head of the next share the
-// chip.  For files in htslib's layout (every block begins with a record); anything else - and any block the device cannot
-// inflate - returns BESST_ERR_UNSUPPORTED with context and reader untouched, and the caller takes besst_ctx_push_bam.
+// block walks its records, a scan places them and a thread per record fills the columns.  Three slots, each with its own
+// staging, scratch and stream: chunk j + 1 is INFLATING and chunk j + 2 read, uploaded and queued behind it while the host
+// waits for chunk j's record count (the columns may have to grow before its decode) - the tail of one chunk's waves and the
+// head of the next share the chip.  Any block layout: a chunk's blocks are inflated back to back behind a slot that receives the record the chunk before
+// left unfinished, and the record starts are guessed per block and verified from block to block (bgzf_gpu.hip).  A block
+// the device cannot inflate returns BESST_ERR_UNSUPPORTED with context and reader untouched, and the caller takes
+// besst_ctx_push_bam.
 int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
     return besst_ctx_push_bam_device_part(c, bam, 0, 1, chunk_blocks, head_records, head_rlen, head_alen, head_qlen, stats);
@@ -680,24 +685,28 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     }
     if (comp_cap > map_len - (size_t)f0 + 65536) comp_cap = align_up(map_len - (size_t)f0 + 65536, 4096);
     if (comp_cap < ((size_t)1 << 20)) comp_cap = (size_t)1 << 20;
-    const size_t desc_bytes = align_up(nb * sizeof(BgzfBlock), 4096);
+    // descriptor 0 of every chunk is the slot for the tail of the chunk before (a record that its bytes did not finish)
+    const size_t nbw = nb + 1;
+    constexpr size_t kTailRoom = (size_t)4 << 20;            // bytes a chunk may carry into the next one (one record)
+    const size_t desc_bytes = align_up(nbw * sizeof(BgzfBlock), 4096);
     const size_t slot_bytes = desc_bytes + comp_cap + 4096;      // (the bit reader's windows run up to 512 bytes past a payload)
-    struct Chunk { uint32_t n_blocks = 0, first_off = 0; size_t comp = 0, inflated = 0; };
+    struct Chunk { uint32_t n_blocks = 0, first_off = 0; size_t comp = 0, inflated = 0, file_end = 0; };
+    constexpr int kSlots = 3;        // chunk j's starts being verified, j + 1 inflating, j + 2 on its way to the device
     struct Slot {
         char* pin = nullptr;         // pinned: descriptors, then the chunk's bytes as they lie in the file
         char* dev = nullptr;         // the same on the device
         uint8_t* inflated = nullptr;
         uint16_t* offs = nullptr;
-        uint32_t* words = nullptr;   // status | count | closed | rec_base (nb each), then 4 summary words
+        uint32_t* words = nullptr;   // status | count | exits | rec_base | guess | tail_at (nbw each), then 8 summary words
         hipStream_t work = nullptr;
-        hipEvent_t h2d_done = nullptr, slot_free = nullptr, summ_done = nullptr;
+        hipEvent_t h2d_done = nullptr, slot_free = nullptr, summ_done = nullptr, tail_taken = nullptr;
         Chunk ck;
-    } sl[2];
+    } sl[kSlots];
     char* heads = nullptr;           // head_rlen | head_alen | head_qlen on the device
     uint32_t* d_flags = nullptr;     // corrupt-record bit, saturated-qlen count
-    uint32_t* summ_host = nullptr;   // pinned: 2 x 4 summary words + 2 flag words
+    uint32_t* summ_host = nullptr;   // pinned: kSlots x 8 summary words | [28] [29] flag words | [32..] kSlots tail descriptors
     hipStream_t copy_stream = nullptr;
-    const size_t inflated_cap = nb * 65536 + nb * 256 + 4096;
+    const size_t inflated_cap = kTailRoom + nb * 65536 + 4096;
     auto release = [&]() {
         for (Slot& q : sl) {
             if (q.pin) (void)hipHostFree(q.pin);
@@ -708,6 +717,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             if (q.h2d_done) (void)hipEventDestroy(q.h2d_done);
             if (q.slot_free) (void)hipEventDestroy(q.slot_free);
             if (q.summ_done) (void)hipEventDestroy(q.summ_done);
+            if (q.tail_taken) (void)hipEventDestroy(q.tail_taken);
             if (q.work) (void)hipStreamDestroy(q.work);
             q = Slot();
         }
@@ -720,33 +730,34 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     for (Slot& q : sl)
         ok = ok && hipHostMalloc((void**)&q.pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
              hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
-             hipMalloc((void**)&q.offs, nb * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
-             hipMalloc((void**)&q.words, (nb * 4 + 4) * sizeof(uint32_t)) == hipSuccess &&
+             hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
+             hipMalloc((void**)&q.words, (nbw * 6 + 8) * sizeof(uint32_t)) == hipSuccess &&
              hipStreamCreateWithFlags(&q.work, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q.tail_taken, hipEventDisableTiming) == hipSuccess;
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
-         hipHostMalloc((void**)&summ_host, 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void**)&summ_host, 64 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
          hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
     const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (!ok) {
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
-                  (2 * slot_bytes) >> 20, (2 * (slot_bytes + inflated_cap)) >> 20);
+                  (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap)) >> 20);
         return BESST_ERR_NOMEM;
     }
     double stage_s = 0.0, wait_s = 0.0;
-    int64_t pushed = 0, chunks = 0, comp_total = 0, inflated_total = 0, blocks_total = 0;
+    int64_t pushed = 0, chunks = 0, comp_total = 0, inflated_total = 0, blocks_total = 0, repaired = 0;
     size_t fpos = (size_t)f0;
     double bytes_per_block = 0.0;
     rc = BESST_OK;
     auto hip_fail = [&](hipError_t e) { set_error("push_bam_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; };
-    // read chunk j (the next blocks of the file) into slot j & 1 and start its upload
+    // read chunk j (the next blocks of the file) into slot j % kSlots and start its upload
     auto stage = [&](int64_t j) -> bool {
-        Slot& q = sl[j & 1];
-        if (j >= 2) {                                        // the upload that last read this pinned slot
+        Slot& q = sl[j % kSlots];
+        if (j >= kSlots) {                                        // the upload that last read this pinned slot
             const auto t0 = std::chrono::steady_clock::now();
             const hipError_t e = hipEventSynchronize(q.h2d_done);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -771,19 +782,22 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             return false;
         }
         size_t used = 0;
-        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(q.pin + desc_bytes), want, &used, nb, comp_cap,
-                             reinterpret_cast<BgzfBlock*>(q.pin), &q.ck.n_blocks, &q.ck.comp, &q.ck.inflated, begin + want < map_len) ||
+        BgzfBlock* desc = reinterpret_cast<BgzfBlock*>(q.pin);
+        desc[0] = BgzfBlock{0u, 0u, (uint32_t)kTailRoom, 0u, 0u, 0u};   // the tail slot: empty until the chunk before says otherwise
+        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(q.pin + desc_bytes), want, &used, nb, comp_cap, desc + 1,
+                             &q.ck.n_blocks, &q.ck.comp, &q.ck.inflated, begin + want < map_len, kTailRoom, true) ||
             (q.ck.n_blocks == 0 && want > 0)) {
             set_error("push_bam_device: not a BGZF block at file offset %zu", begin + used);
             rc = BESST_ERR_UNSUPPORTED;
             return false;
         }
         fpos = begin + q.ck.comp;
+        q.ck.file_end = fpos;
         bytes_per_block = (double)q.ck.comp / (double)q.ck.n_blocks;
         stage_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         hipError_t e = hipSuccess;
-        if (j >= 2) e = hipStreamWaitEvent(copy_stream, q.slot_free, 0);    // the kernels that last read this device slot
-        if (e == hipSuccess) e = hipMemcpyAsync(q.dev, q.pin, (size_t)q.ck.n_blocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, copy_stream);
+        if (j >= kSlots) e = hipStreamWaitEvent(copy_stream, q.slot_free, 0);    // the kernels that last read this device slot
+        if (e == hipSuccess) e = hipMemcpyAsync(q.dev, q.pin, ((size_t)q.ck.n_blocks + 1) * sizeof(BgzfBlock), hipMemcpyHostToDevice, copy_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(q.dev + desc_bytes, q.pin + desc_bytes, q.ck.comp + 1024, hipMemcpyHostToDevice, copy_stream);
         if (e == hipSuccess) e = hipEventRecord(q.h2d_done, copy_stream);
         if (e != hipSuccess) { hip_fail(e); return false; }
@@ -792,20 +806,46 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         blocks_total += q.ck.n_blocks;
         return true;
     };
-    // inflate + walk + scan of the chunk in slot k on the slot's stream, its summary on the way to the host
+    // inflate + CRC of the chunk in slot k on the slot's stream (descriptor 0, the tail slot, is empty here: skipped)
     auto enqueue_inflate = [&](int k) -> bool {
         Slot& q = sl[k];
-        const BgzfBlock* d_blocks = reinterpret_cast<const BgzfBlock*>(q.dev);
-        uint32_t* w = q.words;
         hipError_t e = hipStreamWaitEvent(q.work, q.h2d_done, 0);
+        // (the chunk two before inflated into this buffer; its tail may still be on its way to the chunk in between)
+        if (e == hipSuccess) e = hipStreamWaitEvent(q.work, q.tail_taken, 0);
         if (e != hipSuccess) { hip_fail(e); return false; }
-        if (launch_bgzf_inflate(q.work, reinterpret_cast<const uint8_t*>(q.dev + desc_bytes), d_blocks, q.ck.n_blocks, q.inflated, w) ||
-            launch_bam_walk_scan(q.work, q.inflated, d_blocks, q.ck.n_blocks, q.ck.first_off, w, q.offs, w + nb, w + 2 * nb, w + 3 * nb,
-                                 w + 4 * nb)) {
+        if (launch_bgzf_inflate(q.work, reinterpret_cast<const uint8_t*>(q.dev + desc_bytes), reinterpret_cast<const BgzfBlock*>(q.dev),
+                                q.ck.n_blocks + 1, q.inflated, q.words)) {
             rc = BESST_ERR_HIP;
             return false;
         }
-        e = hipMemcpyAsync(summ_host + 4 * k, w + 4 * nb, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, q.work);
+        return true;
+    };
+    // where the records of the chunk in slot k begin (entry guesses, walks, verification, scan), its summary on the way to the
+    // host.  tail_len bytes at `tail_at` of the buffer of the slot BEFORE are the record the chunk before did not finish: they
+    // are copied in front of this chunk's first block and become its block 0.  first_entry: where the first record begins
+    // in block 1 when there is no tail (the end of the header in the file's first chunk, else 0).
+    const int32_t n_ref = besst_bam_n_references(bam);
+    auto enqueue_walk = [&](int k, uint64_t tail_at, uint32_t tail_len, uint32_t first_entry) -> bool {
+        Slot& q = sl[k];
+        Slot& other = sl[(k + kSlots - 1) % kSlots];
+        uint32_t* w = q.words;
+        hipError_t e = hipSuccess;
+        if (tail_len) {
+            BgzfBlock* patch = reinterpret_cast<BgzfBlock*>(summ_host + 32) + k;
+            *patch = BgzfBlock{0u, 0u, (uint32_t)(kTailRoom - tail_len), 0u, tail_len, 0u};
+            e = hipMemcpyAsync(q.dev, patch, sizeof(BgzfBlock), hipMemcpyHostToDevice, q.work);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(q.inflated + kTailRoom - tail_len, other.inflated + tail_at, tail_len, hipMemcpyDeviceToDevice, q.work);
+        }
+        if (e == hipSuccess) e = hipEventRecord(other.tail_taken, q.work);
+        if (e != hipSuccess) { hip_fail(e); return false; }
+        if (launch_bam_walk_scan(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks + 1,
+                                 (uint64_t)kTailRoom + q.ck.inflated, n_ref, tail_len ? 0xffffffffu : 1u, first_entry, w, q.offs,
+                                 w + nbw, w + 2 * nbw, w + 3 * nbw, w + 4 * nbw, w + 5 * nbw, w + 6 * nbw)) {
+            rc = BESST_ERR_HIP;
+            return false;
+        }
+        e = hipMemcpyAsync(summ_host + 8 * k, w + 6 * nbw, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, q.work);
         if (e == hipSuccess) e = hipEventRecord(q.summ_done, q.work);
         if (e != hipSuccess) { hip_fail(e); return false; }
         return true;
@@ -820,40 +860,69 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the slots' streams start behind these
         if (e != hipSuccess) hip_fail(e);
     }
-    if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks) enqueue_inflate(0);
-    for (int64_t j = 0; rc == BESST_OK && sl[j & 1].ck.n_blocks; ++j) {
-        Slot& q = sl[j & 1];
-        Slot& nx = sl[(j + 1) & 1];
-        // chunk j + 1: read, uploaded and inflating while chunk j's count is on its way
-        if (!stage(j + 1)) break;
-        if (nx.ck.n_blocks && !enqueue_inflate((int)((j + 1) & 1))) break;
+    if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, u0) && stage(1) &&
+        sl[1].ck.n_blocks)
+        enqueue_inflate(1);
+    for (int64_t j = 0; rc == BESST_OK && sl[j % kSlots].ck.n_blocks; ++j) {
+        Slot& q = sl[j % kSlots];
+        Slot& nx = sl[(j + 1) % kSlots];
+        // chunk j + 2: read, uploaded and queued behind chunk j + 1's inflate while chunk j's count is on its way (with two
+        // slots the inflate of chunk j + 2 could not be queued before chunk j's verdict had been seen AND the file read:
+        // the chip idled between two inflates whenever the two took longer than one inflate)
+        if (nx.ck.n_blocks) {
+            if (!stage(j + 2)) break;
+            if (sl[(j + 2) % kSlots].ck.n_blocks && !enqueue_inflate((int)((j + 2) % kSlots))) break;
+        }
         {
             const auto t0 = std::chrono::steady_clock::now();
             const hipError_t e = hipEventSynchronize(q.summ_done);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); break; }
         }
-        const uint32_t* sm = summ_host + 4 * (j & 1);
+        const uint32_t* sm = summ_host + 8 * (j % kSlots);
         if (!sm[1]) {
-            if (sm[3]) set_error("push_bam_device: block %u of chunk %lld did not inflate on the device (status %u)", sm[2], (long long)j, sm[3]);
-            else set_error("push_bam_device: a record straddles BGZF blocks (block %u of chunk %lld): not htslib's layout", sm[2], (long long)j);
+            if (sm[3]) set_error("push_bam_device: block %u of chunk %lld did not inflate on the device (status %u)", sm[2] ? sm[2] - 1u : 0u, (long long)j, sm[3]);
+            else set_error("push_bam_device: the records of chunk %lld could not be located on the device (block %u: a record start "
+                           "that its neighbours do not confirm, or a corrupt length)", (long long)j, sm[2] ? sm[2] - 1u : 0u);
             rc = BESST_ERR_UNSUPPORTED;
             break;
         }
+        if (parts > 1 && sm[7]) {
+            set_error("push_bam_device: a record straddles BGZF blocks (chunk %lld): a part of such a file cannot be cut at a block", (long long)j);
+            rc = BESST_ERR_UNSUPPORTED;
+            break;
+        }
+        const uint32_t tail_len = sm[4];
+        if (tail_len > (uint32_t)kTailRoom) {
+            set_error("push_bam_device: a record of more than %zu MB", kTailRoom >> 20);
+            rc = BESST_ERR_UNSUPPORTED;
+            break;
+        }
+        if (nx.ck.n_blocks) {
+            // chunk j + 1's records can be located now: it starts with chunk j's unfinished record, if there is one
+            if (!enqueue_walk((int)((j + 1) % kSlots), (uint64_t)sm[5] | ((uint64_t)sm[6] << 32), tail_len, 0u)) break;
+        } else if (tail_len) {
+            set_error("push_bam_device: the %s ends inside a record", parts > 1 ? "part of the file" : "file");
+            rc = parts > 1 ? BESST_ERR_UNSUPPORTED : BESST_ERR_ARG;
+            break;
+        }
         const int64_t got = (int64_t)sm[0];
+        repaired += (int64_t)sm[2];
         const int64_t have = c->n_records + pushed;
         if (have + got >= ((int64_t)1 << 32)) { set_error("more than 2^32-1 records in one context"); rc = BESST_ERR_ARG; break; }
         if ((size_t)(have + got) > c->tid.cap) {
             // room for the whole file at the rate of the bytes read so far (+ 6 %), at least for this chunk; the decode of
             // the chunk before may still be writing the columns that are about to move
             int64_t want = have + got;
-            const size_t at = fpos - nx.ck.comp;             // end of chunk j in the file
+            const size_t at = q.ck.file_end;                 // end of chunk j in the file
             if (at > (size_t)f0 && at < map_len)
                 want = c->n_records + (int64_t)((double)(pushed + got) * ((double)(map_len - (size_t)f0) / (double)(at - (size_t)f0)) * 1.06) + 4096;
             if (want < have + got) want = have + got;
             if (want >= ((int64_t)1 << 32)) want = ((int64_t)1 << 32) - 1;
             const auto t0 = std::chrono::steady_clock::now();
-            const hipError_t e = hipStreamSynchronize(nx.work);
+            hipError_t e = hipSuccess;
+            for (Slot& o : sl)                               // (slot_free: behind a slot's last decode)
+                if (e == hipSuccess) e = hipEventSynchronize(o.slot_free);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); break; }
             const int64_t keep = c->n_records;
@@ -864,19 +933,23 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         }
         col.tid = c->tid.p; col.mtid = c->mtid.p; col.pos = c->pos.p; col.mpos = c->mpos.p; col.tlen = c->tlen.p;
         col.flag = c->flag.p; col.qlen = c->qlen.p; col.mapq = c->mapq.p;
-        if (launch_bam_decode(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks, q.offs, q.words + nb,
-                              q.words + 3 * nb, col, have, pushed, head_records, d_flags)) { rc = BESST_ERR_HIP; break; }
+        if (launch_bam_decode(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks + 1, q.offs, q.words + nbw,
+                              q.words + 3 * nbw, col, have, pushed, head_records, d_flags)) { rc = BESST_ERR_HIP; break; }
         const hipError_t e = hipEventRecord(q.slot_free, q.work);
         if (e != hipSuccess) { hip_fail(e); break; }
         pushed += got;
         ++chunks;
     }
     const auto tw = std::chrono::steady_clock::now();
-    const hipError_t e0 = hipStreamSynchronize(sl[0].work), e1 = hipStreamSynchronize(sl[1].work);
+    hipError_t e0 = hipSuccess, e1 = hipSuccess;
+    for (Slot& q : sl) {
+        const hipError_t e = hipStreamSynchronize(q.work);
+        if (e != hipSuccess) e0 = e;
+    }
     const hipError_t ec = hipStreamSynchronize(copy_stream);
     if (rc == BESST_OK && (e0 != hipSuccess || e1 != hipSuccess || ec != hipSuccess)) hip_fail(e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : ec);
     if (rc == BESST_OK) {
-        hipError_t e = hipMemcpyAsync(summ_host + 8, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = hipMemcpyAsync(summ_host + 28, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         const int64_t hn = pushed < head_records ? pushed : head_records;
         if (e == hipSuccess && hn > 0) {
             e = hipMemcpyAsync(head_rlen, col.head_rlen, (size_t)hn * 4, hipMemcpyDeviceToHost, c->stream);
@@ -887,11 +960,11 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (e != hipSuccess) hip_fail(e);
     }
     wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-    if (rc == BESST_OK && (summ_host[8] & 1u)) {
+    if (rc == BESST_OK && (summ_host[28] & 1u)) {
         set_error("push_bam_device: corrupt record (its name and CIGAR do not fit its length)");
         rc = BESST_ERR_ARG;
     }
-    const uint32_t saturated = rc == BESST_OK ? summ_host[9] : 0u;
+    const uint32_t saturated = rc == BESST_OK ? summ_host[29] : 0u;
     const auto t_rel = std::chrono::steady_clock::now();
     release();
     if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
@@ -913,6 +986,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         stats->inflated_bytes = inflated_total;
         stats->blocks = blocks_total;
         stats->on_device = 1;
+        stats->starts_repaired = (int32_t)(repaired > 0x7fffffff ? 0x7fffffff : repaired);
     }
     return BESST_OK;
 }

@@ -1,6 +1,6 @@
 // BAM ingest on the GPU: BGZF inflate + record walk + record decode, the COMPRESSED file is what crosses PCIe.
 // (the device form of bam_reader.hip's host path - `pysam.Samfile` iteration, runBESST:162,
-// CreateGraph.py:111, libmetrics.py:63,257,293 - for files in htslib's block layout, where no record straddles a block.)
+// CreateGraph.py:111, libmetrics.py:63,257,293 - for any BGZF block layout: records may straddle blocks and chunks.)
 //
 // A BGZF block is an independent DEFLATE stream of at most 64 KiB of output, and a BAM of C3's size holds 1.3 million of
 // them: the parallelism is across blocks, so a block belongs to ONE WAVE; what is sequential about the stream - Huffman
@@ -28,10 +28,12 @@
 //                last dist bytes).
 //   bgzf_crc_kernel       the CRC-32 of every block's inflated bytes against the block's gzip trailer (what htslib checks):
 //                         a thread per slice, the slices' values combined as zlib's crc32_combine does
-//   bam_walk_kernel       one lane per block: follows the records' length prefixes from the block's first byte
-//                         (u16 offsets per record, count, and whether the walk ended exactly at the block's end)
-//   bam_scan_kernel       exclusive scan of the blocks' record counts + the chunk's verdict (all blocks inflated, all walks
-//                         closed: htslib's layout) in one workgroup
+//   bam_entry_kernel      one wave per block guesses the block's first record start (offset 0 in htslib's layout)
+//   bam_walk_kernel       one lane per block: follows the records' length prefixes from the guess (u16 offsets per record,
+//                         count, and where the walk leaves the block)
+//   bam_scan_kernel       one workgroup: verifies the guesses from block to block and walks a block again where one was
+//                         wrong, finds the record the chunk leaves unfinished, exclusive scan of the record counts
+//                         (the comment in front of bam_entry_kernel has the scheme)
 //   bam_decode_kernel     one workgroup per block, a thread per record: the 36 fixed bytes as ten aligned dwords, the
 //                         CIGAR walk of pysam 0.8.4's qlen / alen (bam_reader.hip has the semantics), coalesced stores
 //                         into the record columns at the block's place in the stream
@@ -637,44 +639,48 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
         }
     }
     __syncthreads();
-    const uint8_t* base = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
-    // slice t = [t S, (t + 1) S) cut at len; S a multiple of 16, so that every slice is read as aligned 16-byte words
-    // (the next word is requested before the current one's 32 table look-ups - a byte at a time the loads alone, each
-    // waited for, took longer than the inflate)
-    const uint32_t S = (((len + 255u) >> 8) + 15u) & ~15u;
-    const uint32_t lo = t * S < len ? t * S : len;
-    const uint32_t hi = lo + S < len ? lo + S : len;
-    const uint32_t n_slice = hi - lo;
+    const uint8_t* first = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
+    // The blocks of a chunk lie back to back (a record may run on into the next block), so a block begins at any byte: the
+    // slices are cut from the 16-byte boundary in front of it - slice t = [t S, (t + 1) S) of `pad` foreign bytes followed by
+    // the block's, S a multiple of 16, every slice read as aligned 16-byte words (the next word requested before the
+    // current one's look-ups; a byte at a time the loads alone, each waited for, took longer than the inflate) - and
+    // the first slice skips the foreign bytes.
+    const uint32_t pad = (uint32_t)((uintptr_t)first & 15u);
+    const uint8_t* base = first - pad;
+    const uint32_t vlen = len + pad;
+    const uint32_t S = (((vlen + 255u) >> 8) + 15u) & ~15u;
+    const uint32_t lo = t * S < vlen ? t * S : vlen;
+    const uint32_t hi = lo + S < vlen ? lo + S : vlen;
+    uint32_t skip = lo < pad ? (pad - lo < hi - lo ? pad - lo : hi - lo) : 0u;   // (only slice 0: S >= 16 > pad)
+    const uint32_t n_slice = hi - lo - skip;
     const uint4* src = reinterpret_cast<const uint4*>(base + lo);
     uint32_t crc = 0xffffffffu;
-    auto eat = [&](uint32_t w, uint32_t count) {             // the low `count` bytes of a word
-        if (count >= 4u) {
+    auto eat = [&](uint32_t w, uint32_t from, uint32_t count) {   // bytes [from, count) of a word
+        if (from == 0u && count >= 4u) {
             const uint32_t x = crc ^ w;
             crc = s_tab[3][x & 0xffu] ^ s_tab[2][(x >> 8) & 0xffu] ^ s_tab[1][(x >> 16) & 0xffu] ^ s_tab[0][x >> 24];
             return;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 3u; ++k) {
-            if (k < count) {
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (k >= from && k < count) {
                 crc = s_tab[0][(crc ^ (w >> (8u * k))) & 0xffu] ^ (crc >> 8);
             }
         }
     };
-    uint4 cur = n_slice ? src[0] : make_uint4(0, 0, 0, 0);
-    for (uint32_t q = 0; q * 16u < n_slice; ++q) {
-        const uint4 next = (q + 1u) * 16u < n_slice ? src[q + 1u] : make_uint4(0, 0, 0, 0);
-        const uint32_t rem = n_slice - q * 16u;
-        if (rem >= 16u) {
-            eat(cur.x, 4); eat(cur.y, 4); eat(cur.z, 4); eat(cur.w, 4);
-        } else {
-            eat(cur.x, rem); eat(cur.y, rem > 4u ? rem - 4u : 0u); eat(cur.z, rem > 8u ? rem - 8u : 0u);
-            eat(cur.w, rem > 12u ? rem - 12u : 0u);
-        }
+    auto part = [](uint32_t v, uint32_t at) { return v > at ? (v - at < 4u ? v - at : 4u) : 0u; };   // of bytes [0, v): how many lie in dword `at / 4`
+    uint4 cur = hi > lo ? src[0] : make_uint4(0, 0, 0, 0);
+    for (uint32_t q = 0; q * 16u < hi - lo; ++q) {
+        const uint4 next = (q + 1u) * 16u < hi - lo ? src[q + 1u] : make_uint4(0, 0, 0, 0);
+        const uint32_t rem = hi - lo - q * 16u;                  // bytes of the slice from this word on (>= 16: all of it)
+        const uint32_t sk = q == 0u ? skip : 0u;
+        eat(cur.x, part(sk, 0), part(rem, 0)); eat(cur.y, part(sk, 4), part(rem, 4));
+        eat(cur.z, part(sk, 8), part(rem, 8)); eat(cur.w, part(sk, 12), part(rem, 12));
         cur = next;
     }
     crc = n_slice ? ~crc : 0u;
     // carry it over the bytes behind the slice: multiply by x^(8 n)
-    uint32_t n = len - hi;
+    uint32_t n = vlen - hi;
     uint32_t p = 1u << 31;                                   // x^0
     for (uint32_t k = 3; n; n >>= 1, ++k)
         if (n & 1u) p = crc_mul(kCrcX2n[k & 31u], p);
@@ -713,45 +719,190 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) {     // little-endi
 
 }  // namespace
 
-// one lane per block: the chain of length prefixes from `first_off` (block 0 of the file's record stream) or 0
-__global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
-                                                      uint32_t n_blocks, uint32_t first_off, const uint32_t* __restrict__ status,
-                                                      uint16_t* __restrict__ offs, uint32_t* __restrict__ count,
-                                                      uint32_t* __restrict__ closed) {
-    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
-    if (b >= n_blocks) return;
-    const uint32_t len = blocks[b].dst_len;
-    const uint8_t* base = inflated + (size_t)blocks[b].dst_off_lo + ((size_t)blocks[b].dst_off_hi << 32);
-    uint32_t cur = b == 0u ? first_off : 0u, cnt = 0;
-    if (status[b] != kInfOk || cur > len) {
-        count[b] = 0;
-        closed[b] = 0;
-        return;
+// ---- where the records begin, for ANY block layout ------------------------------------------------------------------------
+// htslib never lets a record straddle a BGZF block; htsjdk / Picard cut their blocks at 64 KiB of data wherever that falls.
+// A chunk's blocks are inflated back to back, so a record is contiguous whatever the layout; what is sequential is the chain
+// of length prefixes - which record start lies where depends on every record before it.  It is taken apart per block:
+//   bam_entry_kernel   one wave per block GUESSES the block's first record start: the first offset whose 36 fixed bytes
+//                      look like a record (reference ids inside the header's count, positions >= -1, a name, a body that
+//                      holds name + CIGAR + sequence + qualities) and whose successor looks like one too - offset 0 in
+//                      htslib's layout, found by the first lane;
+//   bam_walk_kernel    one lane per block follows the length prefixes from the guess to the first start that lies in a later
+//                      block - its EXIT, counted from the block's end - or to the record that the chunk's bytes do not
+//                      finish (the chunk's TAIL: it is moved in front of the next chunk's first block);
+//   bam_scan_kernel    makes the guesses exact: every block checks that its exit - carried over blocks that a long record
+//                      covers whole, which must have guessed "no start" - IS the guess of the block it lands in.  The first
+//                      block's entry is known (the end of the header, 0 behind a chunk that ended with a record, or the tail
+//                      in the slot in front of it), so by induction every start of the chunk is a true start; any
+//                      mismatch and the chunk is refused (the caller falls back to the host reader).  Then the exclusive
+//                      scan of the record counts, and the chunk's summary.
+// Descriptor 0 of a chunk is the slot of the previous chunk's tail (dst_len 0: none); the file's blocks follow from 1.
+constexpr uint32_t kNoStart = 0xffffffffu;               // guess: no record begins in the block
+constexpr uint32_t kExitBad = 0xffffffffu, kExitTail = 0xfffffffeu, kExitNone = 0xfffffffdu;   // exit: corrupt / chunk's tail / nothing walked
+
+// do the bytes at p begin a record?  (`avail` of them are the chunk's, >= 36: what lies beyond is not looked at)
+__device__ __forceinline__ bool bam_plausible(const uint8_t* p, unsigned long long avail, int32_t n_ref, uint32_t* size_out) {
+    const uint32_t size = ld32u(p);
+    const int32_t ref = (int32_t)ld32u(p + 4), pos = (int32_t)ld32u(p + 8);
+    const uint32_t w3 = ld32u(p + 12), w4 = ld32u(p + 16);
+    const int32_t l_seq = (int32_t)ld32u(p + 20), mref = (int32_t)ld32u(p + 24), mpos = (int32_t)ld32u(p + 28);
+    const uint32_t l_name = w3 & 0xffu, n_cigar = w4 & 0xffffu;
+    *size_out = size;
+    if (size < 32u || size >= (1u << 28)) return false;
+    if (ref < -1 || ref >= n_ref || mref < -1 || mref >= n_ref || pos < -1 || mpos < -1) return false;
+    if (l_name == 0u || l_seq < 0) return false;
+    const unsigned long long body = 32ull + l_name + 4ull * n_cigar + ((unsigned long long)l_seq + 1ull) / 2ull + (unsigned long long)l_seq;
+    if (body > (unsigned long long)size) return false;
+    // the name: printable, and closed by the NUL that l_name counts
+    if (36ull + l_name <= avail) {
+        if (p[36u + l_name - 1u] != 0u) return false;
+        if (l_name > 1u && (p[36] < 0x21u || p[36] > 0x7eu)) return false;
     }
-    uint16_t* o = offs + (size_t)b * kBamBlockRecs;
-    while (len - cur >= 4u && cnt < (uint32_t)kBamBlockRecs) {
-        const uint32_t block_size = ld32u(base + cur);
-        if (block_size < 32u || len - cur - 4u < block_size) break;
-        o[cnt++] = (uint16_t)cur;
-        cur += 4u + block_size;
-    }
-    count[b] = cnt;
-    closed[b] = cur == len ? 1u : 0u;
+    return true;
 }
 
-// exclusive scan of the blocks' record counts; summary[0] = records of the chunk, [1] = 1 when every block inflated and
-// every walk ended at its block's end, [2] = first block that did not, [3] = that block's inflate status
-__global__ __launch_bounds__(1024) void bam_scan_kernel(const uint32_t* __restrict__ count, const uint32_t* __restrict__ closed,
-                                                        const uint32_t* __restrict__ status, uint32_t n_blocks,
+__global__ __launch_bounds__(64) void bam_entry_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
+                                                       uint32_t n_blocks, unsigned long long chunk_end, int32_t n_ref,
+                                                       uint32_t forced_block, uint32_t forced_entry, uint32_t* __restrict__ guess) {
+    const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t len = blocks[b].dst_len;
+    const unsigned long long at0 = (unsigned long long)blocks[b].dst_off_lo | ((unsigned long long)blocks[b].dst_off_hi << 32);
+    uint32_t found = kNoStart;
+    if (b == 0u) found = len ? 0u : kNoStart;                // the tail of the chunk before begins with a record
+    else if (b == forced_block) found = forced_entry < len ? forced_entry : kNoStart;
+    else {
+        for (uint32_t o0 = 0; o0 < len; o0 += 64u) {          // uniform
+            const uint32_t o = o0 + (uint32_t)lane;
+            bool ok = false;
+            if (o < len && at0 + o + 36ull <= chunk_end) {
+                uint32_t size = 0, size2 = 0;
+                ok = bam_plausible(inflated + at0 + o, chunk_end - (at0 + o), n_ref, &size);
+                const unsigned long long next = at0 + o + 4ull + size;
+                if (ok && next + 36ull <= chunk_end) ok = bam_plausible(inflated + next, chunk_end - next, n_ref, &size2);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                found = o0 + (uint32_t)__ffsll((long long)m) - 1u;
+                break;
+            }
+        }
+    }
+    if (lane == 0) guess[b] = found;
+}
+
+// follow the length prefixes of block b from `entry` (the walk proper: one lane, a chain of dependent loads)
+__device__ __forceinline__ void bam_walk_block(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks, uint32_t b,
+                                               unsigned long long chunk_end, const uint32_t* __restrict__ status, uint32_t entry,
+                                               uint16_t* __restrict__ offs, uint32_t* count, uint32_t* exits, uint32_t* tail_at) {
+    const uint32_t len = blocks[b].dst_len;
+    const unsigned long long at0 = (unsigned long long)blocks[b].dst_off_lo | ((unsigned long long)blocks[b].dst_off_hi << 32);
+    uint32_t cnt = 0, out = kExitNone;
+    unsigned long long cur = entry;
+    if (len != 0u && status[b] != kInfOk) out = kExitBad;
+    else if (entry != kNoStart) {
+        uint16_t* o = offs + (size_t)b * kBamBlockRecs;
+        for (;;) {
+            if (cur >= len) { out = (uint32_t)(cur - len); break; }       // the next start lies in a later block
+            if (at0 + cur + 4ull > chunk_end) { out = kExitTail; break; }
+            const uint32_t size = ld32u(inflated + at0 + cur);
+            if (size < 32u || size >= (1u << 28) || cnt >= (uint32_t)kBamBlockRecs) { out = kExitBad; break; }
+            if (at0 + cur + 4ull + size > chunk_end) { out = kExitTail; break; }
+            o[cnt++] = (uint16_t)cur;
+            cur += 4ull + size;
+        }
+    }
+    count[b] = cnt;
+    exits[b] = out;
+    tail_at[b] = (uint32_t)cur;
+}
+
+__global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
+                                                      uint32_t n_blocks, unsigned long long chunk_end, const uint32_t* __restrict__ status,
+                                                      const uint32_t* __restrict__ guess, uint16_t* __restrict__ offs,
+                                                      uint32_t* __restrict__ count, uint32_t* __restrict__ exits,
+                                                      uint32_t* __restrict__ tail_at) {
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= n_blocks) return;
+    bam_walk_block(inflated, blocks, b, chunk_end, status, guess[b], offs, count, exits, tail_at);
+}
+
+// summary: [0] records, [1] 1 = every start verified, [2] first block that is not (verified: guesses replaced), [3] its inflate status, [4] bytes of the
+// chunk's tail, [5] [6] where it begins in the chunk's buffer, [7] 1 = some block begins inside a record (not htslib's layout)
+//
+// A verdict is the smallest (block << 32 | what its predecessor says its entry is): kVerdictBad in the low word when there is
+// nothing to repair (an inflate / CRC failure, a length that cannot be a record's on the true chain).
+constexpr uint32_t kVerdictNoStart = 0x7fffffffu, kVerdictBad = 0xffffffffu;
+constexpr unsigned long long kNoVerdict = ~0ull;
+constexpr uint32_t kMaxRepairs = 4096;
+
+__global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
+                                                        uint16_t* __restrict__ offs, uint32_t* count, uint32_t* exits, uint32_t* guess,
+                                                        uint32_t* tail_at, const uint32_t* __restrict__ status,
+                                                        uint32_t n_blocks, unsigned long long chunk_end, uint32_t forced_block,
                                                         uint32_t* __restrict__ rec_base, uint32_t* __restrict__ summary) {
-    __shared__ uint32_t s_w[16], s_bad[16];
+    __shared__ uint32_t s_w[16], s_tail, s_straddle;
+    __shared__ unsigned long long s_bad;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t tail_b = 0xffffffffu, round = 0;
+    unsigned long long bad = kNoVerdict;
+    for (;; ++round) {
+        if (t == 0) { s_bad = kNoVerdict; s_tail = 0xffffffffu; s_straddle = 0u; }
+        __syncthreads();
+        // ---- every walked block vouches for the block its exit lands in
+        for (uint32_t b = (uint32_t)t; b < n_blocks; b += 1024u) {
+            const uint32_t ex = exits[b], g = guess[b];
+            const unsigned long long here = (unsigned long long)b << 32;
+            if (blocks[b].dst_len != 0u && status[b] != kInfOk) { atomicMin(&s_bad, here | kVerdictBad); continue; }
+            if (b > 0u && b != forced_block && g != kNoStart && g != 0u) s_straddle = 1u;
+            if (ex == kExitNone) continue;                   // guessed "no start": a block before it vouches for that (or fails to)
+            if (ex == kExitBad) { atomicMin(&s_bad, here | kVerdictBad); continue; }
+            if (ex == kExitTail) { atomicMin(&s_tail, b); continue; }
+            uint32_t carry = ex, nb = b + 1u;
+            while (nb < n_blocks && carry >= blocks[nb].dst_len) {       // blocks the record covers whole
+                if (guess[nb] != kNoStart && blocks[nb].dst_len != 0u) break;
+                carry -= blocks[nb].dst_len;
+                ++nb;
+            }
+            if (nb < n_blocks) {
+                if (guess[nb] != carry)
+                    atomicMin(&s_bad, ((unsigned long long)nb << 32) | (carry >= blocks[nb].dst_len ? kVerdictNoStart : carry));
+            } else if (carry != 0u) {
+                atomicMin(&s_bad, here | kVerdictBad);       // (a record that ends beyond the chunk would have been its tail)
+            }
+        }
+        if (t == 0) {
+            // the first block that holds bytes must hold a start: block 0 (a tail) or the forced block right behind an empty
+            // slot 0 - nobody vouches for a block in front of the first walked one
+            uint32_t f = 0;
+            while (f < n_blocks && exits[f] == kExitNone && blocks[f].dst_len == 0u) ++f;
+            if (f < n_blocks && exits[f] == kExitNone && f != 0u) atomicMin(&s_bad, ((unsigned long long)f << 32) | kVerdictBad);
+        }
+        __syncthreads();
+        bad = s_bad;
+        tail_b = s_tail;
+        const uint32_t bad_b = (uint32_t)(bad >> 32), want = (uint32_t)bad;
+        // settled: nothing wrong in front of the chunk's tail (behind it lie the unfinished record's bytes, whatever they look like)
+        if (bad == kNoVerdict || (tail_b != 0xffffffffu && bad_b > tail_b)) break;
+        if (want == kVerdictBad || round >= kMaxRepairs) break;
+        // ---- a guess was wrong - a stretch of bytes that looks like a record and is none, or a record that looks like none.
+        // Every block before it has been vouched for, so what its predecessor says IS its entry: walk it again from there.
+        if (t == 0) {
+            const uint32_t entry = want == kVerdictNoStart ? kNoStart : want;
+            guess[bad_b] = entry;
+            bam_walk_block(inflated, blocks, bad_b, chunk_end, status, entry, offs, count, exits, tail_at);
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+    const uint32_t bad_b = (uint32_t)(bad >> 32);
     const uint32_t per = (n_blocks + 1023u) / 1024u;
     const uint32_t b0 = (uint32_t)t * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
-    uint32_t sum = 0, bad = 0xffffffffu;
+    uint32_t sum = 0;
     for (uint32_t b = b0; b < b1; ++b) {
+        if (b > tail_b) count[b] = 0u;                       // behind the tail's block: the unfinished record's bytes
         sum += count[b];
-        if ((status[b] != kInfOk || !closed[b]) && bad == 0xffffffffu) bad = b;
     }
     uint32_t x = sum;
 #pragma unroll
@@ -759,31 +910,31 @@ __global__ __launch_bounds__(1024) void bam_scan_kernel(const uint32_t* __restri
         const uint32_t v = (uint32_t)__shfl_up((int)x, d, 64);
         if (lane >= d) x += v;
     }
-    uint32_t mb = bad;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint32_t v = (uint32_t)__shfl_xor((int)mb, d, 64);
-        mb = v < mb ? v : mb;
-    }
     if (lane == 63) s_w[wave] = x;
-    if (lane == 0) s_bad[wave] = mb;
     __syncthreads();
-    uint32_t off = x - sum, total = 0, first_bad = 0xffffffffu;
+    uint32_t off = x - sum, total = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         if (q < wave) off += s_w[q];
         total += s_w[q];
-        first_bad = s_bad[q] < first_bad ? s_bad[q] : first_bad;
     }
     for (uint32_t b = b0; b < b1; ++b) {
         rec_base[b] = off;
         off += count[b];
     }
     if (t == 0) {
+        const bool ok = bad == kNoVerdict || (tail_b != 0xffffffffu && bad_b > tail_b);
         summary[0] = total;
-        summary[1] = first_bad == 0xffffffffu ? 1u : 0u;
-        summary[2] = first_bad;
-        summary[3] = first_bad == 0xffffffffu ? 0u : status[first_bad];
+        summary[1] = ok ? 1u : 0u;
+        summary[2] = ok ? round : bad_b;
+        summary[3] = ok ? 0u : (bad_b < n_blocks ? status[bad_b] : 0u);
+        unsigned long long at = chunk_end;
+        if (tail_b != 0xffffffffu)
+            at = ((unsigned long long)blocks[tail_b].dst_off_lo | ((unsigned long long)blocks[tail_b].dst_off_hi << 32)) + tail_at[tail_b];
+        summary[4] = (uint32_t)(chunk_end - at);
+        summary[5] = (uint32_t)at;
+        summary[6] = (uint32_t)(at >> 32);
+        summary[7] = s_straddle;
     }
 }
 
@@ -869,13 +1020,16 @@ int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* bloc
     return BESST_OK;
 }
 
-int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint32_t first_off,
-                         const uint32_t* status, uint16_t* offs, uint32_t* count, uint32_t* closed, uint32_t* rec_base,
-                         uint32_t* summary) {
+int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint64_t chunk_end,
+                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, const uint32_t* status, uint16_t* offs,
+                         uint32_t* count, uint32_t* exits, uint32_t* rec_base, uint32_t* guess, uint32_t* tail_at, uint32_t* summary) {
     if (n_blocks == 0) return BESST_OK;
-    hipLaunchKernelGGL(bam_walk_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, s, inflated, blocks, n_blocks, first_off,
-                       status, offs, count, closed);
-    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, s, count, closed, status, n_blocks, rec_base, summary);
+    hipLaunchKernelGGL(bam_entry_kernel, dim3(n_blocks), dim3(64), 0, s, inflated, blocks, n_blocks, (unsigned long long)chunk_end,
+                       n_ref, forced_block, forced_entry, guess);
+    hipLaunchKernelGGL(bam_walk_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, s, inflated, blocks, n_blocks,
+                       (unsigned long long)chunk_end, status, guess, offs, count, exits, tail_at);
+    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, s, inflated, blocks, offs, count, exits, guess, tail_at, status, n_blocks,
+                       (unsigned long long)chunk_end, forced_block, rec_base, summary);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

@@ -58,9 +58,9 @@ struct BamColumns {
 };
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
                         uint32_t* status);
-int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint32_t first_off,
-                         const uint32_t* status, uint16_t* offs, uint32_t* count, uint32_t* closed, uint32_t* rec_base,
-                         uint32_t* summary);
+int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint64_t chunk_end,
+                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, const uint32_t* status, uint16_t* offs,
+                         uint32_t* count, uint32_t* exits, uint32_t* rec_base, uint32_t* guess, uint32_t* tail_at, uint32_t* summary);
 int launch_bam_decode(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, const uint16_t* offs,
                       const uint32_t* count, const uint32_t* rec_base, const BamColumns& col, int64_t out_base,
                       int64_t rel_base, int64_t head_records, uint32_t* flags);

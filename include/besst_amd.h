@@ -180,25 +180,30 @@ typedef struct {
     int64_t inflated_bytes;      /* device form: bytes the BGZF blocks inflated to */
     int64_t blocks;              /* device form: BGZF blocks */
     int32_t on_device;           /* 1: inflate + record decode ran on the GPU (bytes_h2d = the compressed bytes) */
-    int32_t reserved;
+    int32_t starts_repaired;     /* device form: blocks whose guessed first record start the verification replaced (0 in htslib's layout) */
 } besst_ingest_stats;
 int besst_ctx_push_bam(besst_ctx* ctx, besst_bam* bam, int64_t chunk_records, int64_t head_records, int32_t* head_rlen,
                        int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
 
 /* The same with BGZF inflate, record walk and record decode ON THE GPU (csrc/bgzf_gpu.hip): the file's compressed bytes
  * are what crosses PCIe - staged through pinned memory chunk by chunk (chunk_blocks BGZF blocks, <= 0: 8192), chunk
- * j + 1 uploaded while chunk j inflates (one wave per block).  For files in htslib's block layout, where every BGZF
- * block begins with a record (samtools, bwa | samtools, this library's writer).  Returns BESST_ERR_UNSUPPORTED - context
- * and reader unchanged - for any other layout (a record that straddles blocks) and for a block the device does not
- * inflate or whose CRC-32 does not match its gzip trailer: call besst_ctx_push_bam then (which checks the CRC-32 too and
- * reports the file as corrupt, as htslib would). */
+ * j + 1 uploaded while chunk j inflates (one wave per block).  ANY block layout: htslib's (samtools, bwa | samtools, this
+ * library's writer), where every BGZF block begins with a record, and htsjdk's / Picard's, where blocks are cut wherever
+ * 64 KiB of data end - a chunk's blocks are inflated back to back, the first record start of every block is guessed from
+ * the bytes and VERIFIED from block to block (a wrong guess is replaced by what the block before it says and the block
+ * is walked again), and the record that a chunk does not finish travels in front of the next chunk's first block (at most
+ * 4 MiB).  Returns BESST_ERR_UNSUPPORTED - context and reader unchanged - for a block the device does not inflate or
+ * whose CRC-32 does not match its gzip trailer and for record starts that cannot be established: call besst_ctx_push_bam
+ * then (which checks the CRC-32 too and reports the file as corrupt, as htslib would). */
 int besst_ctx_push_bam_device(besst_ctx* ctx, besst_bam* bam, int64_t chunk_blocks, int64_t head_records, int32_t* head_rlen,
                               int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
 
 /* The same for one PART of the file's records - multi-GPU ingest: rank r of W calls it with (r, W) and holds the r-th
  * contiguous slice of the stream, the slice phase 1 of the sharded graph build works on.  The file is
  * cut at the BGZF block boundaries nearest to part / parts of its bytes; every caller finds the same boundaries on its own
- * (gzip magic + BC subfield + two chained blocks behind it).  The head_* arrays describe the part's first records. */
+ * (gzip magic + BC subfield + two chained blocks behind it).  The head_* arrays describe the part's first records.
+ * parts > 1 needs htslib's layout, where every block boundary is a record boundary: BESST_ERR_UNSUPPORTED (context and
+ * reader unchanged) for a file whose records straddle blocks - one rank reads such a file whole. */
 int besst_ctx_push_bam_device_part(besst_ctx* ctx, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks,
                                    int64_t head_records, int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen,
                                    besst_ingest_stats* stats);

@@ -13,11 +13,15 @@ def _bgzf_block(data):
     return head + payload + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data))
 
 
-def write_bam(path, batch, soft_clip=None, block_bytes=60000, align_records=False):
+def write_bam(path, batch, soft_clip=None, block_bytes=60000, align_records=False, decoys=False):
     """Write ``batch`` as BAM.  CIGAR per record: [soft clip S] qlen M, so that qlen/rlen/alen round-trip:
     rlen = qlen + clip (or 0 when batch.rlen is 0), alen = qlen.
     align_records=False cuts BGZF blocks at arbitrary bytes (records straddle blocks); True flushes the block
-    before a record that would not fit, like htslib's bam_write1, so that every block starts with a record."""
+    before a record that would not fit, like htslib's bam_write1, so that every block starts with a record.
+    decoys=True makes the qualities of every record with room for them spell the fixed fields of a record (legal
+    reference ids and positions, a NUL-closed name, a length that points far beyond the file): bytes that a reader
+    which looks for record starts inside a block must not take for one."""
+    decoy = struct.pack('<IiiBBHHHIiii', 1 << 26, 0, 5, 3, 30, 4680, 0, 99, 0, 0, 7, 0) + b'zz\x00'
     out = bytearray()
     cuts = []                        # block boundaries when align_records
     text = b'@HD\tVN:1.0\tSO:coordinate\n'
@@ -41,7 +45,10 @@ def write_bam(path, batch, soft_clip=None, block_bytes=60000, align_records=Fals
                            len(cigar), int(batch.flag[i]), seq_len, int(batch.mtid[i]), int(batch.mpos[i]),
                            int(batch.tlen[i]))
         body += name + b''.join(struct.pack('<I', c) for c in cigar)
-        body += b'\x11' * ((seq_len + 1) // 2) + b'\xff' * seq_len
+        qual = b'\xff' * seq_len
+        if decoys and seq_len >= len(decoy):
+            qual = decoy + qual[len(decoy):]
+        body += b'\x11' * ((seq_len + 1) // 2) + qual
         if align_records and (not cuts or len(out) + 4 + len(body) - cuts[-1] > block_bytes):
             cuts.append(len(out))    # the header gets blocks of its own, then a new block whenever one is full
         out += struct.pack('<I', len(body)) + body

@@ -7,7 +7,7 @@ tools/profile_round.sh C3 400000000 > /dev/null 2>&1
 tools/profile_round.sh C2 20000000 > /dev/null 2>&1
 cp gpurun_out/prof_c3/kernel_stats.csv $O/c3_kernel_stats.csv; cp gpurun_out/prof_c3/pmc_traffic.json $O/c3_pmc_traffic.json
 cp gpurun_out/prof_c2/kernel_stats.csv $O/c2_kernel_stats.csv; cp gpurun_out/prof_c2/pmc_traffic.json $O/c2_pmc_traffic.json
-cp $O/c3_pmc_traffic.json profiles/r03_c3_pmc_traffic.json; cp $O/c2_pmc_traffic.json profiles/r03_c2_pmc_traffic.json
+cp $O/c3_pmc_traffic.json profiles/r04_c3_pmc_traffic.json; cp $O/c2_pmc_traffic.json profiles/r04_c2_pmc_traffic.json
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench.err
 tools/ingest_prof.sh C3 50000000 > $O/ingest_prof.txt 2>&1
 cp gpurun_out/ingest_prof/kernel_stats.csv $O/ingest_kernel_stats.csv

@@ -8,7 +8,7 @@ grep "records/s" $O/stats.log | tail -1 | cut -c1-60
 python - <<PY
 import csv, glob
 f = glob.glob('$O/stats/**/*kernel_stats.csv', recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:6]:
+for r in list(csv.DictReader(open(f)))[:12]:
     n = r['Name'].replace('besst::(anonymous namespace)::','')[:40]
     if 'bgzf' in n or 'bam_' in n:
         print('  $1 %-40s %6s calls %10.1f us avg %10.1f ms total' % (n, r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6))

@@ -30,9 +30,9 @@ for mode, blocks, threads in [(m.split(':')[0], int(m.split(':')[1]), 0) for m i
     dt = time.perf_counter() - t0
     s = bam.ingest
     print('%-6s blocks/chunk %5d: %.3f s = %6.1f M records/s (%.2f GB/s compressed) | in the call %.3f s: staging / decode %.3f, waiting '
-          '%.3f, %d chunks, %.2f GB to HBM, %.2f GB inflated, %d blocks' % (
+          '%.3f, %d chunks, %.2f GB to HBM, %.2f GB inflated, %d blocks, %d starts repaired' % (
               mode, blocks, dt, n / dt / 1e6, size / dt / 1e9, s.seconds, s.decode_seconds, s.copy_wait_seconds, s.chunks,
-              s.bytes_h2d / 1e9, s.inflated_bytes / 1e9, s.blocks), flush=True)
+              s.bytes_h2d / 1e9, s.inflated_bytes / 1e9, s.blocks, s.starts_repaired), flush=True)
     if ref is None:
         ref = bam.ctx.fetch_records()
         for k in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen'):

@@ -12,13 +12,14 @@ import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'fused_kernel', 'stitch_kernel', 'compact_kernel', 'radix_hist_kernel',
+STEP_KERNELS = ('stream_kernel', 'ordered_kernel', 'stitch_kernel', 'compact_kernel', 'radix_hist_kernel',
                 'radix_rowscan_kernel', 'radix_scatter_kernel', 'bucket_sort_kernel', 'bucket_reduce_kernel',
                 'row_heads_kernel', 'row_scan_kernel', 'row_reduce_kernel', 'os_hist_kernel', 'os_offsets_kernel',
                 'os_scatter_kernel', 'os_reduce_kernel', 'os_fixup_kernel', 'os_bucket_start_kernel', 'os_bucket_wave_kernel',
                 'os_bucket_sort_kernel', 'os_bucket_rows_kernel', 'os_bucket_wave_lds_kernel', 'os_seg_tiles_kernel',
                 'stitch_spans_kernel', 'presort_fixup_kernel', 'fused_wave_kernel', 'rg_group_kernel', 'rg_compact_kernel',
-                'rg_tile_sums_kernel', 'rg_dst_kernel', 'rg_rows_kernel', 'rg_copy_kernel', 'msd_partition_kernel')
+                'rg_tile_sums_kernel', 'rg_dst_kernel', 'rg_rows_kernel', 'rg_copy_kernel', 'msd_partition_kernel',
+                'rl_list_kernel', 'rl_place_kernel', 'rl_rows_kernel')
 
 
 def source_hash():
