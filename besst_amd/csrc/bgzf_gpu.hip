@@ -836,13 +836,16 @@ __global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict_
 constexpr uint32_t kVerdictNoStart = 0x7fffffffu, kVerdictBad = 0xffffffffu;
 constexpr unsigned long long kNoVerdict = ~0ull;
 constexpr uint32_t kMaxRepairs = 4096;
+// four waves: the workgroup has to find room on ONE compute unit next to the other chunks' inflate waves (sixteen waves waited
+// 1-3 ms for that, on the path to the chunk's verdict)
+constexpr uint32_t kScanThreads = 256;
 
-__global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
+__global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
                                                         uint16_t* __restrict__ offs, uint32_t* count, uint32_t* exits, uint32_t* guess,
                                                         uint32_t* tail_at, const uint32_t* __restrict__ status,
                                                         uint32_t n_blocks, unsigned long long chunk_end, uint32_t forced_block,
                                                         uint32_t* __restrict__ rec_base, uint32_t* __restrict__ summary) {
-    __shared__ uint32_t s_w[16], s_tail, s_straddle;
+    __shared__ uint32_t s_w[kScanThreads / 64], s_tail, s_straddle;
     __shared__ unsigned long long s_bad;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t tail_b = 0xffffffffu, round = 0;
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restric
         if (t == 0) { s_bad = kNoVerdict; s_tail = 0xffffffffu; s_straddle = 0u; }
         __syncthreads();
         // ---- every walked block vouches for the block its exit lands in
-        for (uint32_t b = (uint32_t)t; b < n_blocks; b += 1024u) {
+        for (uint32_t b = (uint32_t)t; b < n_blocks; b += kScanThreads) {
             const uint32_t ex = exits[b], g = guess[b];
             const unsigned long long here = (unsigned long long)b << 32;
             if (blocks[b].dst_len != 0u && status[b] != kInfOk) { atomicMin(&s_bad, here | kVerdictBad); continue; }
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restric
         __syncthreads();
     }
     const uint32_t bad_b = (uint32_t)(bad >> 32);
-    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t per = (n_blocks + kScanThreads - 1u) / kScanThreads;
     const uint32_t b0 = (uint32_t)t * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
     uint32_t sum = 0;
     for (uint32_t b = b0; b < b1; ++b) {
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restric
     __syncthreads();
     uint32_t off = x - sum, total = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < (int)(kScanThreads / 64); ++q) {
         if (q < wave) off += s_w[q];
         total += s_w[q];
     }
@@ -1028,7 +1031,7 @@ int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock
                        n_ref, forced_block, forced_entry, guess);
     hipLaunchKernelGGL(bam_walk_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, s, inflated, blocks, n_blocks,
                        (unsigned long long)chunk_end, status, guess, offs, count, exits, tail_at);
-    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, s, inflated, blocks, offs, count, exits, guess, tail_at, status, n_blocks,
+    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, inflated, blocks, offs, count, exits, guess, tail_at, status, n_blocks,
                        (unsigned long long)chunk_end, forced_block, rec_base, summary);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;

@@ -9,8 +9,11 @@ cp gpurun_out/prof_c3/kernel_stats.csv $O/c3_kernel_stats.csv; cp gpurun_out/pro
 cp gpurun_out/prof_c2/kernel_stats.csv $O/c2_kernel_stats.csv; cp gpurun_out/prof_c2/pmc_traffic.json $O/c2_pmc_traffic.json
 cp $O/c3_pmc_traffic.json profiles/r04_c3_pmc_traffic.json; cp $O/c2_pmc_traffic.json profiles/r04_c2_pmc_traffic.json
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench.err
-tools/ingest_prof.sh C3 50000000 > $O/ingest_prof.txt 2>&1
+tools/ingest_prof.sh C3 50000000 17 > $O/ingest_prof.txt 2>&1
 cp gpurun_out/ingest_prof/kernel_stats.csv $O/ingest_kernel_stats.csv
+tools/ingest_pmc.sh final 17 > $O/ingest_pmc.txt 2>&1
+tools/metrics_prof.sh 30000000 > $O/metrics_prof.txt 2>&1
+cp gpurun_out/metrics_prof/kernel_stats.csv $O/metrics_kernel_stats.csv; cp gpurun_out/metrics_prof/pmc.json $O/metrics_pmc.json
 python - <<PY
 import json
 d=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
