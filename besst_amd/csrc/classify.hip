@@ -22,6 +22,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace besst {
@@ -1221,6 +1223,9 @@ __global__ __launch_bounds__(1024) void stitch_spans_kernel(SummView summ, uint3
     }
 }
 
+// kRuns: the record loop grouped its runs and the blocks' run offsets ride in the upper half of the scanned word; without
+// them the scans are 32 bits wide (C2's single stitch workgroup is a chain of such scans: 64-bit shuffles cost it 1.1 us of 10)
+template <bool kRuns>
 __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nblocks, int32_t* carry, int detect,
                                                       uint32_t* __restrict__ offsets,
                                                       uint32_t* __restrict__ skip_slot,
@@ -1244,10 +1249,15 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
     __shared__ int32_t s_head[4];    // its obs1, obs2, info, slot
     __shared__ int s_tab[64];
     __shared__ int s_total;
-    __shared__ long long s_tab64[64];
-    __shared__ long long s_total64;
+    using acc_t = typename std::conditional<kRuns, long long, int>::type;
+    auto pack_counts = [](uint32_t tuples, uint32_t runs) -> acc_t {
+        if (kRuns) return (acc_t)((long long)tuples | ((long long)runs << 32));
+        return (acc_t)tuples;
+    };
+    __shared__ acc_t s_tab64[64];
+    __shared__ acc_t s_total64;
     __shared__ int32_t s_carry[2];
-    __shared__ long long s_base;         // tuples | runs << 32 in front of this span
+    __shared__ acc_t s_base;             // tuples | runs << 32 in front of this span
     __shared__ int s_redc[16][7];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool last_span = blockIdx.x == gridDim.x - 1;
@@ -1260,10 +1270,11 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
                 if (tails[j * 4]) { p1 = tails[j * 4 + 1]; p2 = tails[j * 4 + 2]; }
         // the spans before this one: what their first reaching records resolve to, where their tuples end
         int any = 0;
-        long long base = 0;
+        acc_t base = 0;
         for (uint32_t j = 0; j < blockIdx.x; ++j) {
             const StitchAgg a = agg[j];
-            long long tot = (long long)a.total | ((long long)a.runs << 32);
+            acc_t tot = (acc_t)a.total;
+            if (kRuns) tot = (acc_t)((long long)a.total | ((long long)a.runs << 32));
             if (a.head_present && !(slice_info && !any)) {   // (the slice head keeps its provisional tuple)
                 const CEDelta d = create_edge(a.f1, a.f2, p1, p2, a.head_info & 1u, a.head_info & 2u, a.head_info & 4u,
                                               detect != 0);
@@ -1288,7 +1299,7 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
             n_emit[r] = 0; has[r] = 0; f1[r] = f2[r] = l1[r] = l2[r] = 0; head_info[r] = 0; head_slot[r] = kNoSlot;
             n_runs[r] = 0;
             if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
-                n_runs[r] = run_offsets ? summ.at(kSumRuns, b) : 0u;
+                n_runs[r] = kRuns ? summ.at(kSumRuns, b) : 0u;
                 n_emit[r] = summ.at(kSumEmit, b); has[r] = summ.at(kSumHas, b);
                 f1[r] = (int32_t)summ.at(kSumFirst1, b); f2[r] = (int32_t)summ.at(kSumFirst2, b);
                 l1[r] = (int32_t)summ.at(kSumLast1, b); l2[r] = (int32_t)summ.at(kSumLast2, b);
@@ -1354,13 +1365,13 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
         }
         __syncthreads();
         // ---- tuple offsets (and run offsets: upper half of the word)
-        long long sincl[kStitchRounds];
+        acc_t sincl[kStitchRounds];
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
-            long long v = (long long)n_final[r] | ((long long)n_runs[r] << 32);
+            acc_t v = pack_counts(n_final[r], n_runs[r]);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const long long o = __shfl_up(v, d, 64);
+                const acc_t o = __shfl_up(v, d, 64);
                 if (lane >= d) v += o;
             }
             sincl[r] = v;
@@ -1368,30 +1379,29 @@ __global__ __launch_bounds__(1024) void stitch_kernel(SummView summ, uint32_t nb
         }
         __syncthreads();
         if (wave == 0) {
-            const long long own = s_tab64[lane];
-            long long v = own;
+            const acc_t own = s_tab64[lane];
+            acc_t v = own;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const long long o = __shfl_up(v, d, 64);
+                const acc_t o = __shfl_up(v, d, 64);
                 if (lane >= d) v += o;
             }
             s_tab64[lane] = v - own;
             if (lane == 63) s_total64 = v;
         }
         __syncthreads();
-        const long long base = s_base;
+        const acc_t base = s_base;
 #pragma unroll
         for (int r = 0; r < kStitchRounds; ++r) {
             const uint32_t b = c0 + (uint32_t)r * 1024u + (uint32_t)t;
             if (b < nblocks && (uint32_t)r * 1024u + (uint32_t)t < span) {
-                const long long ex = base + s_tab64[r * 16 + wave] + sincl[r] -
-                                     ((long long)n_final[r] | ((long long)n_runs[r] << 32));
+                const acc_t ex = base + s_tab64[r * 16 + wave] + sincl[r] - pack_counts(n_final[r], n_runs[r]);
                 offsets[b] = (uint32_t)ex;
                 skip_slot[b] = skip[r];
-                if (run_offsets) run_offsets[b] = (uint32_t)(ex >> 32);
+                if (kRuns) run_offsets[b] = (uint32_t)((long long)ex >> 32);
             }
         }
-        const long long span_total = s_total64;
+        const acc_t span_total = s_total64;
         __syncthreads();
         if (t == 0) {
             s_base = base + span_total;
@@ -1755,12 +1765,21 @@ int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carr
             int32_t* carry_in = reinterpret_cast<int32_t*>(w.agg + w.agg_spans);
             hipLaunchKernelGGL(stitch_spans_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, span, detect_dup, carry,
                                w.agg, carry_in);
-            hipLaunchKernelGGL(stitch_kernel, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
-                               w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span, run_offsets);
+            if (run_offsets)
+                hipLaunchKernelGGL(stitch_kernel<true>, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                                   w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span, run_offsets);
+            else
+                hipLaunchKernelGGL(stitch_kernel<false>, dim3(spans), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                                   w.skip, n_out, ctr, tails, rank, slice_info, w.agg, carry_in, span, run_offsets);
         } else {
-            hipLaunchKernelGGL(stitch_kernel, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
-                               w.skip, n_out, ctr, tails, rank, slice_info, (const StitchAgg*)nullptr,
-                               (const int32_t*)nullptr, span, run_offsets);
+            if (run_offsets)
+                hipLaunchKernelGGL(stitch_kernel<true>, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                                   w.skip, n_out, ctr, tails, rank, slice_info, (const StitchAgg*)nullptr,
+                                   (const int32_t*)nullptr, span, run_offsets);
+            else
+                hipLaunchKernelGGL(stitch_kernel<false>, dim3(1), dim3(1024), 0, s, w.summ, nblocks, carry, detect_dup, w.offsets,
+                                   w.skip, n_out, ctr, tails, rank, slice_info, (const StitchAgg*)nullptr,
+                                   (const int32_t*)nullptr, span, run_offsets);
         }
     }
     {
