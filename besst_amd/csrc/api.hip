@@ -178,8 +178,8 @@ const char* besst_prof_slot_name(int slot) {
         "os_bucket_start_kernel+os_bucket_wave_kernel+os_bucket_wave_lds_kernel+os_bucket_sort_kernel", "os_bucket_rows_kernel",
         "os_reduce_kernel", "os_fixup_kernel",
         "metrics_kernels", "score_kernels", "rg_group_kernel", "rg_compact_kernel",
-        "rg_tile_sums_kernel+rg_dst_kernel+rg_rows_kernel", "rg_copy_kernel", "msd_partition_kernel",
-        "rl_list_kernel", "rl_place_kernel"};
+        "rg_tile_sums_kernel+rg_dst_kernel(+rg_rows_kernel)", "rg_copy_kernel", "msd_partition_kernel",
+        "rl_list_kernel", "rl_place_kernel", "rl_rows_kernel"};
     return (slot >= 0 && slot < kProfSlots) ? names[slot] : "";
 }
 

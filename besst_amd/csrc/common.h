@@ -73,7 +73,7 @@ enum ProfSlot {
     kProfRadixHist, kProfRadixScan, kProfRadixScatter, kProfBucketSort, kProfBucketReduce, kProfRowHeads, kProfRowScan, kProfRowReduce,
     kProfOsHist, kProfOsOffsets, kProfOsScatter, kProfOsBucket, kProfOsBucketRows, kProfOsReduce, kProfOsFixup,
     kProfMetrics, kProfScore, kProfRunGroup, kProfRunCompact, kProfRunScan, kProfRunCopy, kProfMsdPartition,
-    kProfRunList, kProfRunPlace, kProfSlots
+    kProfRunList, kProfRunPlace, kProfRunRows, kProfSlots
 };
 static_assert(kProfSlots <= 32, "besst_prof_enable takes a 32-bit slot mask");
 struct ProfScope {

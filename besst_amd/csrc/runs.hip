@@ -900,7 +900,7 @@ int launch_runs_reduce(hipStream_t s, int64_t cap, const uint32_t* n_tuples, int
             hipLaunchKernelGGL(rl_place_kernel, dim3(bgrid), dim3(kRlWaves * 64), 0, s, *seg, w.status, n_rows, rc, obs_lo, obs_hi);
         }
         {
-            ProfScope ps(s, kProfRunCopy);
+            ProfScope ps(s, kProfRunRows);
             hipLaunchKernelGGL(rl_rows_kernel, dim3((w.run_cap + 255) / 256), dim3(256), 0, s, w.status, n_rows, w.r_runs,
                                w.r_first_run, w.run_len, w.run_at, w.run_dst, rc.first, rc.mask, rc.sum, rc.sq, row_mask, row_n,
                                reinterpret_cast<unsigned long long*>(row_sum), reinterpret_cast<unsigned long long*>(row_sum_sq),
