@@ -171,6 +171,48 @@ def test_bytes_that_look_like_a_record_do_not_mislead_the_device(block_bytes, ch
         assert np.array_equal(getattr(host, col), getattr(batch, col)), col
 
 
+def test_long_reads_cover_blocks_and_chunks_whole():
+    """Reads of 150-400 kb (a record of up to 0.6 MB) in 64 KiB blocks and chunks of 64 blocks: records cover several blocks
+    whole - blocks in which no record begins -, some run on into the next chunk as a tail of several blocks; the device form
+    leaves the host reader's columns."""
+    batch = _library(3000)
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(batch), 60, replace=False)
+    batch.rlen[pick] = rng.integers(150000, 400000, 60).astype(batch.rlen.dtype)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=65280, align_records=False)
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=2, mode='device', chunk_blocks=64)
+        try:
+            assert bam.ingest.on_device == 1 and bam.ingest.chunks >= 3
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+    for col in COLS:
+        assert np.array_equal(getattr(host, col), getattr(batch, col)), col
+
+
+def test_a_file_that_ends_inside_a_record_is_an_error():
+    """A straddling file cut off behind a block in the middle of a record (and closed with an EOF marker): the device form
+    reports it (BESST_ERR_ARG: corrupt input, not an unsupported form) and appends nothing."""
+    batch = _library(2000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path, cut = os.path.join(tmp, 'x.bam'), os.path.join(tmp, 'cut.bam')
+        bam_writer.write_bam(path, batch, block_bytes=5000, align_records=False)
+        data = open(path, 'rb').read()
+        offs, at = [], 0
+        while at < len(data):
+            offs.append(at)
+            at += struct.unpack_from('<H', data, at + 16)[0] + 1
+        eof = data[offs[-1]:]
+        with open(cut, 'wb') as fh:
+            fh.write(data[:offs[len(offs) // 2]] + eof)
+        with pytest.raises(_lib.BesstDeviceError) as e:
+            bamio.ResidentBam(cut, threads=2, mode='device')
+        assert 'ends inside a record' in str(e.value)
+
+
 def test_a_part_of_a_straddling_file_is_refused():
     """Multi-rank ingest cuts a file at BGZF block boundaries, which only htslib's layout allows: a part of a file whose
     records straddle blocks answers BESST_ERR_UNSUPPORTED (context and reader untouched)."""
