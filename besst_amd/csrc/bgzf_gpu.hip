@@ -49,6 +49,9 @@ namespace {
 
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
+constexpr int kDistBits = 10;                    // the distance code's primary table (9 or 8 bits and a seventh wave per SIMD: +-1 %)
+constexpr int kInfWaves = 6;                     // per SIMD (80 VGPRs, 6.2 KB of LDS)
+constexpr int kDistSize = 1 << kDistBits;
 constexpr int kClBits = 7;
 constexpr int kLaneLongBits = 3;                 // literal / length codes of up to kTabBits + 3 bits are decoded by the lanes too
 constexpr uint32_t kGroupLit = 0x80000000u;   // output group: the lane holds a literal (else a source position, < 2^31)
@@ -67,7 +70,7 @@ struct CanonLds {               // per code: count / first code / offset per len
 
 struct InflateLds {
     uint16_t lit_tab[kTabSize];
-    uint16_t dist_tab[kTabSize];
+    uint16_t dist_tab[kDistSize];
     uint16_t cl_tab[1 << kClBits];
     uint16_t lit_sorted[288];
     uint16_t dist_sorted[32];
@@ -241,7 +244,7 @@ struct BitReader {
 constexpr uint32_t kWalkStop = 0x40u;
 constexpr uint32_t kBadDist = 0x80u;                    // lane's distance symbol: bits | distance << 8, or this
 
-__global__ __launch_bounds__(64, 6) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+__global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
                                                           uint32_t n_blocks, uint8_t* dst, uint32_t* __restrict__ status) {
     __shared__ InflateLds s;
     const int lane = threadIdx.x;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64, 6) void bgzf_inflate_kernel(const uint8_t* __re
             }
             __builtin_amdgcn_wave_barrier();
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
-            if (!build_code(s.lens + 288, n_dist, kTabBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
+            if (!build_code(s.lens + 288, n_dist, kDistBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
             // ---- the symbols, a batch per turn.  One symbol at a time cost ~50 scalar instructions and branches per symbol,
             // and a SIMD issues ONE of those per four cycles for all its waves: by the counters that slot was 90 % in use
             // and the vector slot 30 % (a sequencer's file: 14 000 symbols per block, more than half of them matches of ~7
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(64, 6) void bgzf_inflate_kernel(const uint8_t* __re
                 const uint32_t lo = t < 32u ? v[0] : t < 64u ? v[1] : v[2], hi = t < 32u ? v[1] : t < 64u ? v[2] : v[3];
                 const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, t & 31u);     // 32 bits of input from that bit on
                 const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
-                const uint32_t eb = s.dist_tab[x & (uint32_t)(kTabSize - 1)];
+                const uint32_t eb = s.dist_tab[x & (uint32_t)(kDistSize - 1)];
                 uint32_t la = ea & 15u, sa = ea >> 4;
                 {
                     // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals), decoded
@@ -551,9 +554,9 @@ __global__ __launch_bounds__(64, 6) void bgzf_inflate_kernel(const uint8_t* __re
                 const uint32_t length = (li2 & 0x1ffu) + ((xs >> used) & ((1u << (li2 >> 9)) - 1u));
                 used += li2 >> 9;                            // <= 20: the distance symbol begins inside the window
                 const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)used);
-                uint32_t d = uni(s.dist_tab[xq & (uint32_t)(kTabSize - 1)]);
+                uint32_t d = uni(s.dist_tab[xq & (uint32_t)(kDistSize - 1)]);
                 if ((d & 15u) == 0u) {
-                    d = uni(slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kTabBits));
+                    d = uni(slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kDistBits));
                     if (d == 0u) { err = kInfBadCode; break; }
                 }
                 if ((d >> 4) >= 30u) { err = kInfBadCode; break; }
