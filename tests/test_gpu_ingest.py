@@ -171,6 +171,28 @@ def test_bytes_that_look_like_a_record_do_not_mislead_the_device(block_bytes, ch
         assert np.array_equal(getattr(host, col), getattr(batch, col)), col
 
 
+def test_columns_grow_again_while_chunks_are_in_flight():
+    """The record columns are sized from the records-per-byte of the chunks seen so far; a file whose first part holds long
+    reads and whose rest holds short ones (many more records per compressed byte) makes that estimate fall short again and
+    again, so the columns move while other chunks' kernels are queued: the result is still the host reader's."""
+    batch = _library(24000)
+    n = len(batch)
+    batch.rlen[:] = 0
+    batch.rlen[:n // 8] = 4000
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=60000, align_records=True)
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=2, mode='device', chunk_blocks=64)
+        try:
+            assert bam.ingest.on_device == 1 and bam.ingest.chunks >= 6
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+    for col in COLS:
+        assert np.array_equal(getattr(host, col), getattr(batch, col)), col
+
+
 def test_long_reads_cover_blocks_and_chunks_whole():
     """Reads of 150-400 kb (a record of up to 0.6 MB) in 64 KiB blocks and chunks of 64 blocks: records cover several blocks
     whole - blocks in which no record begins -, some run on into the next chunk as a tail of several blocks; the device form
