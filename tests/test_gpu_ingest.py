@@ -171,6 +171,47 @@ def test_bytes_that_look_like_a_record_do_not_mislead_the_device(block_bytes, ch
         assert np.array_equal(getattr(host, col), getattr(batch, col)), col
 
 
+def test_random_block_layouts():
+    """Blocks cut at random sizes (30 bytes ... 64 KiB, changing from block to block; now and then an empty block), reads of
+    random lengths incl. none, some with bytes in their qualities that pass for a record header, random chunk sizes: the device
+    form leaves the host reader's columns.  BESST_FUZZ_ROUNDS (default 12) sets the number of files."""
+    rounds = int(os.environ.get('BESST_FUZZ_ROUNDS', '12'))
+    for seed in range(rounds):
+        rng = np.random.default_rng(1000 + seed)
+        batch = _library(int(rng.integers(200, 3000)), seed=40 + seed)
+        n = len(batch)
+        want = rng.choice([0, 36, 100, 151, 250, 5000, 70000], n, p=[.1, .2, .4, .2, .08, .015, .005])
+        batch.rlen[:] = np.where(want == 0, 0, np.maximum(want, batch.qlen)).astype(batch.rlen.dtype)    # (soft clip = rlen - qlen)
+        with tempfile.TemporaryDirectory() as tmp:
+            raw_path, path = os.path.join(tmp, 'raw.bam'), os.path.join(tmp, 'x.bam')
+            bam_writer.write_bam(raw_path, batch, block_bytes=65280, align_records=False, decoys=bool(seed & 1))
+            # re-cut the same BAM bytes into blocks of random sizes
+            data, at, raw = open(raw_path, 'rb').read(), 0, bytearray()
+            while at < len(data):
+                size = struct.unpack_from('<H', data, at + 16)[0] + 1
+                raw += zlib.decompress(data[at + 18:at + size - 8], -15)
+                at += size
+            small = int(rng.choice([30, 90, 400, 3000, 20000, 65280]))
+            with open(path, 'wb') as fh:
+                at = 0
+                while at < len(raw):
+                    take = int(rng.integers(1, small + 1))
+                    fh.write(bam_writer._bgzf_block(bytes(raw[at:at + take])))
+                    at += take
+                    if rng.random() < 0.02:
+                        fh.write(bam_writer._bgzf_block(b''))
+                fh.write(bam_writer._bgzf_block(b''))
+            host = bamio.read_bam(path, threads=2)
+            bam = bamio.ResidentBam(path, threads=2, mode='device', chunk_blocks=int(rng.choice([0, 64, 100, 1000])))
+            try:
+                assert bam.ingest.on_device == 1, seed
+                _check_against_host(path, bam, host)
+            finally:
+                bam.close()
+        for col in COLS:
+            assert np.array_equal(getattr(host, col), getattr(batch, col)), (seed, col)
+
+
 def test_columns_grow_again_while_chunks_are_in_flight():
     """The record columns are sized from the records-per-byte of the chunks seen so far; a file whose first part holds long
     reads and whose rest holds short ones (many more records per compressed byte) makes that estimate fall short again and
