@@ -9,8 +9,8 @@
 //   D  B and opposite-orientation pair with read_len < fragment size          [:71-81]
 // The reference stops collecting A after exactly 1,000,000 observations and stops the contamination
 // scan at the record where sample_counter reaches 1,000,000 - both are "first N in stream order".
-// Ordered semantics come from exclusive prefixes of A, B and D in stream order (a single pass with a look-back
-// over the tiles in front, metrics_onepass_kernel): they decide inclusion and the output slot, so isize_out /
+// Ordered semantics come from exclusive prefixes of A, B and D in stream order (per tile, once every tile has been counted:
+// metrics_stage / tiles / place below): they decide inclusion and the output slot, so isize_out /
 // contam_out hold |tlen| in BAM order exactly like the Python lists.  The float finishing (means, trimming, GetDistr) replays the
 // reference's operation order on the host from those lists.
 #include "common.h"
@@ -186,28 +186,28 @@ __global__ __launch_bounds__(1024) void metrics_scan_kernel(uint32_t* __restrict
     if (t < 3) totals[t] = s_carry[t];
 }
 
-// ---- count + scan + emit in ONE pass over the records (round 4: the three-kernel form read every record twice and ran
-// at 0.11 of the pass's 22 B/pair roofline).  A workgroup takes a tile of kMetSubs x 1024 records - sixteen per thread, all
-// their loads in flight together, the flags kept in registers -; tiles are numbered by an arrival ticket, so a tile's
-// predecessors are always running or done.  A tile publishes its three counts in one {status, counts} word - status 1: the
-// tile's own counts, 2: the inclusive counts of the stream up to and including the tile - and its first wave looks back over
-// the words of the 64 tiles in front of it (one per lane), further while none of them is inclusive: the look-back is a
-// serial chain of memory round trips (~2 us each across the chip), one per 64 tiles, which is why tiles are large (1024-record tiles: 58 k
-// tiles, 1.5 ms for 60 M records - the chain, not the bytes); a wider window was slower, not faster: 512 words per step
-// 0.17 of the roofline, 128 words 0.24, 64 words 0.26 - every waiting tile polls uncached words, and that traffic is what
-// slows the tiles that could make progress.  The
-// words are relaxed agent-scope atomics, each self-describing; the workspace is zeroed per call.
-constexpr unsigned long long kMdShift = 62;
-constexpr long long kMdSat = (1ll << 20) - 1;            // >= kSampleCap
+// ---- ONE read of the records, no waiting between tiles (round 4).  Three forms came before: count + scan + emit read every
+// record twice (0.11 of the pass's 22 B/pair roofline); a single kernel with a decoupled look-back over packed tile
+// descriptors read them once but ran at 0.21 - 0.33: a tile cannot place its samples before every tile in front of it has
+// its loads back, and with 1280 tiles in flight the slowest of those is always late (7 of a tile's 20 us were that wait, 1.5
+// the arrival ticket; polling through the scalar data path changed nothing: the wait is for data, not for the poll).  So the
+// samples are STAGED where no order is needed and placed when the order is known:
+//   metrics_stage_kernel   a workgroup per tile of kMetSubs x 1024 records, any order: the flags of its sixteen records per
+//                          thread (all loads in flight together), the tile's four counts, and the tile's A and D samples
+//                          compacted in stream order at the TILE's place in the staging arrays;
+//   metrics_tiles_kernel   one workgroup: exclusive scan of the tiles' counts behind the stream's running counts, the counts
+//                          of the tiles that lie wholly inside the 1,000,000 cut-off of B, the one tile that straddles it;
+//   metrics_place_kernel   a workgroup per tile: its staged samples copied to their places in the lists (nothing for a tile
+//                          behind the cut-offs); the straddling tile evaluates its records again to find the cut.
+// A call is cut into parts of kMetPart records (the staging arrays' size) that follow each other on the stream without
+// the host; a tile of a part that begins with both lists full returns at once.
 #ifndef BESST_MET_SUBS
 #define BESST_MET_SUBS 4
 #endif
-#ifndef BESST_MET_LOOK
-#define BESST_MET_LOOK 1
-#endif
 constexpr int kMetSubs = BESST_MET_SUBS;
-constexpr int kMetBig = kMetSubs * kMetTile;             // records per tile of the one-pass kernel
-constexpr int kMetLook = BESST_MET_LOOK;                              // predecessors per lane and look-back step
+constexpr int kMetBig = kMetSubs * kMetTile;             // records per tile
+constexpr int64_t kMetPart = (int64_t)64 << 20;          // records per part: 16 384 tiles, 2 x 256 MB of staging
+static_assert(kMetPart % kMetBig == 0, "parts are whole tiles");
 
 __device__ __forceinline__ long long wsum64(long long v) {
 #pragma unroll
@@ -215,113 +215,191 @@ __device__ __forceinline__ long long wsum64(long long v) {
     return v;
 }
 
-__global__ __launch_bounds__(kMetThreads) void metrics_onepass_kernel(MetricsArgs m, int64_t start, int64_t end, uint32_t nb,
-                                                                      unsigned long long* __restrict__ desc,
-                                                                      uint32_t* __restrict__ ticket, int want_isize,
-                                                                      int32_t* __restrict__ isize_out,
-                                                                      int32_t* __restrict__ contam_out,
-                                                                      unsigned long long* __restrict__ state) {
-    __shared__ unsigned long long s_w[kMetSubs][4];          // per sub-tile and wave: the three counts, 16 bits apart
-    __shared__ int s_tot[4][2];
-    __shared__ long long s_pre[3];
-    __shared__ uint32_t s_tile;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const int64_t tile0 = start + (int64_t)tile * kMetBig;
-    Flags4 f[kMetSubs];
+// The flags of a tile's records (whole aligned tiles: two memory round trips, else the generic path) and, per sub-tile, the
+// thread's counts a | b << 16 | d << 32 | c << 48 (`mine`), their inclusive scan over the wave (`incl`) and the waves' totals in
+// s_w - what a thread needs to know its records' ranks inside the tile.
+__device__ __forceinline__ void tile_flags(const MetricsArgs& m, int64_t tile0, int64_t end, int t, Flags4 (&f)[kMetSubs],
+                                           unsigned long long (&mine)[kMetSubs], unsigned long long (&incl)[kMetSubs],
+                                           unsigned long long (*s_w)[4], bool scan) {
+    const int lane = t & 63, wave = t >> 6;
     if ((tile0 & 3) == 0 && tile0 + kMetBig <= end && m.n_contigs > 0) {           // uniform
         eval_tile<kMetSubs>(m, tile0 + (int64_t)t * kMetVec, kMetTile, f);
     } else {
 #pragma unroll
         for (int u = 0; u < kMetSubs; ++u) f[u] = eval4(m, tile0 + (int64_t)u * kMetTile + (int64_t)t * kMetVec, end);
     }
-    unsigned long long mine[kMetSubs], incl[kMetSubs];       // a | b << 16 | d << 32 of the thread / scanned over the wave
 #pragma unroll
     for (int u = 0; u < kMetSubs; ++u) {
-        mine[u] = (unsigned long long)__popc(f[u].a) | ((unsigned long long)__popc(f[u].b) << 16) | ((unsigned long long)__popc(f[u].d) << 32);
+        mine[u] = (unsigned long long)__popc(f[u].a) | ((unsigned long long)__popc(f[u].b) << 16) |
+                  ((unsigned long long)__popc(f[u].d) << 32) | ((unsigned long long)__popc(f[u].c) << 48);
         unsigned long long x = mine[u];
+        if (scan) {                                          // uniform
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = __shfl_up(x, d, 64);
-            if (lane >= d) x += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long o = __shfl_up(x, d, 64);
+                if (lane >= d) x += o;
+            }
+        } else {
+            x = (unsigned long long)wsum64((long long)x);    // (only the wave's total is needed)
         }
         incl[u] = x;
         if (lane == 63) s_w[u][wave] = x;
     }
+}
+
+__global__ __launch_bounds__(kMetThreads) void metrics_stage_kernel(MetricsArgs m, int64_t start, int64_t end, int want_isize,
+                                                                    const unsigned long long* __restrict__ state,
+                                                                    uint32_t* __restrict__ tilecnt,
+                                                                    int32_t* __restrict__ stage_a, int32_t* __restrict__ stage_d) {
+    __shared__ unsigned long long s_w[kMetSubs][4];          // per sub-tile and wave: the four counts, 16 bits apart
+    const int t = threadIdx.x, wave = t >> 6;
+    const uint32_t tile = blockIdx.x;
+    // what the stream had counted when this part began: a list that is full takes no more
+    const bool live_a = want_isize && (long long)state[0] < kSampleCap;
+    const bool live_b = (long long)state[1] < kSampleCap;
+    if (!live_a && !live_b) {                                // uniform: nothing this tile could add
+        if (t < 4) tilecnt[tile * 4u + (uint32_t)t] = 0u;
+        return;
+    }
+    const int64_t tile0 = start + (int64_t)tile * kMetBig;
+    Flags4 f[kMetSubs];
+    unsigned long long mine[kMetSubs], incl[kMetSubs];
+    tile_flags(m, tile0, end, t, f, mine, incl, s_w, true);
     __syncthreads();
-    if (wave == 0) {
-        long long tot[3] = {0, 0, 0};
+    unsigned long long run = 0;                              // the counts of the sub-tiles before the one at hand
+    const size_t at = (size_t)tile * kMetBig;
 #pragma unroll
-        for (int u = 0; u < kMetSubs; ++u)
+    for (int u = 0; u < kMetSubs; ++u) {
+        unsigned long long sub = 0, mywaves = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned long long v = s_w[u][w];
-                tot[0] += (long long)(v & 0xffffu); tot[1] += (long long)((v >> 16) & 0xffffu); tot[2] += (long long)(v >> 32);
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long v = s_w[u][w];
+            sub += v;                                        // (fields of at most 1024 per sub-tile, 4096 per tile: no carries)
+            if (w < wave) mywaves += v;
+        }
+        const unsigned long long ex = run + mywaves + incl[u] - mine[u];
+        uint32_t ra = (uint32_t)(ex & 0xffffu), rd = (uint32_t)((ex >> 32) & 0xffffu);
+#pragma unroll
+        for (int k = 0; k < kMetVec; ++k) {
+            const uint32_t bit = 1u << k;
+            if (f[u].a & bit) {
+                if (live_a) stage_a[at + ra] = f[u].val[k];
+                ra++;
             }
-        // ONE word per tile: status << 62 | three 20-bit counts.  A tile's own counts are at most 4096; inclusive counts are
-        // saturated at kMdSat = 2^20 - 1 >= the 1,000,000 cut-offs - a position at or beyond a cut-off is never written to and
-        // every comparison with the cut-off comes out the same -, so that a look-back step polls 4 KB of words, not 12 KB
-        // (three words per tile: hundreds of waiting tiles polling uncached words slowed the whole chip, 0.09 of the roofline).
-        unsigned long long* own = desc + tile;
-        auto pack = [](const long long (&v)[3], unsigned long long status) {
-            unsigned long long w = status << kMdShift;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) w |= (unsigned long long)(v[j] < kMdSat ? v[j] : kMdSat) << (20 * j);
-            return w;
-        };
-        long long before[3] = {0, 0, 0};
-        if (tile == 0u) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) before[j] = (long long)state[j];   // what earlier chunks of the stream counted
-        } else {
-            if (lane == 0) __hip_atomic_store(own, pack(tot, 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            long long look = (long long)tile - 1;
-            for (;;) {                                       // uniform: a step of 64 x kMetLook tiles back per turn
-                // the lane's own tiles, nearest first: their counts up to and including the first inclusive one
-                long long part[3] = {0, 0, 0};
-                bool closed = false, again = false;
-#pragma unroll
-                for (int q = 0; q < kMetLook; ++q) {
-                    const long long idx = look - (lane * kMetLook + q);
-                    // (in front of tile 0: nothing, and tile 0 is always inclusive)
-                    const unsigned long long w = idx >= 0 ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                          : (2ull << kMdShift);
-                    if (!closed) {
-                        again = again || (w >> kMdShift) == 0ull;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) part[j] += (long long)((w >> (20 * j)) & kMdSat);
-                        closed = (w >> kMdShift) == 2ull;
-                    }
-                }
-                const unsigned long long cm = __ballot(closed);
-                const int first = cm ? __ffsll((long long)cm) - 1 : 64;
-                if (__ballot(again && lane <= first) != 0ull) {   // (tiles beyond the first inclusive one do not matter)
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) before[j] += wsum64(lane <= first ? part[j] : 0ll);
-                if (cm) break;
-                look -= 64 * kMetLook;
+            if (f[u].d & bit) {
+                if (live_b) stage_d[at + rd] = f[u].val[k];
+                rd++;
             }
         }
-        if (lane == 0) {
-            long long after[3];
+        run += sub;
+    }
+    if (t < 4) tilecnt[tile * 4u + (uint32_t)t] = (uint32_t)((run >> (t == 0 ? 0 : t == 1 ? 16 : t == 2 ? 32 : 48)) & 0xffffu);   // a b d c
+}
+
+// info: [0] the tile in which B passes its cut-off (-1: none in this part).  Every WAVE takes a run of consecutive tiles, 64 at
+// a time (coalesced): first the run's totals, one barrier, then the run again with the totals of the waves before it as
+// carry.  (A loop of 1024 tiles per turn over the whole workgroup, two barriers and three 64-bit scans each: 52 us for a
+// part's 16 384 tiles, a quarter of the pass; a run of tiles per THREAD, strided loads and stores: 45 us.)
+__global__ __launch_bounds__(1024) void metrics_tiles_kernel(const uint32_t* __restrict__ tilecnt, uint32_t nt, long long records,
+                                                             unsigned long long* state, long long* __restrict__ base /* [nt * 3] */,
+                                                             int32_t* __restrict__ info) {
+    __shared__ uint32_t s_w[16][3];
+    __shared__ unsigned long long s_in_c, s_in_d;
+    __shared__ int s_cut;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) { s_in_c = 0ull; s_in_d = 0ull; s_cut = -1; }
+    const uint32_t per = (((nt + 15u) / 16u) + 63u) & ~63u;  // tiles per wave, whole rounds of 64
+    const uint32_t lo = (uint32_t)wave * per < nt ? (uint32_t)wave * per : nt, hi = lo + per < nt ? lo + per : nt;
+    const uint4* cnt4 = reinterpret_cast<const uint4*>(tilecnt);                  // a b d c
+    uint32_t v[3] = {0u, 0u, 0u};                            // (a part holds at most 2^26 records: 32 bits)
+    for (uint32_t b = lo + (uint32_t)lane; b < hi; b += 64u) {
+        const uint4 q = cnt4[b];
+        v[0] += q.x; v[1] += q.y; v[2] += q.z;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = (uint32_t)wsum((int)v[j]);
+    if (lane == 0) { s_w[wave][0] = v[0]; s_w[wave][1] = v[1]; s_w[wave][2] = v[2]; }
+    __syncthreads();
+    long long carry[3], total[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        uint32_t pre = 0, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) pre += s_w[w][j];
+            all += s_w[w][j];
+        }
+        const long long before = (long long)state[j];
+        carry[j] = before + (long long)pre;
+        total[j] = before + (long long)all;
+    }
+    long long in_c = 0, in_d = 0;
+    for (uint32_t r0 = lo; r0 < hi; r0 += 64u) {             // uniform per wave
+        const uint32_t b = r0 + (uint32_t)lane;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (b < hi) q = cnt4[b];
+        uint32_t x[3] = {q.x, q.y, q.z};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                before[j] = before[j] < kMdSat ? before[j] : kMdSat;
-                after[j] = before[j] + tot[j];
-                s_pre[j] = before[j];
-                if (tile == nb - 1u) state[j] = (unsigned long long)(after[j] < kMdSat ? after[j] : kMdSat);   // (tile 0 has read it long ago)
+                const uint32_t o = (uint32_t)__shfl_up((int)x[j], d, 64);
+                if (lane >= d) x[j] += o;
             }
-            __hip_atomic_store(own, pack(after, 2ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (lane == 0 && tile == nb - 1u) state[5] += (unsigned long long)(end - start);
+        const long long ex1 = carry[1] + (long long)(x[1] - q.y);
+        if (b < hi) {
+            base[(size_t)b * 3] = carry[0] + (long long)(x[0] - q.x);
+            base[(size_t)b * 3 + 1] = ex1;
+            base[(size_t)b * 3 + 2] = carry[2] + (long long)(x[2] - q.z);
+            if (ex1 + (long long)q.y <= kSampleCap) { in_c += q.w; in_d += q.z; }     // wholly inside the cut-off of B
+            else if (ex1 < kSampleCap) s_cut = (int)b;                                // (one tile at most)
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) carry[j] += (long long)(uint32_t)__builtin_amdgcn_readlane((int)x[j], 63);
     }
+    in_c = wsum64(in_c);
+    in_d = wsum64(in_d);
+    if (lane == 0) { atomicAdd(&s_in_c, (unsigned long long)in_c); atomicAdd(&s_in_d, (unsigned long long)in_d); }
+    __syncthreads();                                         // (every thread has read state[0..2] by now)
+    if (t < 3) state[t] = (unsigned long long)total[t];
+    if (t == 3) state[3] += s_in_c;
+    if (t == 4) state[4] += s_in_d;
+    if (t == 5) state[5] += (unsigned long long)records;
+    if (t == 6) info[0] = s_cut;
+}
+
+__global__ __launch_bounds__(kMetThreads) void metrics_place_kernel(MetricsArgs m, int64_t start, int64_t end, int want_isize,
+                                                                    const uint32_t* __restrict__ tilecnt,
+                                                                    const long long* __restrict__ base,
+                                                                    const int32_t* __restrict__ info,
+                                                                    const int32_t* __restrict__ stage_a,
+                                                                    const int32_t* __restrict__ stage_d,
+                                                                    int32_t* __restrict__ isize_out, int32_t* __restrict__ contam_out,
+                                                                    unsigned long long* state) {
+    __shared__ unsigned long long s_w[kMetSubs][4];
+    __shared__ int s_tot[4][2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t na = tilecnt[tile * 4u], nb = tilecnt[tile * 4u + 1u], nd = tilecnt[tile * 4u + 2u];
+    const long long pa = base[(size_t)tile * 3], pb = base[(size_t)tile * 3 + 1], pd = base[(size_t)tile * 3 + 2];
+    const size_t at = (size_t)tile * kMetBig;
+    if (want_isize && pa < kSampleCap) {
+        const long long room = kSampleCap - pa;
+        const uint32_t n = (long long)na < room ? na : (uint32_t)room;
+        for (uint32_t i = (uint32_t)t; i < n; i += kMetThreads) isize_out[pa + i] = stage_a[at + i];
+    }
+    if (pb + (long long)nb <= kSampleCap) {                  // wholly inside the cut-off of B: every D sample counts
+        for (uint32_t i = (uint32_t)t; i < nd; i += kMetThreads) contam_out[pd + i] = stage_d[at + i];
+        return;
+    }
+    if ((int)tile != info[0]) return;                        // behind the cut-off
+    // the tile in which B reaches 1,000,000: which of its records come before that is found by looking at them again
+    const int64_t tile0 = start + (int64_t)tile * kMetBig;
+    Flags4 f[kMetSubs];
+    unsigned long long mine[kMetSubs], incl[kMetSubs];
+    tile_flags(m, tile0, end, t, f, mine, incl, s_w, true);
     __syncthreads();
-    long long run[3] = {s_pre[0], s_pre[1], s_pre[2]};       // the counts in front of the sub-tile at hand
+    unsigned long long run = 0;
     int n_c = 0, n_d = 0;
 #pragma unroll
     for (int u = 0; u < kMetSubs; ++u) {
@@ -329,31 +407,25 @@ __global__ __launch_bounds__(kMetThreads) void metrics_onepass_kernel(MetricsArg
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const unsigned long long v = s_w[u][w];
-            sub += v;                                        // (fields of at most 1024: no carries)
+            sub += v;
             if (w < wave) mywaves += v;
         }
-        const unsigned long long ex = mywaves + incl[u] - mine[u];
-        long long pa = run[0] + (long long)(ex & 0xffffu);
-        long long pb = run[1] + (long long)((ex >> 16) & 0xffffu);
-        long long pd = run[2] + (long long)(ex >> 32);
+        const unsigned long long ex = run + mywaves + incl[u] - mine[u];
+        long long rb = pb + (long long)((ex >> 16) & 0xffffu), rd = pd + (long long)((ex >> 32) & 0xffffu);
 #pragma unroll
         for (int k = 0; k < kMetVec; ++k) {
             const uint32_t bit = 1u << k;
-            if (f[u].a & bit) {
-                if (want_isize && pa < kSampleCap) isize_out[pa] = f[u].val[k];
-                pa++;
-            }
             if (f[u].b & bit) {
-                const bool in = pb < kSampleCap;   // this record is among the first 1,000,000 on the top contigs
-                pb++;
+                const bool in = rb < kSampleCap;             // this record is among the first 1,000,000 on the top contigs
+                rb++;
                 if (in) {
                     if (f[u].c & bit) n_c++;
-                    if (f[u].d & bit) { contam_out[pd] = f[u].val[k]; n_d++; }
+                    if (f[u].d & bit) { contam_out[rd] = f[u].val[k]; n_d++; }
                 }
             }
-            if (f[u].d & bit) pd++;
+            if (f[u].d & bit) rd++;
         }
-        run[0] += (long long)(sub & 0xffffu); run[1] += (long long)((sub >> 16) & 0xffffu); run[2] += (long long)(sub >> 32);
+        run += sub;
     }
     n_c = wsum(n_c);
     n_d = wsum(n_d);
@@ -365,6 +437,7 @@ __global__ __launch_bounds__(kMetThreads) void metrics_onepass_kernel(MetricsArg
     }
 }
 
+// the count-only form's last step: the running counts take the scan's totals
 __global__ void metrics_commit_kernel(long long* __restrict__ state, const long long* __restrict__ totals,
                                       long long scanned) {
     if (threadIdx.x < 3) state[threadIdx.x] = totals[threadIdx.x];
@@ -386,12 +459,32 @@ __global__ __launch_bounds__(256) void value_hist_kernel(const int32_t* __restri
 
 }  // namespace
 
+namespace {
+struct MetWs { size_t tilecnt, base, info, stage_a, stage_d, total; };
+MetWs metrics_staged_layout(int64_t n) {
+    const int64_t part = n < kMetPart ? n : kMetPart;
+    const size_t nt = (size_t)((part + kMetBig - 1) / kMetBig);
+    MetWs w;
+    size_t off = 0;
+    w.tilecnt = off; off += align_up(nt * 16, 256);
+    w.base = off; off += align_up(nt * 24, 256);
+    w.info = off; off += 256;
+    w.stage_a = off; off += align_up(nt * (size_t)kMetBig * 4, 256);
+    w.stage_d = off; off += align_up(nt * (size_t)kMetBig * 4, 256);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
 size_t metrics_workspace_bytes(int64_t n) {
     const size_t nb = (size_t)((n + kMetTile - 1) / kMetTile) + 1;
-    return align_up(nb * 3 * 4, 256) + align_up(nb * 3 * 8, 256) + 256;
+    const size_t counting = align_up(nb * 3 * 4, 256) + align_up(nb * 3 * 8, 256) + 256;        // the count-only form
+    const size_t staged = metrics_staged_layout(n < 1 ? 1 : n).total;
+    return counting > staged ? counting : staged;
 }
 
-// Scan records [start, start+count).  state: 6 x int64 on the device (see layout above).
+// Scan records [start, start+count).  state: 6 x int64 on the device (see layout above); state[0..2] are exact up to the
+// cut-offs and at least the cut-off beyond them (a part that begins with both lists full is not looked at).
 // count_only: only the three running counts (state[0..2]) advance - the first phase of a sharded scan, whose
 // slices need the counts of the slices before them to place their samples.
 int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t count, int32_t* isize_out,
@@ -399,26 +492,36 @@ int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t c
     if (count <= 0) return BESST_OK;
     BESST_REQUIRE((start & 3) == 0, "metrics: chunk start must be a multiple of 4");
     BESST_REQUIRE(ws && ws_bytes >= metrics_workspace_bytes(count), "metrics: workspace too small");
-    const uint32_t nb = (uint32_t)((count + kMetTile - 1) / kMetTile);
     char* p = static_cast<char*>(ws);
-    uint32_t* blk = reinterpret_cast<uint32_t*>(p);
-    long long* base = reinterpret_cast<long long*>(p + align_up((size_t)(nb + 1) * 3 * 4, 256));
-    long long* totals = reinterpret_cast<long long*>(p + align_up((size_t)(nb + 1) * 3 * 4, 256) +
-                                                     align_up((size_t)(nb + 1) * 3 * 8, 256));
     const int64_t end = start + count;
     ProfScope ps(s, kProfMetrics);
     if (!count_only) {
-        // one pass: the descriptor words (in the place of the old form's bases) and the ticket start from zero
-        const uint32_t nbig = (uint32_t)((count + kMetBig - 1) / kMetBig);
-        BESST_HIP_TRY(hipMemsetAsync(base, 0, (size_t)nbig * 8 + 64, s));
-        uint32_t* ticket = reinterpret_cast<uint32_t*>(base + (size_t)nbig);
-        hipLaunchKernelGGL(metrics_onepass_kernel, dim3(nbig), dim3(kMetThreads), 0, s, a, start, end, nbig,
-                           reinterpret_cast<unsigned long long*>(base), ticket, isize_out != nullptr ? 1 : 0, isize_out,
-                           contam_out, reinterpret_cast<unsigned long long*>(state));
+        const MetWs w = metrics_staged_layout(count);
+        uint32_t* tilecnt = reinterpret_cast<uint32_t*>(p + w.tilecnt);
+        long long* base = reinterpret_cast<long long*>(p + w.base);
+        int32_t* info = reinterpret_cast<int32_t*>(p + w.info);
+        int32_t* stage_a = reinterpret_cast<int32_t*>(p + w.stage_a);
+        int32_t* stage_d = reinterpret_cast<int32_t*>(p + w.stage_d);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(state);
+        const int want_isize = isize_out != nullptr ? 1 : 0;
+        for (int64_t at = start; at < end; at += kMetPart) {
+            const int64_t part_end = at + kMetPart < end ? at + kMetPart : end;
+            const uint32_t nt = (uint32_t)((part_end - at + kMetBig - 1) / kMetBig);
+            hipLaunchKernelGGL(metrics_stage_kernel, dim3(nt), dim3(kMetThreads), 0, s, a, at, part_end, want_isize, st, tilecnt,
+                               stage_a, stage_d);
+            hipLaunchKernelGGL(metrics_tiles_kernel, dim3(1), dim3(1024), 0, s, tilecnt, nt, (long long)(part_end - at), st, base, info);
+            hipLaunchKernelGGL(metrics_place_kernel, dim3(nt), dim3(kMetThreads), 0, s, a, at, part_end, want_isize, tilecnt, base,
+                               info, stage_a, stage_d, isize_out, contam_out, st);
+        }
         BESST_HIP_TRY(hipGetLastError());
         return BESST_OK;
     }
     // count only (the first phase of a sharded scan): one read, the three totals
+    const uint32_t nb = (uint32_t)((count + kMetTile - 1) / kMetTile);
+    uint32_t* blk = reinterpret_cast<uint32_t*>(p);
+    long long* base = reinterpret_cast<long long*>(p + align_up((size_t)(nb + 1) * 3 * 4, 256));
+    long long* totals = reinterpret_cast<long long*>(p + align_up((size_t)(nb + 1) * 3 * 4, 256) +
+                                                     align_up((size_t)(nb + 1) * 3 * 8, 256));
     hipLaunchKernelGGL(metrics_count_kernel, dim3(nb), dim3(kMetThreads), 0, s, a, start, end, blk);
     hipLaunchKernelGGL(metrics_scan_kernel, dim3(1), dim3(1024), 0, s, blk, nb,
                        reinterpret_cast<const long long*>(state), base, totals);
