@@ -492,8 +492,11 @@ int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, co
  * A record's sample slot is its running count, so a slice of the stream whose state[0..2] was preset to the
  * counts of the slices before it writes exactly its share of the two 1,000,000-entry sample buffers (everything
  * else stays untouched): with zeroed buffers, an all-reduce(sum) over the slices' buffers is the ordered sample
- * of the whole stream.  count_only != 0 advances state[0..2] only (first phase of a sharded scan).
- * n is limited to 2^31 records per call; workspace: besst_dev_metrics_workspace_bytes(n). */
+ * of the whole stream.  count_only != 0 advances state[0..2] only (first phase of a sharded scan) and
+ * leaves them exact; the sampling form leaves [0..2] exact up to the cut-offs and at least 1,000,000 beyond them (the
+ * call works in parts of 64 Mi records and does not look at a part that begins with both samples full).
+ * n is limited to 2^31 records per call; workspace: besst_dev_metrics_workspace_bytes(n) - the tile counts and, for
+ * min(n, 64 Mi) records, 8 bytes of sample staging per record. */
 size_t besst_dev_metrics_workspace_bytes(int64_t n_records);
 int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,
                              const int32_t* tlen, const uint16_t* flag, const uint8_t* mapq,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development helper (GPU box): the library-metrics pass (tools/metrics_probe.py: prefix scan + forced full scan of a C3-shaped
-# library) under rocprofv3 - kernel stats, then FETCH_SIZE / WRITE_SIZE of metrics_onepass_kernel (separate --pmc passes).
+# library) under rocprofv3 - kernel stats, then FETCH_SIZE / WRITE_SIZE of metrics_stage_kernel, the pass's one read of the records (separate --pmc passes).
 #   tools/metrics_prof.sh [pairs]   -> gpurun_out/metrics_prof/{kernel_stats.csv,pmc.json,probe.json}
 cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/metrics_prof; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
@@ -15,13 +15,13 @@ python - "$O" "$P" <<'PY'
 import csv, glob, json, os, sys
 O, pairs = sys.argv[1], int(sys.argv[2])
 out = {'_about': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/metrics_probe.py: KB per dispatch of '
-                 'metrics_onepass_kernel, largest dispatch = the forced full scan of the library; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KB '
+                 'metrics_stage_kernel, largest dispatch = one 64 M-record part of the forced full scan (or the whole of a shorter one); traffic = (2 * FETCH_SIZE + WRITE_SIZE) KB '
                  '(gfx950 correction of MI355X_MICROARCH.md); algorithmic = 22 B per pair', 'pairs': pairs}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     vals = []
     for path in glob.glob(os.path.join(O, c, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(path, newline='')):
-            if 'metrics_onepass_kernel' in row['Kernel_Name'] and row['Counter_Name'] == c:
+            if 'metrics_stage_kernel' in row['Kernel_Name'] and row['Counter_Name'] == c:
                 vals.append(float(row['Counter_Value']))
     out[c + '_KB_per_dispatch'] = {'dispatches': len(vals), 'max': max(vals) if vals else None, 'sum': sum(vals)}
 f, w = out['FETCH_SIZE_KB_per_dispatch'], out['WRITE_SIZE_KB_per_dispatch']
