@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--settle-seconds', type=float, default=0.3,
+                    help='untimed passes before the warm-up steps (setup: the clocks of an idle GPU need work to settle)')
     ap.add_argument('--config', default=None,
                     help='BASELINE.json config of the workload; default C3 (configs[2], the largest single-GPU config) '
                          'at N = 1, a C2-sized slice per rank at N > 1')
@@ -651,7 +653,7 @@ def measure_single(args, device, config, steps, warmup, copies, pairs=None, cont
     # pool measured 5.3 ms per step in a 30 ms timed region that its own per-kernel breakdown, taken right after, put
     # at 2.9), so the passes run untimed for 0.3 s before the W warm-up steps
     t_setup = time.perf_counter()
-    while time.perf_counter() - t_setup < 0.3:
+    while time.perf_counter() - t_setup < args.settle_seconds:
         for _ in range(4):
             runner.step()
         torch.cuda.synchronize()
