@@ -89,6 +89,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     'besst_abi_version': (C.c_int, []),
     'besst_last_error': (C.c_char_p, []),
+    'besst_release_cached_memory': (None, []),
     'besst_device_count': (C.c_int, []),
     'besst_prof_enable': (None, [C.c_uint32]),
     'besst_prof_sample_every': (None, [C.c_uint32]),

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -89,6 +90,68 @@ int bits_for(uint64_t v) {
 
 using namespace besst;
 
+// ---- pinned staging buffers are kept -------------------------------------------------------------------------------
+// Pinning and unpinning host memory costs ~90 ms per GB on the bench host - 47 of the 220 ms an ingest of a 40 M-record
+// file took, most of it the release at the end of the call.  The staging buffers of the two ingest forms therefore come
+// from a process-wide pool and go back to it: a later call (the next library's file, the other form, the next context)
+// finds them pinned.  The pool holds at most kPinnedKeep bytes (what comes back beyond that is freed), is never freed at
+// exit (the runtime may be gone by then), and besst_release_cached_memory() empties it.
+namespace {
+constexpr size_t kPinnedKeep = (size_t)1 << 30;
+struct PinnedPool {
+    struct Entry { void* p; size_t bytes; bool busy; };
+    std::mutex mu;
+    std::vector<Entry> all;
+    void* acquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            Entry* best = nullptr;
+            for (Entry& e : all)
+                if (!e.busy && e.bytes >= bytes && e.bytes <= bytes + bytes / 2 + ((size_t)1 << 20) && (!best || e.bytes < best->bytes)) best = &e;
+            if (best) { best->busy = true; return best->p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+            trim(0);                                          // (what is cached may be what is missing)
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        all.push_back(Entry{p, bytes, true});
+        return p;
+    }
+    void give_back(void* p) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (Entry& e : all)
+                if (e.p == p) e.busy = false;
+        }
+        trim(kPinnedKeep);
+    }
+    // free idle buffers, largest first, until at most `keep` idle bytes are left
+    void trim(size_t keep) {
+        for (;;) {
+            void* victim = nullptr;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                size_t idle = 0;
+                size_t at = all.size();
+                for (size_t i = 0; i < all.size(); ++i)
+                    if (!all[i].busy) {
+                        idle += all[i].bytes;
+                        if (at == all.size() || all[i].bytes > all[at].bytes) at = i;
+                    }
+                if (idle <= keep || at == all.size()) return;
+                victim = all[at].p;
+                all.erase(all.begin() + (long)at);
+            }
+            (void)hipHostFree(victim);
+        }
+    }
+};
+PinnedPool g_pinned;
+}  // namespace
+
 struct besst_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -158,6 +221,8 @@ extern "C" {
 int besst_abi_version(void) { return BESST_ABI_VERSION; }
 
 const char* besst_last_error(void) { return g_error; }
+
+void besst_release_cached_memory(void) { g_pinned.trim(0); }
 
 void besst_prof_enable(uint32_t slot_mask) {
     g_prof_mask = slot_mask;
@@ -440,12 +505,12 @@ int besst_ctx_push_bam(besst_ctx* c, besst_bam* bam, int64_t chunk_records, int6
     auto release = [&]() {
         for (Slot& sl : slot) {
             void* ptrs[8] = {sl.tid, sl.mtid, sl.pos, sl.mpos, sl.tlen, sl.flag, sl.qlen, sl.mapq};
-            for (void* q : ptrs) if (q) (void)hipHostFree(q);
+            for (void* q : ptrs) g_pinned.give_back(q);
             if (sl.done) (void)hipEventDestroy(sl.done);
             sl = Slot();
         }
     };
-    auto pinned = [&](void** out, size_t bytes) { return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess; };
+    auto pinned = [&](void** out, size_t bytes) { return (*out = g_pinned.acquire(bytes)) != nullptr; };
     bool ok = true;
     for (Slot& sl : slot) {
         const size_t m = (size_t)chunk_records;
@@ -707,9 +772,12 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     uint32_t* summ_host = nullptr;   // pinned: kSlots x 8 summary words | [28] [29] flag words | [32..] kSlots tail descriptors
     hipStream_t copy_stream = nullptr;
     const size_t inflated_cap = kTailRoom + nb * 65536 + 4096;
+    double unpin_s = 0.0;
     auto release = [&]() {
         for (Slot& q : sl) {
-            if (q.pin) (void)hipHostFree(q.pin);
+            const auto t0 = std::chrono::steady_clock::now();
+            g_pinned.give_back(q.pin);
+            unpin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (q.dev) (void)hipFree(q.dev);
             if (q.inflated) (void)hipFree(q.inflated);
             if (q.offs) (void)hipFree(q.offs);
@@ -726,9 +794,15 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (summ_host) (void)hipHostFree(summ_host);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
-    bool ok = true;
-    for (Slot& q : sl)
-        ok = ok && hipHostMalloc((void**)&q.pin, slot_bytes, hipHostMallocDefault) == hipSuccess &&
+    // A slot is allocated when the first chunk that uses it is about to be read: slots 1 and 2 (pinning 2 x 170 MB takes
+    // longer than reading a chunk) come into being while chunk 0 uploads and inflates, and a file of one chunk never pays
+    // for them.
+    double alloc_s = 0.0;
+    auto alloc_slot = [&](int k) -> bool {
+        Slot& q = sl[k];
+        if (q.pin) return true;
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool got = (q.pin = static_cast<char*>(g_pinned.acquire(slot_bytes))) != nullptr &&
              hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
              hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
              hipMalloc((void**)&q.words, (nbw * 6 + 8) * sizeof(uint32_t)) == hipSuccess &&
@@ -737,11 +811,14 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
              hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.tail_taken, hipEventDisableTiming) == hipSuccess;
+        alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return got;
+    };
+    bool ok = alloc_slot(0);
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
          hipHostMalloc((void**)&summ_host, 64 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
          hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
-    const double alloc_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (!ok) {
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
@@ -757,6 +834,13 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     // read chunk j (the next blocks of the file) into slot j % kSlots and start its upload
     auto stage = [&](int64_t j) -> bool {
         Slot& q = sl[j % kSlots];
+        if (fpos >= map_len) { q.ck = Chunk(); return true; }   // (nothing left: no slot is allocated for it)
+        if (!alloc_slot((int)(j % kSlots))) {
+            set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
+                      (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap)) >> 20);
+            rc = BESST_ERR_NOMEM;
+            return false;
+        }
         if (j >= kSlots) {                                        // the upload that last read this pinned slot
             const auto t0 = std::chrono::steady_clock::now();
             const hipError_t e = hipEventSynchronize(q.h2d_done);
@@ -837,7 +921,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             if (e == hipSuccess)
                 e = hipMemcpyAsync(q.inflated + kTailRoom - tail_len, other.inflated + tail_at, tail_len, hipMemcpyDeviceToDevice, q.work);
         }
-        if (e == hipSuccess) e = hipEventRecord(other.tail_taken, q.work);
+        if (e == hipSuccess && other.tail_taken) e = hipEventRecord(other.tail_taken, q.work);   // (a slot no chunk has used yet has no buffer to protect)
         if (e != hipSuccess) { hip_fail(e); return false; }
         if (launch_bam_walk_scan(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks + 1,
                                  (uint64_t)kTailRoom + q.ck.inflated, n_ref, tail_len ? 0xffffffffu : 1u, first_entry, w, q.offs,
@@ -922,7 +1006,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             const auto t0 = std::chrono::steady_clock::now();
             hipError_t e = hipSuccess;
             for (Slot& o : sl)                               // (slot_free: behind a slot's last decode)
-                if (e == hipSuccess) e = hipEventSynchronize(o.slot_free);
+                if (e == hipSuccess && o.slot_free) e = hipEventSynchronize(o.slot_free);
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); break; }
             const int64_t keep = c->n_records;
@@ -943,6 +1027,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     const auto tw = std::chrono::steady_clock::now();
     hipError_t e0 = hipSuccess, e1 = hipSuccess;
     for (Slot& q : sl) {
+        if (!q.work) continue;
         const hipError_t e = hipStreamSynchronize(q.work);
         if (e != hipSuccess) e0 = e;
     }
@@ -968,8 +1053,8 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     const auto t_rel = std::chrono::steady_clock::now();
     release();
     if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
-        fprintf(stderr, "[push_bam_device] alloc %.3f s  staging %.3f s  waiting %.3f s  release %.3f s  total %.3f s\n", alloc_s, stage_s,
-                wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count(),
+        fprintf(stderr, "[push_bam_device] alloc %.3f s  staging %.3f s  waiting %.3f s  release %.3f s (unpinning %.3f)  total %.3f s\n", alloc_s, stage_s,
+                wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count(), unpin_s,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     if (rc) return rc;
     c->n_records += pushed;

@@ -113,6 +113,12 @@ typedef struct besst_ctx besst_ctx;
 int besst_abi_version(void);
 /* Last error text of the calling thread's most recent failing call (never NULL). */
 const char* besst_last_error(void);
+
+/* The pinned staging buffers of besst_ctx_push_bam / besst_ctx_push_bam_device are kept in a process-wide pool between
+ * calls (pinning and unpinning host memory costs ~90 ms per GB: a third of the ingest of a 40 M-record file); at most 1 GiB
+ * stays cached.  This call frees what is idle in the pool (a long-lived host process that is done reading files). */
+void besst_release_cached_memory(void);
+
 /* Number of visible HIP devices, or a negative status. */
 int besst_device_count(void);
 

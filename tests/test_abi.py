@@ -10,7 +10,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     text = open(os.path.join(REPO, 'include', 'besst_amd.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(besst_(?:abi|last|device|prof|ctx|dev|owner|bam|bgzf|host)_\w+|besst_linearize|besst_score_paths|besst_chain_scaffolds)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(besst_(?:abi|last|release|device|prof|ctx|dev|owner|bam|bgzf|host)_\w+|besst_linearize|besst_score_paths|besst_chain_scaffolds)\s*\(', text)))
 
 
 def test_header_symbols_exported_and_bound():
