@@ -171,6 +171,27 @@ def test_bytes_that_look_like_a_record_do_not_mislead_the_device(block_bytes, ch
         assert np.array_equal(getattr(host, col), getattr(batch, col)), col
 
 
+def test_pinned_staging_is_pooled_and_can_be_released():
+    """The ingest forms' pinned staging buffers go back to a process-wide pool: a second ingest finds them (same result), and
+    besst_release_cached_memory() empties the pool without disturbing the next call."""
+    batch = _library(8000)
+    lib = _lib.load()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bamio.write_bam(path, batch, threads=4, level=1)
+        host = bamio.read_bam(path, threads=2)
+        for mode in ('device', 'device', 'host', 'release', 'device', 'host'):
+            if mode == 'release':
+                lib.besst_release_cached_memory()
+                continue
+            bam = bamio.ResidentBam(path, threads=2, mode=mode)
+            try:
+                assert bam.ingest.on_device == (1 if mode == 'device' else 0)
+                _check_against_host(path, bam, host)
+            finally:
+                bam.close()
+
+
 def test_random_block_layouts():
     """Blocks cut at random sizes (30 bytes ... 64 KiB, changing from block to block; now and then an empty block), reads of
     random lengths incl. none, some with bytes in their qualities that pass for a record header, random chunk sizes: the device
