@@ -130,11 +130,11 @@ class GraphContext(object):
     @_timed
     def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0, part=None):
         """Stream an open besst_bam (bamio) into the context.  mode 'device': BGZF inflate + record decode on the GPU, the
-        compressed file crosses PCIe (besst_ctx_push_bam_device; files in htslib's block layout); 'host': inflate + decode
-        on the reader's host threads into pinned staging, copies under the next chunk's decode (besst_ctx_push_bam, any
-        layout); 'auto' (default; BESST_INGEST overrides): the device form, and the host form when the library answers
+        compressed file crosses PCIe (besst_ctx_push_bam_device; any BGZF block layout); 'host': inflate + decode
+        on the reader's host threads into pinned staging, copies under the next chunk's decode (besst_ctx_push_bam); 'auto' (default; BESST_INGEST overrides): the device form, and the host form when the library answers
         BESST_ERR_UNSUPPORTED (``stats.on_device`` tells which one ran).  part = (r, W): only the r-th of W parts of the
-        file's records (cut at BGZF block boundaries; multi-GPU ingest: rank r's slice of the stream) - device form only.
+        file's records (cut at BGZF block boundaries; multi-GPU ingest: rank r's slice of the stream) - device form only, and
+        only for files in htslib's layout, where a block boundary is a record boundary (else BesstDeviceError, status 5).
         -> (IngestStats, head rlen, head alen, head qlen)."""
         import os
         from ._lib import IngestStats
@@ -161,8 +161,7 @@ class GraphContext(object):
             elif rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_NOMEM) or mode == 'device':
                 _lib.check(rc, 'push_bam_device')
             else:
-                # (out of memory: the device form wants two slots of scratch - ~1 GB of HBM, 2 x 160 MB pinned - before it
-                # reads anything, the host form 2 x 25 B x chunk_records of pinned staging; context and reader are untouched)
+                # (out of memory: the device form wants up to three slots of scratch - ~0.7 GB of HBM and 170 MB pinned each -, the host form 2 x 25 B x chunk_records of pinned staging; context and reader are untouched)
                 self.ingest_fallback = _lib.last_error()
         if not done:
             _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),
