@@ -109,6 +109,8 @@ _SIGNATURES = {
     'besst_ctx_push_bam_device': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.POINTER(IngestStats)]),
     'besst_ctx_push_bam_device_part': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P, _P,
                                                  C.POINTER(IngestStats)]),
+    'besst_ctx_push_bam_device_slice': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P,
+                                                  C.POINTER(IngestStats)]),
     'besst_bgzf_inflate_device': (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     'besst_ctx_metrics_sample': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P,
                                            C.POINTER(MetricsCounts)]),

@@ -49,7 +49,8 @@ class ResidentBam(object):
     records (the read-length step, libmetrics.py:246-273); ``ctx`` is the GraphContext that holds the records and
     ``ingest`` the timings of the upload."""
 
-    def __init__(self, path, device_index=0, threads=None, chunk_records=4 << 20, mode=None, chunk_blocks=0, part=None):
+    def __init__(self, path, device_index=0, threads=None, chunk_records=4 << 20, mode=None, chunk_blocks=0, part=None,
+                 first_skip=None):
         from . import device
         lib = _lib.load()
         threads = threads or reader_threads()
@@ -60,7 +61,9 @@ class ResidentBam(object):
             self.ctx = device.GraphContext(device_index)     # (inside the try: a context that cannot be made must not leak the reader)
             zeros = np.zeros(len(self.references), dtype=np.int32)
             self.ctx.set_contigs(scaf_id=zeros, scaf_len=zeros, ctg_pos=zeros, ctg_len=zeros, direction=zeros, cls=zeros)
-            self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records, mode=mode, chunk_blocks=chunk_blocks, part=part)
+            self.ingest, self.rlen, self.alen, self.qlen = self.ctx.push_bam(handle, chunk_records, mode=mode, chunk_blocks=chunk_blocks, part=part,
+                                                                              first_skip=first_skip)
+            self.boundary = getattr(self.ctx, 'slice_boundary', None)
             clamped = lib.besst_bam_clamped_records(handle)
         except Exception:
             if self.ctx is not None:

@@ -697,8 +697,12 @@ int besst_ctx_push_bam_device(besst_ctx* c, besst_bam* bam, int64_t chunk_blocks
 // the stream, which is what phase 1 of the sharded build works on): the file is cut at the BGZF block boundaries nearest
 // to part / parts of its bytes - in htslib's layout every block begins with a record, so every boundary is a valid place
 // to start, and every rank finds the same boundaries on its own.
-int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks, int64_t head_records,
-                                   int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
+namespace {
+// first_skip / boundary: the slice form (besst_ctx_push_bam_device_slice; boundary == nullptr: the part form, which takes
+// htslib's layout only and begins every part with its first block's first byte).
+int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks, int64_t head_records,
+                         int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats,
+                         int64_t first_skip, int64_t* boundary) {
     BESST_REQUIRE(c && bam, "push_bam_device: null context or reader");
     BESST_REQUIRE(parts >= 1 && part >= 0 && part < parts, "push_bam_device: part must be in [0, parts)");
     BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)),
@@ -716,6 +720,8 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         return BESST_ERR_UNSUPPORTED;
     }
     size_t map_len = (size_t)bam_file_bytes(bam);        // (from here on: the end of this call's part of the file)
+    const size_t whole_file = map_len;
+    const bool slice = boundary != nullptr;
     if (parts > 1) {
         const uint8_t* map = bam_file_map(bam);
         const size_t file_len = map_len;
@@ -769,7 +775,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     } sl[kSlots];
     char* heads = nullptr;           // head_rlen | head_alen | head_qlen on the device
     uint32_t* d_flags = nullptr;     // corrupt-record bit, saturated-qlen count
-    uint32_t* summ_host = nullptr;   // pinned: kSlots x 8 summary words | [28] [29] flag words | [32..] kSlots tail descriptors
+    uint32_t* summ_host = nullptr;   // pinned: kSlots x 12 summary words | [40] [41] flag words | [48..] kSlots tail descriptors
     hipStream_t copy_stream = nullptr;
     const size_t inflated_cap = kTailRoom + nb * 65536 + 4096;
     double unpin_s = 0.0;
@@ -805,7 +811,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         const bool got = (q.pin = static_cast<char*>(g_pinned.acquire(slot_bytes))) != nullptr &&
              hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
              hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
-             hipMalloc((void**)&q.words, (nbw * 6 + 8) * sizeof(uint32_t)) == hipSuccess &&
+             hipMalloc((void**)&q.words, (nbw * 6 + 12) * sizeof(uint32_t)) == hipSuccess &&
              hipStreamCreateWithFlags(&q.work, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
@@ -817,7 +823,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     bool ok = alloc_slot(0);
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
-         hipHostMalloc((void**)&summ_host, 64 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
          hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
         release();
@@ -831,6 +837,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     double bytes_per_block = 0.0;
     rc = BESST_OK;
     auto hip_fail = [&](hipError_t e) { set_error("push_bam_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; };
+    size_t max_blocks = nb;                                  // (blocks per chunk: fewer for the blocks behind a part's end)
     // read chunk j (the next blocks of the file) into slot j % kSlots and start its upload
     auto stage = [&](int64_t j) -> bool {
         Slot& q = sl[j % kSlots];
@@ -857,7 +864,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         // window is sized from the blocks seen so far, the block it cuts is read again with the next chunk.
         size_t want = map_len - begin < comp_cap ? map_len - begin : comp_cap;
         if (bytes_per_block > 0.0) {
-            const size_t guess = (size_t)((double)nb * bytes_per_block * 1.08) + 65536;
+            const size_t guess = (size_t)((double)max_blocks * bytes_per_block * 1.08) + 65536;
             if (guess < want) want = guess;
         }
         if (!bam_parallel_read(bam, q.pin + desc_bytes, (int64_t)begin, want)) {
@@ -868,7 +875,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         size_t used = 0;
         BgzfBlock* desc = reinterpret_cast<BgzfBlock*>(q.pin);
         desc[0] = BgzfBlock{0u, 0u, (uint32_t)kTailRoom, 0u, 0u, 0u};   // the tail slot: empty until the chunk before says otherwise
-        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(q.pin + desc_bytes), want, &used, nb, comp_cap, desc + 1,
+        if (!scan_bgzf_chunk(reinterpret_cast<const uint8_t*>(q.pin + desc_bytes), want, &used, max_blocks, comp_cap, desc + 1,
                              &q.ck.n_blocks, &q.ck.comp, &q.ck.inflated, begin + want < map_len, kTailRoom, true) ||
             (q.ck.n_blocks == 0 && want > 0)) {
             set_error("push_bam_device: not a BGZF block at file offset %zu", begin + used);
@@ -909,13 +916,13 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     // are copied in front of this chunk's first block and become its block 0.  first_entry: where the first record begins
     // in block 1 when there is no tail (the end of the header in the file's first chunk, else 0).
     const int32_t n_ref = besst_bam_n_references(bam);
-    auto enqueue_walk = [&](int k, uint64_t tail_at, uint32_t tail_len, uint32_t first_entry) -> bool {
+    auto enqueue_walk = [&](int k, uint64_t tail_at, uint32_t tail_len, uint32_t forced_block, uint32_t forced_entry, uint32_t mode) -> bool {
         Slot& q = sl[k];
         Slot& other = sl[(k + kSlots - 1) % kSlots];
         uint32_t* w = q.words;
         hipError_t e = hipSuccess;
         if (tail_len) {
-            BgzfBlock* patch = reinterpret_cast<BgzfBlock*>(summ_host + 32) + k;
+            BgzfBlock* patch = reinterpret_cast<BgzfBlock*>(summ_host + 48) + k;
             *patch = BgzfBlock{0u, 0u, (uint32_t)(kTailRoom - tail_len), 0u, tail_len, 0u};
             e = hipMemcpyAsync(q.dev, patch, sizeof(BgzfBlock), hipMemcpyHostToDevice, q.work);
             if (e == hipSuccess)
@@ -924,12 +931,12 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (e == hipSuccess && other.tail_taken) e = hipEventRecord(other.tail_taken, q.work);   // (a slot no chunk has used yet has no buffer to protect)
         if (e != hipSuccess) { hip_fail(e); return false; }
         if (launch_bam_walk_scan(q.work, q.inflated, reinterpret_cast<const BgzfBlock*>(q.dev), q.ck.n_blocks + 1,
-                                 (uint64_t)kTailRoom + q.ck.inflated, n_ref, tail_len ? 0xffffffffu : 1u, first_entry, w, q.offs,
+                                 (uint64_t)kTailRoom + q.ck.inflated, n_ref, tail_len ? 0xffffffffu : forced_block, forced_entry, mode, w, q.offs,
                                  w + nbw, w + 2 * nbw, w + 3 * nbw, w + 4 * nbw, w + 5 * nbw, w + 6 * nbw)) {
             rc = BESST_ERR_HIP;
             return false;
         }
-        e = hipMemcpyAsync(summ_host + 8 * k, w + 6 * nbw, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, q.work);
+        e = hipMemcpyAsync(summ_host + 12 * k, w + 6 * nbw, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, q.work);
         if (e == hipSuccess) e = hipEventRecord(q.summ_done, q.work);
         if (e != hipSuccess) { hip_fail(e); return false; }
         return true;
@@ -944,9 +951,31 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the slots' streams start behind these
         if (e != hipSuccess) hip_fail(e);
     }
-    if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, u0) && stage(1) &&
-        sl[1].ck.n_blocks)
-        enqueue_inflate(1);
+    // where the first chunk's first record begins: the end of the header / the first byte of a part of a file in htslib's
+    // layout; a slice behind the first one: where the caller says (the bytes in front belong to the last record of the slice
+    // before), or a guess that the caller will check against what the slice before reports
+    uint32_t fb0 = 1u, fe0 = u0, mode0 = 0u;
+    if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks) {
+        if (slice && part > 0 && first_skip < 0) {
+            fb0 = 0xffffffffu; fe0 = 0u; mode0 = kWalkFirstGuessed;
+        } else if (slice && part > 0) {
+            const BgzfBlock* desc = reinterpret_cast<const BgzfBlock*>(sl[0].pin);
+            uint64_t skip = (uint64_t)first_skip;
+            fb0 = 0u;
+            for (uint32_t i = 1; i <= sl[0].ck.n_blocks; ++i) {
+                if (skip < desc[i].dst_len) { fb0 = i; fe0 = (uint32_t)skip; break; }
+                skip -= desc[i].dst_len;
+            }
+            if (fb0 == 0u) {
+                set_error("push_bam_device: the slice's first record begins behind its first chunk (%lld bytes in)", (long long)first_skip);
+                rc = BESST_ERR_UNSUPPORTED;
+            }
+        }
+        if (rc == BESST_OK && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, fb0, fe0, mode0) && stage(1) && sl[1].ck.n_blocks)
+            enqueue_inflate(1);
+    }
+    int64_t first_at = -1, carry_out = 0;                    // (the slice form's answers)
+    bool overhang = false;                                   // the chunk at hand holds the blocks behind the part's end
     for (int64_t j = 0; rc == BESST_OK && sl[j % kSlots].ck.n_blocks; ++j) {
         Slot& q = sl[j % kSlots];
         Slot& nx = sl[(j + 1) % kSlots];
@@ -963,7 +992,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (e != hipSuccess) { hip_fail(e); break; }
         }
-        const uint32_t* sm = summ_host + 8 * (j % kSlots);
+        const uint32_t* sm = summ_host + 12 * (j % kSlots);
         if (!sm[1]) {
             if (sm[3]) set_error("push_bam_device: block %u of chunk %lld did not inflate on the device (status %u)", sm[2] ? sm[2] - 1u : 0u, (long long)j, sm[3]);
             else set_error("push_bam_device: the records of chunk %lld could not be located on the device (block %u: a record start "
@@ -971,7 +1000,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             rc = BESST_ERR_UNSUPPORTED;
             break;
         }
-        if (parts > 1 && sm[7]) {
+        if (parts > 1 && sm[7] && !slice) {
             set_error("push_bam_device: a record straddles BGZF blocks (chunk %lld): a part of such a file cannot be cut at a block", (long long)j);
             rc = BESST_ERR_UNSUPPORTED;
             break;
@@ -982,9 +1011,30 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
             rc = BESST_ERR_UNSUPPORTED;
             break;
         }
+        if (j == 0) {
+            const uint64_t at = (uint64_t)sm[8] | ((uint64_t)sm[9] << 32);
+            first_at = at == ~0ull ? -1 : (int64_t)(at - (uint64_t)kTailRoom);
+            if (slice && first_at < 0) {
+                set_error("push_bam_device: no record begins in the first chunk of the slice");
+                rc = BESST_ERR_UNSUPPORTED;
+                break;
+            }
+        }
+        if (overhang) carry_out = (int64_t)sm[8];            // bytes of the slice's last record that lie in the next slice
         if (nx.ck.n_blocks) {
             // chunk j + 1's records can be located now: it starts with chunk j's unfinished record, if there is one
-            if (!enqueue_walk((int)((j + 1) % kSlots), (uint64_t)sm[5] | ((uint64_t)sm[6] << 32), tail_len, 0u)) break;
+            if (!enqueue_walk((int)((j + 1) % kSlots), (uint64_t)sm[5] | ((uint64_t)sm[6] << 32), tail_len, 1u, 0u, 0u)) break;
+        } else if (tail_len && slice && !overhang && map_len < whole_file) {
+            // the slice's last record runs on behind the slice's end: the blocks that follow are inflated for its bytes (and for
+            // nothing else: the records that begin in them are the next slice's)
+            overhang = true;
+            map_len = whole_file;
+            max_blocks = nb < 4096 ? nb : 4096;
+            sl[(j + 2) % kSlots].ck = Chunk();
+            if (!stage(j + 1)) break;
+            if (!nx.ck.n_blocks) { set_error("push_bam_device: the file ends inside a record"); rc = BESST_ERR_ARG; break; }
+            if (!enqueue_inflate((int)((j + 1) % kSlots))) break;
+            if (!enqueue_walk((int)((j + 1) % kSlots), (uint64_t)sm[5] | ((uint64_t)sm[6] << 32), tail_len, 0xffffffffu, 0u, kWalkOverhang)) break;
         } else if (tail_len) {
             set_error("push_bam_device: the %s ends inside a record", parts > 1 ? "part of the file" : "file");
             rc = parts > 1 ? BESST_ERR_UNSUPPORTED : BESST_ERR_ARG;
@@ -1034,7 +1084,7 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
     const hipError_t ec = hipStreamSynchronize(copy_stream);
     if (rc == BESST_OK && (e0 != hipSuccess || e1 != hipSuccess || ec != hipSuccess)) hip_fail(e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : ec);
     if (rc == BESST_OK) {
-        hipError_t e = hipMemcpyAsync(summ_host + 28, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = hipMemcpyAsync(summ_host + 40, d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
         const int64_t hn = pushed < head_records ? pushed : head_records;
         if (e == hipSuccess && hn > 0) {
             e = hipMemcpyAsync(head_rlen, col.head_rlen, (size_t)hn * 4, hipMemcpyDeviceToHost, c->stream);
@@ -1045,11 +1095,11 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         if (e != hipSuccess) hip_fail(e);
     }
     wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-    if (rc == BESST_OK && (summ_host[28] & 1u)) {
+    if (rc == BESST_OK && (summ_host[40] & 1u)) {
         set_error("push_bam_device: corrupt record (its name and CIGAR do not fit its length)");
         rc = BESST_ERR_ARG;
     }
-    const uint32_t saturated = rc == BESST_OK ? summ_host[29] : 0u;
+    const uint32_t saturated = rc == BESST_OK ? summ_host[41] : 0u;
     const auto t_rel = std::chrono::steady_clock::now();
     release();
     if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
@@ -1073,7 +1123,31 @@ int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, i
         stats->on_device = 1;
         stats->starts_repaired = (int32_t)(repaired > 0x7fffffff ? 0x7fffffff : repaired);
     }
+    if (boundary) { boundary[0] = first_at; boundary[1] = carry_out; }
     return BESST_OK;
+}
+}  // namespace
+
+int besst_ctx_push_bam_device_part(besst_ctx* c, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks, int64_t head_records,
+                                   int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats) {
+    return push_bam_device_impl(c, bam, part, parts, chunk_blocks, head_records, head_rlen, head_alen, head_qlen, stats, -1, nullptr);
+}
+
+// Slice `part` of `parts` of a file in ANY block layout (multi-GPU ingest of files whose records straddle BGZF blocks): the
+// slices are cut at block boundaries as above, and a record belongs to the slice it BEGINS in.  Where a slice's first record
+// begins is the one thing a rank cannot know alone: first_skip < 0 lets it guess (the heuristics of the block-to-block
+// verification; everything behind the guess is verified as usual), and boundary[0] reports the offset used - in inflated
+// bytes from the slice's first block -, boundary[1] how many bytes of the slice's last record lie in the next slice.  The
+// callers exchange these two numbers: slice r is right iff boundary[0] of slice r equals boundary[1] of slice r - 1 (slice 0
+// begins behind the header and is always right); a slice whose guess was wrong is read again with first_skip = that
+// number (besst_amd.distributed.ingest_slice does this).  The bytes of a slice's last record that lie behind its end are
+// read from the blocks that follow (at most 4 MiB).
+int besst_ctx_push_bam_device_slice(besst_ctx* c, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks, int64_t first_skip,
+                                    int64_t* boundary, int64_t head_records, int32_t* head_rlen, int32_t* head_alen,
+                                    uint16_t* head_qlen, besst_ingest_stats* stats) {
+    BESST_REQUIRE(boundary, "push_bam_device_slice: boundary is null");
+    return push_bam_device_impl(c, bam, part, parts, chunk_blocks, head_records, head_rlen, head_alen, head_qlen, stats, first_skip,
+                                boundary);
 }
 
 int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void* out, size_t out_cap, size_t* out_len) {

@@ -766,7 +766,7 @@ __device__ __forceinline__ bool bam_plausible(const uint8_t* p, unsigned long lo
 
 __global__ __launch_bounds__(64) void bam_entry_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
                                                        uint32_t n_blocks, unsigned long long chunk_end, int32_t n_ref,
-                                                       uint32_t forced_block, uint32_t forced_entry, uint32_t* __restrict__ guess) {
+                                                       uint32_t forced_block, uint32_t forced_entry, uint32_t mode, uint32_t* __restrict__ guess) {
     const uint32_t b = blockIdx.x;
     const int lane = threadIdx.x;
     if (b >= n_blocks) return;
@@ -774,7 +774,9 @@ __global__ __launch_bounds__(64) void bam_entry_kernel(const uint8_t* __restrict
     const unsigned long long at0 = (unsigned long long)blocks[b].dst_off_lo | ((unsigned long long)blocks[b].dst_off_hi << 32);
     uint32_t found = kNoStart;
     if (b == 0u) found = len ? 0u : kNoStart;                // the tail of the chunk before begins with a record
+    else if (mode & kWalkOverhang) found = kNoStart;        // (only the record in the tail slot is this chunk's)
     else if (b == forced_block) found = forced_entry < len ? forced_entry : kNoStart;
+    else if (forced_block != 0xffffffffu && b < forced_block) found = kNoStart;   // (the bytes of a record of the part before)
     else {
         for (uint32_t o0 = 0; o0 < len; o0 += 64u) {          // uniform
             const uint32_t o = o0 + (uint32_t)lane;
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict_
     bam_walk_block(inflated, blocks, b, chunk_end, status, guess[b], offs, count, exits, tail_at);
 }
 
-// summary: [0] records, [1] 1 = every start verified, [2] first block that is not (verified: guesses replaced), [3] its inflate status, [4] bytes of the
+// summary (12 words): [0] records, [1] 1 = every start verified, [2] first block that is not (verified: guesses replaced), [3] its inflate status, [4] bytes of the
 // chunk's tail, [5] [6] where it begins in the chunk's buffer, [7] 1 = some block begins inside a record (not htslib's layout)
 //
 // A verdict is the smallest (block << 32 | what its predecessor says its entry is): kVerdictBad in the low word when there is
@@ -846,7 +848,7 @@ constexpr uint32_t kScanThreads = 256;
 __global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* __restrict__ inflated, const BgzfBlock* __restrict__ blocks,
                                                         uint16_t* __restrict__ offs, uint32_t* count, uint32_t* exits, uint32_t* guess,
                                                         uint32_t* tail_at, const uint32_t* __restrict__ status,
-                                                        uint32_t n_blocks, unsigned long long chunk_end, uint32_t forced_block,
+                                                        uint32_t n_blocks, unsigned long long chunk_end, uint32_t forced_block, uint32_t mode,
                                                         uint32_t* __restrict__ rec_base, uint32_t* __restrict__ summary) {
     __shared__ uint32_t s_w[kScanThreads / 64], s_tail, s_straddle;
     __shared__ unsigned long long s_bad;
@@ -861,6 +863,10 @@ __global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* _
             const uint32_t ex = exits[b], g = guess[b];
             const unsigned long long here = (unsigned long long)b << 32;
             if (blocks[b].dst_len != 0u && status[b] != kInfOk) { atomicMin(&s_bad, here | kVerdictBad); continue; }
+            if (mode & kWalkOverhang) {                      // only the tail slot's record: it must end inside the chunk
+                if (b == 0u && (ex == kExitBad || ex == kExitNone || ex == kExitTail)) atomicMin(&s_bad, here | kVerdictBad);
+                continue;
+            }
             if (b > 0u && b != forced_block && g != kNoStart && g != 0u) s_straddle = 1u;
             if (ex == kExitNone) continue;                   // guessed "no start": a block before it vouches for that (or fails to)
             if (ex == kExitBad) { atomicMin(&s_bad, here | kVerdictBad); continue; }
@@ -878,11 +884,11 @@ __global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* _
                 atomicMin(&s_bad, here | kVerdictBad);       // (a record that ends beyond the chunk would have been its tail)
             }
         }
-        if (t == 0) {
-            // the first block that holds bytes must hold a start: block 0 (a tail) or the forced block right behind an empty
-            // slot 0 - nobody vouches for a block in front of the first walked one
+        if (t == 0 && !(mode & (kWalkFirstGuessed | kWalkOverhang))) {
+            // the first block that holds bytes must hold a start: block 0 (a tail) or the forced block (in front of it lie
+            // the bytes of a record of the part before) - nobody vouches for a block in front of the first walked one
             uint32_t f = 0;
-            while (f < n_blocks && exits[f] == kExitNone && blocks[f].dst_len == 0u) ++f;
+            while (f < n_blocks && exits[f] == kExitNone && (blocks[f].dst_len == 0u || (forced_block != 0xffffffffu && f < forced_block))) ++f;
             if (f < n_blocks && exits[f] == kExitNone && f != 0u) atomicMin(&s_bad, ((unsigned long long)f << 32) | kVerdictBad);
         }
         __syncthreads();
@@ -941,6 +947,20 @@ __global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* _
         summary[5] = (uint32_t)at;
         summary[6] = (uint32_t)(at >> 32);
         summary[7] = s_straddle;
+        // [8] [9]: where the chunk's first record begins in the chunk's buffer (~0: no record begins in it); for the blocks
+        // behind a part's end: how many bytes of the tail slot's record lie in them (i.e. in the next part)
+        unsigned long long first = ~0ull;
+        if (mode & kWalkOverhang) {
+            first = exits[0];
+        } else {
+            for (uint32_t f = 0; f < n_blocks; ++f)
+                if (exits[f] != kExitNone) {
+                    first = ((unsigned long long)blocks[f].dst_off_lo | ((unsigned long long)blocks[f].dst_off_hi << 32)) + guess[f];
+                    break;
+                }
+        }
+        summary[8] = (uint32_t)first;
+        summary[9] = (uint32_t)(first >> 32);
     }
 }
 
@@ -1027,15 +1047,15 @@ int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* bloc
 }
 
 int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint64_t chunk_end,
-                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, const uint32_t* status, uint16_t* offs,
+                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, uint32_t mode, const uint32_t* status, uint16_t* offs,
                          uint32_t* count, uint32_t* exits, uint32_t* rec_base, uint32_t* guess, uint32_t* tail_at, uint32_t* summary) {
     if (n_blocks == 0) return BESST_OK;
     hipLaunchKernelGGL(bam_entry_kernel, dim3(n_blocks), dim3(64), 0, s, inflated, blocks, n_blocks, (unsigned long long)chunk_end,
-                       n_ref, forced_block, forced_entry, guess);
+                       n_ref, forced_block, forced_entry, mode, guess);
     hipLaunchKernelGGL(bam_walk_kernel, dim3((n_blocks + 63u) / 64u), dim3(64), 0, s, inflated, blocks, n_blocks,
                        (unsigned long long)chunk_end, status, guess, offs, count, exits, tail_at);
     hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, inflated, blocks, offs, count, exits, guess, tail_at, status, n_blocks,
-                       (unsigned long long)chunk_end, forced_block, rec_base, summary);
+                       (unsigned long long)chunk_end, forced_block, mode, rec_base, summary);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

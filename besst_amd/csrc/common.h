@@ -58,8 +58,12 @@ struct BamColumns {
 };
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
                         uint32_t* status);
+// modes of a chunk's walk: the first start of the chunk is a guess nobody vouches for (the first chunk of a part of the
+// file whose entry is not known yet) / only the record in the tail slot counts (the blocks behind a part's end, inflated
+// for the bytes of the part's last record); summary: 12 words (bgzf_gpu.hip)
+constexpr uint32_t kWalkFirstGuessed = 1u, kWalkOverhang = 2u;
 int launch_bam_walk_scan(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, uint64_t chunk_end,
-                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, const uint32_t* status, uint16_t* offs,
+                         int32_t n_ref, uint32_t forced_block, uint32_t forced_entry, uint32_t mode, const uint32_t* status, uint16_t* offs,
                          uint32_t* count, uint32_t* exits, uint32_t* rec_base, uint32_t* guess, uint32_t* tail_at, uint32_t* summary);
 int launch_bam_decode(hipStream_t s, const uint8_t* inflated, const BgzfBlock* blocks, uint32_t n_blocks, const uint16_t* offs,
                       const uint32_t* count, const uint32_t* rec_base, const BamColumns& col, int64_t out_base,

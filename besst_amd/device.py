@@ -128,13 +128,16 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_push_records(self._ctx, n, *[_lib.ptr(c) for c in cols]), 'push_records')
 
     @_timed
-    def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0, part=None):
+    def push_bam(self, handle, chunk_records=0, head_records=1000, mode=None, chunk_blocks=0, part=None, first_skip=None):
         """Stream an open besst_bam (bamio) into the context.  mode 'device': BGZF inflate + record decode on the GPU, the
         compressed file crosses PCIe (besst_ctx_push_bam_device; any BGZF block layout); 'host': inflate + decode
         on the reader's host threads into pinned staging, copies under the next chunk's decode (besst_ctx_push_bam); 'auto' (default; BESST_INGEST overrides): the device form, and the host form when the library answers
         BESST_ERR_UNSUPPORTED (``stats.on_device`` tells which one ran).  part = (r, W): only the r-th of W parts of the
         file's records (cut at BGZF block boundaries; multi-GPU ingest: rank r's slice of the stream) - device form only, and
-        only for files in htslib's layout, where a block boundary is a record boundary (else BesstDeviceError, status 5).
+        only for files in htslib's layout, where a block boundary is a record boundary (else BesstDeviceError, status 5) -
+        unless first_skip is given: the SLICE form for any block layout (besst_ctx_push_bam_device_slice: -1 = guess where the
+        slice's first record begins, >= 0 = it begins that many inflated bytes in); ``self.slice_boundary`` then holds
+        (offset used, bytes of the slice's last record that lie in the next slice) for distributed.ingest_slice's check.
         -> (IngestStats, head rlen, head alen, head qlen)."""
         import os
         from ._lib import IngestStats
@@ -154,8 +157,17 @@ class GraphContext(object):
         else:
             r, w = 0, 1
         if mode in ('auto', 'device'):
-            rc = self._lib.besst_ctx_push_bam_device_part(self._ctx, handle, r, w, int(chunk_blocks), int(head_records),
-                                                          _lib.ptr(rlen), _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
+            if first_skip is not None:
+                if part is None:
+                    raise ValueError('push_bam: first_skip goes with part=(r, W)')
+                bound = np.zeros(2, dtype=np.int64)
+                rc = self._lib.besst_ctx_push_bam_device_slice(self._ctx, handle, r, w, int(chunk_blocks), int(first_skip),
+                                                               _lib.ptr(bound), int(head_records), _lib.ptr(rlen), _lib.ptr(alen),
+                                                               _lib.ptr(qlen), C.byref(stats))
+                self.slice_boundary = (int(bound[0]), int(bound[1]))
+            else:
+                rc = self._lib.besst_ctx_push_bam_device_part(self._ctx, handle, r, w, int(chunk_blocks), int(head_records),
+                                                              _lib.ptr(rlen), _lib.ptr(alen), _lib.ptr(qlen), C.byref(stats))
             if rc == 0:
                 done = True
             elif rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_NOMEM) or mode == 'device':

@@ -121,16 +121,94 @@ def device_records(wl, device):
     return rec
 
 
-def ingest_slice(path, rank, world, device_index=None, threads=None):
-    """Rank ``rank``'s slice of a BAM file for the sharded build: part (rank, world) of the file - cut at BGZF block
-    boundaries every rank finds on its own - is inflated and decoded on the rank's GPU (besst_ctx_push_bam_device_part), and the
-    resident columns are handed on where they lie (besst_ctx_record_pointers).  -> (bamio.ResidentBam, column dict for
+def _read_slice(bamio, path, dev, threads, rank, world, skip, chunk_blocks):
+    """One attempt at a slice.  A GUESSED first record start (skip < 0, rank > 0) that leads nowhere - the walk from it runs
+    into bytes that are no record - answers BESST_ERR_UNSUPPORTED: None, the caller reads again once the slice before it
+    has said where the slice begins."""
+    try:
+        return bamio.ResidentBam(path, device_index=dev, threads=threads, part=(rank, world), first_skip=skip,
+                                 chunk_blocks=chunk_blocks)
+    except _lib.BesstDeviceError as e:
+        if skip < 0 and rank > 0 and 'status %d' % _lib.ERR_UNSUPPORTED in str(e):
+            return None
+        raise
+
+
+def _first_wrong(pairs):
+    """The first slice whose offset is not what the slice before it reports (None: a guess that led nowhere); slice 0 begins
+    behind the header and is always right."""
+    for r in range(1, len(pairs)):
+        if pairs[r] is None or pairs[r - 1] is None or pairs[r][0] != pairs[r - 1][1]:
+            return r
+    return None
+
+
+def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None, chunk_blocks=0):
+    """Rank ``rank``'s slice of a BAM file for the sharded build: slice (rank, world) of the file - cut at BGZF block
+    boundaries every rank finds on its own - is inflated and decoded on the rank's GPU (besst_ctx_push_bam_device_slice), and
+    the resident columns are handed on where they lie (besst_ctx_record_pointers).  -> (bamio.ResidentBam, column dict for
     ``wl['cols']`` / pipeline.DeviceRecords.from_columns).  The ResidentBam owns the memory: keep it while the columns are
-    in use, close() it afterwards."""
+    in use, close() it afterwards.
+
+    Any block layout: a record belongs to the slice it begins in, and where a slice's first record begins is the one thing a
+    rank cannot know alone - it guesses, the ranks gather every slice's (offset used, bytes of the last record that lie in
+    the next slice), and a rank whose offset is not what the slice before it reports reads its slice again from there
+    (htslib's layout: all zeros, one round).  ``gather``: callable (rank's pair) -> list of all ranks' pairs; default
+    torch.distributed.all_gather_object when a process group of that size is up (a single rank needs none)."""
     from . import bamio
-    bam = bamio.ResidentBam(path, device_index=rank if device_index is None else device_index, threads=threads,
-                            part=(int(rank), int(world)))
-    return bam, bam.ctx.record_tensors()
+    dev = rank if device_index is None else device_index
+    if world == 1:
+        bam = bamio.ResidentBam(path, device_index=dev, threads=threads, chunk_blocks=chunk_blocks)
+        return bam, bam.ctx.record_tensors()
+    if gather is None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == world):
+            raise RuntimeError('ingest_slice: pass gather= or initialise a process group of %d ranks' % world)
+
+        def gather(pair):
+            out = [None] * world
+            dist.all_gather_object(out, pair)
+            return out
+    skip, bam, failed = -1, None, False
+    for _ in range(world + 1):
+        if bam is None and not failed:
+            bam = _read_slice(bamio, path, dev, threads, int(rank), int(world), skip, chunk_blocks)
+            failed = bam is None
+        pairs = gather(tuple(bam.boundary) if bam is not None else None)
+        # slices 0 .. k - 1 are right when each one's offset is what the slice before it reports; the first that is not -
+        # or whose guess led nowhere - reads its slice again from there (what IT reports may change with that, so the slices
+        # behind it are checked again in the next round: at most world - 1 rounds, one in htslib's layout); every rank sees
+        # the same pairs
+        wrong = _first_wrong(pairs)
+        if wrong is None:
+            return bam, bam.ctx.record_tensors()
+        if wrong == rank:
+            if bam is not None:
+                bam.close()
+            bam, skip, failed = None, pairs[rank - 1][1], False
+    raise RuntimeError('ingest_slice: the slices did not settle')
+
+
+def ingest_all_slices(path, world, device_index=0, threads=None, chunk_blocks=0):
+    """ingest_slice for every rank of ``world`` in ONE process (simulated ranks on one GPU; tests): the same protocol - guess,
+    compare every slice's offset with what the slice before reports, read the first wrong slice again - without a process
+    group.  -> list of (bamio.ResidentBam, column dict), rereads (how many slices were read twice)."""
+    from . import bamio
+
+    def read(r, skip):
+        return _read_slice(bamio, path, device_index, threads, r, world, skip, chunk_blocks)
+    bams = [read(r, -1) for r in range(world)]
+    rereads = 0
+    for _ in range(world + 1):
+        wrong = _first_wrong([b.boundary if b is not None else None for b in bams])
+        if wrong is None:
+            return [(b, b.ctx.record_tensors()) for b in bams], rereads
+        skip = bams[wrong - 1].boundary[1]
+        if bams[wrong] is not None:
+            bams[wrong].close()
+        bams[wrong] = read(wrong, skip)
+        rereads += 1
+    raise RuntimeError('ingest_all_slices: the slices did not settle')
 
 
 class HipBackend(object):

@@ -209,10 +209,25 @@ int besst_ctx_push_bam_device(besst_ctx* ctx, besst_bam* bam, int64_t chunk_bloc
  * cut at the BGZF block boundaries nearest to part / parts of its bytes; every caller finds the same boundaries on its own
  * (gzip magic + BC subfield + two chained blocks behind it).  The head_* arrays describe the part's first records.
  * parts > 1 needs htslib's layout, where every block boundary is a record boundary: BESST_ERR_UNSUPPORTED (context and
- * reader unchanged) for a file whose records straddle blocks - one rank reads such a file whole. */
+ * reader unchanged) for a file whose records straddle blocks - such files take besst_ctx_push_bam_device_slice. */
 int besst_ctx_push_bam_device_part(besst_ctx* ctx, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks,
                                    int64_t head_records, int32_t* head_rlen, int32_t* head_alen, uint16_t* head_qlen,
                                    besst_ingest_stats* stats);
+
+/* Slice `part` of `parts` of a file in ANY block layout (multi-GPU ingest of files whose records straddle BGZF blocks:
+ * htsjdk / Picard).  The slices are cut at block boundaries as above, and a record belongs to the slice it BEGINS in.  Where
+ * a slice's first record begins is the one thing a rank cannot know alone:
+ *   first_skip < 0   the rank guesses (the heuristics of the block-to-block verification; everything behind the guess is
+ *                    verified as usual);
+ *   first_skip >= 0  the first record begins that many inflated bytes behind the slice's first block's first byte.
+ * boundary[0] reports the offset used, boundary[1] how many bytes of the slice's last record lie in the next slice (they
+ * are read from the blocks that follow, at most 4 MiB).  The callers exchange the two numbers: slice r is right iff
+ * boundary[0] of slice r equals boundary[1] of slice r - 1 (slice 0 begins behind the header and is always right); a slice
+ * whose guess was wrong is read again - into a fresh context - with first_skip = boundary[1] of the slice before
+ * (besst_amd.distributed.ingest_slice runs this protocol).  In htslib's layout both numbers are 0. */
+int besst_ctx_push_bam_device_slice(besst_ctx* ctx, besst_bam* bam, int32_t part, int32_t parts, int64_t chunk_blocks,
+                                    int64_t first_skip, int64_t* boundary, int64_t head_records, int32_t* head_rlen,
+                                    int32_t* head_alen, uint16_t* head_qlen, besst_ingest_stats* stats);
 
 /* Test hook of the device inflate: the BGZF blocks of `bgzf` (n_bytes, host) inflated on `device`, their output
  * concatenated in out (capacity out_cap, length in *out_len).  BESST_ERR_UNSUPPORTED when a block does not inflate

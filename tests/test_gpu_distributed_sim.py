@@ -486,7 +486,7 @@ def test_empty_and_linkless_slices_in_the_middle(heads):
 
 @pytest.mark.parametrize('world', [3, 8])
 def test_simulated_ranks_ingest_their_part_of_a_bam_file(world, tmp_path):
-    """The whole multi-GPU path from the file: rank r ingests part (r, W) of the BAM on the GPU (besst_ctx_push_bam_device_part:
+    """The whole multi-GPU path from the file: rank r ingests slice (r, W) of the BAM on the GPU (besst_ctx_push_bam_device_slice:
     its slice of the stream, cut at BGZF block boundaries), the sharded build runs on the context's columns where they lie
     (besst_ctx_record_pointers, no copy), and the merged edge tables equal the single-process oracle's on the whole file."""
     import torch
@@ -497,9 +497,10 @@ def test_simulated_ranks_ingest_their_part_of_a_bam_file(world, tmp_path):
     dev = torch.device('cuda', 0)
     pair_cap = 16384
     backends, bams, total = [], [], 0
-    for r in range(world):
-        bam, cols = distributed.ingest_slice(path, r, world, device_index=0, threads=2)
-        assert bam.ingest.on_device == 1
+    slices, rereads = distributed.ingest_all_slices(path, world, device_index=0, threads=2)
+    assert rereads == 0                                      # (htslib's layout: every slice begins with its first block's first byte)
+    for r, (bam, cols) in enumerate(slices):
+        assert bam.ingest.on_device == 1 and bam.boundary == (0, 0)
         bams.append(bam)
         total += len(bam)
         sub = {k: v for k, v in wl.items() if k not in ('batch', 'cols', '_rec')}

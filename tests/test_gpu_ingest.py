@@ -297,9 +297,46 @@ def test_a_file_that_ends_inside_a_record_is_an_error():
         assert 'ends inside a record' in str(e.value)
 
 
+@pytest.mark.parametrize('block_bytes,world,decoys,chunk_blocks', [(5000, 2, False, 0), (5000, 5, False, 64), (700, 3, False, 64),
+                                                                   (90, 4, False, 0), (5000, 6, True, 64), (65280, 3, False, 64)])
+def test_slices_of_a_straddling_file_tile_its_records(block_bytes, world, decoys, chunk_blocks):
+    """Multi-GPU ingest of a file whose records straddle BGZF blocks: a record belongs to the slice it begins in; every rank
+    guesses where its slice's first record begins, the slices' (offset used, bytes of the last record in the next slice)
+    are compared and a slice whose guess was wrong is read again (distributed.ingest_all_slices: the protocol of
+    ingest_slice with simulated ranks).  The slices are contiguous pieces of the stream and together the whole of it; with
+    bytes in the qualities that pass for a record header some guesses ARE wrong."""
+    from besst_amd import distributed
+    batch = _library(6000)
+    if block_bytes == 65280:
+        batch.rlen[::50] = 9000                              # (records long enough to straddle 64 KiB blocks often)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=block_bytes, align_records=False, decoys=decoys)
+        slices, rereads = distributed.ingest_all_slices(path, world, device_index=0, threads=2, chunk_blocks=chunk_blocks)
+        try:
+            got = {c: [] for c in COLS}
+            for r, (bam, _) in enumerate(slices):
+                assert bam.ingest.on_device == 1
+                if r > 0:
+                    assert bam.boundary[0] == slices[r - 1][0].boundary[1]
+                cols = bam.ctx.fetch_records()
+                for c in COLS:
+                    got[c].append(cols[c])
+            assert slices[-1][0].boundary[1] == 0
+            assert any(b.boundary[0] > 0 for b, _ in slices[1:])          # (the layout does straddle)
+        finally:
+            for bam, _ in slices:
+                bam.close()
+    if decoys:
+        assert rereads > 0                                   # (the test tests something)
+    for c in COLS:
+        assert np.array_equal(np.concatenate(got[c]), getattr(batch, c)), c
+
+
 def test_a_part_of_a_straddling_file_is_refused():
-    """Multi-rank ingest cuts a file at BGZF block boundaries, which only htslib's layout allows: a part of a file whose
-    records straddle blocks answers BESST_ERR_UNSUPPORTED (context and reader untouched)."""
+    """The PART form (besst_ctx_push_bam_device_part) begins every part with its first block's first byte, which only
+    htslib's layout allows: a part of a file whose records straddle blocks answers BESST_ERR_UNSUPPORTED (context and reader
+    untouched) - such files take the slice form (test above)."""
     batch = _library(4000)
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, 'x.bam')

@@ -106,6 +106,53 @@ def test_two_processes_one_gpu(config, tail_mode, pair_cap, coverage):
         assert got[0][1] > 512                            # the regions really grew
 
 
+def _slice_worker(rank, port, path, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from besst_amd import distributed
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        torch.cuda.set_device(0)
+        bam, cols = distributed.ingest_slice(path, rank, WORLD, device_index=0, threads=2, chunk_blocks=64)
+        try:
+            rec = bam.ctx.fetch_records()
+            out.put((rank, tuple(bam.boundary), {k: np.asarray(v) for k, v in rec.items()}))
+        finally:
+            bam.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_ingest_slices_of_a_straddling_file(tmp_path):
+    """distributed.ingest_slice over a real process group: a BAM whose records straddle BGZF blocks and whose qualities hold
+    bytes that pass for a record header; the two ranks' slices - guessed, exchanged (all_gather_object), read again where the
+    guess was wrong - are contiguous pieces of the stream and together the whole of it."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from tests import bam_writer, test_gpu_ingest as T
+    batch = T._library(5000)
+    path = str(tmp_path / 'x.bam')
+    bam_writer.write_bam(path, batch, block_bytes=5000, align_records=False, decoys=True)
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slice_worker, args=(r, port, path, out)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted((out.get(timeout=300) for _ in range(WORLD)), key=lambda g: g[0])
+    for p in procs:
+        p.join(120)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert got[1][1][0] == got[0][1][1] and got[1][1][1] == 0
+    for c in T.COLS:
+        assert np.array_equal(np.concatenate([got[0][2][c], got[1][2][c]]), getattr(batch, c)), c
+
+
 def test_memory_budget_covers_what_a_rank_allocates():
     """distributed.memory_budget against the allocator: records + HipBackend of one rank of a two-rank build."""
     import torch
