@@ -974,7 +974,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         if (rc == BESST_OK && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, fb0, fe0, mode0) && stage(1) && sl[1].ck.n_blocks)
             enqueue_inflate(1);
     }
-    int64_t first_at = -1, carry_out = 0;                    // (the slice form's answers)
+    int64_t first_at = -1, carry_out = 0, over_bytes = 0;    // (the slice form's answers)
     bool overhang = false;                                   // the chunk at hand holds the blocks behind the part's end
     for (int64_t j = 0; rc == BESST_OK && sl[j % kSlots].ck.n_blocks; ++j) {
         Slot& q = sl[j % kSlots];
@@ -1020,13 +1020,16 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
                 break;
             }
         }
-        if (overhang) carry_out = (int64_t)sm[8];            // bytes of the slice's last record that lie in the next slice
+        if (overhang) {                                      // bytes of the slice's last record that lie in the next slice
+            if (tail_len) over_bytes += (int64_t)q.ck.inflated;              // (all of this chunk, and the record goes on)
+            else carry_out = over_bytes + (int64_t)sm[8];
+        }
         if (nx.ck.n_blocks) {
             // chunk j + 1's records can be located now: it starts with chunk j's unfinished record, if there is one
             if (!enqueue_walk((int)((j + 1) % kSlots), (uint64_t)sm[5] | ((uint64_t)sm[6] << 32), tail_len, 1u, 0u, 0u)) break;
-        } else if (tail_len && slice && !overhang && map_len < whole_file) {
+        } else if (tail_len && slice && (overhang ? fpos < whole_file : map_len < whole_file)) {
             // the slice's last record runs on behind the slice's end: the blocks that follow are inflated for its bytes (and for
-            // nothing else: the records that begin in them are the next slice's)
+            // nothing else: the records that begin in them are the next slice's) - chunk after chunk until the record ends
             overhang = true;
             map_len = whole_file;
             max_blocks = nb < 4096 ? nb : 4096;

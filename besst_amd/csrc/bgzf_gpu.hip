@@ -863,8 +863,9 @@ __global__ __launch_bounds__(kScanThreads) void bam_scan_kernel(const uint8_t* _
             const uint32_t ex = exits[b], g = guess[b];
             const unsigned long long here = (unsigned long long)b << 32;
             if (blocks[b].dst_len != 0u && status[b] != kInfOk) { atomicMin(&s_bad, here | kVerdictBad); continue; }
-            if (mode & kWalkOverhang) {                      // only the tail slot's record: it must end inside the chunk
-                if (b == 0u && (ex == kExitBad || ex == kExitNone || ex == kExitTail)) atomicMin(&s_bad, here | kVerdictBad);
+            if (mode & kWalkOverhang) {                      // only the tail slot's record (unfinished still: the tail again)
+                if (b == 0u && (ex == kExitBad || ex == kExitNone)) atomicMin(&s_bad, here | kVerdictBad);
+                if (b == 0u && ex == kExitTail) atomicMin(&s_tail, 0u);
                 continue;
             }
             if (b > 0u && b != forced_block && g != kNoStart && g != 0u) s_straddle = 1u;

@@ -229,6 +229,22 @@ def test_random_block_layouts():
                 _check_against_host(path, bam, host)
             finally:
                 bam.close()
+            # the same file in slices (multi-rank ingest): contiguous pieces of the stream, together the whole of it
+            from besst_amd import distributed
+            world = int(rng.integers(2, 5))
+            try:
+                slices, _ = distributed.ingest_all_slices(path, world, device_index=0, threads=2, chunk_blocks=int(rng.choice([0, 64])))
+            except _lib.BesstDeviceError as e:              # (a slice that one long read covers whole)
+                assert 'no record begins' in str(e) or 'behind its first chunk' in str(e), (seed, str(e))
+                slices = None
+            if slices is not None:
+                try:
+                    for col in COLS:
+                        parts = [b.ctx.fetch_records()[col] for b, _ in slices]
+                        assert np.array_equal(np.concatenate(parts), getattr(host, col)), (seed, world, col)
+                finally:
+                    for b, _ in slices:
+                        b.close()
         for col in COLS:
             assert np.array_equal(getattr(host, col), getattr(batch, col)), (seed, col)
 
