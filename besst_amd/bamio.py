@@ -42,7 +42,7 @@ class ResidentBam(object):
     """A BAM file whose records went straight to HBM - besst_ctx_push_bam_device: the compressed file is uploaded and
     inflated + decoded on the GPU (any BGZF block layout); else besst_ctx_push_bam: decode on host threads, pinned
     staging, copies under the next chunk's decode; ``mode`` as in GraphContext.push_bam - the `bam_file` argument for libmetrics.get_metrics and CreateGraph.PE when nothing
-    on the host needs the record columns; ``part=(r, W)``: rank r's slice of the stream (multi-GPU ingest: ``len()`` and the
+    on the host needs the record columns; ``part=(r, W)``: rank r's slice of the stream (htslib's layout; with ``first_skip`` - -1: guess, >= 0: inflated bytes in front of the slice's first record - the SLICE form for any block layout, ``boundary`` = (offset used, bytes of the last record in the next slice): distributed.ingest_slice runs the check between ranks; multi-GPU ingest: ``len()`` and the
     head arrays then describe that slice only - such an object is for distributed.ingest_slice, not for
     libmetrics.get_metrics, whose < 1000-record check and read-length step are about the whole file).  It carries what the host side of those two does read: the header
     (``references``, ``lengths``), the record count (``len()``) and ``rlen`` / ``alen`` / ``qlen`` of the first 1000
