@@ -800,9 +800,9 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         if (summ_host) (void)hipHostFree(summ_host);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
-    // A slot is allocated when the first chunk that uses it is about to be read: slots 1 and 2 (pinning 2 x 170 MB takes
-    // longer than reading a chunk) come into being while chunk 0 uploads and inflates, and a file of one chunk never pays
-    // for them.
+    // All three slots before anything is queued.  (Allocating slots 1 and 2 while chunk 0 was already inflating - to hide
+    // their cost - made every later chunk slower: 0.88 instead of 0.74 s for 200 M records on the same box; buffers and
+    // streams that come into being beside a busy queue do not end up where the ones made up front do.)
     double alloc_s = 0.0;
     auto alloc_slot = [&](int k) -> bool {
         Slot& q = sl[k];
@@ -820,7 +820,8 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return got;
     };
-    bool ok = alloc_slot(0);
+    bool ok = true;
+    for (int k = 0; k < kSlots; ++k) ok = ok && alloc_slot(k);
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
          hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
