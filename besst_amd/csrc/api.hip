@@ -803,6 +803,15 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     // All three slots before anything is queued.  (Allocating slots 1 and 2 while chunk 0 was already inflating - to hide
     // their cost - made every later chunk slower: 0.88 instead of 0.74 s for 200 M records on the same box; buffers and
     // streams that come into being beside a busy queue do not end up where the ones made up front do.)
+    // The three slots' streams and the copy stream must run beside each other.  The runtime spreads a process's streams
+    // over a handful of hardware queues PER PRIORITY LEVEL, in creation order, together with every other stream of the
+    // process (the context's, the caller's: torch's): two of ours on one queue and chunk j's walk / scan / decode wait
+    // behind chunk j + 1's whole inflate - 1.83 instead of 1.40 s for full-size C3 in a process that had made other
+    // streams before, 1.40 in one that had not.  So the slots' streams are created at the LOWEST priority, a level nobody
+    // else in the process uses (its queues are theirs alone; nothing else runs during an ingest for them to yield to), and
+    // the copy stream at the highest.
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     double alloc_s = 0.0;
     auto alloc_slot = [&](int k) -> bool {
         Slot& q = sl[k];
@@ -812,7 +821,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
              hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
              hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
              hipMalloc((void**)&q.words, (nbw * 6 + 12) * sizeof(uint32_t)) == hipSuccess &&
-             hipStreamCreateWithFlags(&q.work, hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithPriority(&q.work, hipStreamNonBlocking, prio_low) == hipSuccess &&
              hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess &&
@@ -825,7 +834,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
          hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
-         hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) == hipSuccess;
+         hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high) == hipSuccess;
     if (!ok) {
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
