@@ -393,6 +393,9 @@ class DeviceMetricsSampler(object):
         return self.samples, self.state
 
 
+_POOL_STREAMS = {}
+
+
 class PassPool(object):
     """Independent graph-build passes in flight on separate HIP streams (one builder and workspace per slot).
 
@@ -414,7 +417,14 @@ class PassPool(object):
         except Exception:                                    # (older torch: no priority_range)
             levels = [0]
         n = max(1, int(in_flight))
-        self.streams = [torch.cuda.Stream(device, priority=levels[k % len(levels)]) for k in range(n)]
+        # (and the streams are the PROCESS's, made once per device and position: a second pool - another library, another
+        # config - that made three more would shift everybody's queues again)
+        self.streams = []
+        for k in range(n):
+            key = (str(device), k)
+            if key not in _POOL_STREAMS:
+                _POOL_STREAMS[key] = torch.cuda.Stream(device, priority=levels[k % len(levels)])
+            self.streams.append(_POOL_STREAMS[key])
         self.builders = []
         for st in self.streams:
             with torch.cuda.stream(st):
