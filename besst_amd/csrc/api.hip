@@ -800,9 +800,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         if (summ_host) (void)hipHostFree(summ_host);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
     };
-    // All three slots before anything is queued.  (Allocating slots 1 and 2 while chunk 0 was already inflating - to hide
-    // their cost - made every later chunk slower: 0.88 instead of 0.74 s for 200 M records on the same box; buffers and
-    // streams that come into being beside a busy queue do not end up where the ones made up front do.)
+    // All three slots, and their streams, before anything is queued.
     // The three slots' streams and the copy stream must run beside each other.  The runtime spreads a process's streams
     // over a handful of hardware queues PER PRIORITY LEVEL, in creation order, together with every other stream of the
     // process (the context's, the caller's: torch's): two of ours on one queue and chunk j's walk / scan / decode wait
@@ -1136,7 +1134,14 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         stats->on_device = 1;
         stats->starts_repaired = (int32_t)(repaired > 0x7fffffff ? 0x7fffffff : repaired);
     }
-    if (boundary) { boundary[0] = first_at; boundary[1] = carry_out; }
+    if (boundary) {
+        if (chunks == 0 && first_at < 0) {                   // a slice without a block (more ranks than blocks): what comes in goes out
+            first_at = first_skip > 0 ? first_skip : 0;
+            carry_out = first_at;
+        }
+        boundary[0] = first_at;
+        boundary[1] = carry_out;
+    }
     return BESST_OK;
 }
 }  // namespace

@@ -537,6 +537,18 @@ def test_parts_of_a_small_file_and_a_false_block_header():
             assert sum(counts) == len(recs), (parts, counts)
             for c in COLS:
                 assert np.array_equal(whole[c], getattr(host, c)), (parts, c)
+        # the slice form on the same file: slices without a block pass on what the slice before them reports
+        from besst_amd import distributed
+        for world in (3, 64):
+            slices, rereads = distributed.ingest_all_slices(path, world, device_index=0, threads=2)
+            try:
+                assert rereads == 0 and sum(len(b) for b, _ in slices) == len(recs)
+                for c in COLS:
+                    got = np.concatenate([b.ctx.fetch_records()[c] for b, _ in slices if len(b)])
+                    assert np.array_equal(got, getattr(host, c)), (world, c)
+            finally:
+                for b, _ in slices:
+                    b.close()
 
 
 def test_endless_empty_blocks_end_at_the_payload():
