@@ -50,10 +50,26 @@ def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaf
 
 
 def _PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file):
+    """One GPU: the whole of PE.  Under a process group (besst_amd.sharded): rank 0 leads - it runs PE's host side and
+    returns the graphs -, every other rank follows rank 0 through the collective stages and returns empty graphs."""
+    sess = session.open_session(bam_file)
+    if sess.is_follower:
+        sess.follow(param)
+        return (Graph(), Graph())
+    try:
+        out = _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds)
+    except BaseException as exc:
+        if not getattr(exc, 'on_every_rank', False):          # (a failed collective stage has been raised on all ranks already)
+            sess.abort(exc)
+        raise
+    sess.done(param)
+    return out
+
+
+def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds):
     G = Graph()
     G_prime = Graph()
     print('Parsing BAM file...', file=Information)
-    sess = session.open_session(bam_file)
     batch = sess.batch
 
     if param.first_lib:

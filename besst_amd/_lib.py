@@ -16,7 +16,12 @@ LIB_PATH = os.environ.get('BESST_AMD_LIB') or os.path.join(_HERE, 'libbesst_amd.
 
 
 class BesstDeviceError(RuntimeError):
-    pass
+    """``status``: the library's return code (include/besst_amd.h, BESST_ERR_*) when the error comes from a C-ABI call, else
+    None."""
+
+    def __init__(self, message, status=None):
+        RuntimeError.__init__(self, message)
+        self.status = status
 
 
 ERR_UNSUPPORTED = 5     # include/besst_amd.h: BESST_ERR_UNSUPPORTED
@@ -218,7 +223,7 @@ def last_error():
 
 def check(status, what):
     if status != 0:
-        raise BesstDeviceError('%s failed (status %d): %s' % (what, status, last_error()))
+        raise BesstDeviceError('%s failed (status %d): %s' % (what, status, last_error()), status=int(status))
 
 
 def ptr(arr):

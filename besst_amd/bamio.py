@@ -83,6 +83,50 @@ class ResidentBam(object):
         self.ctx.close()
 
 
+class ShardedBam(object):
+    """The `bam_file` argument of libmetrics.get_metrics / CreateGraph.PE under a process group (one process per GPU):
+    this rank's slice of the file, inflated and decoded on its GPU (distributed.ingest_slice: any BGZF block layout, the
+    ranks settle where each slice's first record begins), plus what the host side reads of the whole file - header,
+    global record count, rlen / alen / qlen of the stream's first 1000 records (sharded.ShardedHead).  ``ingest``: the
+    slice's timings."""
+
+    def __init__(self, path, group=None, device_index=None, threads=None, chunk_blocks=0):
+        import torch
+        import torch.distributed as dist
+        from . import distributed, pipeline, sharded
+        self.path, self.group = path, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.cuda.current_device() if device_index is None else int(device_index)
+        self.slice, cols = distributed.ingest_slice(path, self.rank, self.world, device_index=dev, threads=threads,
+                                                    chunk_blocks=chunk_blocks, group=group)
+        self.ingest = self.slice.ingest
+        self.references, self.lengths = self.slice.references, self.slice.lengths
+        device = torch.device('cuda', dev)
+        rec = pipeline.DeviceRecords.from_columns(cols)
+        self.engine = sharded.HipRankEngine(device, rec, len(self.references), keep=self.slice)
+        self.head = sharded.ShardedHead(self.references, self.lengths, len(self.slice),
+                                        (self.slice.rlen, self.slice.alen, self.slice.qlen), group, self.world)
+        self.rlen, self.alen, self.qlen = self.head.rlen, self.head.alen, self.head.qlen
+
+    def __len__(self):
+        return len(self.head)
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+def open_bam(path, threads=None, **kw):
+    """What a caller of the two entry points opens in place of ``pysam.Samfile(path, 'rb')`` (runBESST:162): a ResidentBam,
+    or - when torch.distributed is up with more than one rank (torchrun, one process per GPU) - this rank's ShardedBam."""
+    from . import sharded
+    if sharded.active_group() is not None:
+        return ShardedBam(path, group=sharded.PROCESS_GROUP, threads=threads,
+                          **{k: v for k, v in kw.items() if k in ('device_index', 'chunk_blocks')})
+    return ResidentBam(path, threads=threads, **kw)
+
+
 def inflate_bgzf_device(data, device_index=0, out_cap=None):
     """Test hook: the BGZF blocks of ``data`` (bytes) inflated by the GPU kernel, concatenated."""
     import ctypes as C

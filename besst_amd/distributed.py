@@ -108,6 +108,22 @@ def memory_budget(n_records, n_contigs, world, pair_capacity, tuple_capacity=Non
             'received_capacity': recv_cap}
 
 
+class BuildInputs(object):
+    """What one rank's graph build works on: the record columns of its slice in HBM (pipeline.DeviceRecords), the contig
+    table columns (CreateGraph.contig_table: the same on every rank), the library constants of the record loop and the
+    node width of the edge keys.  ``of()`` also takes a bench / test workload dict (workload.make)."""
+    __slots__ = ('rec', 'n_contigs', 'node_bits', 'lib', 'table')
+
+    def __init__(self, rec, n_contigs, node_bits, lib, table):
+        self.rec, self.n_contigs, self.node_bits, self.lib, self.table = rec, int(n_contigs), int(node_bits), lib, table
+
+    @classmethod
+    def of(cls, src, device):
+        if isinstance(src, cls):
+            return src
+        return cls(device_records(src, device), src['asm'].nc, src['node_bits'], src['lib'], src['table'])
+
+
 def device_records(wl, device):
     """The workload's record columns in HBM, uploaded (or adopted, when they were generated on the GPU) once."""
     from . import pipeline
@@ -121,6 +137,15 @@ def device_records(wl, device):
     return rec
 
 
+class SliceIngestError(_lib.BesstDeviceError):
+    """A slice of the file could not be read on some rank; raised on EVERY rank in the same round of ingest_slice's check
+    (``rank``: the first rank that failed, ``status``: its library status or None)."""
+
+    def __init__(self, rank, status, text):
+        _lib.BesstDeviceError.__init__(self, 'ingest_slice: rank %d: %s' % (rank, text), status=status)
+        self.rank = rank
+
+
 def _read_slice(bamio, path, dev, threads, rank, world, skip, chunk_blocks):
     """One attempt at a slice.  A GUESSED first record start (skip < 0, rank > 0) that leads nowhere - the walk from it runs
     into bytes that are no record - answers BESST_ERR_UNSUPPORTED: None, the caller reads again once the slice before it
@@ -129,7 +154,7 @@ def _read_slice(bamio, path, dev, threads, rank, world, skip, chunk_blocks):
         return bamio.ResidentBam(path, device_index=dev, threads=threads, part=(rank, world), first_skip=skip,
                                  chunk_blocks=chunk_blocks)
     except _lib.BesstDeviceError as e:
-        if skip < 0 and rank > 0 and 'status %d' % _lib.ERR_UNSUPPORTED in str(e):
+        if skip < 0 and rank > 0 and e.status == _lib.ERR_UNSUPPORTED:
             return None
         raise
 
@@ -143,7 +168,14 @@ def _first_wrong(pairs):
     return None
 
 
-def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None, chunk_blocks=0):
+def _first_error(pairs):
+    for r, p in enumerate(pairs):
+        if isinstance(p, tuple) and len(p) == 3 and p[0] == 'error':
+            return r, p[1], p[2]
+    return None
+
+
+def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None, chunk_blocks=0, group=None):
     """Rank ``rank``'s slice of a BAM file for the sharded build: slice (rank, world) of the file - cut at BGZF block
     boundaries every rank finds on its own - is inflated and decoded on the rank's GPU (besst_ctx_push_bam_device_slice), and
     the resident columns are handed on where they lie (besst_ctx_record_pointers).  -> (bamio.ResidentBam, column dict for
@@ -154,7 +186,11 @@ def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None
     rank cannot know alone - it guesses, the ranks gather every slice's (offset used, bytes of the last record that lie in
     the next slice), and a rank whose offset is not what the slice before it reports reads its slice again from there
     (htslib's layout: all zeros, one round).  ``gather``: callable (rank's pair) -> list of all ranks' pairs; default
-    torch.distributed.all_gather_object when a process group of that size is up (a single rank needs none)."""
+    torch.distributed.all_gather_object over ``group`` when a process group of that size is up (a single rank needs none).
+
+    A rank whose read fails for any other reason (rank 0, out of memory, a CRC / inflate failure, a re-read that still leads
+    nowhere) gathers ('error', status, text) in place of its pair: every rank sees it in the same round and raises
+    SliceIngestError together - nobody is left waiting in a collective."""
     from . import bamio
     dev = rank if device_index is None else device_index
     if world == 1:
@@ -162,19 +198,27 @@ def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None
         return bam, bam.ctx.record_tensors()
     if gather is None:
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == world):
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) == world):
             raise RuntimeError('ingest_slice: pass gather= or initialise a process group of %d ranks' % world)
 
         def gather(pair):
             out = [None] * world
-            dist.all_gather_object(out, pair)
+            dist.all_gather_object(out, pair, group=group)
             return out
-    skip, bam, failed = -1, None, False
+    skip, bam, failed, error = -1, None, False, None
     for _ in range(world + 1):
-        if bam is None and not failed:
-            bam = _read_slice(bamio, path, dev, threads, int(rank), int(world), skip, chunk_blocks)
-            failed = bam is None
-        pairs = gather(tuple(bam.boundary) if bam is not None else None)
+        if bam is None and not failed and error is None:
+            try:
+                bam = _read_slice(bamio, path, dev, threads, int(rank), int(world), skip, chunk_blocks)
+                failed = bam is None
+            except Exception as e:                           # whatever it is, the other ranks have to hear of it
+                error = ('error', getattr(e, 'status', None), '%s: %s' % (type(e).__name__, e))
+        pairs = gather(error if error is not None else (tuple(bam.boundary) if bam is not None else None))
+        bad = _first_error(pairs)
+        if bad is not None:
+            if bam is not None:
+                bam.close()
+            raise SliceIngestError(*bad)
         # slices 0 .. k - 1 are right when each one's offset is what the slice before it reports; the first that is not -
         # or whose guess led nowhere - reads its slice again from there (what IT reports may change with that, so the slices
         # behind it are checked again in the next round: at most world - 1 rounds, one in htslib's layout); every rank sees
@@ -186,7 +230,9 @@ def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None
             if bam is not None:
                 bam.close()
             bam, skip, failed = None, pairs[rank - 1][1], False
-    raise RuntimeError('ingest_slice: the slices did not settle')
+    if bam is not None:
+        bam.close()
+    raise SliceIngestError(-1, None, 'the slices did not settle')
 
 
 def ingest_all_slices(path, world, device_index=0, threads=None, chunk_blocks=0):
@@ -214,19 +260,19 @@ def ingest_all_slices(path, world, device_index=0, threads=None, chunk_blocks=0)
 class HipBackend(object):
     """Kernel stages of one rank on its GPU."""
 
-    def __init__(self, device, wl, rank, world, pair_capacity, tuple_capacity=None):
+    def __init__(self, device, inputs, rank, world, pair_capacity, tuple_capacity=None):
+        """inputs: BuildInputs (or a workload dict, BuildInputs.of)."""
         from . import pipeline
         self.pipeline = pipeline
         self.lib = _lib.load()
         self.device = device
         self.rank, self.world = rank, world
-        self.wl = wl
-        self.rec = device_records(wl, device)
+        self.inputs = inp = BuildInputs.of(inputs, device)
+        self.rec = inp.rec
         self.pair_cap = int(pair_capacity + (pair_capacity & 1))
         self.recv_cap = self.pair_cap * world
-        self.gb = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], self.rec.n,
-                                              self.recv_cap)
-        self.gb.set_contigs(**wl['table'])
+        self.gb = pipeline.DeviceGraphBuilder(device, inp.n_contigs, inp.node_bits, inp.lib, self.rec.n, self.recv_cap)
+        self.gb.set_contigs(**inp.table)
         # coverage numerators and the 8 summable counter words are adjacent in the builder's state block, so ONE
         # in-place all-reduce sums both
         self._sum_buf = self.gb.state[:self.gb.n_contigs + 8]
@@ -393,13 +439,15 @@ class HipBackend(object):
 class ShardedGraphBuild(object):
     """Orchestrates one sharded graph-build step; ``backend`` supplies the per-rank kernel stages."""
 
-    def __init__(self, device, wl, rank, world, backend=None, group=None, pair_capacity=None):
+    def __init__(self, device, inputs, rank, world, backend=None, group=None, pair_capacity=None):
+        """inputs: BuildInputs or a workload dict (unused when a backend is handed in)."""
         self.rank, self.world, self.group = rank, world, group
         if backend is None:
+            inputs = BuildInputs.of(inputs, device)
             tuple_capacity = None
             if pair_capacity is None:
-                pair_capacity, tuple_capacity = self._probe_pair_capacity(device, wl, world, group)
-            backend = HipBackend(device, wl, rank, world, pair_capacity, tuple_capacity)
+                pair_capacity, tuple_capacity = self._probe_pair_capacity(device, inputs, world, group)
+            backend = HipBackend(device, inputs, rank, world, pair_capacity, tuple_capacity)
         self.backend = backend
         self._tails = None
         # How a slice learns the duplicate chain's state at its first record (see step()): 'exchange' (default) - it does
@@ -420,15 +468,21 @@ class ShardedGraphBuild(object):
         self.side_group = dist.new_group() if want_side else group
 
     @staticmethod
-    def _probe_pair_capacity(device, wl, world, group=None):
-        """One untimed local pass to size the exchange regions (tuples per (src,dst) pair, 1.5x slack)."""
+    def probe_tuples(device, inputs):
+        """Tuples the slice emits: one untimed local pass of the record loop, no collective."""
         from . import pipeline
-        rec = device_records(wl, device)
-        probe = pipeline.DeviceGraphBuilder(device, wl['asm'].nc, wl['node_bits'], wl['lib'], rec.n, 1)
-        probe.set_contigs(**wl['table'])
+        inp = BuildInputs.of(inputs, device)
+        probe = pipeline.DeviceGraphBuilder(device, inp.n_contigs, inp.node_bits, inp.lib, inp.rec.n, 1)
+        probe.set_contigs(**inp.table)
         probe.reset()
-        probe.classify(rec)
+        probe.classify(inp.rec)
         n_out, _ = probe.read_sizes()
+        return int(n_out)
+
+    @staticmethod
+    def _probe_pair_capacity(device, inputs, world, group=None):
+        """Size the exchange regions (tuples per (src,dst) pair, 1.5x slack) from the probe pass, the largest over ranks."""
+        n_out = ShardedGraphBuild.probe_tuples(device, inputs)
         cap = torch.tensor([int(n_out * 1.5 / world) + 4096], dtype=torch.int64, device=device)
         if dist.is_initialized():
             _all_reduce(cap, group, op=dist.ReduceOp.MAX)        # (the build's own group: a group of one must not wait for the world)
@@ -499,9 +553,9 @@ class ShardedGraphBuild(object):
             if not grow or not isinstance(self.backend, HipBackend):
                 raise _lib.BesstDeviceError('exchange region overflow: raise pair_capacity')
             old = self.backend
-            wl = dict(old.wl)
-            self.backend = HipBackend(old.device, wl, self.rank, self.world, old.pair_cap * 2, old.part_cap)
-            del old
+            args = (old.device, old.inputs, self.rank, self.world, old.pair_cap * 2, old.part_cap)
+            self.backend = old = None                        # (free the old regions before the doubled ones are made)
+            self.backend = HipBackend(*args)
             self._tails = None
             self._recv = None
             self.step()

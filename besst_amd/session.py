@@ -17,6 +17,8 @@ _sessions_by_id = {}
 
 
 class Session(object):
+    is_follower = False                     # (sharded.ShardedSession: every rank but 0 follows rank 0 through CreateGraph.PE)
+
     def __init__(self, batch, device_index=0):
         self.batch = batch
         self.ctx = device.GraphContext(device_index)
@@ -37,6 +39,13 @@ class Session(object):
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize):
         return self.ctx.metrics_sample(top_mask, orientation, min_mapq, read_len, want_isize)
 
+    # CreateGraph.PE's epilogue: nothing to tell anybody on one GPU
+    def done(self, param):
+        pass
+
+    def abort(self, exc):
+        pass
+
     def close(self):
         self.ctx.close()
 
@@ -53,8 +62,15 @@ def open_session(bam_file, device_index=0):
             sess = entry[1]
     if sess is not None:
         return sess
-    if hasattr(bam_file, 'ingest') and hasattr(bam_file, 'ctx'):          # bamio.ResidentBam
+    from . import sharded
+    if hasattr(bam_file, 'engine') and hasattr(bam_file, 'head'):         # bamio.ShardedBam: this rank's slice is in HBM
+        sess = sharded.session_for_bam(bam_file)
+    elif hasattr(bam_file, 'ingest') and hasattr(bam_file, 'ctx'):        # bamio.ResidentBam
         sess = Session.resident(bam_file)
+    elif sharded.active_group() is not None:
+        # a stream every rank holds, under a process group: rank r works on the r-th contiguous slice of it
+        rank, world = sharded.active_group()
+        sess = sharded.session_for_batch(RecordBatch.from_pysam_like(bam_file), rank, world, sharded.PROCESS_GROUP)
     else:
         sess = Session(RecordBatch.from_pysam_like(bam_file), device_index)
     try:

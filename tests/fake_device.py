@@ -61,33 +61,90 @@ class FakeGraphContext(object):
         return table, aligned, ctr
 
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
-        r = self.rows
-        m = len(rows)
-        gap = np.zeros(m)
-        sd0 = np.zeros(m)
-        ks = np.zeros(m, np.int32)
-        flags = np.zeros(m, np.uint8)
-        for j in range(m):
-            i = int(rows[j])
-            n = int(r['n'][i])
-            lo, hi = int(r['offset'][i]), int(r['offset'][i]) + n
-            a = r['obs_hi'][lo:hi] if swap[j] else r['obs_lo'][lo:hi]
-            b = r['obs_lo'][lo:hi] if swap[j] else r['obs_hi'][lo:hi]
-            obs = int(r['sum_obs'][i])
-            mean_ = obs / float(n)
-            l1, l2 = int(len1[j]), int(len2[j])
-            long_enough = 2 * sigma < l1 and 2 * sigma < l2
-            g = O.gap_estimator(mean, sigma, read_len, mean_, l1, l2) if long_enough else (n * mean - obs) / float(n)
-            gap[j] = g
-            flags[j] = (1 if long_enough else 0) | (2 if (-g > l1 or -g > l2) else 0)
-            sd0[j] = O.tr_sk_std_dev(mean, sigma, read_len, l1, l2, g) if long_enough else 2.0 ** 32
-            s1 = sorted(int(x) for x in a)
-            m1 = sum(s1) / float(n)
-            mx = int(max(b))
-            s2 = sorted(mx - int(x) for x in b)
-            m2 = sum(s2) / float(n)
-            ks[j] = O.ks_h([x - m1 for x in s1], [x - m2 for x in s2])
-        return gap, sd0, ks, flags
+        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len)
+
+
+def score_rows(r, rows, swap, len1, len2, mean, sigma, read_len):
+    """GiveScoreOnEdges' per-edge numbers (CreateGraph.py:498-614) from the oracle, for rows of an edge-row dict
+    (c_oracle.edge_rows layout)."""
+    m = len(rows)
+    gap = np.zeros(m)
+    sd0 = np.zeros(m)
+    ks = np.zeros(m, np.int32)
+    flags = np.zeros(m, np.uint8)
+    for j in range(m):
+        i = int(rows[j])
+        n = int(r['n'][i])
+        lo, hi = int(r['offset'][i]), int(r['offset'][i]) + n
+        a = r['obs_hi'][lo:hi] if swap[j] else r['obs_lo'][lo:hi]
+        b = r['obs_lo'][lo:hi] if swap[j] else r['obs_hi'][lo:hi]
+        obs = int(r['sum_obs'][i])
+        mean_ = obs / float(n)
+        l1, l2 = int(len1[j]), int(len2[j])
+        long_enough = 2 * sigma < l1 and 2 * sigma < l2
+        g = O.gap_estimator(mean, sigma, read_len, mean_, l1, l2) if long_enough else (n * mean - obs) / float(n)
+        gap[j] = g
+        flags[j] = (1 if long_enough else 0) | (2 if (-g > l1 or -g > l2) else 0)
+        sd0[j] = O.tr_sk_std_dev(mean, sigma, read_len, l1, l2, g) if long_enough else 2.0 ** 32
+        s1 = sorted(int(x) for x in a)
+        m1 = sum(s1) / float(n)
+        mx = int(max(b))
+        s2 = sorted(mx - int(x) for x in b)
+        m2 = sum(s2) / float(n)
+        ks[j] = O.ks_h([x - m1 for x in s1], [x - m2 for x in s2])
+    return gap, sd0, ks, flags
+
+
+class OracleRankEngine(object):
+    """Stand-in for besst_amd.sharded.HipRankEngine: one rank's kernel stages answered by the oracle on CPU tensors, so
+    that the sharded drop-in (besst_amd.sharded: leader / followers, the collective build and score stages) runs under gloo
+    without a GPU.  Injected by `sharded.RankEngine = OracleRankEngine` inside the test processes."""
+
+    def __init__(self, part, n_contigs):
+        self.part, self.n_contigs = part, n_contigs
+
+    @classmethod
+    def from_batch(cls, part, n_contigs):
+        return cls(part, n_contigs)
+
+    def metrics_backend(self, top_mask):
+        from tests import dist_util as DU
+        return DU.OracleMetricsBackend(self.part, top_mask)
+
+    def probe_tuples(self, table, lib, node_bits):
+        from tests import dist_util as DU
+        self.table, self.lib, self.node_bits = table, lib, node_bits
+        res = O.LoopResult(len(table['cls']))
+        res.tuples = []
+        O.record_loop(DU.rec_lists(self.part), DU.table_lists(table), DU.oracle_params(lib), res=res)
+        return len(res.tuples)
+
+    def make_job(self, rank, world, group, pair_capacity, tuple_capacity):
+        import torch
+        from besst_amd import distributed
+        from tests import dist_util as DU
+        backend = DU.OracleBackend(self.part, self.table, self.lib, self.node_bits, rank, world, pair_capacity)
+        return distributed.ShardedGraphBuild(torch.device('cpu'), None, rank, world, backend=backend, group=group)
+
+    def local_table(self, job):
+        rows = job.backend.rows
+        keys = sorted(rows)
+        n = np.array([rows[k]['n'] for k in keys], dtype=np.uint32)
+        off = (np.cumsum(n.astype(np.int64)) - n).astype(np.uint32)
+        lo = np.array([x for k in keys for x in (rows[k]['lo'] if not k & 1 else [0] * rows[k]['n'])], dtype=np.int32)
+        hi = np.array([x for k in keys for x in (rows[k]['hi'] if not k & 1 else [0] * rows[k]['n'])], dtype=np.int32)
+        self.rows = dict(n=n, offset=off, obs_lo=lo, obs_hi=hi,
+                         sum_obs=np.array([rows[k]['s'] if not k & 1 else 0 for k in keys], dtype=np.int64))
+        return device.EdgeTable(np.array(keys, dtype=np.uint64), np.array([rows[k]['mask'] for k in keys], dtype=np.uint32), n,
+                                self.rows['sum_obs'],
+                                np.array([rows[k]['s2'] if not k & 1 else 0 for k in keys], dtype=np.int64),
+                                np.array([rows[k]['first'] for k in keys], dtype=np.uint32), off, self.node_bits, lo, hi)
+
+    def score(self, job, rows, swap, len1, len2, mean, sigma, read_len):
+        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len)
+
+    def close(self):
+        pass
 
 
 def fake_chain_arrays(n_scaffolds, link, gap, scaffold_length, node_order, device=0):

@@ -1,0 +1,142 @@
+"""The sharded drop-in on the real kernels: W processes, one process group (gloo: RCCL refuses two ranks on one device, so
+besst_amd.distributed stages its collectives through host copies), all on the ONE GPU of the test box.
+
+Every rank makes the single-GPU drop-in's calls - bamio.open_bam / libmetrics.get_metrics / CreateGraph.PE - and the process
+group makes them sharded (besst_amd.sharded): slices of the stream (or of the BAM file: distributed.ingest_slice on the
+GPU), ShardedMetricsSample, ShardedGraphBuild, owners scoring their rows, rank 0 assembling the graphs.  Rank 0's graphs,
+objects and `param` must equal (1) the reference goldens and (2) what the single-GPU drop-in returns in the same process,
+`==` on every field including gap and score.
+"""
+import os
+
+import pytest
+
+from tests import golden_util as GU
+from tests.test_sharded_dropin_cpu import _free_port, check_against_golden, follower_checks, run_sharded
+
+pytestmark = pytest.mark.gpu
+
+
+def _snapshot(res):
+    from tests.test_gpu_dropin import edge_rows
+    param, G, G_prime, Contigs, Scaffolds, small_contigs, small_scaffolds = res
+    fields = ('read_len', 'mean_ins_size', 'std_dev_ins_size', 'ins_size_threshold', 'contig_threshold', 'contamination_ratio',
+              'contamination_mean', 'contamination_stddev', 'mean_coverage', 'std_dev_coverage', 'edgesupport',
+              'expected_links_over_mean_plus_stddev', 'scaffold_indexer', 'tot_assembly_length', 'current_N50', 'current_L50',
+              'lognormal')
+    obs = {}
+    for name, graph in (('G', G), ('G_prime', G_prime)):
+        for u, v in graph.edges():
+            d = graph[u][v]
+            if d['nr_links'] is not None:
+                obs[(name, u, v)] = list(d['observations'])
+    return dict(G=edge_rows(G, True), G_prime=edge_rows(G_prime, True), G_nodes=list(G.nodes()),
+                Gp_nodes=list(G_prime.nodes()), obs=obs,
+                contigs=[[c.name, c.scaffold, c.coverage, c.position, c.direction] for c in Contigs.values()],
+                small=[[c.name, c.scaffold, c.coverage] for c in small_contigs.values()],
+                scaffolds=list(Scaffolds), small_scaffolds=list(small_scaffolds),
+                param={k: getattr(param, k, None) for k in fields})
+
+
+def _run_from_file(doc, path, batch):
+    from besst_amd import CreateGraph, bamio, libmetrics, session
+    from tests.test_gpu_dropin import make_param
+    records = bamio.open_bam(path, threads=2, chunk_blocks=64)
+    assert len(records) == len(batch) and list(records.references) == list(batch.references)
+    param = make_param(doc['overrides'])
+    info = param.information_file
+    libmetrics.get_metrics(records, param, info)
+    lens = dict(zip(batch.references, batch.lengths))
+    C_dict = {n: 'A' * int(lens.get(n, 10)) for n in doc['fasta_names']}
+    objs = ({}, {}, {}, {})
+    G, G_prime = CreateGraph.PE(objs[0], objs[1], info, C_dict, param, objs[2], objs[3], records)
+    session.close_session(records)
+    records.close()
+    return (param, G, G_prime) + objs, records
+
+
+def _worker(rank, world, port, names, bam_cases, tmp, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from besst_amd import bamio, sharded
+    from tests import bam_writer
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_scored = 0
+        for name in names:
+            doc, batch = GU.load(name)
+            single = None
+            if rank == 0:
+                os.environ['BESST_SHARDED'] = '0'
+                single = _snapshot(run_sharded(doc, batch))
+                os.environ['BESST_SHARDED'] = '1'
+            assert sharded.active_group() == (rank, world)
+            res = run_sharded(doc, batch)
+            if rank == 0:
+                check_against_golden(name, doc, *res, exact_scores=False)
+                got = _snapshot(res)
+                for k in single:
+                    assert got[k] == single[k], (name, k)
+                n_scored += sum(1 for e in got['G'] if 'score' in e)
+            else:
+                follower_checks(name, doc, res[0], res[1], res[2])
+        for name, layout in bam_cases:
+            doc, batch = GU.load(name)
+            path = os.path.join(tmp, '%s_%s.bam' % (name, layout))
+            if rank == 0:
+                if layout == 'htslib':
+                    bamio.write_bam(path, batch, threads=2)
+                else:
+                    bam_writer.write_bam(path, batch, block_bytes=5000, align_records=False, decoys=True)
+            dist.barrier()
+            single = None
+            if rank == 0:
+                os.environ['BESST_SHARDED'] = '0'
+                res1, rec1 = _run_from_file(doc, path, batch)
+                assert type(rec1).__name__ == 'ResidentBam'
+                single = _snapshot(res1)
+                os.environ['BESST_SHARDED'] = '1'
+            res, rec = _run_from_file(doc, path, batch)
+            assert type(rec).__name__ == 'ShardedBam' and rec.ingest.on_device == 1
+            assert sum(rec.head.slice_records) == len(batch)
+            if rank == 0:
+                got = _snapshot(res)
+                for k in single:
+                    assert got[k] == single[k], (name, layout, k)
+                strip = lambda rows: [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in rows]
+                assert strip(got['G']) == strip(doc['final']['G']) and strip(got['G_prime']) == strip(doc['final']['G_prime'])
+                n_scored += len(got['G'])
+        out.put((rank, n_scored))
+    finally:
+        dist.destroy_process_group()
+
+
+def _launch(world, names, bam_cases, tmp_path, timeout=1500):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, names, bam_cases, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(world))
+    assert [g[0] for g in got] == list(range(world)) and got[0][1] > 0
+
+
+def test_two_ranks_every_golden_and_the_bam_files(tmp_path):
+    _launch(2, GU.scenario_names(), [('fr_infer', 'htslib'), ('rf_contam', 'straddling')], tmp_path)
+
+
+@pytest.mark.parametrize('world', [3, 8])
+def test_more_ranks_second_library_and_a_straddling_file(world, tmp_path):
+    """rf_second_lib: a non-trivial contig table (scaffolds of several contigs, directions, positions) that only rank 0
+    holds as objects - the followers get it with the build command; fr_infer from a file whose records straddle blocks."""
+    _launch(world, ['rf_second_lib', 'fr_edgecases'], [('fr_infer', 'straddling')], tmp_path)
