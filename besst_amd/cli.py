@@ -6,6 +6,13 @@ Flag names and defaults follow runBESST:254-402 for everything the hot path read
 --min_mapq -d -y --no_score).  Per library it runs the BAM front-end, ``libmetrics.get_metrics`` and
 ``CreateGraph.PE`` and writes Statistics.txt plus the scored edge tables of G and G' as TSV; scaffolding itself
 (MakeScaffolds and later) stays with BESST - see INTEGRATION.md for plugging these calls into runBESST.
+
+Several GPUs of one node: launch the same command line under torchrun, one process per GPU -
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m besst_amd.cli -c ... -f ...
+
+Every rank ingests its slice of each BAM on its own GPU and takes part in the library scans and the graph build
+(besst_amd.sharded); rank 0 writes the outputs.
 """
 from __future__ import print_function
 
@@ -75,12 +82,38 @@ def write_edges(path, G):
                                              d.get('gap', ''), d.get('score', ''))), file=fh)
 
 
+def join_process_group():
+    """Under torchrun (WORLD_SIZE > 1): one rank per GPU over RCCL (backend 'nccl'; BESST_DIST_BACKEND=gloo for several
+    ranks on one GPU).  -> (rank, whether this call initialised the group)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world < 2:
+        return 0, False
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
+    if dist.is_initialized():
+        return dist.get_rank(), False
+    dist.init_process_group(os.environ.get('BESST_DIST_BACKEND', 'nccl'))
+    return dist.get_rank(), True
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if len(args.orientation) != len(args.bamfiles):
         sys.exit('need one -orientation per BAM file')
+    rank, joined = join_process_group()
+    try:
+        return _run(args, rank)
+    finally:
+        if joined:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def _run(args, rank):
     out = os.path.join(args.output, 'BESST_output')
     os.makedirs(out, exist_ok=True)
+    lead = rank == 0                                         # the followers compute, rank 0 also writes
     param = Parameter.parameter()
     param.scaffold_indexer = 1
     param.min_mapq = args.min_mapq
@@ -94,9 +127,10 @@ def main(argv=None):
     param.max_contig_overlap = 200
     param.output_directory = out
     param.first_lib = True
-    Information = param.information_file = open(os.path.join(out, 'Statistics.txt'), 'w')
-    C_dict = read_fasta(args.contigfile)
-    print('Number of initial contigs:', len(C_dict))
+    Information = param.information_file = open(os.path.join(out, 'Statistics.txt') if lead else os.devnull, 'w')
+    C_dict = read_fasta(args.contigfile) if lead else {}
+    if lead:
+        print('Number of initial contigs:', len(C_dict))
     Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
     for i, bam in enumerate(args.bamfiles):
         param.pass_number = i + 1
@@ -111,7 +145,8 @@ def main(argv=None):
         print('\nPASS ' + str(i + 1) + '\n\n', file=Information)
         t0 = time()
         # straight to HBM: inflate + record decode on the GPU (files in htslib's block layout; others through the host reader)
-        records = bamio.ResidentBam(bam, threads=args.threads)
+        # (under torchrun: this rank's slice of the file, on this rank's GPU)
+        records = bamio.open_bam(bam, threads=args.threads)
         print('Time elapsed reading %s (%d records): %s' % (bam, len(records), time() - t0), file=Information)
         param.contig_index = dict(enumerate(records.references))
         t0 = time()
@@ -123,6 +158,10 @@ def main(argv=None):
         print('Total time for CreateGraph-module, iteration ' + str(i) + ': ' + str(time() - t0) + '\n',
               file=Information)
         session.close_session(records)
+        records.close()
+        param.first_lib = False
+        if not lead:
+            continue
         pass_dir = os.path.join(out, 'pass%d' % (i + 1))
         os.makedirs(pass_dir, exist_ok=True)
         write_edges(os.path.join(pass_dir, 'edges_G.tsv'), G)
@@ -138,7 +177,6 @@ def main(argv=None):
         print('pass %d: %d records, G %d link edges, G_prime %d link edges' % (
             i + 1, len(records), sum(1 for u, v in G.edges() if G[u][v]['nr_links'] is not None),
             sum(1 for u, v in G_prime.edges() if G_prime[u][v]['nr_links'] is not None)))
-        param.first_lib = False
     Information.close()
     return 0
 

@@ -140,3 +140,32 @@ def test_more_ranks_second_library_and_a_straddling_file(world, tmp_path):
     """rf_second_lib: a non-trivial contig table (scaffolds of several contigs, directions, positions) that only rank 0
     holds as objects - the followers get it with the build command; fr_infer from a file whose records straddle blocks."""
     _launch(world, ['rf_second_lib', 'fr_edgecases'], [('fr_infer', 'straddling')], tmp_path)
+
+
+def test_cli_under_torchrun(tmp_path):
+    """python -m torch.distributed.run ... -m besst_amd.cli: two ranks (gloo, one GPU), each ingesting its slice of the BAM;
+    rank 0 writes the same scored edge table the reference golden holds."""
+    import subprocess
+    import sys
+    from tests import bam_writer
+    doc, batch = GU.load('fr_infer')
+    bam = str(tmp_path / 'lib.bam')
+    bam_writer.write_bam(bam, batch, block_bytes=20000, align_records=False)
+    fasta = str(tmp_path / 'contigs.fa')
+    lens = dict(zip(batch.references, batch.lengths))
+    with open(fasta, 'w') as fh:
+        for n in doc['fasta_names']:
+            fh.write('>%s\n%s\n' % (n, 'A' * lens[n]))
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), '-m', 'besst_amd.cli', '-c', fasta, '-f', bam, '-orientation', 'fr', '-o',
+           str(tmp_path)]
+    done = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert done.returncode == 0, done.stdout.decode()[-3000:]
+    rows = [l.rstrip('\n').split('\t') for l in open(str(tmp_path / 'BESST_output' / 'pass1' / 'edges_G.tsv'))][1:]
+    got = [(int(r[0]), r[1], int(r[2]), r[3], int(r[4]), int(r[5]), int(r[6])) for r in rows]
+    want = [(e['u'][0], e['u'][1], e['v'][0], e['v'][1], e['nr_links'], e['obs'], e['obs_sq']) for e in doc['final']['G']]
+    assert got == want and len(got) > 10
+    stats = open(str(tmp_path / 'BESST_output' / 'Statistics.txt')).read()
+    assert 'LIBRARY STATISTICS' in stats and 'Number of edges in G (after repeat removal)' in stats
