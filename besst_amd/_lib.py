@@ -119,6 +119,8 @@ _SIGNATURES = {
     'besst_bgzf_inflate_device': (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     'besst_ctx_metrics_sample': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_double, C.c_int32, _P, _P,
                                            C.POINTER(MetricsCounts)]),
+    'besst_ctx_stream_order': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P]),
+    'besst_dev_stream_order': (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     'besst_ctx_value_histogram': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, _P]),
     'besst_ctx_build_graph': (C.c_int, [_P]),
     'besst_ctx_edge_count': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

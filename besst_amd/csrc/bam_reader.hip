@@ -217,6 +217,7 @@ uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 struct besst_bam {
     int fd = -1;
     const uint8_t* map = nullptr;    // the whole file
+    const uint8_t* copy_map = nullptr;   // a second, plain mapping of it for bam_parallel_read (made on first use)
     size_t map_len = 0;
     size_t file_off = 0;             // first byte of the next BGZF block
     int n_threads = 1;
@@ -378,6 +379,7 @@ besst_bam* besst_bam_open(const char* path, int n_threads) {
 void besst_bam_close(besst_bam* b) {
     if (!b) return;
     if (b->map) munmap(const_cast<uint8_t*>(b->map), b->map_len);
+    if (b->copy_map) munmap(const_cast<uint8_t*>(b->copy_map), b->map_len);
     if (b->fd >= 0) close(b->fd);
     delete b->pool;
     for (void* c : b->ld_ctx) libdeflate().free_(c);
@@ -721,15 +723,37 @@ bool bam_record_position(besst_bam* b, int64_t* block_file_off, uint32_t* in_blo
     return true;
 }
 
-// `bytes` of the file from file_off into dst, read (pread) by the pool's threads in 4 MiB pieces
+// `bytes` of the file from file_off into dst (pinned staging), by the pool's threads in 1 MiB pieces.  The bytes are COPIED
+// OFF A MAPPING of the file, not pread: on the first pass over a file that has just been written (page cache or tmpfs) 32
+// threads pread 19 - 35 GB/s and copy 80 - 155 GB/s off a mapping on the GPU box (tools/probe_pread.cpp: every page's second
+// touch moves it to the active list under the LRU lock in the read path, a mapped page is not marked at all), and later
+// passes are no slower either.  The mapping is a plain shared one of its own - the reader's carries MADV_SEQUENTIAL for the
+// host form's walk - and its faults are spread over the threads (the single-threaded header walk of round 3, which touched
+// every page from one thread, is what made a mapping look slow then).  BESST_STAGE_PREAD=1, or no mapping: pread.
 bool bam_parallel_read(besst_bam* b, void* dst, int64_t file_off, size_t bytes) {
     if (!b || b->fd < 0) return false;
-    constexpr size_t kPiece = (size_t)4 << 20;
+    static const bool use_pread = [] { const char* e = getenv("BESST_STAGE_PREAD"); return e && atoi(e) != 0; }();
+    if (!use_pread && !b->copy_map && b->map_len) {
+        void* m = mmap(nullptr, b->map_len, PROT_READ, MAP_SHARED, b->fd, 0);
+        if (m != MAP_FAILED) b->copy_map = static_cast<const uint8_t*>(m);
+    }
+    const uint8_t* from = use_pread ? nullptr : b->copy_map;
+    if (from && ((size_t)file_off > b->map_len || bytes > b->map_len - (size_t)file_off)) return false;
+    constexpr size_t kPiece = (size_t)1 << 20;
     const size_t pieces = (bytes + kPiece - 1) / kPiece;
     std::atomic<bool> ok(true);
     auto piece = [&](size_t i, int) {
         size_t o = i * kPiece;
         const size_t end = o + kPiece < bytes ? o + kPiece : bytes;
+        if (from) {
+            const uint8_t* src = from + (size_t)file_off + o;
+            memcpy(static_cast<char*>(dst) + o, src, end - o);
+            // the piece's page-table entries go at once, from this thread: left to the munmap at close they were 0.12 s
+            // of one thread for a 5.6 GB file (the pages stay in the page cache, where the next pass finds them)
+            const uintptr_t lo = ((uintptr_t)src + 4095u) & ~(uintptr_t)4095u, hi = ((uintptr_t)src + (end - o)) & ~(uintptr_t)4095u;
+            if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
+            return;
+        }
         while (o < end) {
             const ssize_t got = pread(b->fd, static_cast<char*>(dst) + o, end - o, (off_t)(file_off + (int64_t)o));
             if (got <= 0) { ok = false; return; }

@@ -400,6 +400,7 @@ int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t c
                    bool count_only = false);
 int launch_value_histogram(hipStream_t s, const int32_t* values, int64_t n, int64_t n_bins,
                            unsigned long long* hist, unsigned long long* overflow);
+int launch_stream_order(hipStream_t s, const int32_t* tid, const int32_t* pos, int64_t n, unsigned long long* first_unsorted);
 
 struct ScoreArgs {
     const uint32_t* row;       // edge-table row per scored edge

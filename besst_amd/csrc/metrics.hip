@@ -530,6 +530,56 @@ int launch_metrics(hipStream_t s, const MetricsArgs& a, int64_t start, int64_t c
     return BESST_OK;
 }
 
+// ---- is the stream sorted by coordinate? ---------------------------------------------------------------------------------
+// The reference refuses a BAM without an index (libmetrics.py:237-241: bam_file.fetch() raises), and an index exists only
+// for a coordinate-sorted file.  The record loop here is exact on any order but several times slower on an unsorted one
+// (its run naming relies on neighbouring records sharing contigs), so get_metrics says so: this pass compares every record's
+// (reference id, position) with its predecessor's - reference -1 (unplaced reads) sorts last, as samtools sort leaves it -
+// and reports the first record that lies in front of its predecessor.  8 bytes per record, one launch.
+__global__ __launch_bounds__(256) void stream_order_kernel(const int32_t* __restrict__ tid, const int32_t* __restrict__ pos, long long n,
+                                                           unsigned long long* __restrict__ first_unsorted) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    unsigned long long worst = ~0ull;
+    for (long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; base < n; base += stride) {
+        // four records per thread: aligned 16-byte loads, plus the record in front of them
+        int32_t t[5], p[5];
+        if (base + 4 <= n) {
+            const int4 tv = *reinterpret_cast<const int4*>(tid + base), pv = *reinterpret_cast<const int4*>(pos + base);
+            t[1] = tv.x; t[2] = tv.y; t[3] = tv.z; t[4] = tv.w;
+            p[1] = pv.x; p[2] = pv.y; p[3] = pv.z; p[4] = pv.w;
+        } else {
+            for (int k = 0; k < 4; ++k) {
+                const bool in = base + k < n;
+                t[k + 1] = in ? tid[base + k] : -1;
+                p[k + 1] = in ? pos[base + k] : 0x7fffffff;
+            }
+        }
+        t[0] = base > 0 ? tid[base - 1] : (int32_t)0x80000000;   // (nothing in front of the first record: the smallest key)
+        p[0] = base > 0 ? pos[base - 1] : (int32_t)0x80000000;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) {
+            // key: reference id as unsigned (so that -1 is the largest), then the position + 1 (-1 for a read without one)
+            const unsigned long long a = ((unsigned long long)(uint32_t)t[k - 1] << 32) | ((uint32_t)p[k - 1] + 1u);
+            const unsigned long long b = ((unsigned long long)(uint32_t)t[k] << 32) | ((uint32_t)p[k] + 1u);
+            if (k - 1 == 0 && base == 0) continue;
+            if (base + k - 1 < n && b < a) {
+                const unsigned long long at = (unsigned long long)(base + k - 1);
+                worst = at < worst ? at : worst;
+            }
+        }
+    }
+    if (worst != ~0ull) atomicMin(first_unsorted, worst);
+}
+
+int launch_stream_order(hipStream_t s, const int32_t* tid, const int32_t* pos, int64_t n, unsigned long long* first_unsorted) {
+    if (n <= 1) return BESST_OK;
+    const int64_t want = (n + 1023) / 1024;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(stream_order_kernel, dim3(blocks), dim3(256), 0, s, tid, pos, (long long)n, first_unsorted);
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
 int launch_value_histogram(hipStream_t s, const int32_t* values, int64_t n, int64_t n_bins,
                            unsigned long long* hist, unsigned long long* overflow) {
     if (n <= 0) return BESST_OK;

@@ -213,6 +213,16 @@ class GraphContext(object):
 
     # ---- library statistics ----------------------------------------------------------------------
     @_timed
+    def stream_order(self):
+        """-> (index of the first record that lies in front of its predecessor in (reference, position) order or None,
+        (tid, pos) of the first resident record, of the last) - besst_ctx_stream_order."""
+        first = C.c_int64(-1)
+        keys = np.zeros(4, dtype=np.int32)
+        _lib.check(self._lib.besst_ctx_stream_order(self._ctx, C.byref(first), _lib.ptr(keys[:2]), _lib.ptr(keys[2:])),
+                   'stream_order')
+        return (None if first.value < 0 else int(first.value)), (int(keys[0]), int(keys[1])), (int(keys[2]), int(keys[3]))
+
+    @_timed
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):
         top = _lib.as_col(top_mask, np.uint8)
         isize = np.empty(SAMPLE_CAP, dtype=np.int32)

@@ -193,6 +193,20 @@ def get_metrics(bam_file, param, Information):
     top = largest_reference_indexes(cont_lengths_list)
     param.lognormal = False
 
+    # libmetrics.py:237-241 refuses a BAM without an index - and only a coordinate-sorted file has one.  The kernels here
+    # are exact on any order (and there is no index to ask for), so the drop-in does not refuse: it checks the order of the
+    # resident stream and passes the reference's message on as a warning.
+    unsorted_at = sess.stream_order()
+    if unsorted_at is not None:
+        text = ('WARNING: the alignments are not sorted by coordinate (record {0} lies in front of its predecessor). BESST '
+                'itself stops here: "Need indexed bamfiles, index file should be located in the same directory as the BAM '
+                'file" (only a coordinate-sorted BAM can be indexed).  Results stay exact, but the graph build runs '
+                'several times slower on an unsorted stream - sort the file (samtools sort) for full speed.'
+                .format(unsorted_at))
+        sys.stderr.write(text + '\n')
+        print(text, file=Information)
+        param.stream_unsorted_at = unsorted_at
+
     if not param.read_len:                                        # libmetrics.py:246-273
         if len(batch) < 1000:
             sys.stderr.write('Did not get sufficient readmappings to calculate read_length from mappings. '

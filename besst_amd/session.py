@@ -39,6 +39,10 @@ class Session(object):
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize):
         return self.ctx.metrics_sample(top_mask, orientation, min_mapq, read_len, want_isize)
 
+    def stream_order(self):
+        """Index of the first record that breaks the coordinate order, or None (libmetrics.get_metrics' input guard)."""
+        return self.ctx.stream_order()[0]
+
     # CreateGraph.PE's epilogue: nothing to tell anybody on one GPU
     def done(self, param):
         pass

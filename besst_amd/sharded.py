@@ -135,6 +135,21 @@ class HipRankEngine(object):
         self._sampler.set_top(top_mask)
         return self._sampler
 
+    def stream_order(self):
+        """(first record of the slice that lies in front of its predecessor or None, the slice's first (tid, pos), its last)."""
+        import ctypes as C
+        import torch
+        rec, lib = self.rec, _lib.load()
+        if rec.n == 0:
+            return None, (0, 0), (0, 0)
+        word = torch.zeros(1, dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(lib.besst_dev_stream_order(C.c_void_p(stream), rec.n, C.c_void_p(rec.tid.data_ptr()),
+                                              C.c_void_p(rec.pos.data_ptr()), C.c_void_p(word.data_ptr())), 'dev_stream_order')
+        ends = torch.stack([rec.tid[0], rec.pos[0], rec.tid[-1], rec.pos[-1]]).cpu().tolist()
+        first = int(word.item())
+        return (None if first < 0 else first), (ends[0], ends[1]), (ends[2], ends[3])
+
     def probe_tuples(self, table, lib, node_bits):
         """Tuples this slice emits (one untimed local pass, no collective): sizes the exchange regions."""
         from . import distributed
@@ -361,6 +376,25 @@ class ShardedSession(object):
         job = distributed.ShardedMetricsSample(backend, self.rank, self.world, self.group)
         isize, contam, counts = job.sample(orientation, min_mapq, read_len, want_isize)
         return isize, contam, _Counts(counts)
+
+    def stream_order(self):
+        """Index (in the whole stream) of the first record that breaks the coordinate order, or None: every slice checks
+        itself, and its first record against the last record of the slice before it."""
+        local = self.ctx.engine.stream_order()
+        n_local = self.batch.slice_records[self.rank]
+        out = [None] * self.world
+        _dist().all_gather_object(out, (local, n_local), group=self.group)
+        key = lambda k: ((k[0] & 0xffffffff) << 32) | ((k[1] + 1) & 0xffffffff)
+        base, prev_last = 0, None
+        for (first, first_key, last_key), n in out:
+            if n:
+                if prev_last is not None and key(first_key) < key(prev_last):
+                    return base
+                if first is not None:
+                    return base + first
+                prev_last = last_key
+            base += n
+        return None
 
     # PE's epilogue on rank 0 / the whole of PE on the others
     def follow(self, param):

@@ -242,6 +242,17 @@ int besst_ctx_metrics_sample(besst_ctx* ctx, const uint8_t* top_mask, int32_t or
                              int32_t min_mapq, double read_len, int32_t want_isize,
                              int32_t* isize_out, int32_t* contam_out, besst_metrics_counts* counts);
 
+/* Is the resident stream sorted by coordinate?  Replaces the reference's index check - `bam_file.fetch(cont_names[0])`
+ * raising for a BAM without an index, BESST/libmetrics.py:237-241; an index exists only for a coordinate-sorted file.
+ * *first_unsorted: -1, or the index of the first record whose (reference id, position) lies in front of its predecessor's
+ * (reference -1 sorts last, as `samtools sort` leaves it).  The graph build is exact on any order but several times slower
+ * on an unsorted stream; libmetrics.get_metrics turns a hit into the reference's message as a WARNING.  first_key /
+ * last_key (each 2 x int32, may be NULL): (tid, pos) of the first and last resident record, for the slices of a sharded
+ * stream to compare across ranks.  besst_dev_stream_order: the same pass on caller-owned columns, *first_unsorted on the
+ * device. */
+int besst_ctx_stream_order(besst_ctx* ctx, int64_t* first_unsorted, int32_t* first_key, int32_t* last_key);
+int besst_dev_stream_order(void* stream, int64_t n, const int32_t* tid, const int32_t* pos, int64_t* first_unsorted);
+
 /* Count-per-value histogram of a sample on the device (input to find_bimodality.split_distribution,
  * find_bimodality.py:109-132).  hist_out has n_bins entries; values >= n_bins are counted in
  * *overflow. */

@@ -41,6 +41,9 @@ class FakeGraphContext(object):
         assert len(self.batches) == 1
         return self.batches[0]
 
+    def stream_order(self):
+        return stream_order_of(self._batch())
+
     def metrics_sample(self, top_mask, orientation, min_mapq, read_len, want_isize=True):
         isize, contam, c = CO.metrics_sample(self._batch(), top_mask, orientation, min_mapq, read_len, want_isize)
         counts = MetricsCounts(int(c[0]), int(c[1]), int(c[2]), int(c[3]), len(self._batch()))
@@ -62,6 +65,17 @@ class FakeGraphContext(object):
 
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
         return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len)
+
+
+def stream_order_of(batch):
+    """(first record in front of its predecessor in (reference id with -1 last, position) order or None, first key, last)."""
+    if len(batch) == 0:
+        return None, (0, 0), (0, 0)
+    key = ((batch.tid.astype(np.int64) & 0xffffffff).astype(np.uint64) << np.uint64(32)) | \
+        ((batch.pos.astype(np.int64) + 1) & 0xffffffff).astype(np.uint64)
+    bad = np.flatnonzero(key[1:] < key[:-1])
+    ends = (int(batch.tid[0]), int(batch.pos[0])), (int(batch.tid[-1]), int(batch.pos[-1]))
+    return (int(bad[0]) + 1 if bad.size else None,) + ends
 
 
 def score_rows(r, rows, swap, len1, len2, mean, sigma, read_len):
@@ -106,6 +120,9 @@ class OracleRankEngine(object):
     @classmethod
     def from_batch(cls, part, n_contigs):
         return cls(part, n_contigs)
+
+    def stream_order(self):
+        return stream_order_of(self.part)
 
     def metrics_backend(self, top_mask):
         from tests import dist_util as DU

@@ -257,3 +257,23 @@ def test_extend_within_components_contract():
     assert seen[0][2] == [] and seen[1][2] == [(41, 'L'), (41, 'R')]   # the second search sees the first component renamed
     assert sorted(Gp.nodes()) == [(41, 'L'), (41, 'R'), (42, 'L'), (42, 'R')]
     assert Gp[(41, 'R')][(42, 'L')]['nr_links'] == 5          # the link between the two paths' ends travelled with them
+
+
+def test_unsorted_stream_gets_the_reference_message_as_a_warning(fake_gpu, capsys):
+    """libmetrics.py:237-241 refuses a BAM without an index (only a coordinate-sorted file has one); the drop-in checks the
+    order of the resident stream instead and warns - on stderr and in `Information` - without refusing."""
+    doc, batch = GU.load('fr_given')
+    param = make_param(doc['overrides'])
+    libmetrics.get_metrics(batch, param, param.information_file)
+    session.close_session(batch)
+    assert not hasattr(param, 'stream_unsorted_at') and 'Need indexed bamfiles' not in capsys.readouterr().err
+    order = numpy.arange(len(batch))
+    order[1000], order[5000] = order[5000], order[1000]       # two records change places
+    shuffled = batch.take(order)
+    assert (shuffled.tid[1000], shuffled.pos[1000]) != (batch.tid[1000], batch.pos[1000])
+    param = make_param(doc['overrides'])
+    libmetrics.get_metrics(shuffled, param, param.information_file)
+    session.close_session(shuffled)
+    assert param.stream_unsorted_at == 1001
+    assert 'Need indexed bamfiles' in capsys.readouterr().err
+    assert 'WARNING: the alignments are not sorted by coordinate (record 1001 ' in param.information_file.getvalue()

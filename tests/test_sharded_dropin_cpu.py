@@ -106,6 +106,18 @@ def _worker(rank, port, names, out):
                 check_against_golden(name, doc, *res)
             else:
                 follower_checks(name, doc, res[0], res[1], res[2])
+        # the input guard across the slice boundary: both halves sorted, the second half's first record in front of the first's
+        # last one (libmetrics.py:237-241; every rank warns, the index is the stream's)
+        import numpy
+        from besst_amd import libmetrics, session
+        from tests.test_gpu_dropin import make_param
+        doc, batch = GU.load('fr_given')
+        half = len(batch) * 1 // WORLD
+        swapped = batch.take(numpy.concatenate([numpy.arange(half, len(batch)), numpy.arange(half)]))
+        param = make_param(doc['overrides'])
+        libmetrics.get_metrics(swapped, param, param.information_file)
+        session.close_session(swapped)
+        assert param.stream_unsorted_at == len(batch) - half
         out.put((rank, len(names)))
     finally:
         dist.destroy_process_group()
