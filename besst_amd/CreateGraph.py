@@ -104,7 +104,7 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     # ---- record loop on the device ------------------------------------------------------------------------
     print('Reading bam file and creating scaffold graph...', file=Information)
     staart = time()
-    table_cols, tid_of = contig_table(batch.references, Contigs, small_contigs, Scaffolds, small_scaffolds)
+    table_cols, tids_of_group = contig_table(batch.references, Contigs, small_contigs, Scaffolds, small_scaffolds)
     ctx = sess.ctx
     ctx.set_contigs(**table_cols)
     ctx.set_library(param.read_len, param.ins_size_threshold, param.min_mapq, param.orientation,
@@ -132,13 +132,14 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     # ---- coverage (CreateGraph.py:237-246) -----------------------------------------------------------------
     # a contig that is not in THIS library's BAM header has no aligned bases: the reference starts every contig's
     # counter at 0 (CreateGraph.py:89-95), so its coverage is 0 there too
-    aligned = aligned.tolist()
-    for name, cont in Contigs.items():
-        tid = tid_of.get(name)
-        cont.coverage = (aligned[tid] if tid is not None else 0) / float(cont.length)
-    for name, cont in small_contigs.items():
-        tid = tid_of.get(name)
-        cont.coverage = (aligned[tid] if tid is not None else 0) / float(cont.length)
+    aligned = np.asarray(aligned, dtype=np.int64)
+    for contigs, tids in zip((Contigs, small_contigs), tids_of_group):
+        if len(contigs):
+            objs = list(contigs.values())
+            numer = np.where(tids >= 0, aligned[np.maximum(tids, 0)], 0)
+            cov = numer / _column(objs, 'length', np.float64)             # (int / float(length), as the reference divides)
+            for cont, value in zip(objs, cov.tolist()):
+                cont.coverage = value
 
     if param.first_lib and param.lower_cov_cutoff:
         filter_low_coverage_contigs(Contigs, Scaffolds, plan_G, param, plan_Gp, small_contigs, small_scaffolds, Information)
@@ -174,7 +175,7 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     plan_G.build(G, scores)
     plan_Gp.build(G_prime, None)
     print('Number of edges in G_prime  (after removing edges under -e threshold (if not specified, default is '
-          '-e 3): ', G_prime.number_of_edges(), file=Information)
+          '-e 3): ', plan_Gp.number_of_edges(), file=Information)
     print('\n -------------------------------------------------------------\n', file=Information)
     print('Nr of contigs/scaffolds included in this pass: ' + str(len(Scaffolds) + len(small_scaffolds)),
           file=Information)
@@ -186,39 +187,42 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
 # device boundary helpers
 # -----------------------------------------------------------------------------------------------------------
 def contig_table(references, Contigs, small_contigs, Scaffolds, small_scaffolds):
-    """Flatten the object dicts into the per-tid table the kernels gather from."""
+    """Flatten the object dicts into the per-tid table the kernels gather from: one column per attribute and dictionary
+    (attribute getters and dictionary look-ups mapped in C), scattered to the contigs' places in the BAM header.  Also
+    returns, per dictionary, the tid of every contig in dictionary order (-1: not in this library's header)."""
     n = len(references)
     cols = dict(scaf_id=np.zeros(n, np.int32), scaf_len=np.zeros(n, np.int32), ctg_pos=np.zeros(n, np.int32),
                 ctg_len=np.zeros(n, np.int32), direction=np.zeros(n, np.uint8), cls=np.zeros(n, np.uint8))
-    tid_of = {}
-    for tid, name in enumerate(references):
-        if name in tid_of:
+    # a name that occurs twice in the header keeps its first place (the later entries stay absent)
+    tid_of = dict(zip(reversed(references), range(n - 1, -1, -1)))
+    tids_of_group = []
+    for contigs, scaffolds, k in ((Contigs, Scaffolds, CLS_LARGE), (small_contigs, small_scaffolds, CLS_SMALL)):
+        count = len(contigs)
+        tids = np.fromiter(map(tid_of.get, contigs, repeat(-1)), dtype=np.int64, count=count)
+        tids_of_group.append(tids)
+        if count == 0:
             continue
-        tid_of[name] = tid
-        if name in Contigs:
-            c, scaf, k = Contigs[name], Scaffolds, CLS_LARGE
-        elif name in small_contigs:
-            c, scaf, k = small_contigs[name], small_scaffolds, CLS_SMALL
-        else:
-            continue
-        cols['cls'][tid] = k
-        cols['scaf_id'][tid] = c.scaffold
-        cols['scaf_len'][tid] = scaf[c.scaffold].s_length
-        cols['ctg_pos'][tid] = c.position
-        cols['ctg_len'][tid] = c.length
-        cols['direction'][tid] = 1 if c.direction else 0
-    return cols, tid_of
+        objs = list(contigs.values())
+        here = tids >= 0
+        # (a contig of the small dictionary that is also a key of the large one cannot exist: the dictionaries are disjoint)
+        scaf = _column(objs, 'scaffold', np.int64)
+        s_len = dict(zip(scaffolds, map(operator.attrgetter('s_length'), scaffolds.values())))
+        slen = np.fromiter(map(s_len.__getitem__, scaf.tolist()), dtype=np.int64, count=count)
+        at = tids[here]
+        cols['cls'][at] = k
+        cols['scaf_id'][at] = scaf[here]
+        cols['scaf_len'][at] = slen[here]
+        cols['ctg_pos'][at] = _column(objs, 'position', np.int64)[here]
+        cols['ctg_len'][at] = _column(objs, 'length', np.int64)[here]
+        cols['direction'][at] = _column(objs, 'direction', np.bool_)[here]
+    return cols, tids_of_group
 
 
 class LinkData(dict):
     """Attribute dict of a link edge.  'observations' - one int per link, in BAM order (CreateGraph.py:849,862) - is cut
     out of the device's observation column the first time anything asks for it (its readers are
     MakeScaffolds.py:322,331,425,1139: a few edges per extended path); every other key is an ordinary item."""
-    __slots__ = ('_col', '_lo', '_hi')
-
-    def __init__(self, *args, **kw):
-        dict.__init__(self, *args, **kw)
-        self._col, self._lo, self._hi = None, 0, 0           # (a LinkData built anywhere is a plain dict until GraphPlan lends it a column)
+    __slots__ = ('_col', '_lo', '_hi')                       # unset on a LinkData built anywhere: a plain dict until GraphPlan lends it a column
 
     def _cut(self):
         col = getattr(self, '_col', None)
@@ -227,7 +231,7 @@ class LinkData(dict):
             dict.__setitem__(self, 'observations', col[self._lo:self._hi].tolist())
 
     def __missing__(self, key):
-        if key == 'observations' and self._col is not None:
+        if key == 'observations' and getattr(self, '_col', None) is not None:
             self._cut()
             return dict.__getitem__(self, key)
         raise KeyError(key)
@@ -314,6 +318,23 @@ class LinkData(dict):
         return dict.__repr__(self)
 
 
+class ObservationColumn(object):
+    """`observations` of every link, one int per link in BAM order, grouped by edge row: a slice of it is an edge's list.
+    Taken from the table when a slice is first asked for (EdgeTable.observation_sums: by then the background fetch is
+    normally done)."""
+    __slots__ = ('_table', '_col')
+
+    def __init__(self, table):
+        self._table, self._col = table, None
+
+    def __getitem__(self, index):
+        col = self._col
+        if col is None:
+            col = self._col = self._table.observation_sums()
+            self._table = None
+        return col[index]
+
+
 class LinkTable(object):
     """The device's edge rows as columns, link rows in order of first occurrence in the BAM.
 
@@ -334,8 +355,9 @@ class LinkTable(object):
         self.pair = table.key[rows] >> np.uint64(1)
         self.fishy_pair = table.key[fishy] >> np.uint64(1)
         self.fishy_n = table.n[fishy].astype(np.int64)
-        # one observation per link: obs1 + obs2 (the device keeps the two ends apart for the scoring stage)
-        self.observations = table.obs_lo + table.obs_hi
+        # one observation per link: obs1 + obs2 (the device keeps the two ends apart for the scoring stage); the column is
+        # summed on the device and crosses PCIe beside this call's host work (device.ObservationSource)
+        self.observations = ObservationColumn(table)
 
     def __len__(self):
         return int(self.rows.shape[0])
@@ -430,17 +452,30 @@ class GraphPlan(object):
             return
         col = lk.observations
         lo = lk.lo[idx]
-        datas = [LinkData(nr_links=n, obs=s1, obs_sq=s2)
-                 for n, s1, s2 in zip(lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist())]
-        for data, span in zip(datas, zip(lo.tolist(), (lo + lk.n[idx]).tolist())):
-            data._col = col
-            data._lo, data._hi = span
+        n_l, s1_l, s2_l = lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist()
+        order = None
         if scores is not None:
-            at = dict(zip(idx.tolist(), datas))
-            for k, gap, score in zip(scores[0].tolist(), scores[1], scores[2]):
-                data = at[k]
-                data['gap'] = gap
-                data['score'] = score
+            order = np.argsort(scores[0], kind='stable')
+            if order.shape[0] != idx.shape[0] or not np.array_equal(np.asarray(scores[0])[order], idx):
+                order = None
+        if order is not None:
+            # scored links (GiveScoreOnEdges scores every live link of G) get gap and score with the dictionary they are born with
+            order = order.tolist()
+            gaps, vals = scores[1], scores[2]
+            datas = [LinkData(nr_links=n, obs=s1, obs_sq=s2, gap=gaps[k], score=vals[k])
+                     for n, s1, s2, k in zip(n_l, s1_l, s2_l, order)]
+        else:
+            datas = [LinkData(nr_links=n, obs=s1, obs_sq=s2) for n, s1, s2 in zip(n_l, s1_l, s2_l)]
+            if scores is not None:
+                at = dict(zip(idx.tolist(), datas))
+                for k, gap, score in zip(np.asarray(scores[0]).tolist(), scores[1], scores[2]):
+                    data = at[k]
+                    data['gap'] = gap
+                    data['score'] = score
+        for data, a, b in zip(datas, lo.tolist(), (lo + lk.n[idx]).tolist()):
+            data._col = col
+            data._lo = a
+            data._hi = b
         # where every node code sits in `nodes`: the link's two adjacency dictionaries without hashing a node twice
         slot = np.full(2 * self.node_alive.shape[0], -1, dtype=np.int64)
         kept = self.sid_arr[keep]
@@ -485,6 +520,10 @@ def CalculateStats(sorted_contig_lengths, sorted_contig_lengths_small, param, In
 
 
 def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime, small_contigs, small_scaffolds, C_dict):
+    """One contig and one scaffold object per sequence of the FASTA that the BAM header names, in header order, scaffold
+    ids counting on from param.scaffold_indexer; contigs of at least param.contig_threshold bases are the large ones
+    (CreateGraph.py:729-786).  The selection is a mask over the header's length column; the objects are made in
+    comprehensions and handed to the dictionaries in bulk."""
     contig_threshold = param.contig_threshold
     cont_lengths = [int(nr) for nr in bam_file.lengths]
     cont_names = bam_file.references
@@ -493,27 +532,37 @@ def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime,
     N50, L50 = CalculateStats(sorted(contig_lengths, reverse=True), [], param, Information)
     param.current_L50 = L50
     param.current_N50 = N50
-    for i in range(len(cont_names)):
-        name = cont_names[i]
-        if name not in C_dict:
-            continue
-        if cont_lengths[i] >= contig_threshold:
-            target_c, target_s = Contigs, Scaffolds
-        elif cont_lengths[i] > 0:
-            target_c, target_s = small_contigs, small_scaffolds
-        else:
-            continue
-        C = Contig.contig(name)
-        C.length = cont_lengths[i]
-        C.sequence = C_dict[name]
-        del C_dict[name]
-        C.direction = True
-        C.position = 0
-        target_c[C.name] = C
-        S = Scaffold.scaffold(param.scaffold_indexer, [C], C.length)
-        target_s[S.name] = S
-        C.scaffold = S.name
-        param.scaffold_indexer += 1
+    n = len(cont_names)
+    lens = np.asarray(cont_lengths, dtype=np.int64)
+    known = np.fromiter(map(C_dict.__contains__, cont_names), dtype=np.bool_, count=n)
+    if len(set(cont_names)) != n:
+        # a name that occurs twice in the header: the reference takes the first entry (the sequence is gone from C_dict by
+        # the time the second comes)
+        seen = set()
+        for i, name in enumerate(cont_names):
+            if name in seen:
+                known[i] = False
+            seen.add(name)
+    large = known & (lens >= contig_threshold)
+    chosen = np.flatnonzero(known & (large | (lens > 0)))
+    is_large = large[chosen].tolist()
+    names = [cont_names[i] for i in chosen.tolist()]
+    lengths = lens[chosen].tolist()
+    first_id = param.scaffold_indexer
+    ids = range(first_id, first_id + len(names))
+    seqs = list(map(C_dict.pop, names))
+    contigs = [Contig.contig(name, sid, True, 0, length, None, False, False, seq)
+               for name, sid, length, seq in zip(names, ids, lengths, seqs)]
+    scaffolds = [Scaffold.scaffold(sid, [c], length) for sid, c, length in zip(ids, contigs, lengths)]
+    if all(is_large):
+        Contigs.update(zip(names, contigs))
+        Scaffolds.update(zip(ids, scaffolds))
+    else:
+        Contigs.update((nm, c) for nm, c, big in zip(names, contigs, is_large) if big)
+        Scaffolds.update((sid, sc) for sid, sc, big in zip(ids, scaffolds, is_large) if big)
+        small_contigs.update((nm, c) for nm, c, big in zip(names, contigs, is_large) if not big)
+        small_scaffolds.update((sid, sc) for sid, sc, big in zip(ids, scaffolds, is_large) if not big)
+    param.scaffold_indexer = first_id + len(names)
     return ()
 
 

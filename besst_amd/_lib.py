@@ -126,6 +126,7 @@ _SIGNATURES = {
     'besst_ctx_edge_count': (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'besst_ctx_fetch_edges': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int32)]),
     'besst_ctx_fetch_observations': (C.c_int, [_P, _P, _P]),
+    'besst_ctx_fetch_observation_sums': (C.c_int, [_P, _P]),
     'besst_ctx_fetch_coverage': (C.c_int, [_P, _P]),
     'besst_ctx_fetch_counters': (C.c_int, [_P, C.POINTER(Counters)]),
     'besst_ctx_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,

@@ -177,6 +177,8 @@ struct besst_ctx {
     DevBuf<uint32_t> row_mask, row_n, row_first, row_offset;
     DevBuf<int64_t> row_sum, row_sum_sq;
     DevBuf<int32_t> obs_lo, obs_hi;
+    DevBuf<int32_t> obs_sum;         // besst_ctx_fetch_observation_sums: obs_lo + obs_hi, made and copied on side_stream
+    hipStream_t side_stream = nullptr;
     DevBuf<char> ws;
     DevBuf<char> small;      // counters + carry + n_out + n_rows
     bool built = false;
@@ -316,6 +318,11 @@ void besst_ctx_destroy(besst_ctx* c) {
     c->row_sum.release(); c->row_sum_sq.release(); c->obs_lo.release(); c->obs_hi.release();
     c->ws.release(); c->small.release(); c->top_mask.release(); c->sample_a.release();
     c->sample_b.release(); c->aux.release();
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    c->obs_sum.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1667,6 +1674,35 @@ int besst_ctx_fetch_observations(besst_ctx* c, int32_t* obs_lo, int32_t* obs_hi)
         BESST_HIP_TRY(hipMemcpyAsync(obs_hi, c->obs_hi.p, L * 4, hipMemcpyDeviceToHost, c->stream));
         BESST_HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return BESST_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void obs_sum_kernel(const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int32_t* __restrict__ out,
+                                                      long long n) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = lo[i] + hi[i];
+}
+}  // namespace
+
+// One observation per link (obs1 + obs2: what the reference keeps in an edge's 'observations', CreateGraph.py:849,862),
+// summed on the device and copied on a stream of the context's own: the ONE call of the ctx layer that may run on a second
+// host thread beside the calling thread's (score_edges, the fetches): it touches nothing those use but reads obs_lo / obs_hi.
+int besst_ctx_fetch_observation_sums(besst_ctx* c, int32_t* out) {
+    BESST_NEED_BUILT(c);
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("fetch_observation_sums: cannot select device %d", c->device); return BESST_ERR_HIP; }
+    const int64_t L = c->n_tuples;
+    if (L <= 0) return BESST_OK;
+    BESST_REQUIRE(out, "fetch_observation_sums: null buffer");
+    if (!c->side_stream) BESST_HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    int rc = c->obs_sum.ensure((size_t)L);
+    if (rc) return rc;
+    const int64_t want = (L + 1023) / 1024;
+    hipLaunchKernelGGL(obs_sum_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, c->side_stream, c->obs_lo.p, c->obs_hi.p,
+                       c->obs_sum.p, (long long)L);
+    BESST_HIP_TRY(hipGetLastError());
+    BESST_HIP_TRY(hipMemcpyAsync(out, c->obs_sum.p, (size_t)L * 4, hipMemcpyDeviceToHost, c->side_stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->side_stream));
     return BESST_OK;
 }
 

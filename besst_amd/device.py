@@ -21,22 +21,103 @@ class EdgeTable(object):
     ``u``/``v`` are node codes (``scaffold_id * 2 + (side == 'R')``) with ``u < v``;
     ``is_fishy`` rows carry the BWA-quirk counts of CreateGraph.py:141-163, the other rows the
     link statistics of CreateEdge (:842-862).  ``obs_lo``/``obs_hi`` hold per-link observations
-    grouped by row (slice ``offset[i] : offset[i] + n[i]``), in BAM order.
+    grouped by row (slice ``offset[i] : offset[i] + n[i]``), in BAM order; ``observation_sums()`` is
+    their sum, one value per link - an edge's `observations`.  A table that comes from a GraphContext
+    holds the three columns lazily (``source``: the context's ObservationSource): they cross PCIe when
+    something reads them.
     """
 
-    def __init__(self, key, mask, n, sum_obs, sum_obs_sq, first_idx, offset, node_bits, obs_lo, obs_hi):
+    def __init__(self, key, mask, n, sum_obs, sum_obs_sq, first_idx, offset, node_bits, obs_lo, obs_hi, source=None):
         self.key, self.mask, self.n = key, mask, n
         self.sum_obs, self.sum_obs_sq = sum_obs, sum_obs_sq
         self.first_idx, self.offset = first_idx, offset
         self.node_bits = node_bits
-        self.obs_lo, self.obs_hi = obs_lo, obs_hi
+        self._obs_lo, self._obs_hi, self._sums, self._source = obs_lo, obs_hi, None, source
         pair = key >> np.uint64(1)
         self.is_fishy = (key & np.uint64(1)).astype(bool)
         self.u = (pair >> np.uint64(node_bits)).astype(np.int64)
         self.v = (pair & np.uint64((1 << node_bits) - 1)).astype(np.int64)
 
+    def _ends(self):
+        if self._obs_lo is None:
+            self._obs_lo, self._obs_hi = self._source.ends()
+        return self._obs_lo, self._obs_hi
+
+    @property
+    def obs_lo(self):
+        return self._ends()[0]
+
+    @property
+    def obs_hi(self):
+        return self._ends()[1]
+
+    def observation_sums(self):
+        if self._sums is None:
+            self._sums = self._source.sums() if self._obs_lo is None else self._obs_lo + self._obs_hi
+        return self._sums
+
     def __len__(self):
         return int(self.key.shape[0])
+
+    def __getstate__(self):                                  # (pickled by the sharded build's gather: plain columns)
+        d = dict(self.__dict__)
+        d['_obs_lo'], d['_obs_hi'] = self._ends()
+        d['_source'] = None
+        return d
+
+
+class ObservationSource(object):
+    """The observation columns of the table a GraphContext has built, while they are still on the device.  The one
+    column the graphs need - obs_lo + obs_hi per link - is summed on the device and fetched by a background thread
+    (besst_ctx_fetch_observation_sums: its own stream; ctypes releases the interpreter lock for the call) from the moment
+    the table exists, under CreateGraph.PE's host work; the two columns apart are fetched when somebody asks.  The context
+    finishes a pending fetch before its records or the context itself go."""
+
+    def __init__(self, ctx, n_tuples):
+        import threading
+        self._ctx, self._n = ctx, int(n_tuples)
+        self._sums, self._error, self._ends_cols = None, None, None
+        self._thread = threading.Thread(target=self._fetch, name='besst-observations', daemon=True)
+        self._thread.start()
+
+    def _fetch(self):
+        try:
+            out = np.empty(self._n, dtype=np.int32)
+            _lib.check(self._ctx._lib.besst_ctx_fetch_observation_sums(self._ctx._ctx, _lib.ptr(out)), 'fetch_observation_sums')
+            self._sums = out
+        except BaseException as e:                           # handed to whoever joins
+            self._error = e
+
+    def finish(self):
+        t = self._thread
+        if t is not None:
+            t.join()
+            self._thread = None
+        if self._error is not None:
+            raise self._error
+
+    def sums(self):
+        self.finish()
+        return self._sums
+
+    def ends(self):
+        if self._ends_cols is None:
+            self.finish()
+            ctx = self._ctx
+            if ctx is None or not ctx._ctx:
+                raise BesstDeviceError('the observation columns were not fetched before the context was closed')
+            lo = np.empty(self._n, dtype=np.int32)
+            hi = np.empty(self._n, dtype=np.int32)
+            _lib.check(ctx._lib.besst_ctx_fetch_observations(ctx._ctx, _lib.ptr(lo), _lib.ptr(hi)), 'fetch_observations')
+            self._ends_cols = (lo, hi)
+        return self._ends_cols
+
+    def detach(self):
+        """The context is about to go (or to build another table): what is pending is finished, nothing refers to it after."""
+        try:
+            self.finish()
+        finally:
+            self._ctx = None
 
 
 # Wall time spent inside the C-ABI calls of GraphContext (seconds per method), filled only while `CALL_SECONDS` is a dict:
@@ -78,10 +159,18 @@ class GraphContext(object):
         self.device = int(device)
         self.n_contigs = 0
 
+    def _detach_observations(self):
+        src, self._observations = getattr(self, '_observations', None), None
+        if src is not None:
+            src.detach()
+
     def close(self):
         if getattr(self, '_ctx', None):
-            self._lib.besst_ctx_destroy(self._ctx)
-            self._ctx = None
+            try:
+                self._detach_observations()
+            finally:
+                self._lib.besst_ctx_destroy(self._ctx)
+                self._ctx = None
 
     def __del__(self):
         try:
@@ -115,11 +204,13 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_set_library(self._ctx, C.byref(p)), 'set_library')
 
     def clear_records(self):
+        self._detach_observations()
         _lib.check(self._lib.besst_ctx_clear_records(self._ctx), 'clear_records')
 
     @_timed
     def push_records(self, batch):
         """``batch``: a RecordBatch (or anything with the eight SoA columns)."""
+        self._detach_observations()
         cols = [_lib.as_col(batch.tid, np.int32), _lib.as_col(batch.mtid, np.int32),
                 _lib.as_col(batch.pos, np.int32), _lib.as_col(batch.mpos, np.int32),
                 _lib.as_col(batch.tlen, np.int32), _lib.as_col(batch.flag, np.uint16),
@@ -141,6 +232,7 @@ class GraphContext(object):
         -> (IngestStats, head rlen, head alen, head qlen)."""
         import os
         from ._lib import IngestStats
+        self._detach_observations()
         mode = mode or os.environ.get('BESST_INGEST', 'auto')
         if mode not in ('auto', 'device', 'host'):
             raise ValueError("push_bam: mode must be 'auto', 'device' or 'host'")
@@ -253,6 +345,7 @@ class GraphContext(object):
     # ---- graph build -----------------------------------------------------------------------------
     @_timed
     def build_graph(self):
+        self._detach_observations()                          # (an earlier table's columns, before they are overwritten)
         _lib.check(self._lib.besst_ctx_build_graph(self._ctx), 'build_graph')
         rows, tuples = C.c_int64(), C.c_int64()
         _lib.check(self._lib.besst_ctx_edge_count(self._ctx, C.byref(rows), C.byref(tuples)), 'edge_count')
@@ -268,15 +361,13 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_fetch_edges(self._ctx, _lib.ptr(key), _lib.ptr(mask), _lib.ptr(n),
                                                    _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(first), _lib.ptr(off),
                                                    C.byref(nb)), 'fetch_edges')
-        lo = np.empty(L, dtype=np.int32)
-        hi = np.empty(L, dtype=np.int32)
-        _lib.check(self._lib.besst_ctx_fetch_observations(self._ctx, _lib.ptr(lo), _lib.ptr(hi)),
-                   'fetch_observations')
+        # the observation columns stay on the device: their sum starts crossing in the background now (ObservationSource)
+        self._observations = ObservationSource(self, L)
         aligned = np.empty(self.n_contigs, dtype=np.int64)
         _lib.check(self._lib.besst_ctx_fetch_coverage(self._ctx, _lib.ptr(aligned)), 'fetch_coverage')
         ctr = Counters()
         _lib.check(self._lib.besst_ctx_fetch_counters(self._ctx, C.byref(ctr)), 'fetch_counters')
-        return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, lo, hi), aligned, ctr
+        return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, None, None, source=self._observations), aligned, ctr
 
     @_timed
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):

@@ -278,6 +278,12 @@ int besst_ctx_fetch_edges(besst_ctx* ctx, uint64_t* key, uint32_t* mask, uint32_
 /* Per-tuple observations grouped by edge row, BAM order inside a row: obs_lo belongs to the row's
  * min node, obs_hi to its max node; observations[i] = obs_lo[i] + obs_hi[i] (CreateGraph.py:842-862). */
 int besst_ctx_fetch_observations(besst_ctx* ctx, int32_t* obs_lo, int32_t* obs_hi);
+/* The same as ONE column: out[i] = obs_lo[i] + obs_hi[i], the entries of an edge's `observations` list
+ * (BESST/CreateGraph.py:849,862) - summed on the device, half the bytes across PCIe.  It works on a stream and a buffer of
+ * its own and is the one call of the ctx layer that may run on a second host thread while the caller's thread goes on with
+ * besst_ctx_score_edges / the other fetches (the Python drop-in starts it in the background when the table has been built
+ * and joins it when an edge's observations are first read, or the session closes). */
+int besst_ctx_fetch_observation_sums(besst_ctx* ctx, int32_t* out);
 
 /* cont_aligned_len numerators (CreateGraph.py:138-139), one int64 per tid. */
 int besst_ctx_fetch_coverage(besst_ctx* ctx, int64_t* aligned);

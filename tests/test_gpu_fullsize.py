@@ -226,3 +226,89 @@ def test_variant_streams_resident_builder(config, pairs, nc, variant):
         plain = workload.make_device(dev, config, 0, pairs=pairs, nc=nc)
         keys, _, _, _ = CO.record_loop(plain['batch'], plain['table'], plain['lib'], plain['node_bits'])
         assert len(table) > 1.5 * len(np.unique(keys))                           # the chimeric links did make edges
+
+
+def oracle_in_slices(cols, asm, table, lib, node_bits, slice_records=100_000_000, threads=None, read_len=100):
+    """The C oracle over device-resident columns without a host copy of the whole stream: slices of `slice_records`, the
+    duplicate chain's state (CreateGraph.py:835-838,869-870) carried from slice to slice, counters and coverage summed,
+    tuples concatenated in stream order."""
+    from besst_amd import synth
+    n = int(cols['tid'].shape[0])
+    threads = threads or max(1, min(64, os.cpu_count() or 1))
+    prev, keys, payload = (-1, -1), [], []
+    aligned, ctr = None, None
+    for lo in range(0, n, slice_records):
+        part = synth.device_columns_to_batch(asm, {k: v[lo:lo + slice_records] for k, v in cols.items()}, read_len)
+        k, p, a, c = CO.record_loop(part, table, lib, node_bits, prev=prev, threads=threads)
+        prev = (int(c[8]), int(c[9]))
+        keys.append(k)
+        payload.append(p)
+        aligned = a.copy() if aligned is None else aligned + a
+        ctr = c.copy() if ctr is None else np.concatenate([ctr[:8] + c[:8], c[8:]])
+        del part
+    return np.concatenate(keys), np.concatenate(payload), aligned, ctr
+
+
+def test_full_size_c4_one_gpu(record_path):
+    """BASELINE.json configs[3] at FULL size on ONE GPU: 500 k contigs, two libraries of 5e8 read pairs = 1e9 records (25 GB)
+    each - more than 2^30 records in one stream, 41-bit edge keys at full density - the PE library on the first-library
+    table, then the mate-pair library with PE contamination on the contig table a previous pass leaves behind (scaffold ids
+    counting on, MakeScaffolds.py:276), each through DeviceGraphBuilder.step() against the C oracle on every record."""
+    import torch
+    from besst_amd import pipeline, synth
+    if os.environ.get('BESST_FULL_SIZE') == '0':
+        pytest.skip('BESST_FULL_SIZE=0')
+    if record_path != 'fused':
+        pytest.skip('once (the record loop is selected per library by its candidate density)')
+    os.environ.pop('BESST_RECORD_PATH', None)
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 150e9 or _host_memory_gib() < 64:
+        pytest.skip('needs 150 GB of free HBM and 64 GiB of host memory (%.0f GB / %.0f GiB here)' % (free / 1e9, _host_memory_gib()))
+    dev = torch.device('cuda', 0)
+    cfg = synth.CONFIGS['C4']
+    seed = synth.config_seed('C4')
+    asm = synth.make_assembly(cfg['nc'], cfg['median'], seed)
+    per_lib = cfg['pairs'] // len(cfg['libs'])
+    assert per_lib == 500_000_000
+    for li, spec in enumerate(cfg['libs']):
+        lib = workload.library_constants(spec)
+        thr = spec.mean + 4 * spec.sd
+        table = workload.first_library_table(asm.lengths, thr) if li == 0 else \
+            workload.later_library_table(asm, seed + 50 + li, thr, first_scaffold_id=asm.nc * li + 1)
+        node_bits = workload.node_bits_for(table)
+        assert node_bits >= 20
+        cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li, dev)
+        rec = pipeline.DeviceRecords.from_columns(cols)
+        assert rec.n == 1_000_000_000
+        probe = pipeline.DeviceGraphBuilder(dev, asm.nc, node_bits, lib, rec.n, 1)
+        probe.set_contigs(**table)
+        probe.reset()
+        probe.classify(rec)
+        n_tuples, _ = probe.read_sizes()
+        del probe
+        gb = pipeline.DeviceGraphBuilder(dev, asm.nc, node_bits, lib, rec.n, int(n_tuples * 1.1) + 4096)
+        gb.set_contigs(**table)
+        for _ in range(2):
+            gb.step(rec)
+        got = gb.fetch_table()
+        ctr = gb.read_counters()
+        keys, payload, c_aligned, c_ctr = oracle_in_slices(cols, asm, table, lib, node_bits)
+        rows = CO.edge_rows(keys, payload)
+        assert [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates, ctr.reads_with_too_long_insert,
+                ctr.fishy_reads, ctr.n_tuples, ctr.n_reach, ctr.prev_obs1, ctr.prev_obs2] == c_ctr.tolist()
+        assert np.array_equal(gb.aligned.cpu().numpy(), c_aligned)
+        link = ~got.is_fishy
+        assert np.array_equal(got.key, rows['key']) and np.array_equal(got.n.astype(np.int64), rows['n'])
+        assert np.array_equal(got.first_idx.astype(np.int64), rows['first_idx'])
+        assert np.array_equal(got.offset.astype(np.int64), rows['offset'])
+        assert np.array_equal(got.sum_obs[link], rows['sum_obs'][link])
+        assert np.array_equal(got.sum_obs_sq[link], rows['sum_obs_sq'][link])
+        assert np.array_equal(got.mask[link].astype(np.int64), rows['mask'][link])
+        assert np.array_equal(got.obs_lo.astype(np.int64), rows['obs_lo'])
+        assert np.array_equal(got.obs_hi.astype(np.int64), rows['obs_hi'])
+        assert np.all(np.diff(got.key.astype(np.uint64)) > 0) and int(got.n.sum()) == ctr.n_tuples == len(keys)
+        assert len(rows['key']) > 100_000 and ctr.nr_of_duplicates > 0
+        print('C4 library %d (%s): %d tuples, %d edge rows, record path %s' % (li, spec.orientation, ctr.n_tuples, len(got),
+                                                                               'fused' if gb.params.record_path else 'two-pass'))
+        del gb, rec, cols, got, keys, payload, rows
+        torch.cuda.empty_cache()
