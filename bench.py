@@ -67,6 +67,10 @@ def parse_args():
                     help='N > 1: what a rank holds of a library - "contiguous": the rank-th (tid, pos)-contiguous cut of ONE '
                          'stream, what distributed.ingest_slice yields on a real file (a slice\'s tuples concentrate on few '
                          'owners); "independent": a whole-genome stream of its own per rank (rounds 2 and 3)')
+    ap.add_argument('--from-bam', action='store_true',
+                    help='--gpus N: rank 0 writes every library as ONE sequencer-like BAM (untimed), every rank ingests its '
+                         'slice of the file on its GPU (distributed.ingest_slice, timed and reported per rank), and the timed '
+                         'steps run on the ingested records; default 12.5 M pairs per library and GPU')
     ap.add_argument('--in-flight', type=int, default=3,
                     help='library passes kept in flight (one HIP stream each) for the extra "overlapped" figure; '
                          '0 skips it.  The headline value is always measured with ONE pass at a time.')
@@ -237,6 +241,7 @@ def dropin_timing(device, config, pairs=None, contigs=None):
 
     C_dict = {name: _SeqLen(int(n)) for name, n in zip(batch.references, batch.lengths)}
     dev_mod.CALL_SECONDS = {}
+    CreateGraph.STAGE_SECONDS = {}
     t0 = time.perf_counter()
     libmetrics.get_metrics(batch, p, p.information_file)
     t1 = time.perf_counter()
@@ -244,11 +249,13 @@ def dropin_timing(device, config, pairs=None, contigs=None):
     t2 = time.perf_counter()
     lib_s = dict(dev_mod.CALL_SECONDS)
     dev_mod.CALL_SECONDS = None
+    pe_stages = {k: round(v, 3) for k, v in CreateGraph.STAGE_SECONDS.items()}
+    CreateGraph.STAGE_SECONDS = None
     session.close_session(batch)
     total = t2 - t0
     return {'records': len(batch), 'get_metrics_s': round(t1 - t0, 3), 'PE_s': round(t2 - t1, 3), 'total_s': round(total, 3),
             'library_s': round(sum(lib_s.values()), 3), 'library_calls_s': {k: round(v, 3) for k, v in lib_s.items()},
-            'host_share': round(1.0 - sum(lib_s.values()) / total, 3), 'edges_G': G.number_of_edges(),
+            'PE_stages_s': pe_stages, 'host_share': round(1.0 - sum(lib_s.values()) / total, 3), 'edges_G': G.number_of_edges(),
             'edges_G_prime': Gp.number_of_edges(), 'pairs_per_s': (len(batch) // 2) / total}
 
 
@@ -990,7 +997,8 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     seed = synth.config_seed(config)
     n_ctg = int(args.contigs if args.contigs is not None else cfg['nc'])
     asm = synth.make_assembly(n_ctg, cfg['median'], seed)
-    per_lib = int(args.pairs if args.pairs is not None else cfg['pairs'] // len(cfg['libs']) // 8)
+    per_lib = int(args.pairs if args.pairs is not None else
+                  (12_500_000 if args.from_bam else cfg['pairs'] // len(cfg['libs']) // 8))
     cap_env = os.environ.get('BESST_PAIR_CAPACITY')     # start from a (too small) region capacity: grow-and-retry path
     # the step's HBM budget, item by item (distributed.memory_budget), against what the GPU has free - before anything
     # is allocated.  Tuples per record as in tools/memory_budget.py: twice what the libraries' streams measure.
@@ -1007,9 +1015,16 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
                          % (world, need / 1e9, ', '.join('%s %.1f GB' % (k, v / 1e9) for k, v in budget.items()),
                             free_hbm / 1e9))
     jobs, wls = [], []
+    from_bam = [] if args.from_bam else None
+    keep_bams = []
     for li, spec in enumerate(cfg['libs']):
-        cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device,
-                                             window=(rank, world) if (args.slices == 'contiguous' and world > 1) else None)
+        if args.from_bam:
+            cols, report, bam = ingest_library_from_bam(asm, spec, per_lib, seed + 100 + li, device, rank, world, li)
+            from_bam.append(report)
+            keep_bams.append(bam)                            # (owns the columns' memory)
+        else:
+            cols = synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li + 7919 * rank, device,
+                                                 window=(rank, world) if (args.slices == 'contiguous' and world > 1) else None)
         thr = spec.mean + 4 * spec.sd
         table = (workload.first_library_table(asm.lengths, thr) if li == 0 else
                  workload.later_library_table(asm, seed + 50 + li, thr, first_scaffold_id=asm.nc * li + 1))
@@ -1144,10 +1159,80 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
             'single_gpu_same_shape': same_shape,
             'cpu_baseline': sharded_cpu_baseline(args, wls[0]),
         }
+        if from_bam is not None:
+            out['from_bam'] = from_bam
+            out['slices'] = 'slices of one BAM file per library (distributed.ingest_slice)'
+            out['data'] = 'synthetic (written as BAM files by rank 0, untimed; ingested by every rank on its GPU)'
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def ingest_library_from_bam(asm, spec, per_lib, seed, device, rank, world, li):
+    """--from-bam: ONE file for the library (rank 0 draws world x per_lib pairs, writes them as a sequencer-like BAM into
+    /dev/shm - untimed scaffolding), then every rank ingests its slice on its GPU.  Timed: rank 0's slice on its own first
+    (the other ranks wait: the like-for-like one-rank figure), then all slices together - what tells whether the host's page
+    cache and cores or the GPUs bound an N-GPU ingest.  -> (column dict, report for the bench line on rank 0, ResidentBam)."""
+    import shutil
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from besst_amd import bamio, distributed, synth
+    multi = world > 1 and dist.is_initialized()
+    box = [None]
+    if rank == 0:
+        cols = synth.simulate_library_device(asm, spec, per_lib * world, seed, device)
+        batch = synth.device_columns_to_batch(asm, cols, int(spec.read_len))
+        del cols
+        torch.cuda.empty_cache()
+        base = '/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > 128 * len(batch) else None
+        tmp = tempfile.mkdtemp(prefix='besst_amd_bam_', dir=base)
+        path = os.path.join(tmp, 'library%d.bam' % (li + 1))
+        t0 = time.perf_counter()
+        bamio.write_bam(path, batch, realistic=True)
+        box[0] = (path, len(batch), os.path.getsize(path), round(time.perf_counter() - t0, 2))
+        del batch
+    if multi:
+        dist.broadcast_object_list(box, src=0)
+    path, n_records, n_bytes, write_s = box[0]
+    solo = None
+    try:
+        if multi:
+            if rank == 0:                                    # slice 0 alone: it begins behind the header, nothing to settle
+                t0 = time.perf_counter()
+                alone = bamio.ResidentBam(path, device_index=device.index, part=(0, world), first_skip=-1)
+                dt = time.perf_counter() - t0
+                solo = {'records': len(alone), 'ingest_s': round(dt, 4), 'records_per_s': len(alone) / dt,
+                        'staging_s': round(alone.ingest.decode_seconds, 4), 'wait_s': round(alone.ingest.copy_wait_seconds, 4)}
+                alone.close()
+            dist.barrier()
+        info = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bam, cols = distributed.ingest_slice(path, rank, world, device_index=device.index, info=info)
+        dt = time.perf_counter() - t0
+        mine = {'rank': rank, 'records': len(bam), 'ingest_s': round(dt, 4), 'staging_s': round(bam.ingest.decode_seconds, 4),
+                'wait_s': round(bam.ingest.copy_wait_seconds, 4), 'chunks': int(bam.ingest.chunks), 'rounds': info.get('rounds', 1),
+                'reads': info.get('reads', 1), 'compressed_bytes': int(bam.ingest.bytes_h2d)}
+        per_rank = [mine]
+        if multi:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+    finally:
+        if multi:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+    slowest = max(r['ingest_s'] for r in per_rank)
+    assert sum(r['records'] for r in per_rank) == n_records
+    report = {'library': li + 1, 'file': 'sequencer-like: pseudo-random bases, slowly changing qualities, %.1f B/record compressed'
+                                         % (n_bytes / float(n_records)),
+              'bam_bytes': n_bytes, 'records': n_records, 'write_bam_s_untimed': write_s, 'per_rank': per_rank,
+              'ingest_s_slowest_rank': slowest, 'aggregate_records_per_s': n_records / slowest,
+              'handshake_rounds': max(r['rounds'] for r in per_rank), 'slices_read_twice': sum(r['reads'] - 1 for r in per_rank),
+              'rank0_slice_alone': solo}
+    return cols, report, bam
 
 
 def sharded_cpu_baseline(args, wl):

@@ -35,6 +35,26 @@ from .mathstats_compat import MaxObsDistr
 from .nxcompat import Graph
 
 
+# Wall time of PE's stages on the leading rank (seconds, summed over calls), filled only while this is a dict: bench.py and
+# tools/pe_host_profile.py set it to {} to report where PE's host time goes.
+STAGE_SECONDS = None
+
+
+class _Stages(object):
+    __slots__ = ('t',)
+
+    def __init__(self):
+        from time import perf_counter
+        self.t = perf_counter() if STAGE_SECONDS is not None else None
+
+    def mark(self, name):
+        if self.t is not None:
+            from time import perf_counter
+            now = perf_counter()
+            STAGE_SECONDS[name] = STAGE_SECONDS.get(name, 0.0) + now - self.t
+            self.t = now
+
+
 def PE(Contigs, Scaffolds, Information, C_dict, param, small_contigs, small_scaffolds, bam_file):
     """CreateGraph.PE (CreateGraph.py:45).  The cyclic garbage collector is paused for the duration of the call: the
     objects and graphs built here are hundreds of thousands of small containers that reference nothing but numbers and
@@ -71,6 +91,7 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     G_prime = Graph()
     print('Parsing BAM file...', file=Information)
     batch = sess.batch
+    stages = _Stages()
 
     if param.first_lib:
         start_init = time()
@@ -80,6 +101,7 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
         start_clean = time()
         CleanObjects(Contigs, Scaffolds, param, Information, small_contigs, small_scaffolds)
         print('Time cleaning BESST objects for next library: ', time() - start_clean, file=Information)
+    stages.mark('objects (InitializeObjects / CleanObjects)')
 
     if len(Scaffolds) == 0:
         if param.output_directory and not os.path.isfile(param.output_directory + '/repeats.fa'):
@@ -105,13 +127,15 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     print('Reading bam file and creating scaffold graph...', file=Information)
     staart = time()
     table_cols, tids_of_group = contig_table(batch.references, Contigs, small_contigs, Scaffolds, small_scaffolds)
+    stages.mark('graph plans + contig table')
     ctx = sess.ctx
     ctx.set_contigs(**table_cols)
     ctx.set_library(param.read_len, param.ins_size_threshold, param.min_mapq, param.orientation,
                     param.detect_duplicate, param.extend_paths, param.no_score)
-    table, aligned, ctr = ctx.build_graph()
+    table, aligned, ctr = ctx.build_graph(lazy_observations=True)
     counter = counters(ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates,
                        ctr.prev_obs1, ctr.prev_obs2, ctr.reads_with_too_long_insert)
+    stages.mark('device: record loop, edge table, fetch')
     links = LinkTable(table)
     plan_G.take(links, MASK_G)
     plan_Gp.take(links, MASK_GPRIME)
@@ -169,11 +193,15 @@ def _PE_leader(sess, Contigs, Scaffolds, Information, C_dict, param, small_conti
     print('Removed {0} edges from graph G of border contigs.'.format(counter_low_support), file=Information)
     remove_edges_below_threshold(plan_Gp, param)
 
+    stages.mark('coverage, repeats, filters (columns)')
     scores = None
     if not param.no_score:
         scores = GiveScoreOnEdges(plan_G, Scaffolds, small_scaffolds, Contigs, param, Information, 'G', ctx)
+    stages.mark('GiveScoreOnEdges (device scoring + host scalars)')
     plan_G.build(G, scores)
+    stages.mark('assemble G')
     plan_Gp.build(G_prime, None)
+    stages.mark('assemble G_prime')
     print('Number of edges in G_prime  (after removing edges under -e threshold (if not specified, default is '
           '-e 3): ', plan_Gp.number_of_edges(), file=Information)
     print('\n -------------------------------------------------------------\n', file=Information)
@@ -376,7 +404,7 @@ class GraphPlan(object):
 
     def add_scaffolds(self, scaffolds):
         self.sid.extend(scaffolds)
-        self.length.extend(s.s_length for s in scaffolds.values())
+        self.length.extend(map(operator.attrgetter('s_length'), scaffolds.values()))
 
     def take(self, links, mask_bit):
         self.links = links

@@ -49,11 +49,13 @@ namespace {
 
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
-constexpr int kDistBits = 10;                    // the distance code's primary table (9 or 8 bits and a seventh wave per SIMD: +-1 %)
+constexpr int kDistBits = 9;                     // the distance code's primary table (10 bits: the same speed; the KB went to the second-level table)
 constexpr int kInfWaves = 6;                     // per SIMD (80 VGPRs, 6.2 KB of LDS)
 constexpr int kDistSize = 1 << kDistBits;
 constexpr int kClBits = 7;
-constexpr int kLaneLongBits = 3;                 // literal / length codes of up to kTabBits + 3 bits are decoded by the lanes too
+constexpr int kLaneLongBits = 3;                 // literal / length codes of up to kTabBits + 3 bits are decoded by the lanes too:
+constexpr int kSubCap = 64;                      // through a SECOND-LEVEL table of 2^kLaneLongBits entries per primary slot that is the prefix of longer codes
+constexpr uint32_t kLinkFlag = 0x8000u, kLinkMask = 0xC000u;   // primary entry of such a slot: kLinkFlag | first entry of its second-level table << 4
 constexpr uint32_t kGroupLit = 0x80000000u;   // output group: the lane holds a literal (else a source position, < 2^31)
 constexpr uint32_t kNoEntry = 0xFFF0u;     // table entry of a pattern that is no short code: length nibble 0, and not below 0x1000 (a literal)
 
@@ -72,6 +74,7 @@ struct InflateLds {
     uint16_t lit_tab[kTabSize];
     uint16_t dist_tab[kDistSize];
     uint16_t cl_tab[1 << kClBits];
+    uint16_t lit_sub[kSubCap << kLaneLongBits];   // second-level entries: symbol << 4 | length (kTabBits + 1 ..), or kNoEntry
     uint16_t lit_sorted[288];
     uint16_t dist_sorted[32];
     uint16_t cl_sorted[32];
@@ -87,7 +90,12 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // `sorted` (symbols by length, then by value), then the primary table of 2^bits entries (symbol << 4 | length; kNoEntry:
 // the code is longer than the table, or the pattern is not a code).  Returns false when the lengths oversubscribe the
 // code space.  All lanes take part; everything returned in LDS.
-__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits, uint16_t* tab, uint16_t* sorted, CanonLds* c, int lane) {
+// sub / owner (literal / length code only): the second-level table.  Every primary slot that is no short code is the prefix
+// of longer ones (or of nothing, in an incomplete code); the first kSubCap of them, in slot order, get 2^kLaneLongBits entries
+// each - the slot's pattern extended by that many bits, decoded canonically like the primary slots - and a primary entry that
+// points there; what lies beyond (more such slots, longer codes) keeps kNoEntry and is left to the one-symbol path.
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits, uint16_t* tab, uint16_t* sorted, CanonLds* c, int lane,
+                                           uint16_t* sub = nullptr, uint32_t* owner = nullptr) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t cnt[16];
 #pragma unroll
@@ -152,6 +160,35 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
         tab[slot] = (uint16_t)e;
     }
     __builtin_amdgcn_wave_barrier();
+    if (sub != nullptr) {
+        uint32_t n_sub = 0;                                  // uniform
+        for (int base = 0; base < (1 << bits); base += 64) {
+            const int slot = base + lane;
+            const bool open = tab[slot] == (uint16_t)kNoEntry;
+            const unsigned long long m = __ballot(open);
+            const uint32_t r = n_sub + (uint32_t)__popcll(m & lt);
+            if (open && r < (uint32_t)kSubCap) {
+                owner[r] = (uint32_t)slot;
+                tab[slot] = (uint16_t)(kLinkFlag | (r << (kLaneLongBits + 4)));
+            }
+            n_sub += (uint32_t)__popcll(m);
+        }
+        if (n_sub > (uint32_t)kSubCap) n_sub = (uint32_t)kSubCap;
+        __builtin_amdgcn_wave_barrier();
+        const int wide = bits + kLaneLongBits;
+        for (uint32_t e = (uint32_t)lane; e < (n_sub << kLaneLongBits); e += 64u) {
+            const uint32_t pat = owner[e >> kLaneLongBits] | ((e & ((1u << kLaneLongBits) - 1u)) << bits);   // LSB first, as the input arrives
+            const uint32_t r = __brev(pat) >> (32 - wide);
+            uint32_t v = kNoEntry;
+#pragma unroll
+            for (int L = kTabBits + 1; L <= kTabBits + kLaneLongBits; ++L) {
+                const uint32_t d = (r >> (wide - L)) - first[L];
+                if (v == kNoEntry && d < cnt[L]) v = ((uint32_t)sorted[offs[L] + d] << 4) | (uint32_t)L;
+            }
+            sub[e] = (uint16_t)v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     return true;
 }
 
@@ -418,7 +455,7 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
                 if (uni(s.lens[256]) == 0u) { err = kInfBadLengths; break; }     // no end-of-block code
             }
             __builtin_amdgcn_wave_barrier();
-            if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane)) { err = kInfOversubscribed; break; }
+            if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane, s.lit_sub, s.mark)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kDistBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
             // ---- the symbols, a batch per turn.  One symbol at a time cost ~50 scalar instructions and branches per symbol,
             // and a SIMD issues ONE of those per four cycles for all its waves: by the counters that slot was 90 % in use
@@ -443,23 +480,14 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
                 const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, t & 31u);     // 32 bits of input from that bit on
                 const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
                 const uint32_t eb = s.dist_tab[x & (uint32_t)(kDistSize - 1)];
-                uint32_t la = ea & 15u, sa = ea >> 4;
-                {
-                    // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals), decoded
-                    // by the lanes as well: canonically, a table word per length (the same for every lane)
-                    const uint32_t r = __brev(x) >> 17;      // the next 15 bits, first bit on top
-                    uint32_t at = 0xffffffffu;
-#pragma unroll
-                    for (int L = kTabBits + 1; L <= kTabBits + kLaneLongBits; ++L) {
-                        const unsigned long long k = s.lit_c.pk[L];
-                        const uint32_t d = (r >> (15 - L)) - ((uint32_t)k & 0xffffu);
-                        if (la == 0u && d < ((uint32_t)(k >> 16) & 0xffffu)) {
-                            la = (uint32_t)L;
-                            at = (uint32_t)(k >> 32) + d;
-                        }
-                    }
-                    if (at != 0xffffffffu) sa = s.lit_sorted[at];
-                }
+                // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals) are decoded by the
+                // lanes as well: the primary entry of their first kTabBits bits points to a second-level table, indexed by the
+                // next kLaneLongBits bits (every lane looks - a lane with a short code at entry 0 - so that no branch stands
+                // between the two look-ups)
+                const bool link = (ea & kLinkMask) == kLinkFlag;
+                const uint32_t e2 = s.lit_sub[link ? ((ea >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u)) : 0u];
+                const uint32_t ec = link ? e2 : ea;
+                const uint32_t la = ec & 15u, sa = ec >> 4;
                 const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
                 const bool is_lit = la != 0u && sa < 256u, is_len = la != 0u && sa > 256u && sa < 286u;
                 const uint32_t xa = is_len ? li >> 9 : 0u;

@@ -344,7 +344,10 @@ class GraphContext(object):
 
     # ---- graph build -----------------------------------------------------------------------------
     @_timed
-    def build_graph(self):
+    def build_graph(self, lazy_observations=False):
+        """-> (EdgeTable, coverage numerators, Counters).  lazy_observations (what CreateGraph.PE asks for): the observation
+        columns stay on the device - their per-link sum crosses PCIe in the background (ObservationSource) and obs_lo /
+        obs_hi only if somebody reads them while the context lives; default: the two columns are fetched with the table."""
         self._detach_observations()                          # (an earlier table's columns, before they are overwritten)
         _lib.check(self._lib.besst_ctx_build_graph(self._ctx), 'build_graph')
         rows, tuples = C.c_int64(), C.c_int64()
@@ -361,13 +364,19 @@ class GraphContext(object):
         _lib.check(self._lib.besst_ctx_fetch_edges(self._ctx, _lib.ptr(key), _lib.ptr(mask), _lib.ptr(n),
                                                    _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(first), _lib.ptr(off),
                                                    C.byref(nb)), 'fetch_edges')
-        # the observation columns stay on the device: their sum starts crossing in the background now (ObservationSource)
-        self._observations = ObservationSource(self, L)
+        lo = hi = None
+        if lazy_observations:
+            # the observation columns stay on the device: their sum starts crossing in the background now
+            self._observations = ObservationSource(self, L)
+        else:
+            lo = np.empty(L, dtype=np.int32)
+            hi = np.empty(L, dtype=np.int32)
+            _lib.check(self._lib.besst_ctx_fetch_observations(self._ctx, _lib.ptr(lo), _lib.ptr(hi)), 'fetch_observations')
         aligned = np.empty(self.n_contigs, dtype=np.int64)
         _lib.check(self._lib.besst_ctx_fetch_coverage(self._ctx, _lib.ptr(aligned)), 'fetch_coverage')
         ctr = Counters()
         _lib.check(self._lib.besst_ctx_fetch_counters(self._ctx, C.byref(ctr)), 'fetch_counters')
-        return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, None, None, source=self._observations), aligned, ctr
+        return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, lo, hi, source=self._observations), aligned, ctr
 
     @_timed
     def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):

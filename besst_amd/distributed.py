@@ -175,7 +175,7 @@ def _first_error(pairs):
     return None
 
 
-def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None, chunk_blocks=0, group=None):
+def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None, chunk_blocks=0, group=None, info=None):
     """Rank ``rank``'s slice of a BAM file for the sharded build: slice (rank, world) of the file - cut at BGZF block
     boundaries every rank finds on its own - is inflated and decoded on the rank's GPU (besst_ctx_push_bam_device_slice), and
     the resident columns are handed on where they lie (besst_ctx_record_pointers).  -> (bamio.ResidentBam, column dict for
@@ -190,7 +190,8 @@ def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None
 
     A rank whose read fails for any other reason (rank 0, out of memory, a CRC / inflate failure, a re-read that still leads
     nowhere) gathers ('error', status, text) in place of its pair: every rank sees it in the same round and raises
-    SliceIngestError together - nobody is left waiting in a collective."""
+    SliceIngestError together - nobody is left waiting in a collective.  ``info`` (a dict): receives 'rounds' (gathers
+    until the slices had settled) and 'reads' (how often this rank read its slice)."""
     from . import bamio
     dev = rank if device_index is None else device_index
     if world == 1:
@@ -206,8 +207,12 @@ def ingest_slice(path, rank, world, device_index=None, threads=None, gather=None
             dist.all_gather_object(out, pair, group=group)
             return out
     skip, bam, failed, error = -1, None, False, None
+    info = info if info is not None else {}
+    info.update(rounds=0, reads=0)
     for _ in range(world + 1):
+        info['rounds'] += 1
         if bam is None and not failed and error is None:
+            info['reads'] += 1
             try:
                 bam = _read_slice(bamio, path, dev, threads, int(rank), int(world), skip, chunk_blocks)
                 failed = bam is None

@@ -233,7 +233,7 @@ class ShardedContext(object):
                          orientation=orientation, detect_duplicate=bool(detect_duplicate), extend_paths=bool(extend_paths),
                          no_score=bool(no_score))
 
-    def build_graph(self):
+    def build_graph(self, lazy_observations=False):
         self._send(('build', self._table_cols, self._lib))
         return self._build(self._table_cols, self._lib)
 

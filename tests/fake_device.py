@@ -49,7 +49,7 @@ class FakeGraphContext(object):
         counts = MetricsCounts(int(c[0]), int(c[1]), int(c[2]), int(c[3]), len(self._batch()))
         return isize, contam, counts
 
-    def build_graph(self):
+    def build_graph(self, lazy_observations=False):
         ids = self.table['scaf_id'][self.table['cls'] != 0]
         nb = max(1, int((int(ids.max()) if len(ids) else 1) * 2 + 1).bit_length())
         keys, payload, aligned, c = CO.record_loop(self._batch(), self.table, self.lib, nb)

@@ -86,3 +86,29 @@ def test_two_ranks_with_independent_slices():
     assert d['slices'] == 'independent' and d['verified_vs_c_oracle'] is True
     for lib in d['config']['libraries']:
         assert lib['exchange_consistent'] is True and all(lib['verified_vs_c_oracle'].values()), lib
+
+
+def test_two_ranks_from_one_bam_file_per_library():
+    """--from-bam: rank 0 writes each library as one sequencer-like BAM, both ranks ingest their slices on the GPU
+    (distributed.ingest_slice), the timed steps and the oracle check run on the ingested records."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--from-bam'] + SMALL
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    assert d['n_gpus'] == 2 and d['verified_vs_c_oracle'] is True
+    assert len(d['from_bam']) == 2
+    for lib in d['from_bam']:
+        assert lib['records'] == 2 * 2 * 400000 and sum(r['records'] for r in lib['per_rank']) == lib['records']
+        assert [r['rank'] for r in lib['per_rank']] == [0, 1]
+        assert all(r['ingest_s'] > 0 and r['staging_s'] >= 0 and r['chunks'] >= 1 for r in lib['per_rank'])
+        assert lib['handshake_rounds'] >= 1 and lib['aggregate_records_per_s'] > 0
+        assert lib['rank0_slice_alone']['records'] == lib['per_rank'][0]['records']
+    for lib in d['config']['libraries']:
+        assert lib['exchange_consistent'] is True and all(lib['verified_vs_c_oracle'].values()), lib
+    assert abs(d['value'] - 2 * 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
