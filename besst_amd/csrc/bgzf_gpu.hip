@@ -11,9 +11,10 @@
 //                v_readlane; the buffer itself lives in vector registers (the CU's one scalar ALU is this kernel's limit);
 //       tables   canonical Huffman codes from the code lengths: symbols ranked by (length, symbol) with one ballot per
 //                length and 64 symbols, then every lane fills the primary-table slots it owns by DECODING the slot's bit
-//                pattern canonically (first code / count / offset per length) - balanced, no replication loops; codes
-//                longer than the 10-bit primary table (rare) are decoded the same way on the spot; base and extra-bit
-//                count of a length / distance code come from two per-lane registers (v_readlane);
+//                pattern canonically (first code / count / offset per length) - balanced, no replication loops; a slot
+//                that is the prefix of literal / length codes of 11 - 13 bits points to a second-level table of eight
+//                entries, filled the same way (codes beyond that, rare, are decoded canonically on the spot); base and
+//                extra-bit count of a length / distance code come from two per-lane registers (v_readlane);
 //       symbols  SEVERAL per turn of the loop: lane i decodes - speculatively - the literal / length symbol AND the distance
 //                symbol that would begin at bit i of the next 64 bits of input (two table look-ups, base and extra bits:
 //                vector work, the same for every lane), and the chain of symbols that really begin there is then walked
@@ -49,7 +50,10 @@ namespace {
 
 constexpr int kTabBits = 10;
 constexpr int kTabSize = 1 << kTabBits;
-constexpr int kDistBits = 9;                     // the distance code's primary table (10 bits: the same speed; the KB went to the second-level table)
+#ifndef BESST_INF_DISTBITS
+#define BESST_INF_DISTBITS 9
+#endif
+constexpr int kDistBits = BESST_INF_DISTBITS;                     // the distance code's primary table (10 bits: the same speed; the KB went to the second-level table)
 constexpr int kInfWaves = 6;                     // per SIMD (80 VGPRs, 6.2 KB of LDS)
 constexpr int kDistSize = 1 << kDistBits;
 constexpr int kClBits = 7;
@@ -67,7 +71,6 @@ enum : uint32_t {
 
 struct CanonLds {               // per code: count / first code / offset per length, symbols sorted by (length, symbol)
     uint16_t cnt[16], first[16], offs[16];
-    unsigned long long pk[16];  // the same, one word per length: first | cnt << 16 | offs << 32
 };
 
 struct InflateLds {
@@ -129,7 +132,6 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, int bits,
         c->cnt[lane] = (uint16_t)cv;
         c->first[lane] = (uint16_t)fv;
         c->offs[lane] = (uint16_t)ov;
-        c->pk[lane] = (unsigned long long)fv | ((unsigned long long)cv << 16) | ((unsigned long long)ov << 32);
     }
     uint32_t run[16];
 #pragma unroll
