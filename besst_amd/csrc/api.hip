@@ -746,10 +746,12 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         f0 = (int64_t)begin;
         if (map_len < begin) map_len = begin;
     }
-    const size_t nb = (size_t)chunk_blocks;
+    size_t nb = (size_t)chunk_blocks;
     // a chunk: nb blocks or comp_cap compressed bytes, whichever comes first.  The staging slots are pinned (~70 us per
     // MB to allocate and release), so they are sized from the file's first blocks - ~5 KB each in a file of constant
     // qualities, ~18 KB in a sequencer's - with a third in hand; denser blocks further on just make a chunk hold fewer.
+    // A file (or part) of fewer blocks than a chunk gets slots for what it holds: every slot carries 64 KiB of inflated
+    // scratch per block, 0.5 GB at the default chunk, whatever the file's size.
     size_t comp_cap = (size_t)160 << 20;
     {
         const uint8_t* map = bam_file_map(bam);
@@ -757,6 +759,11 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         while (seen < 256 && at + 18 <= map_len && map[at] == 31 && map[at + 1] == 139) {
             at += ((size_t)map[at + 16] | ((size_t)map[at + 17] << 8)) + 1;
             ++seen;
+        }
+        if (seen >= 1 && at <= map_len + 65536) {
+            const double per_block = (double)(at - (size_t)f0) / (double)seen;
+            const size_t blocks = at >= map_len ? seen : (size_t)((double)(map_len - (size_t)f0) / per_block * 1.25) + 64;
+            if (blocks < nb) nb = blocks < 64 ? 64 : blocks;
         }
         if (seen >= 16 && at <= map_len) {
             const size_t guess = align_up((size_t)((double)(at - (size_t)f0) / (double)seen * (double)nb * 1.35) + ((size_t)4 << 20), 4096);
@@ -1070,9 +1077,11 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         } else if (tail_len && slice && (overhang ? fpos < whole_file : map_len < whole_file)) {
             // the slice's last record runs on behind the slice's end: the blocks that follow are inflated for its bytes (and for
             // nothing else: the records that begin in them are the next slice's) - chunk after chunk until the record ends
+            // (a few blocks at first - a record seldom runs over more than one or two -, four times as many while it goes on: the
+            // blocks belong to the next slice, and a damaged one among them is that slice's to report)
+            max_blocks = overhang ? (max_blocks * 4 < nb ? max_blocks * 4 : nb) : (nb < 64 ? nb : 64);
             overhang = true;
             map_len = whole_file;
-            max_blocks = nb < 4096 ? nb : 4096;
             sl[(j + 2) % kSlots].ck = Chunk();
             if (!stage(j + 1)) break;
             if (!nx.ck.n_blocks) { set_error("push_bam_device: the file ends inside a record"); rc = BESST_ERR_ARG; break; }
