@@ -808,6 +808,14 @@ __global__ __launch_bounds__(64) void bam_entry_kernel(const uint8_t* __restrict
     else if (b == forced_block) found = forced_entry < len ? forced_entry : kNoStart;
     else if (forced_block != 0xffffffffu && b < forced_block) found = kNoStart;   // (the bytes of a record of the part before)
     else {
+        // an EMPTY forced block (an interior EOF marker on a chunk boundary) hands its entry on to the first block behind it
+        // that holds bytes: that block's start is KNOWN too, not guessed - nobody in front of it could vouch for a guess
+        bool inherits = forced_block != 0xffffffffu && len != 0u;
+        for (uint32_t k = forced_block; inherits && k < b; ++k) inherits = blocks[k].dst_len == 0u;     // (stops at the first block with bytes)
+        if (inherits) {
+            if (lane == 0) guess[b] = forced_entry < len ? forced_entry : kNoStart;
+            return;
+        }
         for (uint32_t o0 = 0; o0 < len; o0 += 64u) {          // uniform
             const uint32_t o = o0 + (uint32_t)lane;
             bool ok = false;

@@ -113,7 +113,8 @@ class DeviceGraphBuilder(object):
         self._density = torch.zeros(2, dtype=torch.int64, device=device)
         self._presorted = False
         self._last_rec = None
-        self.keys_valid = False                              # self.keys / self.payload hold the last pass's dense tuple stream
+        self.keys_valid = False                              # self.keys holds the last pass's dense tuple stream
+        self.payload_valid = False                           # ... and self.payload (include/besst_amd.h, besst_presort: not after a pass whose record loop kept its tuples in the block segments)
         self.candidate_share = None
         # BESST_REDUCE_* flags of this builder's stage-2 calls.  A large stream is first reduced in the run-grouped form;
         # if its keys do not cluster (read_sizes() sees BESST_ROWS_RUN_OVERFLOW) the builder repeats the call with
@@ -197,6 +198,8 @@ class DeviceGraphBuilder(object):
         # from the block segments: self.keys was not written then)
         self._presorted = ref is not None
         self.keys_valid = not (ref is not None and self._args['presort'][0].segmented)
+        # (segmented with in_record_loop 1: stage 2 writes the dense payload; 2 or 3: nobody does)
+        self.payload_valid = self.keys_valid or self._args['presort'][0].in_record_loop == 1
 
     def _presort_ref(self, on):
         """The hand-over of the sort's digit histograms from stage 1 to stage 2 (include/besst_amd.h, besst_presort)
@@ -255,7 +258,7 @@ class DeviceGraphBuilder(object):
             again()
             return
         self._presorted = False
-        if keys is None and not self.keys_valid:
+        if (keys is None and not self.keys_valid) or (payload is None and keys is not None and not self.payload_valid):
             raise _lib.BesstDeviceError('reduce: the last classify(presort=True) left its tuples in the block segments; '
                                         'self.keys holds an earlier pass (classify without presort to get the dense stream)')
         keys = self.keys if keys is None else keys

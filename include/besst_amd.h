@@ -431,8 +431,11 @@ typedef struct besst_presort {
     /* The tuple stream itself can be handed over as the record loop leaves it - one segment per 16 384-record block,
      * ordered by the block offsets of the stitch - when stage 2's first stream pass can read it that way:
      * besst_dev_reduce_presort sets `segmented` to say so, besst_dev_classify_presort leaves it 1 (and fills the seg_*
-     * fields) when it did NOT write the dense keys / payload, and besst_dev_reduce_presorted then reads the segments and
-     * writes the dense payload (the `payload` argument of both calls) itself.  in_record_loop (out): 1 = the record loop
+     * fields) when it did NOT write the dense keys / payload, and besst_dev_reduce_presorted then reads the segments and -
+     * in_record_loop 1 only - writes the dense payload (the `payload` argument of both calls) itself.  With in_record_loop 2
+     * or 3 NEITHER dense column exists after the pass: stage 2 works on the segments and writes the row columns and the
+     * observations only; `keys` / `payload` keep whatever an earlier pass left there (a caller that wants the dense tuple
+     * stream classifies with BESST_REDUCE_NO_RUNS in `flags`, or without a presort).  in_record_loop (out): 1 = the record loop
      * counted the digits while it emitted; 2 = it handed its segments over without counting, because `flags` did not carry
      * BESST_REDUCE_NO_RUNS and stage 2 then groups runs and reads no histogram; 3 = as 2, and the record loop grouped the
      * runs of equal keys itself while it emitted: the key segments then hold run tables and a run byte per tuple instead

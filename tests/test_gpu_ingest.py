@@ -753,3 +753,36 @@ def test_device_columns_equal_an_independent_decode(name):
                 assert got[k].astype(np.int64).tolist() == want[k], k
         finally:
             bam.close()
+
+
+def test_empty_block_on_a_chunk_boundary_hands_the_known_start_on():
+    """htslib's layout, 64 blocks per chunk, and an EMPTY block (an interior EOF marker) as the first block of the second chunk;
+    the record that begins the block behind it carries a name no heuristic would take for one (a control byte).  That block's
+    start is known - offset 0, like the empty block's would have been - and must not be left to a guess that nobody in front
+    of it can vouch for: a later offset would be accepted and the record dropped."""
+    batch = _library(6000)
+    with tempfile.TemporaryDirectory() as tmp:
+        raw_path, path = os.path.join(tmp, 'raw.bam'), os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(raw_path, batch, block_bytes=1500, align_records=True)
+        data, at, payloads = open(raw_path, 'rb').read(), 0, []
+        while at < len(data):
+            size = struct.unpack_from('<H', data, at + 16)[0] + 1
+            payloads.append(bytearray(zlib.decompress(data[at + 18:at + size - 8], -15)))
+            at += size
+        assert len(payloads) > 200 and len(payloads[-1]) == 0
+        first = payloads[64]
+        assert struct.unpack_from('<i', first, 0)[0] >= 32 and chr(first[36]) == 'r'
+        first[36] = 1                                        # the read name begins with a control byte
+        with open(path, 'wb') as fh:
+            for k, pl in enumerate(payloads):
+                if k == 64:
+                    fh.write(bam_writer._bgzf_block(b''))
+                fh.write(bam_writer._bgzf_block(bytes(pl)))
+        host = bamio.read_bam(path, threads=2)
+        assert len(host) == len(batch)
+        bam = bamio.ResidentBam(path, threads=2, mode='device', chunk_blocks=64)
+        try:
+            assert bam.ingest.on_device == 1 and len(bam) == len(batch)
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
