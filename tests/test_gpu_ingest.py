@@ -755,11 +755,14 @@ def test_device_columns_equal_an_independent_decode(name):
             bam.close()
 
 
-def test_empty_block_on_a_chunk_boundary_hands_the_known_start_on():
+@pytest.mark.parametrize('shift', [0, 1])
+def test_empty_block_on_a_chunk_boundary_hands_the_known_start_on(shift):
     """htslib's layout, 64 blocks per chunk, and an EMPTY block (an interior EOF marker) as the first block of the second chunk;
     the record that begins the block behind it carries a name no heuristic would take for one (a control byte).  That block's
     start is known - offset 0, like the empty block's would have been - and must not be left to a guess that nobody in front
-    of it can vouch for: a later offset would be accepted and the record dropped."""
+    of it can vouch for: a later offset would be accepted and the record dropped.  (Every second block around the boundary is
+    empty and every block behind one is patched; `shift` moves the pattern by one block, so that in one of the two files an
+    empty block is the chunk's first whether or not the header's block counts.)"""
     batch = _library(6000)
     with tempfile.TemporaryDirectory() as tmp:
         raw_path, path = os.path.join(tmp, 'raw.bam'), os.path.join(tmp, 'x.bam')
@@ -770,12 +773,13 @@ def test_empty_block_on_a_chunk_boundary_hands_the_known_start_on():
             payloads.append(bytearray(zlib.decompress(data[at + 18:at + size - 8], -15)))
             at += size
         assert len(payloads) > 200 and len(payloads[-1]) == 0
-        first = payloads[64]
-        assert struct.unpack_from('<i', first, 0)[0] >= 32 and chr(first[36]) == 'r'
-        first[36] = 1                                        # the read name begins with a control byte
+        marked = range(58 + shift, 72 + shift)
+        for k in marked:
+            assert struct.unpack_from('<i', payloads[k], 0)[0] >= 32 and chr(payloads[k][36]) == 'r'
+            payloads[k][36] = 1                              # the read name begins with a control byte
         with open(path, 'wb') as fh:
             for k, pl in enumerate(payloads):
-                if k == 64:
+                if k in marked:
                     fh.write(bam_writer._bgzf_block(b''))
                 fh.write(bam_writer._bgzf_block(bytes(pl)))
         host = bamio.read_bam(path, threads=2)
