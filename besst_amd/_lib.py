@@ -147,6 +147,7 @@ _SIGNATURES = {
     'besst_dev_classify_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_reduce_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_contig_table_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_restore_state': (C.c_int, [_P, _P, _P, C.c_int64]),
     'besst_dev_pack_contigs': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_classify': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P,
                                      C.POINTER(LibParams), C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t]),

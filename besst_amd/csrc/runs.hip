@@ -628,6 +628,7 @@ __device__ __forceinline__ RlBlock rl_block(const SegSource& seg, uint32_t b, in
 }
 static_assert(kRlMaxChunks <= 64, "rl_list_kernel searches the chunk prefixes one wave holds");
 constexpr int kRlWaves = 4;                              // waves per block: wave w takes chunks w, w + 4, ...
+constexpr int kRlSingletonRuns = 32;                     // rl_place_kernel: chunks of more runs than this count their runs' tuples first
 
 // 1'. the run list.  The record loop left per chunk a dense list of its runs - key, tuples | first slot (counted in LDS while
 // it emitted), name - so listing is a copy: ONE WAVE per block walks the block's runs 64 at a time (run -> chunk by a
@@ -702,6 +703,8 @@ __global__ __launch_bounds__(kRlWaves * 64, 6) void rl_place_kernel(SegSource se
                                                                    const uint32_t* __restrict__ n_rows, RunCols rc,
                                                                    int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi) {
     constexpr int R = kRlChunkTuples / 64, Q = kRlSlots / 64;
+    __shared__ uint32_t s_cnt[kRlWaves][kRlSlots], s_dst[kRlWaves][kRlSlots];
+    __shared__ uint8_t s_kk[kRlWaves][kRlSlots];
     const int lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t b = blockIdx.x;
@@ -737,12 +740,49 @@ __global__ __launch_bounds__(kRlWaves * 64, 6) void rl_place_kernel(SegSource se
         // the block's head lies in this chunk (uniform): its place comes with the chunk's other loads
         const bool has_head = k.head_kept && k.hslot >= start && k.hslot < start + cnt;
         const uint32_t head_dst = has_head ? rc.dst[k.head_idx] : 0u;
+        // How many of the chunk's tuples each run holds (LDS counters, per wave): a run of ONE tuple - a chimeric pair's link,
+        // an edge seen once - needs neither a rank nor a reduction: its tuple goes to the run's place and IS the run's
+        // sums.  The loop over the runs (a ballot and two wave sums per run and round) is left to the runs of two tuples and
+        // more: with 3 % chimeric pairs a chunk holds ~90 runs instead of ~15 and the loop was 0.39 of the 0.17 ms.
+        // (only where a chunk holds many runs - uniform: the counters cost a chunk of ~15 runs more than they save)
+        const bool sparse = K > (uint32_t)kRlSingletonRuns;
+        uint32_t* cnt_s = s_cnt[w];
+        uint32_t* dst_s = s_dst[w];
+        uint8_t* kk_s = s_kk[w];
         unsigned long long my_s[Q], my_q[Q];
+        if (sparse) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) cnt_s[q * 64 + lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rid[r] < kRlNoRun) atomicAdd(&cnt_s[rid[r]], 1u);
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (my_slot[q] < kRlNoRun) {
+                    dst_s[my_slot[q]] = my_dst[q];
+                    kk_s[my_slot[q]] = (uint8_t)(q * 64 + lane);
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (rid[r] < kRlNoRun && cnt_s[rid[r]] == 1u) {
+                    const unsigned long long o = (unsigned long long)((uint32_t)pl[r] + ((uint32_t)(pl[r] >> 32) & 0x3fffffffu));
+                    const uint32_t kk = kk_s[rid[r]];
+                    to[r] = dst_s[rid[r]];
+                    rc.sum[idx + kk] = o;
+                    rc.sq[idx + kk] = o * o;
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             my_s[q] = 0; my_q[q] = 0;
-            const uint32_t kq = K > (uint32_t)(q * 64) ? (K - (uint32_t)(q * 64) < 64u ? K - (uint32_t)(q * 64) : 64u) : 0u;
-            for (uint32_t kk = 0; kk < kq; ++kk) {           // uniform
+            const bool many = my_slot[q] < kRlNoRun && (!sparse || cnt_s[my_slot[q]] >= 2u);
+            unsigned long long todo = __ballot(many);
+            while (todo) {                                   // uniform: the runs of two tuples and more, in list order
+                const uint32_t kk = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)my_dst[q], (int)kk);
                 const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)my_slot[q], (int)kk);
                 unsigned long long s2 = 0, q2 = 0;
@@ -763,11 +803,12 @@ __global__ __launch_bounds__(kRlWaves * 64, 6) void rl_place_kernel(SegSource se
                 q2 = rg_wave_sum64(q2);
                 if ((uint32_t)lane == kk) { my_s[q] = s2; my_q[q] = q2; }
             }
-            if ((uint32_t)lane < kq) {
+            if (many || (sparse && my_slot[q] < kRlNoRun && cnt_s[my_slot[q]] == 0u)) {     // (a listed run without a tuple here: zero sums, as the loop over all runs left them)
                 rc.sum[idx + (uint32_t)(q * 64 + lane)] = my_s[q];
                 rc.sq[idx + (uint32_t)(q * 64 + lane)] = my_q[q];
             }
         }
+        __builtin_amdgcn_wave_barrier();                     // (the counters are the next chunk's again)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (rid[r] < kRlNoRun) {

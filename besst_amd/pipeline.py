@@ -158,8 +158,12 @@ class DeviceGraphBuilder(object):
             self._args.pop('presort', None)
 
     def reset(self):
-        """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99)."""
-        self.state.copy_(self._init)
+        """Zero coverage / counters, prev_obs = (-1, -1) (CreateGraph.py:89-99): the state block restored from its template."""
+        args = self._args.get('reset')
+        if args is None:
+            args = self._args['reset'] = (_p(self.state), _p(self._init), self.state.numel() * 8)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.besst_dev_restore_state(C.c_void_p(stream), *args), 'restore_state')
 
     def record_path(self, rec):
         """Which form of the record loop serves this record set (include/besst_amd.h, besst_lib_params.record_path):

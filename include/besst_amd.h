@@ -357,6 +357,10 @@ size_t besst_dev_reduce_workspace_bytes(int64_t n_tuples);
 /* Pack the contig table into the 16-byte rows the kernels gather from, followed by one class byte per
  * contig (host pointers in, device pointer out; table must hold besst_dev_contig_table_bytes(n) bytes). */
 size_t besst_dev_contig_table_bytes(int64_t n_contigs);
+/* dst[0, bytes) <- src[0, bytes), both on the device and 16-byte aligned, in one small launch: how a pass's state block
+ * (coverage numerators | counters | carry, zero / (-1, -1) at the head of every pass: BESST/CreateGraph.py:89-99) is
+ * restored from a template. */
+int besst_dev_restore_state(void* stream, void* dst, const void* src, int64_t bytes);
 int besst_dev_pack_contigs(void* stream, int64_t n_contigs, const int32_t* h_scaf_id,
                            const int32_t* h_scaf_len, const int32_t* h_ctg_pos,
                            const int32_t* h_ctg_len, const uint8_t* h_direction,
