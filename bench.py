@@ -856,6 +856,10 @@ def main_single(args, device, result_fd):
         out[args.also.lower()] = second
     if not args.no_robustness and not args.no_stages and args.pairs is None and args.config == 'C3':
         out['robustness'] = robustness(args, device)
+        try:
+            out['c4_single_gpu'] = c4_single_gpu(args, device)
+        except Exception as e:                               # noqa: BLE001 - the bench line must still be printed
+            out['c4_single_gpu'] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + '\n').encode())
 
@@ -889,6 +893,95 @@ def main():
             args.config = 'C3'
         return main_single(args, device, result_fd)
     return main_sharded(args, device, rank, world, backend, force_dist, result_fd)
+
+
+def c4_single_gpu(args, device):
+    """BASELINE.json configs[3] (C4) at FULL size on ONE GPU: 500 k contigs, the PE library on the first-library table, then
+    the mate-pair library on the table a previous pass leaves behind - 5e8 read pairs = 1e9 records (25 GB) each, both
+    resident at once, a step = both libraries' passes one after the other (and, labelled, with three passes in flight).
+    Correctness of this shape at this size is tests/test_gpu_fullsize.py::test_full_size_c4_one_gpu (every record against
+    the C oracle); here it is timed."""
+    import torch
+    from besst_amd import pipeline, synth, workload
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 150e9:
+        return {'skipped': 'needs 150 GB of free HBM (%.0f GB here)' % (free / 1e9)}
+    cfg = synth.CONFIGS['C4']
+    seed = synth.config_seed('C4')
+    asm = synth.make_assembly(cfg['nc'], cfg['median'], seed)
+    per_lib = cfg['pairs'] // len(cfg['libs'])
+    libs, t_gen = [], time.perf_counter()
+    for li, spec in enumerate(cfg['libs']):
+        lib = workload.library_constants(spec)
+        thr = spec.mean + 4 * spec.sd
+        table = workload.first_library_table(asm.lengths, thr) if li == 0 else \
+            workload.later_library_table(asm, seed + 50 + li, thr, first_scaffold_id=asm.nc * li + 1)
+        nb = workload.node_bits_for(table)
+        rec = pipeline.DeviceRecords.from_columns(synth.simulate_library_device(asm, spec, per_lib, seed + 100 + li, device))
+        probe = pipeline.DeviceGraphBuilder(device, asm.nc, nb, lib, rec.n, 1)
+        probe.set_contigs(**table)
+        probe.reset()
+        probe.classify(rec)
+        n_tuples, _ = probe.read_sizes()
+        del probe
+        gb = pipeline.DeviceGraphBuilder(device, asm.nc, nb, lib, rec.n, int(n_tuples * 1.1) + 4096)
+        gb.set_contigs(**table)
+        libs.append((spec, rec, gb, nb, lib, table))
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t_gen
+
+    def step():
+        for _, rec, gb, _, _, _ in libs:
+            gb.step(rec)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    steps = max(5, min(args.steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out_libs, tuples = [], 0
+    for spec, rec, gb, nb, lib, table in libs:
+        n_t, n_r = gb.read_sizes()
+        tuples += n_t
+        out_libs.append({'library': '%s N(%g, %g)' % (spec.orientation, spec.mean, spec.sd), 'records': rec.n, 'node_bits': nb,
+                         'key_bits': gb.key_bits, 'link_tuples': n_t, 'edge_rows': n_r,
+                         'record_path': 'fused' if gb.params.record_path else 'two-pass'})
+    pairs = per_lib * len(libs)
+    f = tuples / float(pairs)
+    alg = pairs * (38.0 + 32.0 * f)
+    res = {'workload': 'C4 at full size on one GPU: %d contigs, %d libraries x %d read-pairs (%d records resident)'
+                       % (asm.nc, len(libs), per_lib, 2 * pairs),
+           'ms_per_step': round(dt * 1e3, 4), 'value': pairs / dt, 'unit': 'read-pairs/s', 'steps': steps,
+           'link_tuples_per_pair': round(f, 5), 'libraries': out_libs, 'generate_s': round(gen_s, 1),
+           'roofline_frac': round(alg / dt / 1e9 / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_step': alg,
+           'hbm_allocated_bytes': int(torch.cuda.max_memory_allocated(device)),
+           'verified': 'tests/test_gpu_fullsize.py::test_full_size_c4_one_gpu (same seeds, every record against the C oracle)'}
+    # three passes in flight (labelled: never the figure above): the second library's pass under the first one's tail
+    if args.in_flight > 1 and torch.cuda.mem_get_info(device)[0] > 110e9:
+        pools = []
+        for spec, rec, gb, nb, lib, table in libs:
+            pool = pipeline.PassPool(device, asm.nc, nb, lib, rec.n, gb.tup_cap, 2)
+            pool.set_contigs(**table)
+            pools.append((pool, rec))
+        torch.cuda.synchronize()
+        for _ in range(2):
+            for pool, rec in pools:
+                pool.submit(rec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for pool, rec in pools:
+                pool.submit(rec)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / steps
+        res['overlapped'] = {'in_flight': 2 * len(pools), 'ms_per_step': round(dt2 * 1e3, 4), 'value': pairs / dt2}
+        del pools
+    del libs
+    torch.cuda.empty_cache()
+    return res
 
 
 def owner_checksums(keys, payload, owners, world):
