@@ -1,6 +1,6 @@
 """Copy the round's profile set from gpurun_out/final/ (tools/final_profiles.sh) into profiles/ under the round's names;
 kernel-stats CSVs keep this library's kernels and the runtime's copy / fill kernels (the generator's torch kernels go).
-usage: python tools/collect_profiles.py r04 [source dir]"""
+usage: python tools/collect_profiles.py r05 [source dir]"""
 import csv, os, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,13 @@ for name in ('c3', 'c2', 'ingest', 'metrics'):
         w.writerows(keep)
 for a, b in (('bench_default.json', 'bench_default.json'), ('c3_pmc_traffic.json', 'c3_pmc_traffic.json'),
              ('c2_pmc_traffic.json', 'c2_pmc_traffic.json'), ('metrics_pmc.json', 'metrics_pmc.json'),
-             ('ingest_pmc.txt', 'ingest_pmc.txt')):
+             ('ingest_pmc.txt', 'ingest_pmc.txt'), ('c4_rank1.json', 'c4_rank1.json'),
+             ('from_bam_2ranks_one_gpu.json', 'from_bam_2ranks_one_gpu.json')):
     shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
+
+# the C4-at-full-size-on-one-GPU object of the bench line, on its own
+import json
+line = json.loads(open(os.path.join(src, 'bench_default.json')).read().strip().splitlines()[-1])
+if 'c4_single_gpu' in line:
+    json.dump(line['c4_single_gpu'], open(os.path.join(dst, '%s_c4_single_gpu.json' % tag), 'w'), indent=1)
