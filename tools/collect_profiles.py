@@ -9,7 +9,7 @@ src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, 'gpurun_out', 'fi
 dst = os.path.join(REPO, 'profiles')
 for name in ('c3', 'c2', 'ingest', 'metrics'):
     rows = list(csv.DictReader(open(os.path.join(src, '%s_kernel_stats.csv' % name), newline='')))
-    keep = [r for r in rows if 'besst' in r['Name'] or '__amd_rocclr' in r['Name']]
+    keep = [r for r in rows if 'besst' in r['Name'] or '__amd_rocclr' in r['Name'] or r['Name'] in ('copy_words_kernel', 'obs_sum_kernel')]
     with open(os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, name)), 'w', newline='') as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_ALL)
         w.writeheader()
