@@ -128,6 +128,13 @@ class HipRankEngine(object):
         self.keep = keep                                     # whatever owns the record memory (a ResidentBam slice)
         self._sampler = None
 
+    @classmethod
+    def from_batch(cls, part, n_contigs):
+        """Over a slice of host records: uploaded to the process's current device."""
+        from . import pipeline
+        dev = _cuda_device()
+        return cls(dev, pipeline.DeviceRecords(part, dev), n_contigs)
+
     def metrics_backend(self, top_mask):
         from . import pipeline
         if self._sampler is None:
@@ -425,15 +432,8 @@ def session_for_batch(batch, rank, world, group=None):
     head = tuple(None if col is None else np.asarray(col[:k]) for col in
                  ((part.rlen if part.rlen is not None else part.qlen), (part.alen if part.alen is not None else part.qlen),
                   part.qlen))
-    engine = RankEngine.from_batch(part, len(batch.references)) if hasattr(RankEngine, 'from_batch') else \
-        _hip_engine_from_batch(part, len(batch.references))
+    engine = RankEngine.from_batch(part, len(batch.references))
     return ShardedSession(ShardedHead(batch.references, batch.lengths, hi - lo, head, group, world), engine, rank, world, group)
-
-
-def _hip_engine_from_batch(part, n_contigs):
-    from . import pipeline
-    dev = _cuda_device()
-    return HipRankEngine(dev, pipeline.DeviceRecords(part, dev), n_contigs)
 
 
 def session_for_bam(sbam):

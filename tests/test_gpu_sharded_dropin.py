@@ -169,3 +169,37 @@ def test_cli_under_torchrun(tmp_path):
     assert got == want and len(got) > 10
     stats = open(str(tmp_path / 'BESST_output' / 'Statistics.txt')).read()
     assert 'LIBRARY STATISTICS' in stats and 'Number of edges in G (after repeat removal)' in stats
+
+
+def test_cli_two_libraries_under_torchrun_equals_one_process(tmp_path):
+    """Two libraries through the CLI (fr, then rf on the objects the first pass leaves: CleanObjects, a contig table that only
+    rank 0 holds as objects): three ranks under torchrun write the same edge tables for both passes as one process does."""
+    import subprocess
+    import sys
+    from tests import bam_writer
+    doc, batch = GU.load('fr_infer')
+    doc2, batch2 = GU.load('rf_contam')
+    assert list(batch.references) == list(batch2.references)
+    bams = [str(tmp_path / 'lib1.bam'), str(tmp_path / 'lib2.bam')]
+    bam_writer.write_bam(bams[0], batch, block_bytes=20000, align_records=False)
+    bam_writer.write_bam(bams[1], batch2, block_bytes=30000, align_records=True)
+    fasta = str(tmp_path / 'contigs.fa')
+    lens = dict(zip(batch.references, batch.lengths))
+    with open(fasta, 'w') as fh:
+        for n in doc['fasta_names']:
+            fh.write('>%s\n%s\n' % (n, 'A' * lens[n]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ['-m', 'besst_amd.cli', '-c', fasta, '-f'] + bams + ['-orientation', 'fr', 'rf']
+    one, many = str(tmp_path / 'one'), str(tmp_path / 'many')
+    done = subprocess.run([sys.executable] + args + ['-o', one], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert done.returncode == 0, done.stdout.decode()[-3000:]
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port())] + args + ['-o', many]
+    done = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert done.returncode == 0, done.stdout.decode()[-3000:]
+    for p in ('pass1', 'pass2'):
+        for name in ('edges_G.tsv', 'edges_Gprime.tsv'):
+            a = open(os.path.join(one, 'BESST_output', p, name)).read()
+            b = open(os.path.join(many, 'BESST_output', p, name)).read()
+            assert a == b and a.count('\n') > 5, (p, name)
