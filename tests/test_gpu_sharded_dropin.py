@@ -179,7 +179,7 @@ def test_cli_two_libraries_under_torchrun_equals_one_process(tmp_path):
     from tests import bam_writer
     doc, batch = GU.load('fr_infer')
     doc2, batch2 = GU.load('rf_contam')
-    assert list(batch.references) == list(batch2.references)
+    assert list(batch2.references) == list(batch.references)[:len(batch2.references)]    # (the second library's header names a part of the contigs)
     bams = [str(tmp_path / 'lib1.bam'), str(tmp_path / 'lib2.bam')]
     bam_writer.write_bam(bams[0], batch, block_bytes=20000, align_records=False)
     bam_writer.write_bam(bams[1], batch2, block_bytes=30000, align_records=True)
