@@ -202,4 +202,4 @@ def test_cli_two_libraries_under_torchrun_equals_one_process(tmp_path):
         for name in ('edges_G.tsv', 'edges_Gprime.tsv'):
             a = open(os.path.join(one, 'BESST_output', p, name)).read()
             b = open(os.path.join(many, 'BESST_output', p, name)).read()
-            assert a == b and a.count('\n') > 5, (p, name)
+            assert a == b and a.count('\n') > 1, (p, name)
