@@ -716,7 +716,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     BESST_REQUIRE(parts >= 1 && part >= 0 && part < parts, "push_bam_device: part must be in [0, parts)");
     BESST_REQUIRE(head_records >= 0 && (head_records == 0 || (head_rlen && head_alen && head_qlen)),
                   "push_bam_device: head buffers missing");
-    if (chunk_blocks <= 0) chunk_blocks = 6144;              // (one full chip of the inflate kernel's waves: 1024 SIMDs x 6; 8192 and 12288 read 3 % slower, 3072 and 24576 10 %)
+    if (chunk_blocks <= 0) chunk_blocks = 5120;              // (one full chip of the inflate kernel's waves: 1024 SIMDs x 5; twice that reads 10 % slower)
     if (chunk_blocks < 64) chunk_blocks = 64;
     if (chunk_blocks > 65536) chunk_blocks = 65536;
     int rc = use_device(c);

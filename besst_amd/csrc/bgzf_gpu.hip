@@ -15,12 +15,15 @@
 //                that is the prefix of literal / length codes of 11 - 13 bits points to a second-level table of eight
 //                entries, filled the same way (codes beyond that, rare, are decoded canonically on the spot); base and
 //                extra-bit count of a length / distance code come from two per-lane registers (v_readlane);
-//       symbols  SEVERAL per turn of the loop: lane i decodes - speculatively - the literal / length symbol AND the distance
-//                symbol that would begin at bit i of the next 64 bits of input (two table look-ups, base and extra bits:
-//                vector work, the same for every lane), and the chain of symbols that really begin there is then walked
-//                with one v_readlane per symbol; what the walk cannot take (a code longer than the table, the end of a
-//                block, a window that has to be reloaded) is left to the one-symbol-at-a-time loop;
-//       window   the block's own output in HBM / L2 (6 KB of LDS, seven waves per SIMD) - a wave's vector memory
+//       symbols  A DOZEN per turn of the loop: lane i decodes - speculatively - the literal / length symbol AND the distance
+//                symbol that would begin at bit i, 64 + i and 128 + i of the next 192 bits of input (three windows of 64
+//                positions; per position two table look-ups, base and extra bits: vector work, the same for every lane),
+//                and the chain of symbols that really begin there is then walked window by window with one v_readlane
+//                per symbol and compacted into lanes; what the walk cannot take (a code longer than the tables, the end
+//                of a block) is left to the one-symbol-at-a-time loop.  (One window per turn, round 4: the per-turn part -
+//                input window, scans, the lay-in of the output bytes, loop control - was a third of a turn's ~300
+//                instructions for ~4 symbols; three windows: 8.3 -> 6.4 ms per 6144 blocks of a sequencer-like file.)
+//       window   the block's own output in HBM / L2 (6.4 KB of LDS, five waves per SIMD) - a wave's vector memory
 //                instructions are processed in order, a load behind a store of the same wave returns the stored byte
 //                (round 3's other form, a 32 KiB ring in LDS at one wave per SIMD, was 2.3 x slower and is gone);
 //       output   in groups of 64 bytes: lane k of a group holds a literal or the place its byte is copied from; a full
@@ -53,8 +56,16 @@ constexpr int kTabSize = 1 << kTabBits;
 #ifndef BESST_INF_DISTBITS
 #define BESST_INF_DISTBITS 9
 #endif
+#ifndef BESST_INF_WINDOWS
+#define BESST_INF_WINDOWS 3
+#endif
+constexpr int kWin = BESST_INF_WINDOWS;            // a turn of the symbol loop looks at kWin windows of 64 bit positions (kWin per lane):
+                                                 // per 6144 blocks of a sequencer-like file 8.3 ms with one window, 6.9 with two, 6.4 with three, 6.3 with four
 constexpr int kDistBits = BESST_INF_DISTBITS;                     // the distance code's primary table (10 bits: the same speed; the KB went to the second-level table)
-constexpr int kInfWaves = 6;                     // per SIMD (80 VGPRs, 6.2 KB of LDS)
+#ifndef BESST_INF_WAVES
+#define BESST_INF_WAVES 5
+#endif
+constexpr int kInfWaves = BESST_INF_WAVES;        // per SIMD (96 VGPRs, 6.4 KB of LDS; six waves at 80 VGPRs spill and read 4 % slower, four 14 %)
 constexpr int kDistSize = 1 << kDistBits;
 constexpr int kClBits = 7;
 constexpr int kLaneLongBits = 3;                 // literal / length codes of up to kTabBits + 3 bits are decoded by the lanes too:
@@ -85,6 +96,7 @@ struct InflateLds {
     uint8_t lens[288 + 32 + 16];
     uint8_t cl_lens[32];
     uint32_t mark[64];          // emission: which symbol of the batch begins at a lane of the output group
+    unsigned long long sym[64]; // a batch of several windows: its chain's symbols (bytes | literal or distance << 32), one per lane
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -269,6 +281,14 @@ struct BitReader {
         const uint32_t i = bitpos >> 5;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)i + j);
+        return bitpos & 31u;
+    }
+    // ... and the 2 k + 2 dwords that k windows of 64 positions read from
+    template <int N>
+    __device__ __forceinline__ uint32_t ahead_n(uint32_t (&v)[N]) const {
+        const uint32_t i = bitpos >> 5;
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)i + j);
         return bitpos & 31u;
     }
     // bytes of input consumed so far (rounded up)
@@ -476,55 +496,121 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
                 // (once per turn: a corrupt stream is not followed more than a few hundred bytes past its payload - the
                 // chunk's buffer has 4 KB behind its last block)
                 if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
-                uint32_t v[4];
-                const uint32_t t = br.ahead(v) + (uint32_t)lane;                   // the lane's bit, counted from v[0]
-                const uint32_t lo = t < 32u ? v[0] : t < 64u ? v[1] : v[2], hi = t < 32u ? v[1] : t < 64u ? v[2] : v[3];
-                const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, t & 31u);     // 32 bits of input from that bit on
-                const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
-                const uint32_t eb = s.dist_tab[x & (uint32_t)(kDistSize - 1)];
-                // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals) are decoded by the
-                // lanes as well: the primary entry of their first kTabBits bits points to a second-level table, indexed by the
-                // next kLaneLongBits bits (every lane looks - a lane with a short code at entry 0 - so that no branch stands
-                // between the two look-ups)
-                const bool link = (ea & kLinkMask) == kLinkFlag;
-                const uint32_t e2 = s.lit_sub[link ? ((ea >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u)) : 0u];
-                const uint32_t ec = link ? e2 : ea;
-                const uint32_t la = ec & 15u, sa = ec >> 4;
-                const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
-                const bool is_lit = la != 0u && sa < 256u, is_len = la != 0u && sa > 256u && sa < 286u;
-                const uint32_t xa = is_len ? li >> 9 : 0u;
-                const uint32_t mlen = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
-                const uint32_t lb = eb & 15u, sb = eb >> 4;
-                const uint32_t di = (uint32_t)__shfl((int)dist_info, (int)sb, 64);
-                const uint32_t xb = di >> 16;
-                const uint32_t mdist = (di & 0xffffu) + ((x >> lb) & ((1u << xb) - 1u));
-                const uint32_t wb = (lb != 0u && sb < 30u) ? (lb + xb) | (mdist << 8) : kBadDist;
-                // a length's distance symbol begins la + xa bits on: what the lane there found
-                const uint32_t q = (uint32_t)lane + la + xa;
-                const uint32_t bq = (uint32_t)__shfl((int)wb, (int)q, 64);
-                const bool is_match = is_len && q < 64u && !(bq & kBadDist);
-                const uint32_t bits = is_lit ? la : is_match ? la + xa + (bq & 31u) : kWalkStop;
-                const uint32_t bytes = is_lit ? 1u : is_match ? mlen : 0u;
-                const uint32_t what = is_lit ? kGroupLit | sa : bq >> 8;           // the literal, or the match's distance
-                // ---- 2. the chain from position 0
-                // (a stop is worth 64 bits: the loop's one test ends on it, and what it added is taken back behind the loop -
-                // with a test of its own inside, the compiler turned the loop body into sixteen selects)
-                unsigned long long chain = 0ull;
-                uint32_t p = 0, w, from_p;
-                do {
-                    w = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)p);
-                    from_p = p;
-                    chain |= 1ull << p;
-                    p += w;
-                } while (p < 64u);
-                if (w & kWalkStop) {
-                    chain ^= 1ull << from_p;
-                    p = from_p;
+                // the speculative decode of ONE window of 64 positions: `x` = the 32 bits of input from the lane's position on.
+                // -> bits of the literal / length code + its extra bits (0: nothing the batch can take), the match length,
+                // the literal, and what the lane found as a DISTANCE symbol at its position (bits | distance << 8, or kBadDist)
+                auto decode = [&](uint32_t x, uint32_t& la_xa, uint32_t& mlen, uint32_t& lit, bool& is_lit, bool& is_len, uint32_t& wb) {
+                    const uint32_t ea = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
+                    const uint32_t eb = s.dist_tab[x & (uint32_t)(kDistSize - 1)];
+                    // codes one, two or three bits longer than the table (a seventh of a sequencer file's literals) are decoded by
+                    // the lanes as well: the primary entry of their first kTabBits bits points to a second-level table, indexed by
+                    // the next kLaneLongBits bits (every lane looks - a lane with a short code at entry 0 - so that no branch
+                    // stands between the two look-ups)
+                    const bool link = (ea & kLinkMask) == kLinkFlag;
+                    const uint32_t e2 = s.lit_sub[link ? ((ea >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u)) : 0u];
+                    const uint32_t ec = link ? e2 : ea;
+                    const uint32_t la = ec & 15u, sa = ec >> 4;
+                    const uint32_t li = (uint32_t)__shfl((int)len_info, (int)(sa - 257u), 64);
+                    is_lit = la != 0u && sa < 256u;
+                    is_len = la != 0u && sa > 256u && sa < 286u;
+                    const uint32_t xa = is_len ? li >> 9 : 0u;
+                    mlen = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
+                    lit = kGroupLit | sa;
+                    la_xa = la + xa;
+                    const uint32_t lb = eb & 15u, sb = eb >> 4;
+                    const uint32_t di = (uint32_t)__shfl((int)dist_info, (int)sb, 64);
+                    const uint32_t xb = di >> 16;
+                    const uint32_t mdist = (di & 0xffffu) + ((x >> lb) & ((1u << xb) - 1u));
+                    wb = (lb != 0u && sb < 30u) ? (lb + xb) | (mdist << 8) : kBadDist;
+                };
+                // kWin windows of 64 positions per turn: window k's lane l looks at bit 64 k + l
+                uint32_t bits_w[kWin], bytes_w[kWin], what_w[kWin], x;
+                {
+                    uint32_t v[2 * kWin + 2];
+                    const uint32_t t = br.ahead_n<2 * kWin + 2>(v) + (uint32_t)lane;     // the lane's bit in window 0, counted from v[0]
+                    uint32_t la_xa[kWin], mlen[kWin], lit[kWin], wb[kWin];
+                    bool is_lit[kWin], is_len[kWin];
+#pragma unroll
+                    for (int k = 0; k < kWin; ++k) {
+                        const uint32_t lo = t < 32u ? v[2 * k] : t < 64u ? v[2 * k + 1] : v[2 * k + 2];
+                        const uint32_t hi = t < 32u ? v[2 * k + 1] : t < 64u ? v[2 * k + 2] : v[2 * k + 3];
+                        const uint32_t xk = __builtin_amdgcn_alignbit(hi, lo, t & 31u);   // 32 bits of input from that bit on
+                        if (k == 0) x = xk;
+                        decode(xk, la_xa[k], mlen[k], lit[k], is_lit[k], is_len[k], wb[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kWin; ++k) {
+                        // a length's distance symbol begins la + xa (<= 20) bits on: in this window or in the next one - what the
+                        // lane there found (beyond the last window: not this batch's)
+                        const uint32_t q = (uint32_t)lane + la_xa[k];
+                        uint32_t bq = (uint32_t)__shfl((int)wb[k], (int)q, 64);
+                        if (k + 1 < kWin) {
+                            const uint32_t bn = (uint32_t)__shfl((int)wb[k + 1], (int)q, 64);
+                            bq = q < 64u ? bq : bn;
+                        } else {
+                            bq = q < 64u ? bq : kBadDist;
+                        }
+                        const bool is_match = is_len[k] && !(bq & kBadDist);
+                        bits_w[k] = is_lit[k] ? la_xa[k] : is_match ? la_xa[k] + (bq & 31u) : kWalkStop;
+                        bytes_w[k] = is_lit[k] ? 1u : is_match ? mlen[k] : 0u;
+                        what_w[k] = is_lit[k] ? lit[k] : bq >> 8;                          // the literal, or the match's distance
+                    }
                 }
-                if (chain != 0ull) {                         // uniform
+                // ---- 2. the chain from position 0, window by window
+                // (a stop is worth 64 bits: a window's loop has ONE test and ends on it, and what it added is taken back behind
+                // the loop - with a test of its own inside, the compiler turned the loop body into sixteen selects)
+                unsigned long long chain_w[kWin];
+                uint32_t p = 0, n_sym = 0;
+                bool stopped = false;
+#pragma unroll
+                for (int k = 0; k < kWin; ++k) {
+                    chain_w[k] = 0ull;
+                    if (!stopped) {                          // uniform
+                        uint32_t pk = p - 64u * (uint32_t)k, w, from_p;
+                        unsigned long long c = 0ull;
+                        do {
+                            w = (uint32_t)__builtin_amdgcn_readlane((int)bits_w[k], (int)pk);
+                            from_p = pk;
+                            c |= 1ull << pk;
+                            pk += w;
+                        } while (pk < 64u);
+                        if (w & kWalkStop) {
+                            c ^= 1ull << from_p;
+                            pk = from_p;
+                            stopped = true;
+                        }
+                        // (a batch lays at most 64 symbols into lanes: a window that would not fit is the next turn's)
+                        const uint32_t n_k = (uint32_t)__popcll(c);
+                        if (k > 0 && n_sym + n_k > 64u) {
+                            stopped = true;
+                        } else {
+                            chain_w[k] = c;
+                            n_sym += n_k;
+                            p = 64u * (uint32_t)k + pk;
+                        }
+                    }
+                }
+                if (n_sym != 0u) {                           // uniform
                     // ---- 3. the bytes of the chain's symbols
-                    const bool on = (chain >> lane) & 1ull;
-                    const uint32_t mine = on ? bytes : 0u;
+                    bool on = (chain_w[0] >> lane) & 1ull;
+                    uint32_t mine = on ? bytes_w[0] : 0u, what = what_w[0];
+                    if (kWin > 1 && n_sym != (uint32_t)__popcll(chain_w[0])) {           // uniform
+                        // one symbol per lane for what follows: the chain's symbols of all windows, in order, in lanes 0 ..
+                        uint32_t before = 0;
+#pragma unroll
+                        for (int k = 0; k < kWin; ++k) {
+                            const unsigned long long c = chain_w[k];
+                            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(c >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)c, before));
+                            if ((c >> lane) & 1ull) s.sym[r] = (unsigned long long)bytes_w[k] | ((unsigned long long)what_w[k] << 32);
+                            before += (uint32_t)__popcll(c);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long sy = s.sym[lane];
+                        __builtin_amdgcn_wave_barrier();
+                        on = (uint32_t)lane < n_sym;
+                        mine = on ? (uint32_t)sy : 0u;
+                        what = (uint32_t)(sy >> 32);
+                    }
                     const uint32_t incl = scan_add(mine);
                     const uint32_t begin = incl - mine;      // the symbol's first byte, counted from the batch's first
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
