@@ -99,6 +99,32 @@ using namespace besst;
 // finds them pinned.  The pool holds at most kPinnedKeep bytes (what comes back beyond that is freed), is never freed at
 // exit (the runtime may be gone by then), and besst_release_cached_memory() empties it.
 namespace {
+// Work nobody waits for (freeing an ingest's device scratch): threads that are joined when the next one starts, when a
+// context is destroyed and by besst_release_cached_memory() - never left running behind the library's last call.
+struct Background {
+    std::mutex mu;
+    std::vector<std::thread> threads;
+    ~Background() {                                          // (process exit with a context never destroyed: let them go)
+        for (std::thread& t : threads)
+            if (t.joinable()) t.detach();
+    }
+    void join_all() {
+        std::vector<std::thread> mine;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            mine.swap(threads);
+        }
+        for (std::thread& t : mine)
+            if (t.joinable()) t.join();
+    }
+    template <class F>
+    void run(F f) {
+        join_all();
+        std::lock_guard<std::mutex> g(mu);
+        threads.emplace_back(std::move(f));
+    }
+};
+Background g_background;
 constexpr size_t kPinnedKeep = (size_t)1 << 30;
 struct PinnedPool {
     struct Entry { void* p; size_t bytes; bool busy; };
@@ -226,7 +252,10 @@ int besst_abi_version(void) { return BESST_ABI_VERSION; }
 
 const char* besst_last_error(void) { return g_error; }
 
-void besst_release_cached_memory(void) { g_pinned.trim(0); }
+void besst_release_cached_memory(void) {
+    g_background.join_all();
+    g_pinned.trim(0);
+}
 
 void besst_prof_enable(uint32_t slot_mask) {
     g_prof_mask = slot_mask;
@@ -308,6 +337,7 @@ besst_ctx* besst_ctx_create(int device) {
 
 void besst_ctx_destroy(besst_ctx* c) {
     if (!c) return;
+    g_background.join_all();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->table.release(); c->aligned.release();
@@ -795,26 +825,39 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     hipStream_t copy_stream = nullptr;
     const size_t inflated_cap = kTailRoom + nb * 65536 + 4096;
     double unpin_s = 0.0;
-    auto release = [&]() {
+    // What the call allocated goes back when it ends: the pinned staging to its pool at once; the device scratch, events and
+    // streams - 12-15 ms of hipFree / destroy calls, a tenth of a 40 M-record ingest - on a thread of their own
+    // (`background`: the successful end; every stream has been synchronised by then), nobody waits for it.
+    auto release = [&](bool background = false) {
+        std::vector<void*> dev_mem, host_mem;
+        std::vector<hipEvent_t> events;
+        std::vector<hipStream_t> streams;
         for (Slot& q : sl) {
             const auto t0 = std::chrono::steady_clock::now();
             g_pinned.give_back(q.pin);
             unpin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (q.dev) (void)hipFree(q.dev);
-            if (q.inflated) (void)hipFree(q.inflated);
-            if (q.offs) (void)hipFree(q.offs);
-            if (q.words) (void)hipFree(q.words);
-            if (q.h2d_done) (void)hipEventDestroy(q.h2d_done);
-            if (q.slot_free) (void)hipEventDestroy(q.slot_free);
-            if (q.summ_done) (void)hipEventDestroy(q.summ_done);
-            if (q.tail_taken) (void)hipEventDestroy(q.tail_taken);
-            if (q.work) (void)hipStreamDestroy(q.work);
+            for (void* m : {(void*)q.dev, (void*)q.inflated, (void*)q.offs, (void*)q.words})
+                if (m) dev_mem.push_back(m);
+            for (hipEvent_t e : {q.h2d_done, q.slot_free, q.summ_done, q.tail_taken})
+                if (e) events.push_back(e);
+            if (q.work) streams.push_back(q.work);
             q = Slot();
         }
-        if (heads) (void)hipFree(heads);
-        if (d_flags) (void)hipFree(d_flags);
-        if (summ_host) (void)hipHostFree(summ_host);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (heads) dev_mem.push_back(heads);
+        if (d_flags) dev_mem.push_back(d_flags);
+        if (summ_host) host_mem.push_back(summ_host);
+        if (copy_stream) streams.push_back(copy_stream);
+        heads = nullptr; d_flags = nullptr; summ_host = nullptr; copy_stream = nullptr;
+        const int device = c->device;
+        auto drop = [device, dev_mem, host_mem, events, streams]() {
+            (void)hipSetDevice(device);
+            for (hipEvent_t e : events) (void)hipEventDestroy(e);
+            for (hipStream_t st : streams) (void)hipStreamDestroy(st);
+            for (void* m : dev_mem) (void)hipFree(m);
+            for (void* m : host_mem) (void)hipHostFree(m);
+        };
+        if (background) g_background.run(drop);
+        else drop();
     };
     // All three slots, and their streams, before anything is queued.
     // The three slots' streams and the copy stream must run beside each other.  The runtime spreads a process's streams
@@ -1154,7 +1197,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     const uint32_t saturated = rc == BESST_OK ? summ_host[41] : 0u;
     const auto t_rel = std::chrono::steady_clock::now();
     alloc_join();
-    release();
+    release(rc == BESST_OK);
     if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
         fprintf(stderr, "[push_bam_device] alloc %.3f s (%.3f of it waited for)  staging %.3f s  waiting %.3f s  release %.3f s (unpinning %.3f)  total %.3f s\n", alloc_s, alloc_wait_s, stage_s,
                 wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count(), unpin_s,
