@@ -17,7 +17,8 @@ for name in ('c3', 'c2', 'ingest', 'metrics'):
 for a, b in (('bench_default.json', 'bench_default.json'), ('c3_pmc_traffic.json', 'c3_pmc_traffic.json'),
              ('c2_pmc_traffic.json', 'c2_pmc_traffic.json'), ('metrics_pmc.json', 'metrics_pmc.json'),
              ('ingest_pmc.txt', 'ingest_pmc.txt'), ('c4_rank1.json', 'c4_rank1.json'),
-             ('from_bam_2ranks_one_gpu.json', 'from_bam_2ranks_one_gpu.json')):
+             ('from_bam_2ranks_one_gpu.json', 'from_bam_2ranks_one_gpu.json'),
+             ('bam_to_graph_c3_full.json', 'bam_to_graph_c3_full.json')):
     shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (tag, b)))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 

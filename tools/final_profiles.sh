@@ -25,3 +25,6 @@ BESST_FORCE_DISTRIBUTED=1 timeout 900 python -m torch.distributed.run --nnodes=1
 BESST_DIST_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 \
     bench.py --gpus 2 --from-bam --steps 10 --warmup 2 > $O/from_bam_2ranks_one_gpu.json 2> $O/from_bam.err
 tail -c 600 $O/from_bam_2ranks_one_gpu.json
+# full-size C3 from BAM bytes (a one-off of bench.bam_to_graph_timing with all 200 M pairs: a 28 GB sequencer-like file)
+timeout 1500 python -c "import bench, torch, json; print(json.dumps(bench.bam_to_graph_timing(torch.device('cuda', 0), 'C3', pairs=None, realistic=True)))" > $O/bam_to_graph_c3_full.json 2> $O/bam_full.err
+tail -c 900 $O/bam_to_graph_c3_full.json
