@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE (not part of the product path): scalar model of csrc/bgzf_gpu.hip's DEFLATE decoder - the same
 table construction (canonical counts / first codes / offsets, primary table filled by decoding every slot's bit pattern),
-the same closed forms for RFC 1951's length / distance codes, the same path for codes longer than the primary table -
+the same second-level table for literal / length codes of 11-13 bits, the same closed forms for RFC 1951's length / distance codes, the same path for codes longer than the tables -
 checked against zlib (the published algorithm's reference implementation; BGZF blocks are raw DEFLATE streams, SAM spec
 section 4.1).  The kernel mirrors this step by step, so a logic error shows up here, without a GPU
 (tests/test_inflate_model.py); on the GPU the kernel itself is compared with zlib byte for byte (tests/test_gpu_ingest.py).
@@ -25,10 +25,15 @@ def bitrev(v, n):
 
 class Canon:
     """count / first code / offset per length + symbols sorted by (length, symbol) + primary table of 2^bits entries:
-    entry = symbol << 4 | length, 0 where the code is longer than the table (or unused)."""
+    entry = symbol << 4 | length, 0 where the code is longer than the table (or unused).  sub_bits > 0 (the literal / length
+    code): the first sub_cap primary slots that are no short code, in slot order, point (LINK | index) to second-level tables
+    of 2^sub_bits entries - the slot's pattern extended by sub_bits bits, decoded canonically - as build_code does in
+    csrc/bgzf_gpu.hip; a code beyond bits + sub_bits (or a slot beyond the capacity) is left to slow()."""
+    LINK = 1 << 20
 
-    def __init__(self, lens, bits):
+    def __init__(self, lens, bits, sub_bits=0, sub_cap=64):
         self.bits = bits
+        self.sub_bits = sub_bits
         self.cnt = [0] * 16
         for l in lens:
             if l:
@@ -61,6 +66,24 @@ class Canon:
                 if 0 <= d < self.cnt[L]:
                     self.tab[slot] = (self.sorted[self.offs[L] + d] << 4) | L
                     break
+        self.sub = []
+        if sub_bits:
+            wide = bits + sub_bits
+            n_sub = 0
+            for slot in range(1 << bits):
+                if self.tab[slot] != 0 or n_sub >= sub_cap:
+                    continue
+                self.tab[slot] = self.LINK | n_sub
+                n_sub += 1
+                for ext in range(1 << sub_bits):
+                    r = bitrev(slot | (ext << bits), wide)
+                    entry = 0
+                    for L in range(bits + 1, wide + 1):
+                        d = (r >> (wide - L)) - self.first[L]
+                        if 0 <= d < self.cnt[L]:
+                            entry = (self.sorted[self.offs[L] + d] << 4) | L
+                            break
+                    self.sub.append(entry)
 
     def slow(self, low15):
         r = bitrev(low15, 15)
@@ -96,6 +119,8 @@ def inflate(data):
     def sym(c):
         nonlocal bb, bc
         e = c.tab[bb & ((1 << c.bits) - 1)]
+        if e & Canon.LINK:                        # the second-level table: the next sub_bits bits pick the entry
+            e = c.sub[((e & (Canon.LINK - 1)) << c.sub_bits) + ((bb >> c.bits) & ((1 << c.sub_bits) - 1))]
         l = e & 15
         s = e >> 4
         if l == 0:
@@ -147,8 +172,8 @@ def inflate(data):
                 assert len(lens) == hlit + hdist
                 ll = lens[:hlit]
                 dl = lens[hlit:]
-            lc = Canon(ll, TAB)
-            dc = Canon(dl, TAB)
+            lc = Canon(ll, TAB, sub_bits=3, sub_cap=64)
+            dc = Canon(dl, 9)
             while True:
                 refill()
                 s = sym(lc)
