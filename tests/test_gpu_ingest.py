@@ -63,6 +63,36 @@ def test_inflate_equals_zlib(level, strategy):
     assert got == want
 
 
+def test_inflate_code_shapes_at_random():
+    """Payloads that push the symbol loop's batches to their ends - one- and two-bit codes (more symbols in a window of 64 bit
+    positions than a batch lays into lanes), long skewed codes (the second-level table and the codes beyond it), long
+    matches, runs - under every strategy and level, 3000 blocks against the bytes that were compressed."""
+    rnd = random.Random(77)
+    for _ in range(15):
+        blocks, want = [], []
+        for i in range(200):
+            kind = rnd.randrange(6)
+            n = rnd.randint(1, 65000)
+            if kind == 0:
+                raw = bytes(rnd.choice(b'\x00\xff') for _ in range(min(n, 20000)))
+            elif kind == 1:
+                raw = bytes(rnd.choice(b'ACGT') for _ in range(min(n, 30000)))
+            elif kind == 2:
+                raw = os.urandom(min(n, 3000)) * rnd.randint(1, 20)
+            elif kind == 3:
+                raw = bytes(int(rnd.expovariate(0.02)) & 255 for _ in range(min(n, 20000)))
+            elif kind == 4:
+                raw = bytes([rnd.randrange(3)]) * n
+            else:
+                raw = b''.join(os.urandom(rnd.randint(1, 9)) * rnd.randint(1, 40) for _ in range(300))
+            raw = raw[:65000]
+            strategy = rnd.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED, zlib.Z_FILTERED))
+            blocks.append(_bgzf(raw, rnd.choice((1, 1, 6, 9)), strategy))
+            want.append(raw)
+        got = bamio.inflate_bgzf_device(b''.join(blocks), out_cap=sum(map(len, want)) + 16)
+        assert got == b''.join(want)
+
+
 def test_inflate_many_blocks():
     """More blocks than waves fit the chip, in one call and across the hook's chunks."""
     rnd = random.Random(3)
