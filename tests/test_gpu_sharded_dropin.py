@@ -203,3 +203,56 @@ def test_cli_two_libraries_under_torchrun_equals_one_process(tmp_path):
             a = open(os.path.join(one, 'BESST_output', p, name)).read()
             b = open(os.path.join(many, 'BESST_output', p, name)).read()
             assert a == b and a.count('\n') > 1, (p, name)
+
+
+def _tiny_worker(rank, world, port, tmp, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from tests import bam_writer
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        doc, batch = GU.load('fr_given')
+        batch = batch.slice(0, 1500)                          # ~5 BGZF blocks of 64 KiB: fewer blocks than ranks
+        path = os.path.join(tmp, 'tiny.bam')
+        if rank == 0:
+            bam_writer.write_bam(path, batch, block_bytes=65000, align_records=False)
+        dist.barrier()
+        single = None
+        if rank == 0:
+            os.environ['BESST_SHARDED'] = '0'
+            res1, _ = _run_from_file(doc, path, batch)
+            single = _snapshot(res1)
+            os.environ['BESST_SHARDED'] = '1'
+        res, rec = _run_from_file(doc, path, batch)
+        empty = sum(1 for n in rec.head.slice_records if n == 0)
+        if rank == 0:
+            got = _snapshot(res)
+            for k in single:
+                assert got[k] == single[k], k
+            assert len(got['G_prime']) > 0
+        out.put((rank, empty))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_more_ranks_than_blocks(tmp_path):
+    """A file of a handful of BGZF blocks over eight ranks: several slices hold no block and no record - those ranks still
+    take part in the scans, the exchange and the scoring, and rank 0's result equals the single-GPU one."""
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiny_worker, args=(r, world, port, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(world))
+    assert [g[0] for g in got] == list(range(world)) and got[0][1] >= 2      # at least two ranks held nothing
