@@ -1045,6 +1045,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     // layout; a slice behind the first one: where the caller says (the bytes in front belong to the last record of the slice
     // before), or a guess that the caller will check against what the slice before reports
     uint32_t fb0 = 1u, fe0 = u0, mode0 = 0u;
+    int64_t no_start_left = -1;                              // >= 0: a slice no record begins in; so many bytes of the record before lie behind it
     if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks) {
         if (slice && part > 0 && first_skip < 0) {
             fb0 = 0xffffffffu; fe0 = 0u; mode0 = kWalkFirstGuessed;
@@ -1056,12 +1057,17 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
                 if (skip < desc[i].dst_len) { fb0 = i; fe0 = (uint32_t)skip; break; }
                 skip -= desc[i].dst_len;
             }
-            if (fb0 == 0u) {
+            if (fb0 == 0u && fpos >= map_len) {
+                // the WHOLE slice lies in this chunk and no record begins in it (its blocks are the tail of the record before -
+                // or hold nothing: the EOF marker of a file with fewer blocks than ranks): an empty slice, what comes in goes on
+                no_start_left = (int64_t)skip;
+                sl[0].ck = Chunk();
+            } else if (fb0 == 0u) {
                 set_error("push_bam_device: the slice's first record begins behind its first chunk (%lld bytes in)", (long long)first_skip);
                 rc = BESST_ERR_UNSUPPORTED;
             }
         }
-        if (rc == BESST_OK && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, fb0, fe0, mode0) && stage(1) && sl[1].ck.n_blocks)
+        if (rc == BESST_OK && sl[0].ck.n_blocks && enqueue_inflate(0) && enqueue_walk(0, 0, 0u, fb0, fe0, mode0) && stage(1) && sl[1].ck.n_blocks)
             enqueue_inflate(1);
     }
     int64_t first_at = -1, carry_out = 0, over_bytes = 0;    // (the slice form's answers)
@@ -1222,7 +1228,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     if (boundary) {
         if (chunks == 0 && first_at < 0) {                   // a slice without a block (more ranks than blocks): what comes in goes out
             first_at = first_skip > 0 ? first_skip : 0;
-            carry_out = first_at;
+            carry_out = no_start_left >= 0 ? no_start_left : first_at;
         }
         boundary[0] = first_at;
         boundary[1] = carry_out;
