@@ -43,6 +43,7 @@
 //                         into the record columns at the block's place in the stream
 // DESIGN.md section 8 has the measurements that led here.
 #include <stdlib.h>
+#include <mutex>
 #include <string.h>
 
 #include "common.h"
@@ -712,9 +713,9 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
 // ---- the blocks' CRC32 ---------------------------------------------------------------------------------------------------
 // BGZF stores the CRC-32 of every block's inflated bytes (the gzip trailer); htslib - what the reference reads its files
 // through - checks it, and so does this path: a damaged payload that still decodes, or a byte the window logic got wrong,
-// is a refused block, not a wrong record.  One workgroup per block, a thread per slice of <= 256 bytes: byte-table CRC
-// of the slice, then the slice's CRC is carried over the bytes behind it - multiplication by x^(8n) modulo the CRC polynomial, zlib's
-// crc32_combine - and the 256 values are XORed.
+// is a refused block, not a wrong record.  One workgroup per block, a thread per slice of <= 272 bytes: byte-table CRC
+// of the slice, then the slice's CRC is carried over the bytes behind it - multiplication by x^(8n) modulo the CRC polynomial,
+// zlib's crc32_combine, the powers from two tables - and the 256 values are XORed.
 namespace {
 
 constexpr uint32_t kCrcPoly = 0xedb88320u;
@@ -724,14 +725,36 @@ __device__ const uint32_t kCrcX2n[32] = {           // x^(2^k) mod the polynomia
     0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
     0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
 
-// a(x) * b(x) modulo the polynomial (both reflected: bit 31 is x^0); `a` is the same in every lane
-__device__ __forceinline__ uint32_t crc_mul(uint32_t a, uint32_t b) {
+// a(x) * b(x) modulo the polynomial (both reflected: bit 31 is x^0), any operands per lane
+__device__ __forceinline__ uint32_t crc_mul_lanes(uint32_t a, uint32_t b) {
     uint32_t p = 0;
-    for (uint32_t m = 1u << 31; m; m >>= 1) {                // uniform
-        if (a & m) p ^= b;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        p ^= (a & (1u << 31)) ? b : 0u;
+        a <<= 1;
         b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
     }
     return p;
+}
+
+// x^(8 n) modulo the polynomial for the n a slice's CRC has to be carried over: kCrcPow16[j] = x^(128 j) (whole slices behind
+// it: slices are multiples of 16 bytes), kCrcPow8[r] = x^(8 r) (the last slice's bytes).  Filled once per device by
+// crc_pow_kernel (binary exponentiation over zlib's x2n table); the per-thread exponentiation they replace - up to sixteen
+// 32-step multiplications per slice - was 60 % of the CRC kernel's instructions.
+constexpr int kCrcPow16N = 4352, kCrcPow8N = 288;
+__device__ uint32_t kCrcPow16[kCrcPow16N];
+__device__ uint32_t kCrcPow8[kCrcPow8N];
+
+__global__ __launch_bounds__(256) void crc_pow_kernel() {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)(kCrcPow16N + kCrcPow8N)) return;
+    const bool small = i >= (uint32_t)kCrcPow16N;
+    uint32_t n = small ? i - (uint32_t)kCrcPow16N : i;       // the exponent, in units of 8 bits (small) or 128 bits
+    uint32_t p = 1u << 31;                                   // x^0
+    for (uint32_t k = small ? 3u : 7u; n; n >>= 1, ++k)
+        if (n & 1u) p = crc_mul_lanes(kCrcX2n[k & 31u], p);
+    if (small) kCrcPow8[i - (uint32_t)kCrcPow16N] = p;
+    else kCrcPow16[i] = p;
 }
 
 }  // namespace
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
                                                        uint32_t n_blocks, uint32_t* __restrict__ status) {
     // four tables (slicing by four): entry [j][t] is byte t carried over j further zero bytes, so that a dword of input costs
     // four INDEPENDENT look-ups instead of a chain of four (a thread's 256-byte slice was a chain of 256 LDS round trips)
-    __shared__ uint32_t s_tab[4][256], s_part[4];
+    __shared__ uint32_t s_tab[4][256], s_part[5];
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     if (b >= n_blocks) return;
     const uint32_t len = blocks[b].dst_len;
@@ -798,29 +821,20 @@ __global__ __launch_bounds__(256) void bgzf_crc_kernel(const uint8_t* __restrict
         cur = next;
     }
     crc = n_slice ? ~crc : 0u;
-    // carry it over the bytes behind the slice: multiply by x^(8 n)
-    uint32_t n = vlen - hi;
-    uint32_t p = 1u << 31;                                   // x^0
-    for (uint32_t k = 3; n; n >>= 1, ++k)
-        if (n & 1u) p = crc_mul(kCrcX2n[k & 31u], p);
-    // (p differs per lane: crc_mul's first argument must be uniform, so the product is formed bit by bit of `crc`... the
-    // multiplication is commutative: run it with the per-lane operands swapped into its lane-wise form)
-    uint32_t prod = 0;
-    {
-        uint32_t a = crc, bb = p;
-        for (int j = 0; j < 32; ++j) {
-            if (a & (1u << 31)) prod ^= bb;
-            a <<= 1;
-            bb = (bb & 1u) ? (bb >> 1) ^ kCrcPoly : bb >> 1;
-        }
-    }
-    uint32_t x = prod;
+    // The block's CRC = XOR over the slices of (slice's CRC) x^(8 n), n = the bytes behind the slice (zlib's crc32_combine):
+    // the last slice holds r bytes and every slice in front of it is followed by whole slices and those r bytes, so
+    // x^(8 n_t) = x^(8 r) x^(8 S (L - 2 - t)): the second factor from the table, per lane; the first once, behind the XOR.
+    const uint32_t L = (vlen + S - 1u) / S;                  // slices that hold bytes (uniform)
+    const uint32_t r = vlen - (L - 1u) * S;
+    uint32_t x = t + 1u < L ? crc_mul_lanes(crc, kCrcPow16[(L - 2u - t) * (S >> 4)]) : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d, 64);
     if ((t & 63u) == 0u) s_part[t >> 6] = x;
+    if (t + 1u == L) s_part[4] = crc;                         // the last slice's own CRC
     __syncthreads();
     if (t == 0u) {
-        const uint32_t got = s_part[0] ^ s_part[1] ^ s_part[2] ^ s_part[3];
+        const uint32_t front = s_part[0] ^ s_part[1] ^ s_part[2] ^ s_part[3];
+        const uint32_t got = (L > 1u ? crc_mul_lanes(front, kCrcPow8[r]) : 0u) ^ s_part[4];
         if (got != blocks[b].crc) status[b] = kInfCrcMismatch;
     }
 }
@@ -1166,6 +1180,19 @@ int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* bloc
                         uint32_t* status) {
     if (n_blocks == 0) return BESST_OK;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    {   // the CRC kernel's power tables, once per device (on this stream, in front of the first CRC launch; a second
+        // thread's first launch on the same device waits for the one that fills them)
+        static std::mutex mu;
+        static bool filled[64];
+        int device = 0;
+        BESST_HIP_TRY(hipGetDevice(&device));
+        std::lock_guard<std::mutex> g(mu);
+        if (device >= 0 && device < 64 && !filled[device]) {
+            hipLaunchKernelGGL(crc_pow_kernel, dim3((kCrcPow16N + kCrcPow8N + 255) / 256), dim3(256), 0, s);
+            BESST_HIP_TRY(hipStreamSynchronize(s));
+            filled[device] = true;
+        }
+    }
     hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(256), 0, s, dst, blocks, n_blocks, status);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
