@@ -1044,6 +1044,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     // where the first chunk's first record begins: the end of the header / the first byte of a part of a file in htslib's
     // layout; a slice behind the first one: where the caller says (the bytes in front belong to the last record of the slice
     // before), or a guess that the caller will check against what the slice before reports
+    const double setup_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     uint32_t fb0 = 1u, fe0 = u0, mode0 = 0u;
     int64_t no_start_left = -1;                              // >= 0: a slice no record begins in; so many bytes of the record before lie behind it
     if (rc == BESST_OK && stage(0) && sl[0].ck.n_blocks) {
@@ -1205,7 +1206,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     alloc_join();
     release(rc == BESST_OK);
     if (const char* e = getenv("BESST_INGEST_PROFILE"); e && atoi(e))
-        fprintf(stderr, "[push_bam_device] alloc %.3f s (%.3f of it waited for)  staging %.3f s  waiting %.3f s  release %.3f s (unpinning %.3f)  total %.3f s\n", alloc_s, alloc_wait_s, stage_s,
+        fprintf(stderr, "[push_bam_device] setup %.3f s  alloc %.3f s (%.3f of it waited for)  staging %.3f s  waiting %.3f s  release %.3f s (unpinning %.3f)  total %.3f s\n", setup_s, alloc_s, alloc_wait_s, stage_s,
                 wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rel).count(), unpin_s,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     if (rc) return rc;
