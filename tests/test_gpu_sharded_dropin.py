@@ -256,3 +256,69 @@ def test_more_ranks_than_blocks(tmp_path):
         assert p.exitcode == 0
     got = sorted(out.get(timeout=5) for _ in range(world))
     assert [g[0] for g in got] == list(range(world)) and got[0][1] >= 2      # at least two ranks held nothing
+
+
+class _Seq(object):
+    __slots__ = ('n',)
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def _shaped_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from besst_amd import CreateGraph, libmetrics, session, workload
+    from tests.test_gpu_dropin import make_param
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        snaps = {}
+        for config, pairs, nc in (('C3', 3_000_000, 6000), ('C2', 1_500_000, 3000)):
+            wl = workload.make(config, 0, pairs=pairs, nc=nc)
+            batch = wl['batch']
+            for mode in (('0', '1') if rank == 0 else ('1',)):
+                os.environ['BESST_SHARDED'] = mode
+                param = make_param(dict(orientation=wl['lib']['orientation']))
+                info = param.information_file
+                libmetrics.get_metrics(batch, param, info)
+                objs = ({}, {}, {}, {})
+                C_dict = {name: _Seq(int(n)) for name, n in zip(batch.references, batch.lengths)} if rank == 0 else {}
+                G, Gp = CreateGraph.PE(objs[0], objs[1], info, C_dict, param, objs[2], objs[3], batch)
+                session.close_session(batch)
+                if rank == 0:
+                    snaps[(config, mode)] = _snapshot((param, G, Gp) + objs)
+            os.environ['BESST_SHARDED'] = '1'
+            if rank == 0:
+                one, many = snaps[(config, '0')], snaps[(config, '1')]
+                for k in one:
+                    assert many[k] == one[k], (config, k)
+                assert len(one['G']) > 500 and len(one['G_prime']) > len(one['G'])
+        out.put((rank, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_on_config_shaped_libraries():
+    """The sharded drop-in at a size where the regions, the gather and the owners' scoring carry weight: a mate-pair library
+    with PE contamination (C3's shape, 6 M records, 6000 contigs: the fused record loop, ~600 k link tuples, inferred
+    insert-size statistics through the sharded sampler) and a paired-end one (C2's shape) over three ranks `==` one GPU."""
+    import torch.multiprocessing as mp
+    world = 3
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shaped_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(1500)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(world)) == [(r, True) for r in range(world)]
