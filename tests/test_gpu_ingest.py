@@ -687,7 +687,7 @@ def test_profile_knobs_print_their_phase_times():
     out = subprocess.run([sys.executable, '-c', _PROFILE_SCRIPT % dict(repo=os.path.dirname(here))], env=env,
                          capture_output=True, text=True, timeout=600)
     assert 'DONE' in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
-    assert '[push_bam_device] alloc' in out.stderr and '[bam] read' in out.stderr, out.stderr[-2000:]
+    assert '[push_bam_device] setup' in out.stderr and ' alloc ' in out.stderr and '[bam] read' in out.stderr, out.stderr[-2000:]
 
 
 def _decode_bam_independently(path):
