@@ -1254,6 +1254,9 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
         }
         if from_bam is not None:
             out['from_bam'] = from_bam
+            if isinstance(out.get('single_gpu_same_shape'), dict):
+                # the one-rank figure of the same shape: rank 0's slice of every file ingested alone (the others waiting)
+                out['single_gpu_same_shape']['ingest'] = [dict(lib['rank0_slice_alone'] or {}, library=lib['library']) for lib in from_bam]
             out['slices'] = 'slices of one BAM file per library (distributed.ingest_slice)'
             out['data'] = 'synthetic (written as BAM files by rank 0, untimed; ingested by every rank on its GPU)'
         sys.stdout.flush()

@@ -388,7 +388,7 @@ void besst_bam_close(besst_bam* b) {
         char* m = reinterpret_cast<char*>(const_cast<uint8_t*>(b->copy_map));
         const size_t len = b->map_len;
         std::thread([m, len] {
-            constexpr size_t kPiece = (size_t)64 << 20;
+            constexpr size_t kPiece = (size_t)4 << 20;          // (short holds of the address space's lock: the caller's allocations go on beside it)
             for (size_t at = 0; at < len; at += kPiece) (void)madvise(m + at, len - at < kPiece ? len - at : kPiece, MADV_DONTNEED);
             (void)munmap(m, len);
         }).detach();

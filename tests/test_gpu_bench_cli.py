@@ -109,6 +109,7 @@ def test_two_ranks_from_one_bam_file_per_library():
         assert all(r['ingest_s'] > 0 and r['staging_s'] >= 0 and r['chunks'] >= 1 for r in lib['per_rank'])
         assert lib['handshake_rounds'] >= 1 and lib['aggregate_records_per_s'] > 0
         assert lib['rank0_slice_alone']['records'] == lib['per_rank'][0]['records']
+    assert [i['library'] for i in d['single_gpu_same_shape']['ingest']] == [1, 2] and d['single_gpu_same_shape']['ingest'][0]['records_per_s'] > 0
     for lib in d['config']['libraries']:
         assert lib['exchange_consistent'] is True and all(lib['verified_vs_c_oracle'].values()), lib
     assert abs(d['value'] - 2 * 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
