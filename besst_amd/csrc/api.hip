@@ -125,6 +125,21 @@ struct Background {
     }
 };
 Background g_background;
+
+// What every device ingest needs whatever the file: four streams (4 ms each to create: 17 of a call's 18 ms of set-up), twelve
+// events and three small buffers.  One set per device stays with the process; a call takes it (a second call on the same
+// device at the same time makes its own and destroys it), besst_release_cached_memory() does not touch it (a few KB).
+struct IngestKit {
+    std::mutex mu;
+    bool busy = false;
+    hipStream_t work[3] = {nullptr, nullptr, nullptr}, copy = nullptr;
+    hipEvent_t ev[3][4] = {};
+    char* heads = nullptr;
+    size_t heads_bytes = 0;
+    uint32_t* d_flags = nullptr;
+    uint32_t* summ_host = nullptr;
+};
+IngestKit g_ingest_kit[16];
 constexpr size_t kPinnedKeep = (size_t)1 << 30;
 struct PinnedPool {
     struct Entry { void* p; size_t bytes; bool busy; };
@@ -823,6 +838,8 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     uint32_t* d_flags = nullptr;     // corrupt-record bit, saturated-qlen count
     uint32_t* summ_host = nullptr;   // pinned: kSlots x 12 summary words | [40] [41] flag words | [48..] kSlots tail descriptors
     hipStream_t copy_stream = nullptr;
+    IngestKit* kit = nullptr;        // the device's cached streams / events / small buffers, if no other call holds them
+    const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
     const size_t inflated_cap = kTailRoom + nb * 65536 + 4096;
     double unpin_s = 0.0;
     // What the call allocated goes back when it ends: the pinned staging to its pool at once; the device scratch, events and
@@ -838,15 +855,30 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
             unpin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             for (void* m : {(void*)q.dev, (void*)q.inflated, (void*)q.offs, (void*)q.words})
                 if (m) dev_mem.push_back(m);
-            for (hipEvent_t e : {q.h2d_done, q.slot_free, q.summ_done, q.tail_taken})
-                if (e) events.push_back(e);
-            if (q.work) streams.push_back(q.work);
-            q = Slot();
+            if (!kit) {
+                for (hipEvent_t e : {q.h2d_done, q.slot_free, q.summ_done, q.tail_taken})
+                    if (e) events.push_back(e);
+                if (q.work) streams.push_back(q.work);
+            }
         }
-        if (heads) dev_mem.push_back(heads);
-        if (d_flags) dev_mem.push_back(d_flags);
-        if (summ_host) host_mem.push_back(summ_host);
-        if (copy_stream) streams.push_back(copy_stream);
+        if (kit) {                                           // (whatever exists by now, also after a failed call: valid handles)
+            for (int k = 0; k < kSlots; ++k) {
+                kit->work[k] = sl[k].work;
+                kit->ev[k][0] = sl[k].h2d_done; kit->ev[k][1] = sl[k].slot_free; kit->ev[k][2] = sl[k].summ_done; kit->ev[k][3] = sl[k].tail_taken;
+            }
+            kit->copy = copy_stream;
+            kit->d_flags = d_flags;
+            kit->summ_host = summ_host;
+            if (heads && heads != kit->heads) { kit->heads = heads; kit->heads_bytes = head_n * 10; }
+            std::lock_guard<std::mutex> g(kit->mu);
+            kit->busy = false;
+        } else {
+            if (heads) dev_mem.push_back(heads);
+            if (d_flags) dev_mem.push_back(d_flags);
+            if (summ_host) host_mem.push_back(summ_host);
+            if (copy_stream) streams.push_back(copy_stream);
+        }
+        for (Slot& q : sl) q = Slot();
         heads = nullptr; d_flags = nullptr; summ_host = nullptr; copy_stream = nullptr;
         const int device = c->device;
         auto drop = [device, dev_mem, host_mem, events, streams]() {
@@ -870,6 +902,12 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     double alloc_s = 0.0;
+    if (c->device >= 0 && c->device < 16) {
+        IngestKit& k = g_ingest_kit[c->device];
+        std::lock_guard<std::mutex> g(k.mu);
+        if (!k.busy) { k.busy = true; kit = &k; }
+    }
+
     auto alloc_slot = [&](int k) -> bool {
         Slot& q = sl[k];
         if (q.pin) return true;
@@ -879,22 +917,34 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
              hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
              hipMalloc((void**)&q.words, (nbw * 6 + 12) * sizeof(uint32_t)) == hipSuccess &&
              (q.work || hipStreamCreateWithPriority(&q.work, hipStreamNonBlocking, prio_low) == hipSuccess) &&
-             hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q.tail_taken, hipEventDisableTiming) == hipSuccess;
+             (q.h2d_done || hipEventCreateWithFlags(&q.h2d_done, hipEventDisableTiming) == hipSuccess) &&
+             (q.slot_free || hipEventCreateWithFlags(&q.slot_free, hipEventDisableTiming) == hipSuccess) &&
+             (q.summ_done || hipEventCreateWithFlags(&q.summ_done, hipEventDisableTiming) == hipSuccess) &&
+             (q.tail_taken || hipEventCreateWithFlags(&q.tail_taken, hipEventDisableTiming) == hipSuccess);
         alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return got;
     };
     // Slot 0 now; slots 1 and 2 - 2 x (~190 MB pinned + ~0.7 GB of HBM): 90 of the 130 ms a first ingest spent allocating -
     // on a helper thread while the first chunk is read, uploaded and queued (joined before the second chunk is staged, and
     // before anything is released).  Their streams are created here, in order: the queue placement above depends on it.
+    if (kit) {                                               // what an earlier call on this device left
+        for (int k = 0; k < kSlots; ++k) {
+            sl[k].work = kit->work[k];
+            sl[k].h2d_done = kit->ev[k][0]; sl[k].slot_free = kit->ev[k][1]; sl[k].summ_done = kit->ev[k][2]; sl[k].tail_taken = kit->ev[k][3];
+        }
+        copy_stream = kit->copy;
+        d_flags = kit->d_flags;
+        summ_host = kit->summ_host;
+        if (kit->heads_bytes >= head_n * 10) heads = kit->heads;
+        else if (kit->heads) { (void)hipFree(kit->heads); kit->heads = nullptr; kit->heads_bytes = 0; }
+    }
     bool ok = alloc_slot(0);
-    for (int k = 1; k < kSlots && ok; ++k) ok = hipStreamCreateWithPriority(&sl[k].work, hipStreamNonBlocking, prio_low) == hipSuccess;
-    const size_t head_n = (size_t)(head_records > 0 ? head_records : 1);
-    ok = ok && hipMalloc((void**)&heads, head_n * 10) == hipSuccess && hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess &&
-         hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
-         hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high) == hipSuccess;
+    for (int k = 1; k < kSlots && ok; ++k)
+        ok = sl[k].work || hipStreamCreateWithPriority(&sl[k].work, hipStreamNonBlocking, prio_low) == hipSuccess;
+    ok = ok && (heads || hipMalloc((void**)&heads, head_n * 10) == hipSuccess) &&
+         (d_flags || hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess) &&
+         (summ_host || hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) &&
+         (copy_stream || hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high) == hipSuccess);
     std::thread alloc_helper;
     std::atomic<bool> helper_ok(true);
     double alloc_wait_s = 0.0;                               // (what the calling thread spent waiting for the helper)
