@@ -91,10 +91,18 @@ def AdjustInsertsizeDist(param, mean_insert, std_dev_insert, insert_list):
 
 
 def largest_reference_indexes(lengths, k=1000):
-    """Indexes of the k longest references; ties go to the smaller index (heapq.nlargest, libmetrics.py:233)."""
+    """Indexes of the k longest references; ties go to the smaller index (heapq.nlargest, libmetrics.py:233).  One
+    partition instead of a sort of the whole header: everything longer than the k-th longest, then the first of those that
+    are as long as it, in index order."""
     lengths = np.asarray(lengths, dtype=np.int64)
-    order = np.lexsort((np.arange(lengths.shape[0]), -lengths))
-    return order[:k]
+    n = lengths.shape[0]
+    if n <= k:
+        return np.lexsort((np.arange(n), -lengths))
+    kth = np.partition(lengths, n - k)[n - k]                 # the k-th longest length
+    above = np.flatnonzero(lengths > kth)
+    equal = np.flatnonzero(lengths == kth)[:k - above.shape[0]]
+    chosen = np.concatenate([above, equal])
+    return chosen[np.lexsort((chosen, -lengths[chosen]))]
 
 
 def getdistr(ins_size_reads, cont_lengths_list, param, Information):
