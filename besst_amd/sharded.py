@@ -46,15 +46,17 @@ def _dist():
 
 def active_group():
     """(rank, world) when the sharded form applies: torch.distributed is initialised with more than one rank and
-    BESST_SHARDED is not '0'.  None otherwise - without importing torch when nobody has."""
+    BESST_SHARDED is not '0' ('force': also with ONE rank - the whole orchestration over RCCL on a single GPU, what a
+    one-GPU box can check of the device-side transport).  None otherwise - without importing torch when nobody has."""
     import os
-    if os.environ.get('BESST_SHARDED', '1') == '0' or 'torch.distributed' not in sys.modules:
+    mode = os.environ.get('BESST_SHARDED', '1')
+    if mode == '0' or 'torch.distributed' not in sys.modules:
         return None
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()):
         return None
     world = dist.get_world_size(PROCESS_GROUP)
-    if world < 2:
+    if world < 2 and mode != 'force':
         return None
     return dist.get_rank(PROCESS_GROUP), world
 

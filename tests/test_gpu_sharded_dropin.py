@@ -312,3 +312,50 @@ def test_three_ranks_on_config_shaped_libraries():
             p.kill()
         assert p.exitcode == 0
     assert sorted(out.get(timeout=5) for _ in range(world)) == [(r, True) for r in range(world)]
+
+
+def _rccl_worker(port, tmp, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['BESST_SHARDED'] = 'force'
+    import torch
+    import torch.distributed as dist
+    from besst_amd import sharded
+    from tests import bam_writer
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        assert sharded.active_group() == (0, 1) and dist.get_backend() == 'nccl'
+        n = 0
+        for name in ('fr_infer', 'rf_contam', 'rf_second_lib', 'fr_edgecases', 'fr_dense'):
+            doc, batch = GU.load(name)
+            res = run_sharded(doc, batch)
+            check_against_golden(name, doc, *res, exact_scores=False)
+            n += len(res[1].edges())
+        doc, batch = GU.load('fr_infer')
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=5000, align_records=False, decoys=True)
+        res, rec = _run_from_file(doc, path, batch)
+        assert type(rec).__name__ == 'ShardedBam'
+        strip = lambda rows: [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in rows]
+        got = _snapshot(res)
+        assert strip(got['G']) == strip(doc['final']['G']) and strip(got['G_prime']) == strip(doc['final']['G_prime'])
+        out.put(n)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_over_rccl_through_the_sharded_dropin(tmp_path):
+    """BESST_SHARDED=force with ONE rank over RCCL (backend nccl): the whole sharded orchestration - object collectives on the
+    device, the all-to-all and the all-reduces on device tensors without host staging, owners' scoring, the gather - on the
+    transport a multi-GPU node uses, as far as one GPU can show it; results equal the reference goldens."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path), out))
+    p.start()
+    p.join(900)
+    if p.is_alive():
+        p.kill()
+    assert p.exitcode == 0
+    assert out.get(timeout=5) > 100
