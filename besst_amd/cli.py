@@ -144,7 +144,7 @@ def _run(args, rank):
         param.read_len = _per_lib(args.readlen, i)
         print('\nPASS ' + str(i + 1) + '\n\n', file=Information)
         t0 = time()
-        # straight to HBM: inflate + record decode on the GPU (files in htslib's block layout; others through the host reader)
+        # straight to HBM: inflate + record decode on the GPU (any BGZF block layout)
         # (under torchrun: this rank's slice of the file, on this rank's GPU)
         records = bamio.open_bam(bam, threads=args.threads)
         print('Time elapsed reading %s (%d records): %s' % (bam, len(records), time() - t0), file=Information)
