@@ -36,7 +36,7 @@ from .nxcompat import Graph
 
 
 # Wall time of PE's stages on the leading rank (seconds, summed over calls), filled only while this is a dict: bench.py and
-# tools/pe_host_profile.py set it to {} to report where PE's host time goes.
+# tests/pe_host_profile.py set it to {} to report where PE's host time goes.
 STAGE_SECONDS = None
 
 

@@ -1,7 +1,7 @@
-"""Where does CreateGraph.PE's HOST time go?  No GPU needed: the device stages are answered once by the C oracle (record
+"""TEST INFRASTRUCTURE (asks the oracle; not part of the product path).  Where does CreateGraph.PE's HOST time go?  No GPU needed: the device stages are answered once by the C oracle (record
 loop, edge rows) and by zeros (scores), then PE runs under cProfile / perf_counter on the product's host code with the
 answers at hand.  The contig count is what the host time scales with (objects, graph assembly, filters); the pair count
-only sizes the observation columns.  usage: python tools/pe_host_profile.py [config] [pairs] [contigs] [--cprofile]"""
+only sizes the observation columns.  usage: python tests/pe_host_profile.py [config] [pairs] [contigs] [--cprofile]"""
 import cProfile, io, os, pstats, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
