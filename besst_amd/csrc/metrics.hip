@@ -50,22 +50,40 @@ __device__ __forceinline__ void eval_record(const MetricsArgs& m, int k, int32_t
     if (d) f.d |= bit;
 }
 
-// four records of a thread, any alignment and any end (the count kernel, and the one-pass kernel's ragged tiles)
+// four records of a thread, any alignment and any end (the count kernel, and the one-pass kernel's ragged tiles).
+// Every predicate asks for a record on one of the 1000 longest contigs (bam_parser.py:22-29 is only ever called under
+// libmetrics.py:63,293's `sample in largest` test), so the reference id is read first and a WAVE none of whose records
+// lies on such a contig - nearly every wave of a library on many contigs - reads nothing else.
 __device__ __forceinline__ Flags4 eval4(const MetricsArgs& m, int64_t i0, int64_t end) {
     Flags4 f;
     f.a = f.b = f.c = f.d = 0;
     int32_t tid[kMetVec], mtid[kMetVec], tlen[kMetVec];
     uint32_t flag[kMetVec], mapq[kMetVec];
-    if (i0 + kMetVec <= end && (i0 & 3) == 0) {
+    const bool whole = i0 + kMetVec <= end && (i0 & 3) == 0;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    if (whole) {
         // (every record is read once: non-temporal, as in the record loop)
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
         const v4i v0 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tid + i0));
+        tid[0] = v0.x; tid[1] = v0.y; tid[2] = v0.z; tid[3] = v0.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kMetVec; ++k) tid[k] = i0 + k < end ? m.tid[i0 + k] : -1;
+    }
+    bool top[kMetVec], any = false;
+#pragma unroll
+    for (int k = 0; k < kMetVec; ++k) {
+        top[k] = (uint32_t)tid[k] < (uint32_t)m.n_contigs && m.top_mask[tid[k]] != 0;
+        any = any || top[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kMetVec; ++k) f.val[k] = 0;
+    if (__ballot(any) == 0ull) return f;                     // uniform
+    if (whole) {
         const v4i v1 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.mtid + i0));
         const v4i v2 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tlen + i0));
         const v2u fl = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(m.flag + i0));
         const uint32_t mq = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(m.mapq + i0));
-        tid[0] = v0.x; tid[1] = v0.y; tid[2] = v0.z; tid[3] = v0.w;
         mtid[0] = v1.x; mtid[1] = v1.y; mtid[2] = v1.z; mtid[3] = v1.w;
         tlen[0] = v2.x; tlen[1] = v2.y; tlen[2] = v2.z; tlen[3] = v2.w;
         flag[0] = fl.x & 0xffffu; flag[1] = fl.x >> 16; flag[2] = fl.y & 0xffffu; flag[3] = fl.y >> 16;
@@ -75,7 +93,6 @@ __device__ __forceinline__ Flags4 eval4(const MetricsArgs& m, int64_t i0, int64_
         for (int k = 0; k < kMetVec; ++k) {
             const int64_t i = i0 + k;
             const bool in = i < end;
-            tid[k] = in ? m.tid[i] : -1;
             mtid[k] = in ? m.mtid[i] : -2;
             tlen[k] = in ? m.tlen[i] : 0;
             flag[k] = in ? m.flag[i] : 0;
@@ -83,33 +100,23 @@ __device__ __forceinline__ Flags4 eval4(const MetricsArgs& m, int64_t i0, int64_
         }
     }
 #pragma unroll
-    for (int k = 0; k < kMetVec; ++k) {
-        const bool top = (uint32_t)tid[k] < (uint32_t)m.n_contigs && m.top_mask[tid[k]] != 0;
-        eval_record(m, k, tid[k], mtid[k], tlen[k], flag[k], mapq[k], top, f);
-    }
+    for (int k = 0; k < kMetVec; ++k) eval_record(m, k, tid[k], mtid[k], tlen[k], flag[k], mapq[k], top[k], f);
     return f;
 }
 
-// A whole, aligned tile of the one-pass kernel: kSubs x four records per thread in TWO memory round trips - every column load
-// of the tile is issued before the first is waited for, then every top-1000 look-up (a byte gather through the contig id,
-// clamped instead of branched around), then the arithmetic.  Written sub-tile by sub-tile the compiler kept each sub-tile's
-// loads, and each of its four look-ups, behind the branches of the one before: 20 round trips in a row, 15 of a tile's 27 us.
+// A whole, aligned tile of the one-pass kernel: kSubs x four records per thread.  First the reference ids (every load of the
+// tile issued before the first is waited for) and their top-1000 look-ups (a byte gather through the id, clamped instead of
+// branched around); a wave without a record on such a contig is done - false, 4 of the 15 bytes of a record read, a seventh
+// of the instructions -, the others read the four other columns (again all loads in flight together) and evaluate.
+// (Written sub-tile by sub-tile the compiler kept each sub-tile's loads, and each of its four look-ups, behind the branches
+// of the one before: 20 round trips in a row, 15 of a tile's 27 us.)
 template <int kSubs>
-__device__ __forceinline__ void eval_tile(const MetricsArgs& m, int64_t i0, int64_t stride, Flags4 (&f)[kSubs]) {
+__device__ __forceinline__ bool eval_tile(const MetricsArgs& m, int64_t i0, int64_t stride, Flags4 (&f)[kSubs]) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-    v4i tid[kSubs], mtid[kSubs], tlen[kSubs];
-    v2u fl[kSubs];
-    uint32_t mq[kSubs];
+    v4i tid[kSubs];
 #pragma unroll
-    for (int u = 0; u < kSubs; ++u) {
-        const int64_t i = i0 + (int64_t)u * stride;
-        tid[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tid + i));
-        mtid[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.mtid + i));
-        tlen[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tlen + i));
-        fl[u] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(m.flag + i));
-        mq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(m.mapq + i));
-    }
+    for (int u = 0; u < kSubs; ++u) tid[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tid + i0 + (int64_t)u * stride));
     uint8_t top[kSubs][kMetVec];
 #pragma unroll
     for (int u = 0; u < kSubs; ++u)
@@ -118,9 +125,30 @@ __device__ __forceinline__ void eval_tile(const MetricsArgs& m, int64_t i0, int6
             const uint32_t c = (uint32_t)tid[u][k];
             top[u][k] = m.top_mask[c < (uint32_t)m.n_contigs ? c : 0u];
         }
+    bool any = false;
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
         f[u].a = f[u].b = f[u].c = f[u].d = 0;
+#pragma unroll
+        for (int k = 0; k < kMetVec; ++k) {
+            f[u].val[k] = 0;
+            any = any || ((uint32_t)tid[u][k] < (uint32_t)m.n_contigs && top[u][k] != 0);
+        }
+    }
+    if (__ballot(any) == 0ull) return false;                 // uniform
+    v4i mtid[kSubs], tlen[kSubs];
+    v2u fl[kSubs];
+    uint32_t mq[kSubs];
+#pragma unroll
+    for (int u = 0; u < kSubs; ++u) {
+        const int64_t i = i0 + (int64_t)u * stride;
+        mtid[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.mtid + i));
+        tlen[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(m.tlen + i));
+        fl[u] = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(m.flag + i));
+        mq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(m.mapq + i));
+    }
+#pragma unroll
+    for (int u = 0; u < kSubs; ++u) {
 #pragma unroll
         for (int k = 0; k < kMetVec; ++k) {
             const uint32_t flag = (k & 1) ? fl[u][k >> 1] >> 16 : fl[u][k >> 1] & 0xffffu;
@@ -128,6 +156,7 @@ __device__ __forceinline__ void eval_tile(const MetricsArgs& m, int64_t i0, int6
             eval_record(m, k, tid[u][k], mtid[u][k], tlen[u][k], flag, (mq[u] >> (8 * k)) & 255u, is_top, f[u]);
         }
     }
+    return true;
 }
 
 __device__ __forceinline__ int wsum(int v) {
@@ -215,18 +244,33 @@ __device__ __forceinline__ long long wsum64(long long v) {
     return v;
 }
 
-// The flags of a tile's records (whole aligned tiles: two memory round trips, else the generic path) and, per sub-tile, the
-// thread's counts a | b << 16 | d << 32 | c << 48 (`mine`), their inclusive scan over the wave (`incl`) and the waves' totals in
-// s_w - what a thread needs to know its records' ranks inside the tile.
-__device__ __forceinline__ void tile_flags(const MetricsArgs& m, int64_t tile0, int64_t end, int t, Flags4 (&f)[kMetSubs],
+// The flags of a tile's records (whole aligned tiles: eval_tile, else the generic path) and, per sub-tile, the thread's counts
+// a | b << 16 | d << 32 | c << 48 (`mine`), their inclusive scan over the wave (`incl`) and the waves' totals in s_w - what a
+// thread needs to know its records' ranks inside the tile.  -> false (uniform over the wave): none of the wave's records
+// counts anywhere (no scans, zeros in s_w).
+__device__ __forceinline__ bool tile_flags(const MetricsArgs& m, int64_t tile0, int64_t end, int t, Flags4 (&f)[kMetSubs],
                                            unsigned long long (&mine)[kMetSubs], unsigned long long (&incl)[kMetSubs],
                                            unsigned long long (*s_w)[4], bool scan) {
     const int lane = t & 63, wave = t >> 6;
+    bool any = true;
     if ((tile0 & 3) == 0 && tile0 + kMetBig <= end && m.n_contigs > 0) {           // uniform
-        eval_tile<kMetSubs>(m, tile0 + (int64_t)t * kMetVec, kMetTile, f);
+        any = eval_tile<kMetSubs>(m, tile0 + (int64_t)t * kMetVec, kMetTile, f);
     } else {
+        bool some = false;
 #pragma unroll
-        for (int u = 0; u < kMetSubs; ++u) f[u] = eval4(m, tile0 + (int64_t)u * kMetTile + (int64_t)t * kMetVec, end);
+        for (int u = 0; u < kMetSubs; ++u) {
+            f[u] = eval4(m, tile0 + (int64_t)u * kMetTile + (int64_t)t * kMetVec, end);
+            some = some || (f[u].b != 0u);                   // (every other bit is set together with b's)
+        }
+        any = __ballot(some) != 0ull;
+    }
+    if (!any) {                                              // uniform
+#pragma unroll
+        for (int u = 0; u < kMetSubs; ++u) {
+            mine[u] = incl[u] = 0ull;
+            if (lane == 63) s_w[u][wave] = 0ull;
+        }
+        return false;
     }
 #pragma unroll
     for (int u = 0; u < kMetSubs; ++u) {
@@ -245,6 +289,7 @@ __device__ __forceinline__ void tile_flags(const MetricsArgs& m, int64_t tile0, 
         incl[u] = x;
         if (lane == 63) s_w[u][wave] = x;
     }
+    return true;
 }
 
 __global__ __launch_bounds__(kMetThreads) void metrics_stage_kernel(MetricsArgs m, int64_t start, int64_t end, int want_isize,
@@ -264,8 +309,9 @@ __global__ __launch_bounds__(kMetThreads) void metrics_stage_kernel(MetricsArgs 
     const int64_t tile0 = start + (int64_t)tile * kMetBig;
     Flags4 f[kMetSubs];
     unsigned long long mine[kMetSubs], incl[kMetSubs];
-    tile_flags(m, tile0, end, t, f, mine, incl, s_w, true);
+    const bool any = tile_flags(m, tile0, end, t, f, mine, incl, s_w, true);
     __syncthreads();
+    if (!any && wave != 0) return;                           // uniform per wave: nothing to place (wave 0 still adds the tile up)
     unsigned long long run = 0;                              // the counts of the sub-tiles before the one at hand
     const size_t at = (size_t)tile * kMetBig;
 #pragma unroll
@@ -279,16 +325,18 @@ __global__ __launch_bounds__(kMetThreads) void metrics_stage_kernel(MetricsArgs 
         }
         const unsigned long long ex = run + mywaves + incl[u] - mine[u];
         uint32_t ra = (uint32_t)(ex & 0xffffu), rd = (uint32_t)((ex >> 32) & 0xffffu);
+        if (any) {                                           // uniform
 #pragma unroll
-        for (int k = 0; k < kMetVec; ++k) {
-            const uint32_t bit = 1u << k;
-            if (f[u].a & bit) {
-                if (live_a) stage_a[at + ra] = f[u].val[k];
-                ra++;
-            }
-            if (f[u].d & bit) {
-                if (live_b) stage_d[at + rd] = f[u].val[k];
-                rd++;
+            for (int k = 0; k < kMetVec; ++k) {
+                const uint32_t bit = 1u << k;
+                if (f[u].a & bit) {
+                    if (live_a) stage_a[at + ra] = f[u].val[k];
+                    ra++;
+                }
+                if (f[u].d & bit) {
+                    if (live_b) stage_d[at + rd] = f[u].val[k];
+                    rd++;
+                }
             }
         }
         run += sub;
