@@ -866,6 +866,11 @@ def main_single(args, device, result_fd):
 
 def main():
     args = parse_args()
+    # BESST_BENCH_WATCHDOG=<seconds>: every thread's Python stack to stderr at that interval (where is a run that does not
+    # come back?)
+    if os.environ.get('BESST_BENCH_WATCHDOG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['BESST_BENCH_WATCHDOG']), repeat=True, file=sys.stderr)
     # Only the final JSON line may reach stdout: RCCL prints a version banner to fd 1 when the process group is
     # created, so everything before the result is routed to stderr at the file-descriptor level.
     sys.stdout.flush()
