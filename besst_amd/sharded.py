@@ -322,11 +322,24 @@ class ShardedContext(object):
         except Exception as e:
             err = '%s: %s' % (type(e).__name__, e)
         _agree(group, world, err)
-        # 3. the step: slices -> owners -> rows; a region that overflowed grows and the step repeats (all ranks together)
-        self.job.step()
-        self.job.check_capacity()
+        # 3. the step: slices -> owners -> rows; a region that overflowed grows and the step repeats (all ranks together).
+        # What fails on one rank behind the step's collectives - the capacity check's verdict, the download of the rows -
+        # is agreed on before the gather: nobody is left waiting for a rank that has gone.
+        mine = None
+        try:
+            self.job.step()
+            self.job.check_capacity()
+        except RankFailure:
+            raise
+        except Exception as e:
+            err = '%s: %s' % (type(e).__name__, e)
         t1 = perf_counter()
-        mine = eng.local_table(self.job)
+        if err is None:
+            try:
+                mine = eng.local_table(self.job)
+            except Exception as e:
+                err = '%s: %s' % (type(e).__name__, e)
+        _agree(group, world, err)
         tables = [None] * world if self.rank == 0 else None
         _dist().gather_object(mine, tables, dst=_src(group), group=group)
         self.stats = dict(build_s=t1 - t0, gather_s=perf_counter() - t1, pair_capacity=pair_cap)
@@ -345,23 +358,20 @@ class ShardedContext(object):
         box = [None]
         dist.scatter_object_list(box, requests if self.rank == 0 else None, src=_src(self.group), group=self.group)
         rows, swap, len1, len2, mean, sigma, read_len = box[0]
+        res, err = None, None
         try:
             if rows.shape[0]:
                 res = tuple(np.asarray(a) for a in self.engine.score(self.job, rows, swap, len1, len2, mean, sigma, read_len))
             else:
                 res = (np.zeros(0), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.uint8))
         except Exception as e:
-            res = ('error', '%s: %s' % (type(e).__name__, e))
+            err = '%s: %s' % (type(e).__name__, e)
+        # (EVERY rank learns of a failure: a follower whose own rows were fine would otherwise go back to waiting for the
+        # next command of a rank 0 that has left)
+        _agree(self.group, self.world, err)
         out = [None] * self.world if self.rank == 0 else None
         dist.gather_object(res, out, dst=_src(self.group), group=self.group)
-        if self.rank != 0:
-            if res and isinstance(res[0], str):
-                raise RankFailure('rank %d: %s' % (self.rank, res[1]))
-            return None
-        bad = [(r, o[1]) for r, o in enumerate(out) if isinstance(o[0], str)]
-        if bad:
-            raise RankFailure('; '.join('rank %d: %s' % b for b in bad))
-        return out
+        return out if self.rank == 0 else None
 
     def close(self):
         self.job = None
@@ -389,10 +399,18 @@ class ShardedSession(object):
     def stream_order(self):
         """Index (in the whole stream) of the first record that breaks the coordinate order, or None: every slice checks
         itself, and its first record against the last record of the slice before it."""
-        local = self.ctx.engine.stream_order()
+        local, err = None, None
+        try:
+            local = self.ctx.engine.stream_order()
+        except Exception as e:
+            err = '%s: %s' % (type(e).__name__, e)
         n_local = self.batch.slice_records[self.rank]
         out = [None] * self.world
-        _dist().all_gather_object(out, (local, n_local), group=self.group)
+        _dist().all_gather_object(out, (local, n_local, err), group=self.group)
+        bad = [(r, o[2]) for r, o in enumerate(out) if o[2] is not None]
+        if bad:
+            raise RankFailure('; '.join('rank %d: %s' % b for b in bad))
+        out = [o[:2] for o in out]
         key = lambda k: ((k[0] & 0xffffffff) << 32) | ((k[1] + 1) & 0xffffffff)
         base, prev_last = 0, None
         for (first, first_key, last_key), n in out:

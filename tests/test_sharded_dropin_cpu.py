@@ -123,12 +123,12 @@ def _worker(rank, port, names, out):
         dist.destroy_process_group()
 
 
-def _run(target, args, timeout=900):
+def _run(target, args, timeout=900, world=WORLD):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, port) + args + (out,)) for r in range(WORLD)]
+    procs = [ctx.Process(target=target, args=(r, port) + args + (out,)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -136,7 +136,7 @@ def _run(target, args, timeout=900):
         if p.is_alive():
             p.kill()
         assert p.exitcode == 0
-    return sorted(out.get(timeout=5) for _ in range(WORLD))
+    return sorted(out.get(timeout=5) for _ in range(world))
 
 
 def test_two_rank_sharded_dropin_reproduces_reference_goldens():
@@ -183,3 +183,38 @@ def _abort_worker(rank, port, out):
 def test_followers_leave_pe_when_rank_0_exits():
     got = _run(_abort_worker, ())
     assert got == [(0, 'exit:message'), (1, 'exit:0')]
+
+
+def _failing_score_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from besst_amd import sharded
+    from tests import fake_device
+    dist.init_process_group('gloo', rank=rank, world_size=3)
+    try:
+        class Engine(fake_device.OracleRankEngine):
+            def score(self, *a):
+                if rank == 1:
+                    raise RuntimeError('injected: rank 1 cannot score')
+                return fake_device.OracleRankEngine.score(self, *a)
+        sharded.RankEngine = Engine
+        doc, batch = GU.load('rf_second_lib')
+        try:
+            run_sharded(doc, batch)
+            left = 'returned'
+        except sharded.RankFailure as e:
+            left = 'failure' if 'rank 1: RuntimeError: injected' in str(e) else 'other: %s' % e
+        from besst_amd import session
+        session.close_session(batch)
+        dist.barrier()                                       # nobody is stuck in a collective of the failed stage
+        out.put((rank, left))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_stage_that_fails_on_one_rank_fails_on_all_three():
+    """Rank 1's scoring raises; rank 0 AND rank 2 - whose own rows were fine - must leave PE with the same error instead of
+    waiting for each other (three ranks: with two there is no bystander)."""
+    got = _run(_failing_score_worker, (), world=3)
+    assert got == [(0, 'failure'), (1, 'failure'), (2, 'failure')]
