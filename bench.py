@@ -183,7 +183,10 @@ def stage_timings(wl):
             # the library-metrics pass prices at 22 B/pair (15 B/record: tid mtid tlen flag mapq, read once)
             gbps = records / 2 * 22 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {'records_scanned': int(records), 'kernel_ms': round(ms, 4), 'bytes_per_pair': 22,
-                    'achieved_GBps': round(gbps, 1), 'peak_GBps': 8000.0, 'frac': round(gbps / 8000.0, 4)}
+                    'achieved_GBps': round(gbps, 1), 'peak_GBps': 8000.0, 'frac': round(gbps / 8000.0, 4),
+                    'note': 'on the PRICED bytes: the pass reads every record\'s reference id (4 B) and the other four columns '
+                            'only for waves that hold a record on a top-1000 contig, so a library on many contigs moves '
+                            'fewer bytes than priced (profiles/*_metrics_pmc.json) and frac can pass 1'}
         out['metrics_roofline'] = roofline(counts.records_scanned, out['metrics_kernels_ms'])
         # the same pass forced over the whole library: a top-1000 mask of three short contigs never fills the samples
         # (libmetrics.py:293-303 then scans to the end of the file)
