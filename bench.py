@@ -215,6 +215,32 @@ def stage_timings(wl):
             out['score_ms'] = dt * 1e3
             out['scored_edges'] = int(rows.shape[0])
             out['score_edges_per_s'] = rows.shape[0] / dt
+            # the same edges through the log-normal branch (param.lognormal: a skewed library, CreateGraph.py:522-531):
+            # the library read as LogNormal(ln mean, sd / mean ... 0.25) - the gap is an argmax over ~400 gaps x n links
+            import math
+            from besst_amd import mathstats_compat as MC
+            ln_mu, ln_sigma = math.log(lib['mean']), 0.25
+            ln = (ln_mu, ln_sigma, MC.lognormal_support(ln_mu, ln_sigma), int(0.8 * lib['ins_size_threshold']))
+            ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'], lognormal=ln)
+            pipeline.prof_collect()
+            t0 = time.perf_counter()
+            gap_ln = ctx.score_edges(rows, swap, len1, len2, lib['mean'], lib['sd'], lib['read_len'], lognormal=ln)[0]
+            dt = time.perf_counter() - t0
+            out['score_lognormal_kernel_ms'] = pipeline.prof_collect().get('score_kernels', (0.0, 0))[0]
+            out['score_lognormal_ms'] = dt * 1e3
+            out['score_lognormal_links'] = int(table.n[rows].sum())
+            # a sample of the edges against the host restatement (not timed; ~1 ms per edge)
+            take = rows[:: max(1, rows.shape[0] // 300)][:300]
+            lo, hi = table.obs_lo, table.obs_hi
+            bad = 0
+            for k, rr in zip(range(0, rows.shape[0], max(1, rows.shape[0] // 300)), take.tolist()):
+                if not (2 * lib['sd'] < len1[k] and 2 * lib['sd'] < len2[k]):
+                    continue
+                a, b = int(table.offset[rr]), int(table.offset[rr]) + int(table.n[rr])
+                want = min(MC.lognormal_GapEstimator(ln_mu, ln_sigma, lib['read_len'], (lo[a:b] + hi[a:b]).tolist(),
+                                                     int(len1[k]), c2_len=int(len2[k])), ln[3])
+                bad += int(gap_ln[k]) != want
+            out['score_lognormal_sample_mismatches'] = bad
         lib_h.besst_prof_enable(0)
         out.update(linearize_timing())
         out.update(chain_timing())

@@ -823,22 +823,45 @@ def get_conditional_stddevs(steps, empirical_isize_distr, max_isize):
     return expected
 
 
+def dense_distribution(empirical_isize_distr, max_isize):
+    """param.empirical_distribution as a float64 column indexed by insert size (0 where it has no entry)."""
+    f = np.zeros(max_isize + 1, dtype=np.float64)
+    keys = np.fromiter(empirical_isize_distr.keys(), dtype=np.int64, count=len(empirical_isize_distr))
+    vals = np.fromiter(empirical_isize_distr.values(), dtype=np.float64, count=len(empirical_isize_distr))
+    ok = (keys >= 0) & (keys <= max_isize)                   # (a negative insert size never gets a positive weight, :446)
+    f[keys[ok]] = vals[ok]
+    return f
+
+
+def expand_conditional_stddevs(steps, sigmas):
+    """The flattened list of CreateGraph.py:460-467: the sigma of a step stands for the gaps since the step before."""
+    expected = []
+    previous_gap = 0
+    for gap, sigma in zip(steps, np.asarray(sigmas).tolist()):
+        expected.extend([sigma] if gap == 0 else [sigma] * (gap - previous_gap))
+        previous_gap = gap
+    return expected
+
+
 def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information, plot, ctx):
-    """Score every link edge of G (normal-distribution branch of CreateGraph.py:498-614).
+    """Score every link edge of G (CreateGraph.py:473-614, normal and log-normal branch).
 
     The device returns per edge the ML gap, the expected std-dev and the integer KS numerator h; the
     remaining scalar arithmetic below is evaluated with the reference's expressions so the floats agree.
     """
-    cond_sd = None
+    lognormal = None
     if param.lognormal:
         # skewed library (libmetrics: skew_adj > 0.5): gaps from the log-normal estimator over the raw observations,
         # expected sigma from the empirical distribution conditioned on the gap (CreateGraph.py:485-494).  The
-        # reference's `range(0, int(max_isize*0.8), max_isize/50)` is Python 2 integer division.
+        # reference's `range(0, int(max_isize*0.8), max_isize/50)` is Python 2 integer division.  Both run on the
+        # device: one workgroup per step for the sigmas, one per edge for the gaps.
         emp_distr = param.empirical_distribution
         max_isize = sorted(emp_distr.keys())[-1]
         steps = list(range(0, int(max_isize * 0.8), max_isize // 50))
-        cond_sd = get_conditional_stddevs(steps, emp_distr, max_isize)
+        cond_sd = expand_conditional_stddevs(steps, ctx.conditional_stddevs(dense_distribution(emp_distr, max_isize), steps))
         log_norm_max_gap = len(cond_sd) - 1
+        lognormal = (param.lognormal_mean, param.lognormal_sigma,
+                     mathstats_compat.lognormal_support(param.lognormal_mean, param.lognormal_sigma), log_norm_max_gap)
     score_file = None
     if param.print_scores:
         score_file = open(os.path.join(param.output_directory, 'score_file_pass_{0}.tsv'.format(param.pass_number)), 'w')
@@ -858,37 +881,25 @@ def GiveScoreOnEdges(G, Scaffolds, small_scaffolds, Contigs, param, Information,
     len1_a, len2_a = s_length[first >> 1], s_length[second >> 1]
     # l1 belongs to the first endpoint (:568-579); the device keeps the observations of the smaller node code first
     gap_d, sd0_d, ks_h, flags = ctx.score_edges(lk.rows[idx], from_v.astype(np.uint8), len1_a, len2_a, param.mean_ins_size,
-                                                param.std_dev_ins_size, param.read_len)
+                                                param.std_dev_ins_size, param.read_len, lognormal=lognormal)
+    if lognormal is not None:
+        # :549-553 - conditional_stddevs[int(gap)] for a positive gap, [0] otherwise (only read where flags & 1)
+        at = np.where((gap_d > 0) & ((flags & 1) != 0), gap_d, 0.0).astype(np.int64)
+        sd0_d = np.asarray(cond_sd, dtype=np.float64)[at]
     gap_d, sd0_d, ks_h, flags = gap_d.tolist(), sd0_d.tolist(), ks_h.tolist(), flags.tolist()
     len1, len2 = len1_a.tolist(), len2_a.tolist()
-    n_l, obs_l, obs_sq_l, lo_l = lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist(), lk.lo[idx].tolist()
+    n_l, obs_l, obs_sq_l = lk.n[idx].tolist(), lk.obs[idx].tolist(), lk.obs_sq[idx].tolist()
     gaps, scores = [0] * len(n_l), [None] * len(n_l)
     side = ('L', 'R')
     for j, n in enumerate(n_l):
         mean_ = obs_l[j] / float(n)
-        if cond_sd is not None:               # log-normal branch (:522-531, :549-553): host, per edge
-            long_enough = 2 * param.std_dev_ins_size < len1[j] and 2 * param.std_dev_ins_size < len2[j]
-            if long_enough:
-                gap = mathstats_compat.lognormal_GapEstimator(param.lognormal_mean, param.lognormal_sigma, param.read_len,
-                                                              lk.observations[lo_l[j]:lo_l[j] + n].tolist(), len1[j],
-                                                              c2_len=len2[j])
-                if gap > log_norm_max_gap:
-                    gap = log_norm_max_gap
-            else:
-                gap = (n * param.mean_ins_size - obs_l[j]) / float(n)
-            gaps[j] = int(gap)
-            if -gap > len1[j] or -gap > len2[j]:
-                scores[j] = 0
-                continue
-            std_dev_d_eq_0 = (cond_sd[int(gap)] if gap > 0 else cond_sd[0]) if long_enough else 2 ** 32
-        else:
-            # integer-valued when the ML estimator was used (int in the reference), float otherwise
-            gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
-            gaps[j] = int(gap)
-            if flags[j] & 2:                      # -gap > len1 or -gap > len2
-                scores[j] = 0
-                continue
-            std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
+        # integer-valued when an ML estimator was used (int in the reference), float otherwise
+        gap = int(gap_d[j]) if flags[j] & 1 else gap_d[j]
+        gaps[j] = int(gap)
+        if flags[j] & 2:                      # -gap > len1 or -gap > len2
+            scores[j] = 0
+            continue
+        std_dev_d_eq_0 = sd0_d[j] if flags[j] & 1 else 2 ** 32
         try:
             std_dev = ((obs_sq_l[j] - n * mean_ ** 2) / (n - 1)) ** 0.5
         except ZeroDivisionError:

@@ -131,6 +131,9 @@ _SIGNATURES = {
     'besst_ctx_fetch_counters': (C.c_int, [_P, C.POINTER(Counters)]),
     'besst_ctx_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
                                         _P, _P, _P, _P]),
+    'besst_ctx_score_edges_lognormal': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double,
+                                                  C.c_double, C.c_double, C.c_int64, C.c_int32, _P, _P, _P]),
+    'besst_ctx_conditional_stddevs': (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),
     'besst_host_isize_stats': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_double, _P, _P, _P]),
     'besst_host_contam_stats': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_double, _P, _P]),
     'besst_host_getdistr': (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_double, _P, C.c_int64, _P, C.c_int64, _P, _P]),
@@ -176,6 +179,12 @@ _SIGNATURES = {
     'besst_chain_scaffolds': (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                         C.c_double, _P, _P, _P, _P, _P, C.c_size_t]),
+    'besst_dev_lognormal_tables_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_lognormal_tables': (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, _P, _P, _P, C.c_size_t]),
+    'besst_dev_score_edges_lognormal': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double,
+                                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, _P, _P,
+                                                  C.c_int32, _P, _P, _P, _P, C.c_size_t]),
+    'besst_dev_conditional_stddevs': (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, _P]),
     'besst_dev_metrics_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_metrics_sample': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32, C.c_int32,
                                            C.c_double, C.c_int32, _P, _P, _P, _P, C.c_size_t]),
@@ -215,7 +224,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.besst_abi_version() != 1:
+    if lib.besst_abi_version() != 2:
         raise BesstDeviceError('libbesst_amd.so ABI version mismatch')
     _lib = lib
     return lib

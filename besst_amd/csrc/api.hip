@@ -228,6 +228,10 @@ struct besst_ctx {
     DevBuf<uint8_t> top_mask;
     DevBuf<int32_t> sample_a, sample_b;
     DevBuf<char> aux;
+    // prefix tables of the log-normal pmf (besst_ctx_score_edges_lognormal), kept while (mu, sigma, x_max) stay the same
+    DevBuf<double> ln_tables;
+    double ln_mu = 0.0, ln_sigma = 0.0;
+    int64_t ln_x_max = 0;
 };
 
 namespace {
@@ -362,7 +366,7 @@ void besst_ctx_destroy(besst_ctx* c) {
     c->row_mask.release(); c->row_n.release(); c->row_first.release(); c->row_offset.release();
     c->row_sum.release(); c->row_sum_sq.release(); c->obs_lo.release(); c->obs_hi.release();
     c->ws.release(); c->small.release(); c->top_mask.release(); c->sample_a.release();
-    c->sample_b.release(); c->aux.release();
+    c->sample_b.release(); c->aux.release(); c->ln_tables.release();
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
@@ -1675,6 +1679,46 @@ int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, co
     return launch_score(static_cast<hipStream_t>(stream), a, gap, sd0, ks_h, flags, workspace, workspace_bytes);
 }
 
+int besst_dev_score_edges_lognormal(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                                    const int32_t* len1, const int32_t* len2, const uint32_t* row_n, const int64_t* row_sum,
+                                    const uint32_t* row_offset, const int32_t* obs_lo, const int32_t* obs_hi, double mean,
+                                    double sigma, double read_len, double ln_mu, double ln_sigma, int64_t x_max,
+                                    const double* F0, const double* F1, int32_t max_gap, double* gap, int32_t* ks_h,
+                                    uint8_t* flags, void* workspace, size_t workspace_bytes) {
+    BESST_REQUIRE(n_edges >= 0 && n_edges < ((int64_t)1 << 31), "dev_score_edges_lognormal: edge count out of range");
+    if (n_edges == 0) return BESST_OK;
+    BESST_REQUIRE(row && swap && len1 && len2 && row_n && row_sum && row_offset && obs_lo && obs_hi && gap && ks_h &&
+                      flags && workspace && F0 && F1,
+                  "dev_score_edges_lognormal: null pointer");
+    BESST_REQUIRE(sigma > 0.0 && ln_sigma > 0.0 && x_max >= 1 && max_gap >= 0, "dev_score_edges_lognormal: parameters out of range");
+    // [ big_off | sd0 (unused by the caller: the conditional sigma is looked up with the gap) | sort scratch ]
+    const size_t head = align_up((size_t)n_edges * 8, 256);
+    BESST_REQUIRE(workspace_bytes >= 2 * head, "dev_score_edges_lognormal: workspace too small");
+    ScoreArgs a;
+    a.row = row; a.swap = swap; a.len1 = len1; a.len2 = len2;
+    a.row_n = row_n; a.row_sum = row_sum; a.row_offset = row_offset;
+    a.obs_lo = obs_lo; a.obs_hi = obs_hi;
+    a.mean = mean; a.sigma = sigma; a.read_len = read_len;
+    a.n_edges = n_edges;
+    LogNormalArgs l{ln_mu, ln_sigma, x_max, F0, F1, max_gap};
+    // the kernel wants the sort scratch right behind the offsets: the sd0 column sits at the END of the workspace
+    auto* sd0 = reinterpret_cast<double*>(static_cast<char*>(workspace) + workspace_bytes - head);
+    return launch_score_lognormal(static_cast<hipStream_t>(stream), a, l, gap, sd0, ks_h, flags, workspace, workspace_bytes - head);
+}
+
+size_t besst_dev_lognormal_tables_workspace_bytes(int64_t x_max) { return lognormal_tables_workspace_bytes(x_max); }
+
+int besst_dev_lognormal_tables(void* stream, double mu, double sigma, int64_t x_max, double* F0, double* F1, void* workspace,
+                               size_t workspace_bytes) {
+    return launch_lognormal_tables(static_cast<hipStream_t>(stream), mu, sigma, x_max, F0, F1, workspace, workspace_bytes);
+}
+
+int besst_dev_conditional_stddevs(void* stream, const double* density, int64_t max_isize, const int32_t* steps,
+                                  int32_t n_steps, double* out) {
+    BESST_REQUIRE(n_steps >= 0, "dev_conditional_stddevs: negative step count");
+    return launch_conditional_stddevs(static_cast<hipStream_t>(stream), density, max_isize, steps, n_steps, out);
+}
+
 size_t besst_dev_metrics_workspace_bytes(int64_t n_records) { return metrics_workspace_bytes(n_records < 1 ? 1 : n_records); }
 
 int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, const int32_t* tlen,
@@ -2021,16 +2065,12 @@ int besst_ctx_gap_condition_table(besst_ctx* c, double mean, double sigma, doubl
     return BESST_OK;
 }
 
-int besst_ctx_score_edges(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
-                          const int32_t* len2, double mean, double sigma, double read_len, double* gap, double* sd0,
-                          int32_t* ks_h, uint8_t* flags) {
-    BESST_NEED_BUILT(c);
-    BESST_REQUIRE(n_edges >= 0, "score_edges: negative edge count");
-    if (n_edges == 0) return BESST_OK;
-    BESST_REQUIRE(row && swap && len1 && len2 && gap && sd0 && ks_h && flags, "score_edges: null pointer");
-    BESST_REQUIRE(sigma > 0.0, "score_edges: sigma must be positive");
-    int rc = use_device(c);
-    if (rc) return rc;
+namespace {
+// besst_ctx_score_edges / besst_ctx_score_edges_lognormal: upload the edge list, lay the scratch out, run, download.
+int ctx_score_impl(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
+                   const int32_t* len2, double mean, double sigma, double read_len, const LogNormalArgs* ln, double* gap,
+                   double* sd0, int32_t* ks_h, uint8_t* flags) {
+    int rc;
     // scratch offsets for edges too large for the LDS sort
     std::vector<uint32_t> h_n((size_t)c->n_rows);
     BESST_HIP_TRY(hipMemcpyAsync(h_n.data(), c->row_n.p, (size_t)c->n_rows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2072,11 +2112,75 @@ int besst_ctx_score_edges(besst_ctx* c, int64_t n_edges, const uint32_t* row, co
     a.obs_lo = c->obs_lo.p; a.obs_hi = c->obs_hi.p;
     a.mean = mean; a.sigma = sigma; a.read_len = read_len;
     a.n_edges = n_edges;
-    if ((rc = launch_score(c->stream, a, d_gap, d_sd0, d_ks, d_flags, d_ws, ws_bytes))) return rc;
+    if (ln) rc = launch_score_lognormal(c->stream, a, *ln, d_gap, d_sd0, d_ks, d_flags, d_ws, ws_bytes);
+    else rc = launch_score(c->stream, a, d_gap, d_sd0, d_ks, d_flags, d_ws, ws_bytes);
+    if (rc) return rc;
     BESST_HIP_TRY(hipMemcpyAsync(gap, d_gap, m * 8, hipMemcpyDeviceToHost, c->stream));
-    BESST_HIP_TRY(hipMemcpyAsync(sd0, d_sd0, m * 8, hipMemcpyDeviceToHost, c->stream));
+    if (sd0) BESST_HIP_TRY(hipMemcpyAsync(sd0, d_sd0, m * 8, hipMemcpyDeviceToHost, c->stream));
     BESST_HIP_TRY(hipMemcpyAsync(ks_h, d_ks, m * 4, hipMemcpyDeviceToHost, c->stream));
     BESST_HIP_TRY(hipMemcpyAsync(flags, d_flags, m, hipMemcpyDeviceToHost, c->stream));
+    BESST_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BESST_OK;
+}
+}  // namespace
+
+int besst_ctx_score_edges(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap, const int32_t* len1,
+                          const int32_t* len2, double mean, double sigma, double read_len, double* gap, double* sd0,
+                          int32_t* ks_h, uint8_t* flags) {
+    BESST_NEED_BUILT(c);
+    BESST_REQUIRE(n_edges >= 0, "score_edges: negative edge count");
+    if (n_edges == 0) return BESST_OK;
+    BESST_REQUIRE(row && swap && len1 && len2 && gap && sd0 && ks_h && flags, "score_edges: null pointer");
+    BESST_REQUIRE(sigma > 0.0, "score_edges: sigma must be positive");
+    int rc = use_device(c);
+    if (rc) return rc;
+    return ctx_score_impl(c, n_edges, row, swap, len1, len2, mean, sigma, read_len, nullptr, gap, sd0, ks_h, flags);
+}
+
+int besst_ctx_score_edges_lognormal(besst_ctx* c, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                                    const int32_t* len1, const int32_t* len2, double mean, double sigma, double read_len,
+                                    double ln_mu, double ln_sigma, int64_t x_max, int32_t max_gap, double* gap,
+                                    int32_t* ks_h, uint8_t* flags) {
+    BESST_NEED_BUILT(c);
+    BESST_REQUIRE(n_edges >= 0, "score_edges_lognormal: negative edge count");
+    if (n_edges == 0) return BESST_OK;
+    BESST_REQUIRE(row && swap && len1 && len2 && gap && ks_h && flags, "score_edges_lognormal: null pointer");
+    BESST_REQUIRE(sigma > 0.0 && ln_sigma > 0.0, "score_edges_lognormal: sigma must be positive");
+    BESST_REQUIRE(x_max >= 1 && x_max < ((int64_t)1 << 31) && max_gap >= 0, "score_edges_lognormal: parameters out of range");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!(c->ln_tables.p && c->ln_mu == ln_mu && c->ln_sigma == ln_sigma && c->ln_x_max == x_max)) {
+        c->ln_x_max = 0;
+        if ((rc = c->ln_tables.ensure(2 * (size_t)(x_max + 1)))) return rc;
+        const size_t wsb = lognormal_tables_workspace_bytes(x_max);
+        if ((rc = c->aux.ensure(wsb))) return rc;
+        if ((rc = launch_lognormal_tables(c->stream, ln_mu, ln_sigma, x_max, c->ln_tables.p, c->ln_tables.p + (x_max + 1),
+                                          c->aux.p, wsb)))
+            return rc;
+        BESST_HIP_TRY(hipStreamSynchronize(c->stream));          // aux is laid out anew below
+        c->ln_mu = ln_mu; c->ln_sigma = ln_sigma; c->ln_x_max = x_max;
+    }
+    LogNormalArgs ln{ln_mu, ln_sigma, x_max, c->ln_tables.p, c->ln_tables.p + (x_max + 1), max_gap};
+    return ctx_score_impl(c, n_edges, row, swap, len1, len2, mean, sigma, read_len, &ln, gap, nullptr, ks_h, flags);
+}
+
+int besst_ctx_conditional_stddevs(besst_ctx* c, const double* density, int64_t max_isize, const int32_t* steps,
+                                  int32_t n_steps, double* h_out) {
+    BESST_REQUIRE(c, "conditional_stddevs: null context");
+    BESST_REQUIRE(n_steps >= 0 && max_isize >= 0, "conditional_stddevs: negative size");
+    if (n_steps == 0) return BESST_OK;
+    BESST_REQUIRE(density && steps && h_out, "conditional_stddevs: null pointer");
+    int rc = use_device(c);
+    if (rc) return rc;
+    const size_t fb = align_up((size_t)(max_isize + 1) * 8, 256), sb = align_up((size_t)n_steps * 4, 256);
+    if ((rc = c->aux.ensure(fb + sb + align_up((size_t)n_steps * 8, 256)))) return rc;
+    auto* d_f = reinterpret_cast<double*>(c->aux.p);
+    auto* d_steps = reinterpret_cast<int32_t*>(c->aux.p + fb);
+    auto* d_out = reinterpret_cast<double*>(c->aux.p + fb + sb);
+    BESST_HIP_TRY(hipMemcpyAsync(d_f, density, (size_t)(max_isize + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    BESST_HIP_TRY(hipMemcpyAsync(d_steps, steps, (size_t)n_steps * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_conditional_stddevs(c->stream, d_f, max_isize, d_steps, n_steps, d_out))) return rc;
+    BESST_HIP_TRY(hipMemcpyAsync(h_out, d_out, (size_t)n_steps * 8, hipMemcpyDeviceToHost, c->stream));
     BESST_HIP_TRY(hipStreamSynchronize(c->stream));
     return BESST_OK;
 }

@@ -419,5 +419,20 @@ size_t score_workspace_bytes(int64_t n_edges, int64_t n_tuples);
 int launch_gap_table(hipStream_t s, double mean, double sigma, double r, double c_len, int32_t d_lower, int32_t n, double* out);
 int launch_score(hipStream_t s, const ScoreArgs& a, double* gap, double* sd0, int32_t* ks_h,
                  uint8_t* flags, void* ws, size_t ws_bytes);
+// log-normal branch of GiveScoreOnEdges (CreateGraph.py:485-494,522-531): the pmf's prefix tables and the gap scan
+struct LogNormalArgs {
+    double mu, sigma;          // param.lognormal_mean / lognormal_sigma
+    int64_t x_max;             // support of the pmf: 1 .. x_max
+    const double* F0;          // x_max + 1 entries each (launch_lognormal_tables)
+    const double* F1;
+    int32_t max_gap;           // len(conditional_stddevs) - 1
+};
+size_t lognormal_tables_workspace_bytes(int64_t x_max);
+int launch_lognormal_tables(hipStream_t s, double mu, double sigma, int64_t x_max, double* F0, double* F1, void* ws,
+                            size_t ws_bytes);
+int launch_score_lognormal(hipStream_t s, const ScoreArgs& a, const LogNormalArgs& l, double* gap, double* sd0,
+                           int32_t* ks_h, uint8_t* flags, void* ws, size_t ws_bytes);
+int launch_conditional_stddevs(hipStream_t s, const double* f, int64_t max_isize, const int32_t* steps, int32_t n_steps,
+                               double* out);
 
 }  // namespace besst

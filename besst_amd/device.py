@@ -379,18 +379,40 @@ class GraphContext(object):
         return EdgeTable(key, mask, n, s1, s2, first, off, nb.value, lo, hi, source=self._observations), aligned, ctr
 
     @_timed
-    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
+        """Per-edge numbers of GiveScoreOnEdges -> (gap, sd0, ks_h, flags).  lognormal = (ln_mu, ln_sigma, x_max, max_gap)
+        selects the log-normal gap estimator (param.lognormal, CreateGraph.py:522-531); sd0 is then 2**32 throughout -
+        the caller looks the conditional sigma up with the gap (conditional_stddevs)."""
         rows = _lib.as_col(rows, np.uint32)
         swap = _lib.as_col(swap, np.uint8)
         len1 = _lib.as_col(len1, np.int32)
         len2 = _lib.as_col(len2, np.int32)
         m = rows.shape[0]
         gap = np.empty(m, dtype=np.float64)
-        sd0 = np.empty(m, dtype=np.float64)
         ks_h = np.empty(m, dtype=np.int32)
         flags = np.empty(m, dtype=np.uint8)
+        if lognormal is not None:
+            ln_mu, ln_sigma, x_max, max_gap = lognormal
+            _lib.check(self._lib.besst_ctx_score_edges_lognormal(
+                self._ctx, m, _lib.ptr(rows), _lib.ptr(swap), _lib.ptr(len1), _lib.ptr(len2), float(mean), float(sigma),
+                float(read_len), float(ln_mu), float(ln_sigma), int(x_max), int(max_gap), _lib.ptr(gap), _lib.ptr(ks_h),
+                _lib.ptr(flags)), 'score_edges_lognormal')
+            return gap, np.full(m, 2.0 ** 32), ks_h, flags
+        sd0 = np.empty(m, dtype=np.float64)
         _lib.check(self._lib.besst_ctx_score_edges(self._ctx, m, _lib.ptr(rows), _lib.ptr(swap), _lib.ptr(len1),
                                                    _lib.ptr(len2), float(mean), float(sigma), float(read_len),
                                                    _lib.ptr(gap), _lib.ptr(sd0), _lib.ptr(ks_h), _lib.ptr(flags)),
                    'score_edges')
         return gap, sd0, ks_h, flags
+
+    @_timed
+    def conditional_stddevs(self, density, steps):
+        """sigma of density[x] * max(0, x - gap + 1) over x for every gap of `steps` (get_conditional_stddevs,
+        CreateGraph.py:436-469); density: float64, index = insert size."""
+        density = _lib.as_col(density, np.float64)
+        steps = _lib.as_col(steps, np.int32)
+        out = np.empty(steps.shape[0], dtype=np.float64)
+        _lib.check(self._lib.besst_ctx_conditional_stddevs(self._ctx, _lib.ptr(density), density.shape[0] - 1,
+                                                           _lib.ptr(steps), steps.shape[0], _lib.ptr(out)),
+                   'conditional_stddevs')
+        return out

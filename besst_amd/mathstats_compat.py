@@ -210,9 +210,14 @@ def PreCalcMLvaluesOfdLongContigs(mean, sigma, read_length, ctx=None):
 # x_i inside the support [1, exp(mu + 6 sigma)], found by a coarse scan (stride 64) and an exhaustive scan of the
 # 129 gaps around the coarse optimum.
 # ---------------------------------------------------------------------------------------------------------------
+def lognormal_support(mu, sigma):
+    """x_max: the pmf lives on the integers 1 .. x_max."""
+    return int(min(math.exp(mu + 6.0 * sigma), 4.0e6))
+
+
 def _lognormal_tables(mu, sigma):
     import numpy as np
-    x_max = int(min(math.exp(mu + 6.0 * sigma), 4.0e6))
+    x_max = lognormal_support(mu, sigma)
     x = np.arange(1, x_max + 1, dtype=np.float64)
     lx = np.log(x)
     f = np.exp(-((lx - mu) ** 2) / (2.0 * sigma * sigma)) / (x * sigma * math.sqrt(2.0 * math.pi))
@@ -273,7 +278,9 @@ def lognormal_GapEstimator(mu, sigma, read_length, samples, c1_len, c2_len=None)
             blk = ds[a:a + step]
             lx = np.log((obs[None, :] + blk[:, None]).astype(np.float64))
             out[a:a + step] = (-lx - ((lx - mu) ** 2) / (2.0 * sigma * sigma)).sum(axis=1)
-        return out - n * _lognormal_log_g(ds, x_max, F0, F1, c_min, c_max, r)
+        lg = _lognormal_log_g(ds, x_max, F0, F1, c_min, c_max, r)
+        with np.errstate(invalid='ignore'):
+            return np.where(np.isfinite(lg), out - n * lg, -np.inf)      # no spanning fragment at this gap: never chosen
     coarse = np.arange(d_lo, d_hi + 1, 64, dtype=np.int64)
     best = int(coarse[int(np.argmax(loglik(coarse)))])
     fine = np.arange(max(d_lo, best - 64), min(d_hi, best + 64) + 1, dtype=np.int64)

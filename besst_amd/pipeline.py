@@ -279,8 +279,26 @@ class DeviceGraphBuilder(object):
         self._redo = again
         again()
 
-    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
-        """Score rows of the table this builder holds (besst_dev_score_edges) -> (gap, sd0, ks_h, flags) numpy arrays.
+    def lognormal_tables(self, ln_mu, ln_sigma, x_max):
+        """Prefix tables of the log-normal pmf on this builder's device (besst_dev_lognormal_tables), kept while the
+        library's parameters stay the same -> (F0, F1) float64 tensors of x_max + 1 entries."""
+        key = (float(ln_mu), float(ln_sigma), int(x_max))
+        if getattr(self, '_ln_key', None) != key:
+            dev = self.device
+            F = torch.empty(2 * (key[2] + 1), dtype=torch.float64, device=dev)
+            ws = torch.empty(max(256, int(self.lib.besst_dev_lognormal_tables_workspace_bytes(key[2]))), dtype=torch.uint8,
+                             device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(self.lib.besst_dev_lognormal_tables(C.c_void_p(stream), key[0], key[1], key[2], _p(F),
+                                                           C.c_void_p(F.data_ptr() + 8 * (key[2] + 1)), _p(ws), ws.numel()),
+                       'dev_lognormal_tables')
+            torch.cuda.current_stream(dev).synchronize()         # (ws goes out of scope)
+            self._ln_key, self._ln_F = key, F
+        return self._ln_F[:key[2] + 1], self._ln_F[key[2] + 1:]
+
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
+        """Score rows of the table this builder holds (besst_dev_score_edges / _lognormal) -> (gap, sd0, ks_h, flags)
+        numpy arrays.  lognormal = (ln_mu, ln_sigma, x_max, max_gap): the log-normal gap estimator (sd0 is then 2**32).
         Not part of the timed graph build; synchronises (the scratch layout needs the link counts on the host)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint32)
         m = int(rows.shape[0])
@@ -294,7 +312,8 @@ class DeviceGraphBuilder(object):
         big = np.where(npow > 8192, 2 * npow, 0)
         big_off = (np.cumsum(big) - big).astype(np.uint64)
         off_bytes = (m * 8 + 255) // 256 * 256
-        ws = torch.zeros(off_bytes + int(big.sum()) * 4 + 256, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(off_bytes + (int(big.sum()) * 4 + 256 + 255) // 256 * 256 + (off_bytes if lognormal is not None else 0),
+                         dtype=torch.uint8, device=dev)
         ws[:m * 8] = torch.from_numpy(big_off.view(np.uint8)).to(dev)
         d = [torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
              for a, dt in ((rows.view(np.int32), np.int32), (swap, np.uint8), (len1, np.int32), (len2, np.int32))]
@@ -303,6 +322,15 @@ class DeviceGraphBuilder(object):
         ks = torch.zeros(m, dtype=torch.int32, device=dev)
         flags = torch.zeros(m, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        if lognormal is not None:
+            ln_mu, ln_sigma, x_max, max_gap = lognormal
+            F0, F1 = self.lognormal_tables(ln_mu, ln_sigma, x_max)
+            _lib.check(self.lib.besst_dev_score_edges_lognormal(
+                C.c_void_p(stream), m, _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(self.row_n), _p(self.row_sum),
+                _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), float(mean), float(sigma), float(read_len),
+                float(ln_mu), float(ln_sigma), int(x_max), _p(F0), _p(F1), int(max_gap), _p(gap), _p(ks), _p(flags), _p(ws),
+                ws.numel()), 'dev_score_edges_lognormal')
+            return gap.cpu().numpy(), np.full(m, 2.0 ** 32), ks.cpu().numpy(), flags.cpu().numpy()
         _lib.check(self.lib.besst_dev_score_edges(
             C.c_void_p(stream), m, _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(self.row_n), _p(self.row_sum),
             _p(self.row_offset), _p(self.obs_lo), _p(self.obs_hi), float(mean), float(sigma), float(read_len),

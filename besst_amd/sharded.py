@@ -178,8 +178,22 @@ class HipRankEngine(object):
     def local_table(self, job):
         return job.backend.local_table()
 
-    def score(self, job, rows, swap, len1, len2, mean, sigma, read_len):
-        return job.backend.gb.score_edges(rows, swap, len1, len2, mean, sigma, read_len)
+    def score(self, job, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
+        return job.backend.gb.score_edges(rows, swap, len1, len2, mean, sigma, read_len, lognormal=lognormal)
+
+    def conditional_stddevs(self, density, steps):
+        """get_conditional_stddevs' sigmas on this rank's GPU (besst_dev_conditional_stddevs)."""
+        import ctypes as C
+        import torch
+        lib = _lib.load()
+        f = torch.from_numpy(np.ascontiguousarray(density, dtype=np.float64)).to(self.device)
+        st = torch.from_numpy(np.ascontiguousarray(steps, dtype=np.int32)).to(self.device)
+        out = torch.empty(int(st.shape[0]), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(lib.besst_dev_conditional_stddevs(C.c_void_p(stream), C.c_void_p(f.data_ptr()), int(f.shape[0]) - 1,
+                                                     C.c_void_p(st.data_ptr()), int(st.shape[0]),
+                                                     C.c_void_p(out.data_ptr())), 'dev_conditional_stddevs')
+        return out.cpu().numpy()
 
     def close(self):
         self._sampler = None
@@ -246,7 +260,10 @@ class ShardedContext(object):
         self._send(('build', self._table_cols, self._lib))
         return self._build(self._table_cols, self._lib)
 
-    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+    def conditional_stddevs(self, density, steps):
+        return self.engine.conditional_stddevs(density, steps)          # rank 0 alone: a table of ~40 numbers
+
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
         rows = np.asarray(rows, dtype=np.int64)
         swap, len1, len2 = np.asarray(swap, np.uint8), np.asarray(len1, np.int64), np.asarray(len2, np.int64)
         owner = self._owner[rows]
@@ -255,7 +272,7 @@ class ShardedContext(object):
             at = np.flatnonzero(owner == r)
             where.append(at)
             requests.append((self._local[rows[at]].astype(np.uint32), swap[at], len1[at], len2[at],
-                             float(mean), float(sigma), float(read_len)))
+                             float(mean), float(sigma), float(read_len), lognormal))
         self._send(('score',))
         results = self._score(requests)
         m = int(rows.shape[0])
@@ -357,11 +374,12 @@ class ShardedContext(object):
         dist = _dist()
         box = [None]
         dist.scatter_object_list(box, requests if self.rank == 0 else None, src=_src(self.group), group=self.group)
-        rows, swap, len1, len2, mean, sigma, read_len = box[0]
+        rows, swap, len1, len2, mean, sigma, read_len, lognormal = box[0]
         res, err = None, None
         try:
             if rows.shape[0]:
-                res = tuple(np.asarray(a) for a in self.engine.score(self.job, rows, swap, len1, len2, mean, sigma, read_len))
+                res = tuple(np.asarray(a) for a in self.engine.score(self.job, rows, swap, len1, len2, mean, sigma, read_len,
+                                                                     lognormal=lognormal))
             else:
                 res = (np.zeros(0), np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.uint8))
         except Exception as e:

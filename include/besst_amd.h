@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define BESST_ABI_VERSION 1
+/* 1: rounds 1-4.  2: + the sharded-scan and BAM-slice entry points of round 5 and the log-normal scoring entry points of
+ * round 6 (additions only: a caller built against 1 keeps working). */
+#define BESST_ABI_VERSION 2
 
 /* status codes */
 #define BESST_OK 0
@@ -302,6 +304,27 @@ int besst_ctx_score_edges(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, 
                           const int32_t* len1, const int32_t* len2, double mean, double sigma,
                           double read_len, double* gap, double* sd0, int32_t* ks_h, uint8_t* flags);
 
+/* GiveScoreOnEdges, log-normal branch (param.lognormal: a skewed library; CreateGraph.py:485-494,522-531,549-553).  As
+ * besst_ctx_score_edges, but an edge whose scaffolds are both longer than 2 sigma gets the gap of
+ * mathstats.log_normal_param_est.GapEstimator(ln_mu, ln_sigma, read_len, observations, len1, c2_len=len2) (CreateGraph.py:526;
+ * un-vendored, restated in besst_amd/mathstats_compat.py): the integer d maximising
+ *     L(d) = sum_i log f(o_i + d) - n log g(d),   f = log-normal pmf on 1 .. x_max,   g(d) = sum_x w(x; d) f(x)
+ * over the gaps that keep every o_i + d inside the support - coarse scan with stride 64, then the 129 gaps around the
+ * coarse optimum - clamped to max_gap = len(conditional_stddevs) - 1 (:527-528).  The pmf's prefix tables are built on
+ * the device at the first call and kept while (ln_mu, ln_sigma, x_max) stay the same.  x_max is passed in (the caller's
+ * int(min(exp(ln_mu + 6 ln_sigma), 4e6))) so that host and device agree on the support.  There is no sd0 output: the
+ * caller indexes the conditional sigma table (besst_ctx_conditional_stddevs) with the gap (:549-553). */
+int besst_ctx_score_edges_lognormal(besst_ctx* ctx, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                                    const int32_t* len1, const int32_t* len2, double mean, double sigma,
+                                    double read_len, double ln_mu, double ln_sigma, int64_t x_max, int32_t max_gap,
+                                    double* gap, int32_t* ks_h, uint8_t* flags);
+
+/* get_conditional_stddevs (CreateGraph.py:436-469): out[k] = sigma of the density f(x) * max(0, x - steps[k] + 1) over
+ * x = 0 .. max_isize, where density[x] = f(x) is param.empirical_distribution laid out densely (0 where it has no entry).
+ * The caller repeats out[k] for the gaps up to the next step as the reference does.  Host pointers. */
+int besst_ctx_conditional_stddevs(besst_ctx* ctx, const double* density, int64_t max_isize, const int32_t* steps,
+                                  int32_t n_steps, double* out);
+
 /* ------------------------------------------------------------------------------------------------
  * BAM front-end (host): BGZF inflate + record decode into the SoA columns, replacing the
  * `pysam.Samfile(param.bamfile, 'rb')` iteration of runBESST:162 / CreateGraph.py:111 /
@@ -527,6 +550,25 @@ int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, co
                           const int64_t* row_sum, const uint32_t* row_offset, const int32_t* obs_lo,
                           const int32_t* obs_hi, double mean, double sigma, double read_len, double* gap,
                           double* sd0, int32_t* ks_h, uint8_t* flags, void* workspace, size_t workspace_bytes);
+
+/* The log-normal branch on caller-owned device buffers (device-pointer forms of besst_ctx_score_edges_lognormal and
+ * besst_ctx_conditional_stddevs).
+ *   besst_dev_lognormal_tables   F0[k] = sum_{x <= k} f(x), F1[k] = sum_{x <= k} x f(x) for k = 0 .. x_max (x_max + 1
+ *                                doubles each), f the pmf of LogNormal(mu, sigma) on the integers; workspace:
+ *                                besst_dev_lognormal_tables_workspace_bytes(x_max)
+ *   besst_dev_score_edges_lognormal   workspace as for besst_dev_score_edges plus one more [8 bytes x n_edges, rounded up
+ *                                to 256] at its end */
+size_t besst_dev_lognormal_tables_workspace_bytes(int64_t x_max);
+int besst_dev_lognormal_tables(void* stream, double mu, double sigma, int64_t x_max, double* F0, double* F1,
+                               void* workspace, size_t workspace_bytes);
+int besst_dev_score_edges_lognormal(void* stream, int64_t n_edges, const uint32_t* row, const uint8_t* swap,
+                                    const int32_t* len1, const int32_t* len2, const uint32_t* row_n,
+                                    const int64_t* row_sum, const uint32_t* row_offset, const int32_t* obs_lo,
+                                    const int32_t* obs_hi, double mean, double sigma, double read_len, double ln_mu,
+                                    double ln_sigma, int64_t x_max, const double* F0, const double* F1, int32_t max_gap,
+                                    double* gap, int32_t* ks_h, uint8_t* flags, void* workspace, size_t workspace_bytes);
+int besst_dev_conditional_stddevs(void* stream, const double* density, int64_t max_isize, const int32_t* steps,
+                                  int32_t n_steps, double* out);
 
 /* libmetrics sampling on caller-owned device columns (the device-pointer form of besst_ctx_metrics_sample;
  * libmetrics.py:63-84,293-303).  `state` is 6 x int64 on the device, in/out:

@@ -63,8 +63,20 @@ class FakeGraphContext(object):
         ctr = Counters(*[int(x) for x in c[:8]], int(c[8]), int(c[9]))
         return table, aligned, ctr
 
-    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
-        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len)
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
+        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len, lognormal)
+
+    def conditional_stddevs(self, density, steps):
+        return conditional_sigmas(density, steps)
+
+
+def conditional_sigmas(density, steps):
+    """One sigma per step of get_conditional_stddevs (CreateGraph.py:436-469), from the oracle's flattened list."""
+    emp = {int(x): float(v) for x, v in enumerate(np.asarray(density).tolist()) if v != 0.0}
+    emp.setdefault(len(density) - 1, 0.0)
+    steps = [int(g) for g in steps]
+    flat = O.conditional_stddevs(steps, emp, len(density) - 1)
+    return np.array([flat[g] for g in steps], dtype=np.float64)
 
 
 def stream_order_of(batch):
@@ -78,9 +90,9 @@ def stream_order_of(batch):
     return (int(bad[0]) + 1 if bad.size else None,) + ends
 
 
-def score_rows(r, rows, swap, len1, len2, mean, sigma, read_len):
+def score_rows(r, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
     """GiveScoreOnEdges' per-edge numbers (CreateGraph.py:498-614) from the oracle, for rows of an edge-row dict
-    (c_oracle.edge_rows layout)."""
+    (c_oracle.edge_rows layout).  lognormal = (ln_mu, ln_sigma, x_max, max_gap): the log-normal branch (:522-531)."""
     m = len(rows)
     gap = np.zeros(m)
     sd0 = np.zeros(m)
@@ -96,10 +108,14 @@ def score_rows(r, rows, swap, len1, len2, mean, sigma, read_len):
         mean_ = obs / float(n)
         l1, l2 = int(len1[j]), int(len2[j])
         long_enough = 2 * sigma < l1 and 2 * sigma < l2
-        g = O.gap_estimator(mean, sigma, read_len, mean_, l1, l2) if long_enough else (n * mean - obs) / float(n)
+        if long_enough and lognormal is not None:
+            samples = [int(x) + int(y) for x, y in zip(a, b)]
+            g = min(O.lognormal_gap_estimator(lognormal[0], lognormal[1], read_len, samples, l1, l2), lognormal[3])
+        else:
+            g = O.gap_estimator(mean, sigma, read_len, mean_, l1, l2) if long_enough else (n * mean - obs) / float(n)
         gap[j] = g
         flags[j] = (1 if long_enough else 0) | (2 if (-g > l1 or -g > l2) else 0)
-        sd0[j] = O.tr_sk_std_dev(mean, sigma, read_len, l1, l2, g) if long_enough else 2.0 ** 32
+        sd0[j] = O.tr_sk_std_dev(mean, sigma, read_len, l1, l2, g) if long_enough and lognormal is None else 2.0 ** 32
         s1 = sorted(int(x) for x in a)
         m1 = sum(s1) / float(n)
         mx = int(max(b))
@@ -157,8 +173,11 @@ class OracleRankEngine(object):
                                 np.array([rows[k]['s2'] if not k & 1 else 0 for k in keys], dtype=np.int64),
                                 np.array([rows[k]['first'] for k in keys], dtype=np.uint32), off, self.node_bits, lo, hi)
 
-    def score(self, job, rows, swap, len1, len2, mean, sigma, read_len):
-        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len)
+    def score(self, job, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
+        return score_rows(self.rows, rows, swap, len1, len2, mean, sigma, read_len, lognormal)
+
+    def conditional_stddevs(self, density, steps):
+        return conditional_sigmas(density, steps)
 
     def close(self):
         pass

@@ -194,10 +194,10 @@ def _failing_score_worker(rank, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=3)
     try:
         class Engine(fake_device.OracleRankEngine):
-            def score(self, *a):
+            def score(self, *a, **kw):
                 if rank == 1:
                     raise RuntimeError('injected: rank 1 cannot score')
-                return fake_device.OracleRankEngine.score(self, *a)
+                return fake_device.OracleRankEngine.score(self, *a, **kw)
         sharded.RankEngine = Engine
         doc, batch = GU.load('rf_second_lib')
         try:
