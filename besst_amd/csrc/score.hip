@@ -181,6 +181,36 @@ __device__ double ln_log_g(const LogNormal& ln, long long d, long long c_min, lo
     return g > 0.0 ? log(g) : -INFINITY;
 }
 
+// log x for x >= 1 by table + series (the scan evaluates it ~400 n times per edge; the library routine is ~3x the
+// instructions): x = 2^e m, m in [1, 2); c_j the centre of the j-th 1/128 of [1, 2): m / c_j = 1 + r with |r| < 2^-8, and
+// log x = e ln 2 - log(1 / c_j) + log1p(r), the series cut after r^6 / 6 (the next term is below 2e-18).  The table holds
+// {1 / c_j rounded, -log of that rounded value}, so the rounding of the reciprocal cancels.  Absolute error ~2e-16 + 1 ulp.
+struct LogTable {
+    double inv_c, log_c;
+};
+__device__ __forceinline__ void build_log_table(LogTable* tab) {
+    if (threadIdx.x < 128) {
+        const double inv = 1.0 / (1.0 + ((double)threadIdx.x + 0.5) / 128.0);
+        tab[threadIdx.x] = LogTable{inv, -log(inv)};
+    }
+}
+__device__ __forceinline__ double table_log(double x, const LogTable* tab) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const unsigned hi = (unsigned)(bits >> 32);
+    const int e = (int)(hi >> 20) - 1023;
+    const LogTable t = tab[(hi >> 13) & 127u];
+    const double m = __longlong_as_double((long long)((bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    const double r = __builtin_fma(m, t.inv_c, -1.0);
+    double p = __builtin_fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    p = __builtin_fma(r, p, -1.0 / 4.0);
+    p = __builtin_fma(r, p, 1.0 / 3.0);
+    p = __builtin_fma(r, p, -1.0 / 2.0);
+    p = __builtin_fma(r, p, 1.0);
+    const double ef = (double)e;
+    // ln 2 = hi + lo, hi with 11 trailing zero bits: e hi is exact for |e| < 2048
+    return __builtin_fma(ef, 0x1.62e42fefa38p-1, t.log_c) + __builtin_fma(r, p, ef * 0x1.ef35793c7673p-45);
+}
+
 struct Best {
     double v;
     long long d;
@@ -193,22 +223,29 @@ __device__ __forceinline__ void best_take(Best& b, double v, long long d) {   //
 // its share of the observations, the group's sum is formed by xor-shuffles, the group's first lane adds the g term.
 template <typename ObsAt>
 __device__ long long ln_scan(const LogNormal& ln, long long d0, long long stride, long long count, int n, ObsAt obs_at,
-                             int lpg, long long c_min, long long c_max, long long r, double* s_bv, long long* s_bd) {
+                             int lpg, long long c_min, long long c_max, long long r, double* s_bv, long long* s_bd,
+                             const LogTable* s_log) {
     const int t = threadIdx.x;
     const int slots = kScoreThreads / lpg;
     const int slot = t / lpg, sub = t & (lpg - 1);
-    const double two_s2 = 2.0 * ln.sigma * ln.sigma;
+    const double k2 = 1.0 / (2.0 * ln.sigma * ln.sigma);
     Best best{-INFINITY, 0x7fffffffffffffffll};
     for (long long base = 0; base < count; base += slots) {
         const long long gi = base + slot;
         const bool valid = gi < count;
         const long long d = d0 + (valid ? gi : 0) * stride;
-        double acc = 0.0;
+        // sum_i log f(o_i + d) + n mu = -(sum u + k2 sum u^2), u = log x - mu (the constant n mu is the same for every gap)
+        double s1 = 0.0, s2 = 0.0;
         for (int i = sub; i < n; i += lpg) {
-            const double lx = log((double)(obs_at(i) + d));
-            acc += -lx - ((lx - ln.mu) * (lx - ln.mu)) / two_s2;
+            const double u = table_log((double)(obs_at(i) + d), s_log) - ln.mu;
+            s1 += u;
+            s2 = __builtin_fma(u, u, s2);
         }
-        for (int w = 1; w < lpg; w <<= 1) acc += __shfl_xor(acc, w, 64);
+        for (int w = 1; w < lpg; w <<= 1) {
+            s1 += __shfl_xor(s1, w, 64);
+            s2 += __shfl_xor(s2, w, 64);
+        }
+        const double acc = -(s1 + k2 * s2) - (double)n * ln.mu;
         if (valid && sub == 0) {
             const double lg = ln_log_g(ln, d, c_min, c_max, r);
             const double v = lg == -INFINITY ? -INFINITY : acc - (double)n * lg;
@@ -235,7 +272,7 @@ __device__ long long ln_scan(const LogNormal& ln, long long d0, long long stride
 // (an edge with more reads them from the columns every time).
 __device__ double lognormal_gap(const LogNormal& ln, const int32_t* __restrict__ obs_lo, const int32_t* __restrict__ obs_hi,
                                 int n, double read_len, long long len1, long long len2, int32_t* s_obs, int cap,
-                                double* s_bv, long long* s_bd, int* s_mm) {
+                                double* s_bv, long long* s_bd, int* s_mm, const LogTable* s_log) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool in_lds = n <= cap;
     int mn = 2147483647, mx = -2147483647 - 1;
@@ -269,14 +306,14 @@ __device__ double lognormal_gap(const LogNormal& ln, const int32_t* __restrict__
     long long best;
     if (in_lds) {
         auto at = [s_obs](int i) { return (long long)s_obs[i]; };
-        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd);
+        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
         const long long f_lo = best - 64 > d_lo ? best - 64 : d_lo, f_hi = best + 64 < d_hi ? best + 64 : d_hi;
-        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd);
+        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
     } else {
         auto at = [obs_lo, obs_hi](int i) { return (long long)(obs_lo[i] + obs_hi[i]); };
-        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd);
+        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
         const long long f_lo = best - 64 > d_lo ? best - 64 : d_lo, f_hi = best + 64 < d_hi ? best + 64 : d_hi;
-        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd);
+        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
     }
     return (double)best;
 }
@@ -293,6 +330,7 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, LogNo
     __shared__ int s_max[8];
     __shared__ unsigned char s_cmp[256];
     __shared__ double s_bracket[4];
+    __shared__ LogTable s_log[kLogNormal ? 128 : 1];
     const int e = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t row = a.row[e];
@@ -318,8 +356,9 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, LogNo
         double gap = data_observation;
         if constexpr (kLogNormal) {
             if (long_enough) {
+                build_log_table(s_log);                          // (the barriers of lognormal_gap stand before its use)
                 gap = lognormal_gap(ln, a.obs_lo + off, a.obs_hi + off, n, a.read_len, (long long)a.len1[e],
-                                    (long long)a.len2[e], s_buf, 2 * CAP, s_bracket, s_red, s_max);
+                                    (long long)a.len2[e], s_buf, 2 * CAP, s_bracket, s_red, s_max, s_log);
                 if (gap > (double)ln.max_gap) gap = (double)ln.max_gap;          // :527-528
             }
         } else {
