@@ -889,8 +889,36 @@ def main_single(args, device, result_fd):
             out['c4_single_gpu'] = c4_single_gpu(args, device)
         except Exception as e:                               # noqa: BLE001 - the bench line must still be printed
             out['c4_single_gpu'] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
+        # the N = 1 point of the weak-scaling curve the driver's --gpus 2 / 4 / 8 lines belong to: the per-GPU shape of C4
+        # (one eighth of each library) with one rank through the sharded orchestration over RCCL - this line's own value is
+        # C3, a different workload; efficiency at N is value(N) / (N x this object's value)
+        out['weak_scaling_n1'] = weak_scaling_first_point(args)
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+
+def weak_scaling_first_point(args):
+    """`bench.py --gpus 1 --config C4` in a process of its own (the process group, its buffers and the C4 assembly stay
+    out of this one), after this process has given its HBM back."""
+    import subprocess
+    import torch
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BESST_DIST_BACKEND')}
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--config', 'C4', '--steps', str(args.steps), '--warmup',
+           str(args.warmup), '--no-cpu-baseline']
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+        if res.returncode != 0 or len(lines) != 1:
+            return {'error': 'rc %d: %s' % (res.returncode, res.stderr.strip().splitlines()[-1][:200] if res.stderr.strip() else '')}
+        d = json.loads(lines[0])
+        return {'command': 'python bench.py --gpus 1 --config C4', 'workload': d['config']['workload'], 'value': d['value'],
+                'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'n_gpus': d['n_gpus'], 'backend': d['backend'],
+                'rccl_ranks_seen': d['rccl_ranks_seen'], 'roofline_frac': d['roofline']['frac'],
+                'link_tuples_per_pair': d['config']['link_tuples_per_pair'],
+                'exchange_consistent': all(l['exchange_consistent'] for l in d['config']['libraries'])}
+    except Exception as e:                                   # noqa: BLE001 - the bench line must still be printed
+        return {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
 
 
 def main():
@@ -906,22 +934,45 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
     import torch
-    import torch.distributed as dist
-    from besst_amd import _lib, pipeline, workload
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no GPU visible; besst_amd has no CPU path)')
+    # BESST_DIST_BACKEND=gloo: several ranks on ONE GPU - a check of the sharded orchestration (RCCL refuses two ranks on
+    # one device); collectives are host-staged there, so its timings say nothing about a multi-GPU node.
+    backend = os.environ.get('BESST_DIST_BACKEND', 'nccl')
+    n_dev = torch.cuda.device_count()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU), or say why not.  Never fall
+        # through to the one-GPU line for a request of N.
+        if backend == 'nccl' and n_dev < args.gpus:
+            raise SystemExit('bench.py --gpus %d: %d GPU(s) visible here and RCCL wants one device per rank - nothing was '
+                             'measured (BESST_DIST_BACKEND=gloo runs the ranks on the GPUs there are: an orchestration '
+                             'check, not a scaling figure)' % (args.gpus, n_dev))
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.dup2(result_fd, 1)                                # the ranks route their own output
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+                                  str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no GPU visible; besst_amd has no CPU path)')
-    # BESST_DIST_BACKEND=gloo: the two-ranks-on-ONE-GPU check of the sharded path (RCCL refuses two ranks on one
-    # device); collectives are host-staged there, so its timings say nothing about a multi-GPU node.
-    backend = os.environ.get('BESST_DIST_BACKEND', 'nccl')
+    if args.gpus != world:
+        raise SystemExit('bench.py --gpus %d under a launcher with WORLD_SIZE=%d: the line would carry the wrong n_gpus - '
+                         'start it with --nproc-per-node %d (or without a launcher: it starts its own ranks)'
+                         % (args.gpus, world, args.gpus))
     if backend == 'gloo':
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit('bench.py: rank %d wants GPU %d of %d visible - RCCL needs one device per rank' % (rank, local_rank, n_dev))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    force_dist = os.environ.get('BESST_FORCE_DISTRIBUTED') == '1'   # exercise the RCCL path with one rank
+    # BESST_FORCE_DISTRIBUTED=1, or --config C4 / C5 with one GPU: ONE rank through the sharded orchestration over RCCL - the
+    # N = 1 point of the scaling curve (the same shape per GPU as N = 2, 4, 8) instead of the C3 line
+    force_dist = os.environ.get('BESST_FORCE_DISTRIBUTED') == '1' or (world == 1 and args.config in ('C4', 'C5'))
     if world == 1 and not force_dist:
         if args.config is None:
             args.config = 'C3'
@@ -1113,12 +1164,26 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     if 'MASTER_ADDR' not in os.environ:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ.setdefault('MASTER_PORT', '29531')
+    # a rank that never arrives must end the job, not hold it: every collective gives up after this long (gloo raises in
+    # the waiting ranks; under RCCL the watchdog tears the process down) - BESST_COLLECTIVE_TIMEOUT seconds, default 300
+    import datetime
+    limit = datetime.timedelta(seconds=float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '300')))
     if backend_name == 'gloo':
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=limit)
     else:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=limit)
+    # ---- who is here: the ranks the collective library sees and the devices they run on (a SCALE file whose ranks share a
+    # device, or whose group is smaller than --gpus, is not a scaling measurement) - BEFORE anything is allocated
+    uuid = str(getattr(torch.cuda.get_device_properties(device), 'uuid', '')) or 'device-%d' % device.index
+    uuids = [None] * world
+    if world > 1:
+        dist.all_gather_object(uuids, uuid)
+    else:
+        uuids = [uuid]
+    sharing = uuids.count(uuid)                              # ranks on this rank's GPU
+    if backend_name != 'gloo' and len(set(uuids)) < world:
+        raise SystemExit('bench.py --gpus %d: the %d ranks sit on %d distinct GPU(s) (%s) - RCCL needs one device per rank; '
+                         'nothing was measured' % (world, world, len(set(uuids)), ', '.join(sorted(set(uuids)))))
     config = args.config or 'C4'
     cfg = synth.CONFIGS[config]
     seed = synth.config_seed(config)
@@ -1137,10 +1202,16 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
             int(n_tup * 1.25) + 4096)['total']
     free_hbm, total_hbm = torch.cuda.mem_get_info(device)
     need = sum(budget.values())
-    if need > 0.9 * free_hbm:
-        raise SystemExit('bench.py --gpus %d: the step needs %.1f GB of HBM per GPU (%s), %.1f GB are free'
+    # what drawing a library leaves in flight beside the step's buffers: its columns twice (unsorted parts + sorted copy),
+    # sort key and permutation, and one chunk of the generator's temporaries
+    draw = 2 * per_lib * (2 * 25 + 16) + int(min(32_000_000, per_lib * 1.3) * 260)
+    if (need + draw) * sharing > 0.9 * free_hbm:
+        # (ranks that share a GPU - gloo - share its HBM: eight C4-sized ranks on one device once sat in the allocator
+        # for the rest of the box's time limit instead of failing)
+        raise SystemExit('bench.py --gpus %d: a rank needs %.1f GB of HBM for the step (%s) + %.1f GB while a library is drawn, '
+                         '%d rank(s) share this GPU, %.1f GB are free - nothing was measured; use --pairs to shrink the slices'
                          % (world, need / 1e9, ', '.join('%s %.1f GB' % (k, v / 1e9) for k, v in budget.items()),
-                            free_hbm / 1e9))
+                            draw / 1e9, sharing, free_hbm / 1e9))
     jobs, wls = [], []
     from_bam = [] if args.from_bam else None
     keep_bams = []
@@ -1165,14 +1236,6 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
         for job in jobs:
             job.step()
 
-    # ---- who is here: the ranks the collective library sees and the devices they run on (a SCALE file whose ranks share a
-    # device, or whose group is smaller than --gpus, is not a scaling measurement)
-    uuid = str(getattr(torch.cuda.get_device_properties(device), 'uuid', '')) or 'device-%d' % device.index
-    uuids = [None] * world
-    if world > 1:
-        dist.all_gather_object(uuids, uuid)
-    else:
-        uuids = [uuid]
     # ---- the like-for-like one-GPU figure: the SAME shape (this rank's slice of both libraries) through the same
     # orchestration with a group of one, timed on rank 0 before the timed region - weak-scaling efficiency is value(N) /
     # (N x this), not against the C3 line that `--gpus 1` prints
@@ -1283,7 +1346,10 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
             'verified_vs_c_oracle': ok if not (args.no_verify or args.no_cpu_baseline) else None,
             'rccl_ranks_seen': int(dist.get_world_size()), 'backend': backend_name, 'device_uuids': uuids,
             'distinct_devices': len(set(uuids)), 'slices': args.slices if world > 1 else 'whole stream',
-            'single_gpu_same_shape': same_shape,
+            'single_gpu_same_shape': same_shape if world > 1 else {
+                'ms_per_step': round(step_s * 1e3, 4), 'value': total_pairs / step_s, 'unit': 'read-pairs/s',
+                'what': 'this line: one rank through the sharded orchestration (all-to-all to itself) - the N = 1 point of '
+                        'the weak-scaling curve, the per-GPU shape of --gpus 2 / 4 / 8'},
             'cpu_baseline': sharded_cpu_baseline(args, wls[0]),
         }
         if from_bam is not None:

@@ -24,6 +24,11 @@ class BesstDeviceError(RuntimeError):
         self.status = status
 
 
+class RankFailure(BesstDeviceError):
+    """A collective stage of the sharded path failed on some rank; raised on EVERY rank (besst_amd.sharded / distributed)."""
+    on_every_rank = True
+
+
 ERR_UNSUPPORTED = 5     # include/besst_amd.h: BESST_ERR_UNSUPPORTED
 ERR_NOMEM = 4           # include/besst_amd.h: BESST_ERR_NOMEM
 

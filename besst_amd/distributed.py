@@ -547,20 +547,41 @@ class ShardedGraphBuild(object):
         """The exchange regions have a fixed capacity (sized from a probe pass with 1.5x slack).  If any rank
         truncated a region in the last step, every rank learns it (all-reduce of the flag) and - with ``grow`` -
         rebuilds its buffers with twice the capacity and repeats the step, so that a skewed owner distribution
-        costs a re-run of one step instead of the job."""
-        for _ in range(6):
-            flag = torch.tensor([1 if self.backend.overflowed() else 0], dtype=torch.int32,
-                                device=self.backend.aligned.device)
+        costs a re-run of one step instead of the job.  A rank that cannot read its flag, or cannot allocate the doubled
+        regions, says so in the same all-reduce: every rank raises RankFailure together and nobody enters the repeated
+        step's all-to-all alone."""
+        dev = self.backend.aligned.device
+
+        def agree(over, failed):
+            flag = torch.tensor([1 if over else 0, 1 if failed else 0], dtype=torch.int32, device=dev)
             if dist.is_initialized():
                 _all_reduce(flag, self.group, op=dist.ReduceOp.MAX)
-            if not int(flag.item()):
+            over, failed = (int(x) for x in flag.cpu().tolist())
+            return bool(over), bool(failed)
+        for _ in range(6):
+            mine, why = False, None
+            try:
+                mine = bool(self.backend.overflowed())
+            except Exception as e:                           # noqa: BLE001 - reported to every rank below
+                why = '%s: %s' % (type(e).__name__, e)
+            over, failed = agree(mine, why is not None)
+            if failed:
+                raise _lib.RankFailure('exchange capacity check failed on some rank' + (' (here: %s)' % why if why else ''))
+            if not over:
                 return
             if not grow or not isinstance(self.backend, HipBackend):
                 raise _lib.BesstDeviceError('exchange region overflow: raise pair_capacity')
             old = self.backend
             args = (old.device, old.inputs, self.rank, self.world, old.pair_cap * 2, old.part_cap)
             self.backend = old = None                        # (free the old regions before the doubled ones are made)
-            self.backend = HipBackend(*args)
+            try:
+                self.backend = HipBackend(*args)
+            except Exception as e:                           # noqa: BLE001
+                why = '%s: %s' % (type(e).__name__, e)
+            _, failed = agree(False, why is not None)
+            if failed:
+                raise _lib.RankFailure('growing the exchange regions to %d pairs failed on some rank%s'
+                                       % (args[4], ' (here: %s)' % why if why else ''))
             self._tails = None
             self._recv = None
             self.step()

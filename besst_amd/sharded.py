@@ -69,9 +69,7 @@ class RemoteAbort(_lib.BesstDeviceError):
     """Rank 0 left CreateGraph.PE with an exception; the followers raise this."""
 
 
-class RankFailure(_lib.BesstDeviceError):
-    """A collective stage failed on some rank; raised on every rank."""
-    on_every_rank = True
+RankFailure = _lib.RankFailure      # a collective stage failed on some rank; raised on every rank
 
 
 def _src(group):
@@ -342,14 +340,18 @@ class ShardedContext(object):
         # 3. the step: slices -> owners -> rows; a region that overflowed grows and the step repeats (all ranks together).
         # What fails on one rank behind the step's collectives - the capacity check's verdict, the download of the rows -
         # is agreed on before the gather: nobody is left waiting for a rank that has gone.
+        # (a rank that fails locally inside step() - after its collectives: the per-owner sort and reduction - must not
+        # go on to _agree's all-gather while the others sit in check_capacity's all-reduce: the local verdict is agreed on
+        # between the two, and check_capacity agrees on its own allocation before it repeats the step)
         mine = None
         try:
             self.job.step()
-            self.job.check_capacity()
         except RankFailure:
             raise
         except Exception as e:
             err = '%s: %s' % (type(e).__name__, e)
+        _agree(group, world, err)
+        self.job.check_capacity()                            # (raises RankFailure on every rank, or on none)
         t1 = perf_counter()
         if err is None:
             try:

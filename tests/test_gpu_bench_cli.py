@@ -113,3 +113,58 @@ def test_two_ranks_from_one_bam_file_per_library():
     for lib in d['config']['libraries']:
         assert lib['exchange_consistent'] is True and all(lib['verified_vs_c_oracle'].values()), lib
     assert abs(d['value'] - 2 * 2 * 400000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
+def test_gpus_n_without_a_launcher_refuses_on_a_box_with_fewer_gpus():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset used to fall into the one-GPU path and print n_gpus 1.  Over RCCL it
+    needs two devices: on this box it must say so, quickly, with a non-zero exit code and no JSON line."""
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('a multi-GPU box starts the ranks instead')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BESST_DIST_BACKEND')}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2'] + SMALL, cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert 'one device per rank' in out.stderr and 'nothing was measured' in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
+def test_gpus_n_that_disagrees_with_the_launcher_is_refused():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BESST_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '4'] + SMALL
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode != 0 and 'wrong n_gpus' in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """The self-launch (one rank per requested GPU under torch.distributed.run); gloo so that both fit this box's one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['BESST_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2'] + SMALL, cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    assert d['n_gpus'] == 2 and d['rccl_ranks_seen'] == 2 and d['verified_vs_c_oracle'] is True
+    assert d['single_gpu_same_shape']['value'] > 0
+
+
+def test_one_rank_of_the_c4_shape_is_the_first_point_of_the_curve():
+    """--config C4 --gpus 1: the per-GPU shape of --gpus 2 / 4 / 8 through the same orchestration over RCCL with one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BESST_DIST_BACKEND')}
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--config', 'C4'] + SMALL, cwd=REPO,
+                         env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json_line(out.stdout)
+    assert d['n_gpus'] == 1 and d['backend'] == 'nccl' and d['rccl_ranks_seen'] == 1
+    assert d['config']['workload'].startswith('C4-shaped') and len(d['config']['libraries']) == 2
+    same = d['single_gpu_same_shape']
+    assert same['value'] == d['value'] and same['ms_per_step'] > 0
+    assert d['verified_vs_c_oracle'] is True
