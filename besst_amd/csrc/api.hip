@@ -1726,7 +1726,9 @@ int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const 
                              int32_t orientation, int32_t min_mapq, double read_len, int32_t count_only,
                              int32_t* isize_out, int32_t* contam_out, int64_t* state, void* workspace,
                              size_t workspace_bytes) {
-    BESST_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "dev_metrics_sample: n out of range");
+    // (every record index in metrics.hip is 64 bits wide and the sampling form works in parts of 64 Mi records; the bound is
+    // what the count-only form's one launch of n / 4096 workgroups and their uint32 counts were checked for)
+    BESST_REQUIRE(n >= 0 && n < ((int64_t)1 << 36), "dev_metrics_sample: n out of range");
     BESST_REQUIRE(n_contigs > 0 && n_contigs < ((int64_t)1 << 31), "dev_metrics_sample: n_contigs out of range");
     BESST_REQUIRE(orientation == 0 || orientation == 1, "dev_metrics_sample: orientation must be 0 or 1");
     BESST_REQUIRE(state && top_mask, "dev_metrics_sample: null pointer");

@@ -82,6 +82,43 @@ def make_device(device, config='C2', lib_index=0, pairs=None, nc=None, seed_offs
                           pairs=n_pairs, spec=spec)
 
 
+def make_device_windowed(device, config, lib_index, windows=8, pairs=None, table='later'):
+    """One library of a config too large to draw in one piece (a C5 library: 1.33 G pairs = 2.67 G records - more than
+    2^31 elements in any of the generator's tensors): the genome is cut into `windows` stretches, each stretch's records are
+    drawn and sorted on the GPU (synth.simulate_library_device(window=...)) and written into their place in the
+    preallocated columns; the concatenation is ONE coordinate-sorted stream.  table: 'first' (InitializeObjects' table) or
+    'later' (the state a previous pass leaves: scaffold ids counting on from nc * lib_index + 1, MakeScaffolds.py:276)."""
+    import torch
+    cfg = synth.CONFIGS[config]
+    spec = cfg['libs'][lib_index]
+    n_pairs = int(pairs if pairs is not None else cfg['pairs'] // len(cfg['libs']))
+    seed = synth.config_seed(config)
+    asm = synth.make_assembly(cfg['nc'], cfg['median'], seed)
+    per = [n_pairs // windows + (1 if k < n_pairs % windows else 0) for k in range(windows)]
+    n_rec = 2 * n_pairs
+    dt = dict(tid=torch.int32, mtid=torch.int32, pos=torch.int32, mpos=torch.int32, tlen=torch.int32, flag=torch.int16,
+              mapq=torch.uint8, qlen=torch.int16)
+    cols = {k: torch.empty(n_rec + 64 * windows, dtype=v, device=device) for k, v in dt.items()}
+    at = 0
+    for k in range(windows):
+        part = synth.simulate_library_device(asm, spec, per[k], seed + 100 + lib_index + 7919 * k, device, window=(k, windows))
+        m = int(part['tid'].shape[0])
+        for name in dt:
+            cols[name][at:at + m] = part[name]
+        at += m
+        del part
+        torch.cuda.empty_cache()
+    # (a stretch holds 2 x its pairs records less one per chunk of the generator at most: a chunk's odd record count is
+    # rounded up to whole pairs)
+    assert n_rec - 64 * windows <= at <= n_rec
+    cols = {k: v[:at] for k, v in cols.items()}
+    thr = spec.mean + 4 * spec.sd
+    tab = first_library_table(asm.lengths, thr) if table == 'first' else \
+        later_library_table(asm, seed + 50 + lib_index, thr, first_scaffold_id=asm.nc * lib_index + 1)
+    return DeviceWorkload(config=config, asm=asm, cols=cols, table=tab, lib=library_constants(spec),
+                          node_bits=node_bits_for(tab), pairs=n_pairs, spec=spec)
+
+
 def later_library_table(asm, seed, contig_threshold, max_run=5, first_scaffold_id=1):
     """Contig table of a library >= 2: the state a previous pass leaves behind (MakeScaffolds.py:362-414) - random runs
     of 1..max_run adjacent contigs chained into scaffolds with random per-contig direction, cumulative position (+ true

@@ -582,7 +582,7 @@ int besst_dev_conditional_stddevs(void* stream, const double* density, int64_t m
  * of the whole stream.  count_only != 0 advances state[0..2] only (first phase of a sharded scan) and
  * leaves them exact; the sampling form leaves [0..2] exact up to the cut-offs and at least 1,000,000 beyond them (the
  * call works in parts of 64 Mi records and does not look at a part that begins with both samples full).
- * n is limited to 2^31 records per call; workspace: besst_dev_metrics_workspace_bytes(n) - the tile counts and, for
+ * n is limited to 2^36 records per call (a C5 library is 2.67 x 10^9); workspace: besst_dev_metrics_workspace_bytes(n) - the tile counts and, for
  * min(n, 64 Mi) records, 8 bytes of sample staging per record. */
 size_t besst_dev_metrics_workspace_bytes(int64_t n_records);
 int besst_dev_metrics_sample(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid,

@@ -18,6 +18,11 @@ state) and the reference's OUTPUTS (library metrics, the raw edge tables right a
 loop, counters, coverage, and the final filtered/scored graphs).  `gap`/`score` values involve the
 mathstats shim (tests/refharness/stubs/mathstats -> besst_amd.mathstats_compat) and therefore pin
 plumbing only; every other number is produced by reference code alone.
+
+    BESST_MATHSTATS_PATH=/path/to/dir-holding-mathstats python tests/golden/make_golden.py
+
+re-pins those two fields against the real package the day it is at hand (tests/refharness/loader.py): the documents
+are then tagged "mathstats": "<version>" and the tests compare with the tolerances of tests/golden_util.tolerances.
 """
 import json
 import os
@@ -75,10 +80,13 @@ def run_reference(mods, name, stream, batch, overrides, fasta_names=None, layout
     finally:
         if patched:
             del cg.range
-    return jsonable(dict(name=name, stream=stream, references=list(batch.references), lengths=list(batch.lengths),
-                         fasta_names=fasta, overrides=overrides, metrics=metrics, after_loop=snap, final=final,
-                         layout=None if layout is None else {k: np.asarray(v).tolist() for k, v in layout.items()},
-                         layout_threshold=layout_threshold))
+    doc = dict(name=name, stream=stream, references=list(batch.references), lengths=list(batch.lengths),
+               fasta_names=fasta, overrides=overrides, metrics=metrics, after_loop=snap, final=final,
+               layout=None if layout is None else {k: np.asarray(v).tolist() for k, v in layout.items()},
+               layout_threshold=layout_threshold)
+    if loader.mathstats_tag() is not None:                   # BESST_MATHSTATS_PATH: gap / score come from the real package
+        doc['mathstats'] = loader.mathstats_tag()
+    return jsonable(doc)
 
 
 def replay(mods, name):

@@ -312,3 +312,86 @@ def test_full_size_c4_one_gpu(record_path):
                                                                                'fused' if gb.params.record_path else 'two-pass'))
         del gb, rec, cols, got, keys, payload, rows
         torch.cuda.empty_cache()
+
+
+def test_full_size_c5_library_one_gpu(record_path):
+    """ONE library of BASELINE.json configs[4] (C5) at FULL size on one GPU: 2 M contigs, 1.33 G read pairs = 2.67 G records
+    in one stream - more than 2^31 (every record index past that point needs its 32nd bit) - the 5 kb mate-pair library
+    with PE contamination on the contig table a previous pass leaves behind (scaffold ids counting on from 2 M,
+    MakeScaffolds.py:276: 47-bit edge keys).  DeviceGraphBuilder.step() against the C oracle on every record, in slices with
+    the duplicate chain carried; the library-metrics pass over the whole stream against the oracle's counts."""
+    import torch
+    from besst_amd import pipeline, synth
+    if os.environ.get('BESST_FULL_SIZE') == '0':
+        pytest.skip('BESST_FULL_SIZE=0')
+    if record_path != 'fused':
+        pytest.skip('once (the record loop is selected per library by its candidate density)')
+    os.environ.pop('BESST_RECORD_PATH', None)
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200e9 or _host_memory_gib() < 64:
+        pytest.skip('needs 200 GB of free HBM and 64 GiB of host memory (%.0f GB / %.0f GiB here)' % (free / 1e9, _host_memory_gib()))
+    dev = torch.device('cuda', 0)
+    wl = workload.make_device_windowed(dev, 'C5', 1)
+    asm, cols, table, lib, node_bits = wl['asm'], wl['cols'], wl['table'], wl['lib'], wl['node_bits']
+    rec = pipeline.DeviceRecords.from_columns(cols)
+    assert 0 <= 2_666_666_666 - rec.n <= 512 and rec.n > 1 << 31 and asm.nc == 2_000_000
+    key = (cols['tid'][1:].to(torch.int64) << 32) | cols['pos'][1:].to(torch.int64)
+    assert bool((key >= ((cols['tid'][:-1].to(torch.int64) << 32) | cols['pos'][:-1].to(torch.int64))).all())   # one sorted stream
+    del key
+    torch.cuda.empty_cache()
+    probe = pipeline.DeviceGraphBuilder(dev, asm.nc, node_bits, lib, rec.n, 1)
+    probe.set_contigs(**table)
+    probe.reset()
+    probe.classify(rec)
+    n_tuples, _ = probe.read_sizes()
+    del probe
+    gb = pipeline.DeviceGraphBuilder(dev, asm.nc, node_bits, lib, rec.n, int(n_tuples * 1.1) + 4096)
+    gb.set_contigs(**table)
+    for _ in range(2):
+        gb.step(rec)
+    got = gb.fetch_table()
+    ctr = gb.read_counters()
+    keys, payload, c_aligned, c_ctr = oracle_in_slices(cols, asm, table, lib, node_bits)
+    rows = CO.edge_rows(keys, payload)
+    assert [ctr.count, ctr.non_unique, ctr.non_unique_for_scaf, ctr.nr_of_duplicates, ctr.reads_with_too_long_insert,
+            ctr.fishy_reads, ctr.n_tuples, ctr.n_reach, ctr.prev_obs1, ctr.prev_obs2] == c_ctr.tolist()
+    assert np.array_equal(gb.aligned.cpu().numpy(), c_aligned)
+    link = ~got.is_fishy
+    assert np.array_equal(got.key, rows['key']) and np.array_equal(got.n.astype(np.int64), rows['n'])
+    assert np.array_equal(got.first_idx.astype(np.int64), rows['first_idx'])
+    assert np.array_equal(got.offset.astype(np.int64), rows['offset'])
+    assert np.array_equal(got.sum_obs[link], rows['sum_obs'][link])
+    assert np.array_equal(got.sum_obs_sq[link], rows['sum_obs_sq'][link])
+    assert np.array_equal(got.mask[link].astype(np.int64), rows['mask'][link])
+    assert np.array_equal(got.obs_lo.astype(np.int64), rows['obs_lo'])
+    assert np.array_equal(got.obs_hi.astype(np.int64), rows['obs_hi'])
+    assert np.all(np.diff(got.key.astype(np.uint64)) > 0) and int(got.n.sum()) == ctr.n_tuples == len(keys)
+    assert int(got.key.max()) >> 44, 'keys of a later pass on 2 M contigs need more than 44 bits'
+    # records beyond 2^31 did make tuples: the last tuple's record lies in the last stretch of the stream
+    assert len(rows['key']) > 100_000 and ctr.nr_of_duplicates > 0
+    print('C5 library 1 (%s): %d records, %d tuples, %d edge rows, key bits %d, record path %s'
+          % (wl['spec'].orientation, rec.n, ctr.n_tuples, len(got), gb.key_bits, 'fused' if gb.params.record_path else 'two-pass'))
+    del gb, got, keys, payload, rows
+    torch.cuda.empty_cache()
+    # the library-metrics pass over all 2.67 G records in ONE call (besst_dev_metrics_sample refused n >= 2^31): the "1000
+    # longest contigs" are put at the END of the header, so every sampled record lies beyond 2^31 and the scan has to walk
+    # the whole stream to reach them (libmetrics.py:63-84, 293-303)
+    top = np.zeros(asm.nc, np.uint8)
+    top[asm.nc - 1000:] = 1
+    lo = int(torch.searchsorted(cols['tid'], torch.tensor([asm.nc - 1000], dtype=torch.int32, device=dev))[0].item())
+    assert lo > 1 << 31
+    sampler = pipeline.DeviceMetricsSampler(dev, rec, asm.nc)
+    sampler.set_top(top)
+    local = sampler.count(lib['orientation'], lib['min_mapq'], lib['read_len']).cpu().numpy().copy()
+    samples, state = sampler.emit(torch.zeros(3, dtype=torch.int64, device=dev), lib['orientation'], lib['min_mapq'],
+                                  lib['read_len'], True)
+    state = state.cpu().numpy()
+    host = samples.cpu().numpy()
+    lo -= lo % 4
+    tail = synth.device_columns_to_batch(asm, {k: v[lo:] for k, v in cols.items()}, int(wl['spec'].read_len))
+    want_isize, want_contam, c = CO.metrics_sample(tail, top, lib['orientation'], lib['min_mapq'], lib['read_len'], True)
+    cap = pipeline.SAMPLE_CAP
+    n_isize, n_contam = int(min(local[0], cap)), int(state[4])
+    assert (n_isize, n_contam, int(state[3]), int(min(local[1], cap))) == tuple(int(x) for x in c[:4])
+    assert n_isize > 10_000 and n_contam > 1_000
+    assert np.array_equal(host[:n_isize], want_isize) and np.array_equal(host[cap:cap + n_contam], want_contam)

@@ -54,8 +54,8 @@ def test_host_side_reproduces_reference_goldens(fake_gpu, name):
             got = getattr(param, k, None)
         assert got == want, (name, k)
     fin = doc['final']
-    assert edge_rows(G, True) == fin['G']                 # incl. gap and score: same float expressions
-    assert edge_rows(G_prime, True) == fin['G_prime']
+    GU.assert_scored_rows(edge_rows(G, True), fin['G'], doc, name)          # incl. gap and score: same float expressions
+    GU.assert_scored_rows(edge_rows(G_prime, True), fin['G_prime'], doc, name)
     assert [list(n) for n in G.nodes()] == fin['G_nodes']
     assert [list(n) for n in G_prime.nodes()] == fin['G_prime_nodes']
     assert [[c.name, c.scaffold, c.coverage] for c in Contigs.values()] == fin['contigs']

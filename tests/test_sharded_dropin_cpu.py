@@ -35,8 +35,8 @@ def check_against_golden(name, doc, param, G, G_prime, Contigs, Scaffolds, small
         assert got == want, (name, k)
     fin = doc['final']
     if exact_scores:
-        assert edge_rows(G, True) == fin['G']
-        assert edge_rows(G_prime, True) == fin['G_prime']
+        GU.assert_scored_rows(edge_rows(G, True), fin['G'], doc, name)
+        GU.assert_scored_rows(edge_rows(G_prime, True), fin['G_prime'], doc, name)
     else:
         strip = lambda rows: [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in rows]
         assert edge_rows(G, False) == strip(fin['G'])
