@@ -889,6 +889,10 @@ def main_single(args, device, result_fd):
             out['c4_single_gpu'] = c4_single_gpu(args, device)
         except Exception as e:                               # noqa: BLE001 - the bench line must still be printed
             out['c4_single_gpu'] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
+        try:
+            out['c5_library_single_gpu'] = c5_library_single_gpu(args, device)
+        except Exception as e:                               # noqa: BLE001 - the bench line must still be printed
+            out['c5_library_single_gpu'] = {'error': str(e).splitlines()[0][:200] if str(e) else type(e).__name__}
         # the N = 1 point of the weak-scaling curve the driver's --gpus 2 / 4 / 8 lines belong to: the per-GPU shape of C4
         # (one eighth of each library) with one rank through the sharded orchestration over RCCL - this line's own value is
         # C3, a different workload; efficiency at N is value(N) / (N x this object's value)
@@ -978,6 +982,55 @@ def main():
             args.config = 'C3'
         return main_single(args, device, result_fd)
     return main_sharded(args, device, rank, world, backend, force_dist, result_fd)
+
+
+def c5_library_single_gpu(args, device):
+    """ONE library of BASELINE.json configs[4] (C5) at FULL size on one GPU: 2 M contigs, 1.33 G read pairs = 2.67 G records
+    (66.7 GB) in one stream - the first one past 2^31 records - the 5 kb mate-pair library on the table a previous pass leaves
+    behind (scaffold ids counting on from 2 M: 45-bit keys).  Correctness at this size is
+    tests/test_gpu_fullsize.py::test_full_size_c5_library_one_gpu (every record against the C oracle); here it is timed."""
+    import torch
+    from besst_amd import pipeline, workload
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(device)
+    if free < 200e9:
+        return {'skipped': 'needs 200 GB of free HBM (%.0f GB here)' % (free / 1e9)}
+    t0 = time.perf_counter()
+    wl = workload.make_device_windowed(device, 'C5', 1)
+    rec = pipeline.DeviceRecords.from_columns(wl['cols'])
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    asm, nb, lib, table = wl['asm'], wl['node_bits'], wl['lib'], wl['table']
+    probe = pipeline.DeviceGraphBuilder(device, asm.nc, nb, lib, rec.n, 1)
+    probe.set_contigs(**table)
+    probe.reset()
+    probe.classify(rec)
+    n_tuples, _ = probe.read_sizes()
+    del probe
+    gb = pipeline.DeviceGraphBuilder(device, asm.nc, nb, lib, rec.n, int(n_tuples * 1.1) + 4096)
+    gb.set_contigs(**table)
+    for _ in range(3):
+        gb.step(rec)
+    torch.cuda.synchronize()
+    steps = max(5, min(args.steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gb.step(rec)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_t, n_r = gb.read_sizes()
+    pairs = rec.n / 2.0
+    f = n_t / pairs
+    alg = pairs * (38.0 + 32.0 * f)
+    return {'workload': 'one C5 library at full size on one GPU: %d contigs, %d records (> 2^31) resident, %s N(%g, %g), later-pass '
+                        'contig table' % (asm.nc, rec.n, wl['spec'].orientation, wl['spec'].mean, wl['spec'].sd),
+            'ms_per_step': round(dt * 1e3, 4), 'value': pairs / dt, 'unit': 'read-pairs/s', 'steps': steps,
+            'records': rec.n, 'link_tuples': n_t, 'edge_rows': n_r, 'node_bits': nb, 'key_bits': gb.key_bits,
+            'link_tuples_per_pair': round(f, 5), 'record_path': 'fused' if gb.params.record_path else 'two-pass',
+            'roofline_frac': round(alg / dt / 1e9 / HBM_PEAK_GBS, 4), 'algorithmic_bytes_per_step': alg,
+            'generate_s': round(gen_s, 1), 'hbm_allocated_bytes': int(torch.cuda.memory_allocated(device)),
+            'verified': 'tests/test_gpu_fullsize.py::test_full_size_c5_library_one_gpu (same seeds, every record against the C '
+                        'oracle; the metrics pass on records beyond 2^31)'}
 
 
 def c4_single_gpu(args, device):

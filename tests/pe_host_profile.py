@@ -48,7 +48,7 @@ class Answers(object):
     def build_graph(self, lazy_observations=False):
         return self.ready
 
-    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len):
+    def score_edges(self, rows, swap, len1, len2, mean, sigma, read_len, lognormal=None):
         m = len(rows)
         return np.zeros(m), np.full(m, 100.0), np.zeros(m, np.int32), np.ones(m, np.uint8)
 
