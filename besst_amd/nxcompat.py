@@ -16,6 +16,93 @@ from networkx.classes.reportviews import NodeView as _NodeView
 _BaseGraph = _nx.Graph      # bound at import: test harnesses may later rebind networkx.Graph to this facade
 
 
+class LazyDict(dict):
+    """A dictionary whose keys are all there from the start - in their final order - while a value is made the first
+    time it is read.  ``Graph.adopt`` backs ``_adj`` and ``_node`` of a graph with two of these: CreateGraph.PE hands over
+    200 k nodes and up to a million adjacency entries as columns, and what reads the graph afterwards (MakeScaffolds'
+    walks, ExtendLargeScaffolds' searches) touches a node at a time; the containers of a node - its neighbour dictionary,
+    the attribute dictionaries of its edges - are built when that node is first looked at, the whole graph at once (in
+    bulk, as before) when something asks for every value.
+
+    An unmade value is stored as the ``int`` token the source wants back (a legitimate value is always a dict).
+    ``source.one(token) -> value`` makes one, ``source.rest(lazy_dict)`` makes every value still unmade.  Keys, length,
+    membership and iteration over keys never make anything; assignment and deletion are the dictionary's own."""
+    __slots__ = ('_source',)
+
+    def __init__(self, tokens, source):
+        dict.__init__(self, tokens)
+        self._source = source
+
+    def __getitem__(self, key):
+        value = dict.__getitem__(self, key)
+        if value.__class__ is int:
+            value = self._source.one(value)
+            dict.__setitem__(self, key, value)
+        return value
+
+    def _all(self):
+        source = self._source
+        if source is not None:
+            self._source = None
+            source.rest(self)
+
+    # (defined so that C code which copies or merges a dictionary takes the generic path - keys() + __getitem__ -
+    # instead of reading the raw slots)
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def get(self, key, default=None):
+        return self[key] if dict.__contains__(self, key) else default
+
+    def items(self):
+        self._all()
+        return dict.items(self)
+
+    def values(self):
+        self._all()
+        return dict.values(self)
+
+    def pop(self, key, *default):
+        if dict.__contains__(self, key):
+            self[key]
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        self._all()
+        return dict.popitem(self)
+
+    def setdefault(self, key, default=None):
+        if dict.__contains__(self, key):
+            return self[key]
+        dict.__setitem__(self, key, default)
+        return default
+
+    def copy(self):
+        self._all()
+        return dict(dict.items(self))
+
+    def clear(self):
+        self._source = None
+        dict.clear(self)
+
+    def __eq__(self, other):
+        self._all()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._all()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._all()
+        return (dict, (dict(dict.items(self)),))
+
+
 class Graph(_BaseGraph):
     @property
     def edge(self):
@@ -74,6 +161,14 @@ class Graph(_BaseGraph):
                 if v in keep:
                     H._adj[u][v] = d
         return H
+
+    def adopt(self, node_tokens, node_source, adj_tokens, adj_source):
+        """Back this (empty) graph's nodes and adjacency with values made on first touch (see LazyDict): the keys of both
+        dictionaries are the nodes in their final order."""
+        if self._node or self._adj:
+            raise _nx.NetworkXError('adopt: the graph is not empty')
+        self._node = LazyDict(node_tokens, node_source)
+        self._adj = LazyDict(adj_tokens, adj_source)
 
     def add_scaffold(self, scaffold, length):
         """The two end nodes of a scaffold with their 'length' attribute and the intra-scaffold edge (nr_links=None):

@@ -1,0 +1,169 @@
+"""The graphs CreateGraph.PE returns are backed by columns (nxcompat.LazyDict / CreateGraph.GraphColumns): a node's
+containers are made when it is first read.  Whatever order a consumer reads and mutates them in, the graph must behave like
+one that was filled eagerly with add_node / add_edge (what the reference's InitializeGraph + CreateEdge do,
+BESST/CreateGraph.py:710-722, 842-862): same node order, same adjacency order, shared attribute dictionaries per edge."""
+import copy
+import pickle
+import random
+
+import networkx as nx
+import numpy as np
+import pytest
+
+from besst_amd import CreateGraph as CG
+from besst_amd.nxcompat import Graph, LazyDict
+
+
+class _Links(object):
+    pass
+
+
+def make_plan(n_scaffolds, n_links, seed, scored):
+    rng = np.random.default_rng(seed)
+    plan = CG.GraphPlan()
+    plan.sid = list(range(3, 3 + n_scaffolds))
+    plan.length = [int(x) for x in rng.integers(500, 9000, n_scaffolds)]
+    pairs = set()
+    while len(pairs) < n_links:
+        a, b = (int(x) for x in rng.integers(3, 3 + n_scaffolds, 2))
+        if a != b:
+            u, v = 2 * a + int(rng.integers(0, 2)), 2 * b + int(rng.integers(0, 2))
+            pairs.add((min(u, v), max(u, v)))
+    pairs = list(pairs)
+    rng.shuffle(pairs)
+    lk = _Links()
+    lk.u = np.array([p[0] for p in pairs], np.int64)
+    lk.v = np.array([p[1] for p in pairs], np.int64)
+    lk.n = rng.integers(1, 6, n_links).astype(np.int64)
+    lk.obs = rng.integers(100, 9000, n_links).astype(np.int64)
+    lk.obs_sq = lk.obs * lk.obs
+    lk.mask = np.full(n_links, 3, np.uint32)
+    lk.lo = np.concatenate(([0], np.cumsum(lk.n)[:-1])).astype(np.int64)
+    lk.observations = rng.integers(0, 5000, int(lk.n.sum())).astype(np.int64)
+    lk.__len__ = lambda: n_links
+    plan.links = lk
+    plan.alive = np.ones(n_links, bool)
+    plan.alive[::7] = False                                  # some links did not survive the filters
+    plan.sid_arr = np.asarray(plan.sid, np.int64)
+    plan.len_arr = np.asarray(plan.length, np.int64)
+    plan.node_alive = np.zeros(3 + n_scaffolds + 1, bool)
+    plan.node_alive[plan.sid_arr] = True
+    gone = plan.sid_arr[::11]                                # some scaffolds were retired (repeats, low coverage)
+    plan.node_alive[gone] = False
+    plan.alive &= plan.node_alive[lk.u >> 1] & plan.node_alive[lk.v >> 1]
+    scores = None
+    if scored:
+        idx, _ = plan.edges_order()
+        scores = (idx, [int(x) for x in rng.integers(-50, 900, idx.shape[0])], [float(x) for x in rng.random(idx.shape[0])])
+    return plan, scores
+
+
+def eager(plan, scores):
+    """The same graph, filled through the general path (a graph that already holds a node)."""
+    g = Graph()
+    g.add_node('seed')
+    plan.build(g, scores)
+    g.remove_node('seed')
+    assert type(g._adj) is dict
+    return g
+
+
+def snapshot(g):
+    return ([(n, dict(d)) for n, d in g.nodes(data=True)],
+            [(n, [(m, dict(d)) for m, d in g._adj[n].items()]) for n in g._node])
+
+
+@pytest.mark.parametrize('scored', [False, True])
+def test_filled_graph_equals_the_eagerly_built_one(scored):
+    plan, scores = make_plan(120, 400, 5, scored)
+    lazy = Graph()
+    plan.build(lazy, scores)
+    assert isinstance(lazy._adj, LazyDict) and isinstance(lazy._node, LazyDict)
+    want = eager(plan, scores)
+    assert lazy.nodes() == want.nodes() and len(lazy) == len(want)
+    assert lazy.edges() == want.edges()                       # walks the whole graph: everything is made, in bulk
+    assert snapshot(lazy) == snapshot(want)
+    assert lazy.number_of_edges() == want.number_of_edges()
+
+
+def test_an_edge_has_one_attribute_dictionary_whichever_end_is_read_first():
+    plan, scores = make_plan(60, 150, 9, True)
+    g = Graph()
+    plan.build(g, scores)
+    u, v = next((a, b) for a, b in eager(plan, scores).edges() if a[0] != b[0])
+    g[u][v]['mark'] = 1                                      # (only u has been made)
+    assert g[v][u]['mark'] == 1 and g[v][u] is g[u][v]
+    left, right = (u[0], 'L'), (u[0], 'R')
+    assert g[left][right] is g[right][left] and g[left][right] == {'nr_links': None}
+    assert g.node[left] == {'length': g.node[right]['length']}
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_reads_and_mutations_match_an_eager_graph(seed):
+    plan, scores = make_plan(80, 260, 20 + seed, seed % 2 == 0)
+    a = Graph()
+    plan.build(a, scores)
+    b = eager(plan, scores)
+    rnd = random.Random(seed)
+    for step in range(400):
+        nodes = b.nodes()
+        if not nodes:
+            break
+        n = rnd.choice(nodes)
+        op = rnd.randrange(11)
+        if op == 0:
+            assert a.neighbors(n) == b.neighbors(n)
+        elif op == 1:
+            a.remove_node(n)
+            b.remove_node(n)
+        elif op == 2 and b.neighbors(n):
+            m = rnd.choice(b.neighbors(n))
+            a.remove_edge(n, m)
+            b.remove_edge(n, m)
+        elif op == 3:
+            m = rnd.choice(nodes)
+            if m != n:
+                a.add_edge(n, m, nr_links=step)
+                b.add_edge(n, m, nr_links=step)
+        elif op == 4:
+            assert a.degree(n) == b.degree(n) and (n in a) and a.has_node(n)
+        elif op == 5:
+            m = rnd.choice(nodes)
+            assert a.has_edge(n, m) == b.has_edge(n, m)
+            assert a.edge[n].get(m) == b.edge[n].get(m)
+        elif op == 6:
+            keep = rnd.sample(nodes, min(len(nodes), 9))
+            sa, sb = a.subgraph(keep), b.subgraph(keep)
+            assert sa.nodes() == sb.nodes() and sa.edges(data=True) == sb.edges(data=True)
+        elif op == 7:
+            assert sorted(map(sorted, nx.connected_components(a))) == sorted(map(sorted, nx.connected_components(b)))
+        elif op == 8:
+            a.node[n]['seen'] = step
+            b.node[n]['seen'] = step
+        elif op == 9 and b.neighbors(n):
+            m = rnd.choice(b.neighbors(n))
+            assert a[n][m] == b[n][m]
+            if 'observations' in b[n][m]:
+                assert a[n][m]['observations'] == b[n][m]['observations']
+        elif op == 10 and step % 50 == 0:
+            assert a.edges(data=True) == b.edges(data=True)
+    assert snapshot(a) == snapshot(b)
+    assert a.number_of_edges() == b.number_of_edges() and a.degree() == b.degree()
+
+
+def test_copies_and_pickles_are_plain_and_complete():
+    plan, scores = make_plan(40, 90, 3, True)
+    g = Graph()
+    plan.build(g, scores)
+    want = snapshot(eager(plan, scores))
+    g[g.nodes()[0]]                                          # one node made, the rest not
+    assert snapshot(pickle.loads(pickle.dumps(g))) == want
+    g2 = Graph()
+    plan.build(g2, scores)
+    assert snapshot(copy.deepcopy(g2)) == want
+    g3 = Graph()
+    plan.build(g3, scores)
+    assert snapshot(g3.copy()) == snapshot(eager(plan, scores).copy())     # (networkx re-inserts the edges: its own order)
+    assert dict(g3._adj) == dict(eager(plan, scores)._adj)   # a C-level copy goes through __getitem__, not the raw slots
+    g3.clear()
+    assert len(g3) == 0 and g3.edges() == []
