@@ -118,6 +118,38 @@ def measured_copy_bandwidth(device):
 C_PORT_TIMING = {}
 
 
+_H2D = {}
+
+
+def measured_h2d_bandwidth(device):
+    """GB/s of a pinned host buffer -> HBM copy on this box (1 GiB, best of three): what the COMPRESSED file crosses PCIe at
+    best - the peak the ingest's `ingest_roofline` is priced against, measured in the same run."""
+    import torch
+    key = str(device)
+    if key not in _H2D:
+        n = 1 << 30
+        host = torch.empty(n, dtype=torch.uint8).pin_memory()
+        dev = torch.empty(n, dtype=torch.uint8, device=device)
+        best = 0.0
+        for _ in range(4):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            dev.copy_(host, non_blocking=True)
+            torch.cuda.synchronize(device)
+            best = max(best, n / (time.perf_counter() - t0) / 1e9)
+        del host, dev
+        _H2D[key] = best
+    return _H2D[key]
+
+
+def ingest_roofline(device, compressed_bytes, seconds):
+    """The device ingest moves the compressed file across PCIe once: compressed GB/s over the box's measured H2D rate."""
+    peak = measured_h2d_bandwidth(device)
+    gbps = compressed_bytes / seconds / 1e9
+    return {'bound': 'pcie-h2d', 'achieved': round(gbps, 2), 'peak': round(peak, 1), 'unit': 'GB/s', 'frac': round(gbps / peak, 4),
+            'what': 'compressed bytes of the file / ingest_s over a pinned host -> HBM copy of 1 GiB measured in this run'}
+
+
 def verify_full(runner, wl):
     """Second half of the cpu_baseline leg (rank 0, N=1): the C restatement is timed over the WHOLE workload, on one
     thread and on all host cores, and its edge table doubles as the full-size parity check of the device's."""
@@ -376,6 +408,7 @@ def bam_to_graph_timing(device, config, pairs=None, realistic=False):
                'get_metrics_s': round(t2 - t1, 3), 'PE_s': round(t3 - t2, 3), 'total_s': round(t3 - t0, 3),
                'pairs_per_s': (n_rec // 2) / (t3 - t0), 'edges_G': G.number_of_edges(), 'edges_G_prime': Gp.number_of_edges()}
         if st.on_device:
+            out['ingest_roofline'] = ingest_roofline(device, size, t1 - t0)
             # the same ingest once more: the first read of a file that has just been written is the slower one on the host
             # side (staging reads 20-25 GB/s, 40-50 from the second read on), and then the inflate kernel is the bound
             t0 = time.perf_counter()
@@ -383,7 +416,8 @@ def bam_to_graph_timing(device, config, pairs=None, realistic=False):
             dt = time.perf_counter() - t0
             out['ingest_repeat'] = {'ingest_s': round(dt, 3), 'ingest_records_per_s': n_rec / dt,
                                     'ingest_staging_s': round(again.ingest.decode_seconds, 3),
-                                    'ingest_wait_s': round(again.ingest.copy_wait_seconds, 3)}
+                                    'ingest_wait_s': round(again.ingest.copy_wait_seconds, 3),
+                                    'ingest_roofline': ingest_roofline(device, size, dt)}
             again.close()
         # the other ingest form on the same file (ingest only), and whether the two leave the same records in HBM
         t0 = time.perf_counter()
@@ -442,6 +476,8 @@ def bam_ingest_timing(device, config, pairs):
             out[mode] = {'ingest_s': round(dt, 3), 'records_per_s': n_rec / dt, 'compressed_GBps': round(size / dt / 1e9, 2),
                          'on_device': int(bam.ingest.on_device), 'h2d_bytes': int(bam.ingest.bytes_h2d),
                          'inflated_bytes': int(bam.ingest.inflated_bytes)}
+            if bam.ingest.on_device:
+                out[mode]['ingest_roofline'] = ingest_roofline(device, size, dt)
             held.append(bam)
         agree = len(held[0]) == len(held[1])
         step = 16 << 20
