@@ -119,7 +119,8 @@ class ShardedBam(object):
 
 def open_bam(path, threads=None, **kw):
     """What a caller of the two entry points opens in place of ``pysam.Samfile(path, 'rb')`` (runBESST:162): a ResidentBam,
-    or - when torch.distributed is up with more than one rank (torchrun, one process per GPU) - this rank's ShardedBam."""
+    or - under a process group for which sharding has been switched on (sharded.enable() / BESST_SHARDED=1: torchrun, one
+    process per GPU) - this rank's ShardedBam."""
     from . import sharded
     if sharded.active_group() is not None:
         return ShardedBam(path, group=sharded.PROCESS_GROUP, threads=threads,

@@ -91,9 +91,16 @@ def join_process_group():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
+    from . import sharded
     if dist.is_initialized():
+        sharded.enable()
         return dist.get_rank(), False
-    dist.init_process_group(os.environ.get('BESST_DIST_BACKEND', 'nccl'))
+    # a rank that never arrives ends the job instead of holding it: every collective gives up after this long (gloo raises
+    # in the waiting ranks; under RCCL the watchdog tears the process down)
+    import datetime
+    limit = datetime.timedelta(seconds=float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '1800')))
+    dist.init_process_group(os.environ.get('BESST_DIST_BACKEND', 'nccl'), timeout=limit)
+    sharded.enable()                                         # every rank makes the drop-in's calls together from here on
     return dist.get_rank(), True
 
 

@@ -855,6 +855,19 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         std::vector<void*> dev_mem, host_mem;
         std::vector<hipEvent_t> events;
         std::vector<hipStream_t> streams;
+        if (kit && !background) {
+            // a call that did not end cleanly: a stream or event of it may be in an error state (a failed copy or kernel), and
+            // a handle kept for the process would hand that state to every later ingest on this device.  Nothing is cached:
+            // the kit's handles are destroyed with the call's own, the next call makes fresh ones.
+            kit->heads = nullptr; kit->heads_bytes = 0;      // (== heads when it was reused: freed below)
+            for (int k = 0; k < kSlots; ++k) {
+                kit->work[k] = nullptr;
+                for (int j = 0; j < 4; ++j) kit->ev[k][j] = nullptr;
+            }
+            kit->copy = nullptr; kit->d_flags = nullptr; kit->summ_host = nullptr;
+            { std::lock_guard<std::mutex> g(kit->mu); kit->busy = false; }
+            kit = nullptr;
+        }
         for (Slot& q : sl) {
             const auto t0 = std::chrono::steady_clock::now();
             g_pinned.give_back(q.pin);
@@ -867,7 +880,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
                 if (q.work) streams.push_back(q.work);
             }
         }
-        if (kit) {                                           // (whatever exists by now, also after a failed call: valid handles)
+        if (kit) {                                           // (a call that synchronised cleanly: its handles serve the next one)
             for (int k = 0; k < kSlots; ++k) {
                 kit->work[k] = sl[k].work;
                 kit->ev[k][0] = sl[k].h2d_done; kit->ev[k][1] = sl[k].slot_free; kit->ev[k][2] = sl[k].summ_done; kit->ev[k][3] = sl[k].tail_taken;
@@ -945,8 +958,14 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         else if (kit->heads) { (void)hipFree(kit->heads); kit->heads = nullptr; kit->heads_bytes = 0; }
     }
     bool ok = alloc_slot(0);
+    // (every slot's stream AND its four events are made here, on the calling thread: the helper below only allocates memory,
+    // so no handle the queueing code reads - sl[2].tail_taken while chunk 0 is enqueued - is ever written beside it)
     for (int k = 1; k < kSlots && ok; ++k)
-        ok = sl[k].work || hipStreamCreateWithPriority(&sl[k].work, hipStreamNonBlocking, prio_low) == hipSuccess;
+        ok = (sl[k].work || hipStreamCreateWithPriority(&sl[k].work, hipStreamNonBlocking, prio_low) == hipSuccess) &&
+             (sl[k].h2d_done || hipEventCreateWithFlags(&sl[k].h2d_done, hipEventDisableTiming) == hipSuccess) &&
+             (sl[k].slot_free || hipEventCreateWithFlags(&sl[k].slot_free, hipEventDisableTiming) == hipSuccess) &&
+             (sl[k].summ_done || hipEventCreateWithFlags(&sl[k].summ_done, hipEventDisableTiming) == hipSuccess) &&
+             (sl[k].tail_taken || hipEventCreateWithFlags(&sl[k].tail_taken, hipEventDisableTiming) == hipSuccess);
     ok = ok && (heads || hipMalloc((void**)&heads, head_n * 10) == hipSuccess) &&
          (d_flags || hipMalloc((void**)&d_flags, 2 * sizeof(uint32_t)) == hipSuccess) &&
          (summ_host || hipHostMalloc((void**)&summ_host, 128 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) &&

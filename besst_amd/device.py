@@ -113,11 +113,20 @@ class ObservationSource(object):
         return self._ends_cols
 
     def detach(self):
-        """The context is about to go (or to build another table): what is pending is finished, nothing refers to it after."""
-        try:
-            self.finish()
-        finally:
-            self._ctx = None
+        """The context is about to go (or to build another table): what is pending is finished, nothing refers to it after.
+        A fetch that failed is the business of whoever READS the observations (sums / ends raise it): the unrelated call
+        that happens to detach the source - push_records, build_graph, close - must not fail with the previous table's
+        error, so it is only noted on stderr here and stays with the source."""
+        t = self._thread
+        if t is not None:
+            t.join()
+            self._thread = None
+        if self._error is not None and not getattr(self, '_reported', False):
+            self._reported = True
+            import sys
+            sys.stderr.write('besst_amd: the background fetch of a table\'s observations failed (%s); its readers will see '
+                             'the error\n' % (self._error,))
+        self._ctx = None
 
 
 # Wall time spent inside the C-ABI calls of GraphContext (seconds per method), filled only while `CALL_SECONDS` is a dict:

@@ -45,12 +45,18 @@ def _dist():
 
 
 def active_group():
-    """(rank, world) when the sharded form applies: torch.distributed is initialised with more than one rank and
-    BESST_SHARDED is not '0' ('force': also with ONE rank - the whole orchestration over RCCL on a single GPU, what a
-    one-GPU box can check of the device-side transport).  None otherwise - without importing torch when nobody has."""
+    """(rank, world) when the sharded form applies, None otherwise (without importing torch when nobody has).  Sharding is
+    OPT-IN: a process that uses torch.distributed for something of its own and calls get_metrics / PE on one rank must not
+    be pulled into collectives.  It applies when torch.distributed is initialised with more than one rank AND the caller
+    has said so - ``sharded.enable(group=None)`` (what besst_amd.cli does under torchrun), or BESST_SHARDED=1 in the
+    environment; BESST_SHARDED=0 switches it off whatever the code says, BESST_SHARDED=force applies it with ONE rank too
+    (the whole orchestration over RCCL on a single GPU: what a one-GPU box can check of the device-side transport).  A
+    bamio.ShardedBam handed to get_metrics / PE is sharded by construction."""
     import os
-    mode = os.environ.get('BESST_SHARDED', '1')
+    mode = os.environ.get('BESST_SHARDED')
     if mode == '0' or 'torch.distributed' not in sys.modules:
+        return None
+    if mode is None and not _ENABLED:
         return None
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()):
@@ -61,8 +67,21 @@ def active_group():
     return dist.get_rank(PROCESS_GROUP), world
 
 
-# the process group the sharded sessions use (None: the default group); set it before the first get_metrics call
+# the process group the sharded sessions use (None: the default group); set by enable() before the first get_metrics call
 PROCESS_GROUP = None
+_ENABLED = False
+
+
+def enable(group=None):
+    """Every rank of `group` (default: the whole job) will make the drop-in's calls together from here on: open_bam ingests
+    a slice per rank, get_metrics and PE are collective (see the module docstring)."""
+    global PROCESS_GROUP, _ENABLED
+    PROCESS_GROUP, _ENABLED = group, True
+
+
+def disable():
+    global PROCESS_GROUP, _ENABLED
+    PROCESS_GROUP, _ENABLED = None, False
 
 
 class RemoteAbort(_lib.BesstDeviceError):

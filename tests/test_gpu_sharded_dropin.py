@@ -64,6 +64,8 @@ def _worker(rank, world, port, names, bam_cases, tmp, out):
     from tests import bam_writer
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from besst_amd import sharded as _sh
+    _sh.enable()
     try:
         n_scored = 0
         for name in names:
@@ -213,6 +215,8 @@ def _tiny_worker(rank, world, port, tmp, out):
     from tests import bam_writer
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from besst_amd import sharded as _sh
+    _sh.enable()
     try:
         doc, batch = GU.load('fr_given')
         batch = batch.slice(0, 1500)                          # ~5 BGZF blocks of 64 KiB: fewer blocks than ranks
@@ -267,6 +271,8 @@ def _shaped_worker(rank, world, port, out):
     from tests.test_gpu_dropin import make_param
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from besst_amd import sharded as _sh
+    _sh.enable()
     try:
         snaps = {}
         for config, pairs, nc in (('C3', 3_000_000, 6000), ('C2', 1_500_000, 3000)):
@@ -324,6 +330,8 @@ def _rccl_worker(port, tmp, out):
     from tests import bam_writer
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from besst_amd import sharded as _sh
+    _sh.enable()
     try:
         assert sharded.active_group() == (0, 1) and dist.get_backend() == 'nccl'
         n = 0

@@ -98,6 +98,7 @@ def _worker(rank, port, names, out):
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         sharded.RankEngine = fake_device.OracleRankEngine
+        sharded.enable()
         assert sharded.active_group() == (rank, WORLD)
         for name in names:
             doc, batch = GU.load(name)
@@ -155,6 +156,7 @@ def _abort_worker(rank, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         sharded.RankEngine = fake_device.OracleRankEngine
+        sharded.enable()
         doc, batch = GU.load('fr_infer')
         param = make_param(doc['overrides'])
         libmetrics.get_metrics(batch, param, param.information_file)
@@ -199,6 +201,7 @@ def _failing_score_worker(rank, port, out):
                     raise RuntimeError('injected: rank 1 cannot score')
                 return fake_device.OracleRankEngine.score(self, *a, **kw)
         sharded.RankEngine = Engine
+        sharded.enable()
         doc, batch = GU.load('rf_second_lib')
         try:
             run_sharded(doc, batch)
