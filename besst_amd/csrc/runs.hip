@@ -628,12 +628,6 @@ __device__ __forceinline__ RlBlock rl_block(const SegSource& seg, uint32_t b, in
 }
 static_assert(kRlMaxChunks <= 64, "rl_list_kernel searches the chunk prefixes one wave holds");
 constexpr int kRlWaves = 4;                              // waves per block: wave w takes chunks w, w + 4, ...
-#ifndef BESST_RL_PLACE_WAVES
-#define BESST_RL_PLACE_WAVES 5                           // per SIMD: 96 VGPRs with the tuples' squares kept in registers (6: 80, spills)
-#endif
-#ifndef BESST_RL_HOIST
-#define BESST_RL_HOIST 1
-#endif
 constexpr int kRlSingletonRuns = 32;                     // rl_place_kernel: chunks of more runs than this count their runs' tuples first
 
 // 1'. the run list.  The record loop left per chunk a dense list of its runs - key, tuples | first slot (counted in LDS while
@@ -705,7 +699,7 @@ __global__ __launch_bounds__(256) void rl_list_kernel(SegSource seg, uint32_t ru
 // rg_group_kernel held them), per run of the chunk one compare + ballot + mbcnt per round of 64 - rank inside the run -,
 // the observations stored at the run's sorted place + rank, the run's two sums left for the row kernel.  The payload is
 // read ONCE, where the record loop wrote it, and written once, where the table wants it.
-__global__ __launch_bounds__(kRlWaves * 64, BESST_RL_PLACE_WAVES) void rl_place_kernel(SegSource seg, const uint32_t* __restrict__ status,
+__global__ __launch_bounds__(kRlWaves * 64, 6) void rl_place_kernel(SegSource seg, const uint32_t* __restrict__ status,
                                                                    const uint32_t* __restrict__ n_rows, RunCols rc,
                                                                    int32_t* __restrict__ obs_lo, int32_t* __restrict__ obs_hi) {
     constexpr int R = kRlChunkTuples / 64, Q = kRlSlots / 64;
@@ -781,17 +775,6 @@ __global__ __launch_bounds__(kRlWaves * 64, BESST_RL_PLACE_WAVES) void rl_place_
                 }
             }
         }
-        uint32_t ob[R];
-#if BESST_RL_HOIST
-        unsigned long long osq[R];
-#endif
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            ob[r] = (uint32_t)pl[r] + ((uint32_t)(pl[r] >> 32) & 0x3fffffffu);
-#if BESST_RL_HOIST
-            osq[r] = (unsigned long long)ob[r] * (unsigned long long)ob[r];
-#endif
-        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             my_s[q] = 0; my_q[q] = 0;
@@ -808,16 +791,11 @@ __global__ __launch_bounds__(kRlWaves * 64, BESST_RL_PLACE_WAVES) void rl_place_
                     const bool hit = rid[r] == sl;
                     const unsigned long long mm = __ballot(hit);
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, run));
-                    // (the observation and its square are made once per tuple, in front of the loop over the runs: inside it
-                    // they were made again for every run of the chunk - a third of the kernel's vector instructions)
-#if BESST_RL_HOIST
-                    s2 += hit ? (unsigned long long)ob[r] : 0ull;
-                    q2 += hit ? osq[r] : 0ull;
-#else
-                    const unsigned long long o = hit ? (unsigned long long)ob[r] : 0ull;
+                    const uint32_t ol = hit ? (uint32_t)pl[r] : 0u;
+                    const uint32_t oh = (hit ? (uint32_t)(pl[r] >> 32) : 0u) & 0x3fffffffu;
+                    const unsigned long long o = (unsigned long long)(ol + oh);
                     s2 += o;
                     q2 += o * o;
-#endif
                     if (hit) to[r] = rk;
                     run += (uint32_t)__popcll(mm);
                 }
