@@ -708,10 +708,10 @@ def source_hash():
 
 def pmc_step_traffic(config, n_rec, kernel=None):
     """HBM bytes per graph-build step (all kernels of one step; of one kernel when it is named) from the committed rocprofv3 PMC passes of THIS build
-    on THIS workload (profiles/r05_<config>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
+    on THIS workload (profiles/r06_<config>_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
     passes, gfx950 x2 correction on FETCH_SIZE, tools/pmc_summary.py), else None - a summary collected on other
     kernel sources or another record count says nothing about this run."""
-    path = os.path.join(REPO, 'profiles', 'r05_%s_pmc_traffic.json' % config.lower())
+    path = os.path.join(REPO, 'profiles', 'r06_%s_pmc_traffic.json' % config.lower())
     try:
         with open(path) as fh:
             doc = json.load(fh)

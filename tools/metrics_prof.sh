@@ -27,6 +27,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
 f, w = out['FETCH_SIZE_KB_per_dispatch'], out['WRITE_SIZE_KB_per_dispatch']
 if f['max'] and w['max'] is not None:
     out['largest_dispatch_traffic_bytes'] = int((2 * f['max'] + w['max']) * 1024)
+    # the largest dispatch is the forced full scan's one part: min(2 * pairs, 64 Mi) records
+    out['moved_bytes_per_record'] = round(out['largest_dispatch_traffic_bytes'] / float(min(2 * pairs, 64 << 20)), 3)
 out['probe'] = json.loads(open(os.path.join(O, 'probe.json')).read().strip().splitlines()[-1])
 json.dump(out, open(os.path.join(O, 'pmc.json'), 'w'), indent=1)
 print(json.dumps(out))

@@ -16,5 +16,5 @@ ARGS="--config $CFG --also= --steps $STEPS --warmup 1 --no-cpu-baseline --breakd
 python tools/pmc_summary.py $O/fetch $O/write $CFG $NREC $((STEPS + 2)) $O/pmc_traffic.json
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 rm -rf $O/stats $O/fetch $O/write          # traces are large; the summaries are what is kept
-mkdir -p profiles; cp $O/pmc_traffic.json profiles/r05_${TAG}_pmc_traffic.json   # bench.py reads the traffic figure from here
+mkdir -p profiles; cp $O/pmc_traffic.json profiles/${BESST_ROUND_TAG:-r06}_${TAG}_pmc_traffic.json   # bench.py reads the traffic figure from here
 head -14 $O/kernel_stats.csv
