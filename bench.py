@@ -1003,6 +1003,16 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    # A container limited to a few CPUs of a large host (the GPU boxes: 16 of 256): torch sizes its thread pools by the
+    # machine, and a few hundred threads spinning behind every small CPU op get the whole cgroup throttled for most of each
+    # scheduling period - the host side of a step (a dozen launches and collectives) then takes milliseconds.  Sized by what
+    # the process may use, unless the caller has said otherwise (BESST_BENCH_THREADS=0 leaves the defaults).
+    if os.environ.get('BESST_BENCH_THREADS', '1') != '0':
+        from besst_amd import _lib as _l
+        usable = str(max(1, min(_l.effective_cpus(), 16)))
+        for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+            os.environ.setdefault(var, usable)
+        os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
     import torch
 
     if not torch.cuda.is_available():
@@ -1286,11 +1296,12 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
     # a rank that never arrives must end the job, not hold it: every collective gives up after this long (gloo raises in
     # the waiting ranks; under RCCL the watchdog tears the process down) - BESST_COLLECTIVE_TIMEOUT seconds, default 300
     import datetime
-    limit = datetime.timedelta(seconds=float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '300')))
+    limit = float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '300'))
+    kw = {'timeout': datetime.timedelta(seconds=limit)} if limit > 0 else {}     # (0: the backend's own default)
     if backend_name == 'gloo':
-        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=limit)
+        dist.init_process_group('gloo', rank=rank, world_size=world, **kw)
     else:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, timeout=limit)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device, **kw)
     # ---- who is here: the ranks the collective library sees and the devices they run on (a SCALE file whose ranks share a
     # device, or whose group is smaller than --gpus, is not a scaling measurement) - BEFORE anything is allocated
     uuid = str(getattr(torch.cuda.get_device_properties(device), 'uuid', '')) or 'device-%d' % device.index

@@ -25,5 +25,8 @@ print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 # the C4-at-full-size-on-one-GPU object of the bench line, on its own
 import json
 line = json.loads(open(os.path.join(src, 'bench_default.json')).read().strip().splitlines()[-1])
-if 'c4_single_gpu' in line:
-    json.dump(line['c4_single_gpu'], open(os.path.join(dst, '%s_c4_single_gpu.json' % tag), 'w'), indent=1)
+for key in ('c4_single_gpu', 'c5_library_single_gpu', 'weak_scaling_n1'):
+    if key in line:
+        json.dump(line[key], open(os.path.join(dst, '%s_%s.json' % (tag, key)), 'w'), indent=1)
+if os.path.isfile(os.path.join(src, 'record_loop_sq.json')):
+    shutil.copy(os.path.join(src, 'record_loop_sq.json'), os.path.join(dst, '%s_record_loop_sq.json' % tag))
