@@ -1294,9 +1294,9 @@ def main_sharded(args, device, rank, world, backend_name, force_dist, result_fd)
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ.setdefault('MASTER_PORT', '29531')
     # a rank that never arrives must end the job, not hold it: every collective gives up after this long (gloo raises in
-    # the waiting ranks; under RCCL the watchdog tears the process down) - BESST_COLLECTIVE_TIMEOUT seconds, default 300
+    # the waiting ranks; under RCCL the watchdog tears the process down) - BESST_COLLECTIVE_TIMEOUT seconds, default 900 (rank 0 may spend a minute writing a library's file while the others wait)
     import datetime
-    limit = float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '300'))
+    limit = float(os.environ.get('BESST_COLLECTIVE_TIMEOUT', '900'))
     kw = {'timeout': datetime.timedelta(seconds=limit)} if limit > 0 else {}     # (0: the backend's own default)
     if backend_name == 'gloo':
         dist.init_process_group('gloo', rank=rank, world_size=world, **kw)
