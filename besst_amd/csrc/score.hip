@@ -224,32 +224,40 @@ __device__ __forceinline__ void best_take(Best& b, double v, long long d) {   //
 template <typename ObsAt>
 __device__ long long ln_scan(const LogNormal& ln, long long d0, long long stride, long long count, int n, ObsAt obs_at,
                              int lpg, long long c_min, long long c_max, long long r, double* s_bv, long long* s_bd,
-                             const LogTable* s_log) {
+                             const LogTable* s_log, double* s_lg) {
     const int t = threadIdx.x;
     const int slots = kScoreThreads / lpg;
     const int slot = t / lpg, sub = t & (lpg - 1);
     const double k2 = 1.0 / (2.0 * ln.sigma * ln.sigma);
     Best best{-INFINITY, 0x7fffffffffffffffll};
-    for (long long base = 0; base < count; base += slots) {
-        const long long gi = base + slot;
-        const bool valid = gi < count;
-        const long long d = d0 + (valid ? gi : 0) * stride;
-        // sum_i log f(o_i + d) + n mu = -(sum u + k2 sum u^2), u = log x - mu (the constant n mu is the same for every gap)
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = sub; i < n; i += lpg) {
-            const double u = table_log((double)(obs_at(i) + d), s_log) - ln.mu;
-            s1 += u;
-            s2 = __builtin_fma(u, u, s2);
-        }
-        for (int w = 1; w < lpg; w <<= 1) {
-            s1 += __shfl_xor(s1, w, 64);
-            s2 += __shfl_xor(s2, w, 64);
-        }
-        const double acc = -(s1 + k2 * s2) - (double)n * ln.mu;
-        if (valid && sub == 0) {
-            const double lg = ln_log_g(ln, d, c_min, c_max, r);
-            const double v = lg == -INFINITY ? -INFINITY : acc - (double)n * lg;
-            best_take(best, v, d);
+    // 256 gaps at a time: first their log g, one gap per THREAD (inside the pass every lane of a group would evaluate its
+    // gap's twelve table reads and one log again: an eighth of the scan for an edge of 400 links), then the passes over
+    // them, 256 / lpg gaps per pass
+    for (long long blk = 0; blk < count; blk += kScoreThreads) {
+        __syncthreads();                                     // (the block before has been read)
+        s_lg[t] = blk + t < count ? ln_log_g(ln, d0 + (blk + t) * stride, c_min, c_max, r) : -INFINITY;
+        __syncthreads();
+        for (int g0 = 0; g0 < kScoreThreads && blk + g0 < count; g0 += slots) {      // uniform
+            const int g = g0 + slot;
+            const bool valid = blk + g < count;
+            const long long d = d0 + (valid ? blk + g : 0) * stride;
+            // sum_i log f(o_i + d) + n mu = -(sum u + k2 sum u^2), u = log x - mu (the constant n mu is the same for every gap)
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = sub; i < n; i += lpg) {
+                const double u = table_log((double)(obs_at(i) + d), s_log) - ln.mu;
+                s1 += u;
+                s2 = __builtin_fma(u, u, s2);
+            }
+            for (int w = 1; w < lpg; w <<= 1) {
+                s1 += __shfl_xor(s1, w, 64);
+                s2 += __shfl_xor(s2, w, 64);
+            }
+            const double acc = -(s1 + k2 * s2) - (double)n * ln.mu;
+            if (valid && sub == 0) {
+                const double lg = s_lg[g];
+                const double v = lg == -INFINITY ? -INFINITY : acc - (double)n * lg;
+                best_take(best, v, d);
+            }
         }
     }
 #pragma unroll
@@ -272,7 +280,7 @@ __device__ long long ln_scan(const LogNormal& ln, long long d0, long long stride
 // (an edge with more reads them from the columns every time).
 __device__ double lognormal_gap(const LogNormal& ln, const int32_t* __restrict__ obs_lo, const int32_t* __restrict__ obs_hi,
                                 int n, double read_len, long long len1, long long len2, int32_t* s_obs, int cap,
-                                double* s_bv, long long* s_bd, int* s_mm, const LogTable* s_log) {
+                                double* s_bv, long long* s_bd, int* s_mm, const LogTable* s_log, double* s_lg) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool in_lds = n <= cap;
     int mn = 2147483647, mx = -2147483647 - 1;
@@ -306,14 +314,14 @@ __device__ double lognormal_gap(const LogNormal& ln, const int32_t* __restrict__
     long long best;
     if (in_lds) {
         auto at = [s_obs](int i) { return (long long)s_obs[i]; };
-        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
+        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log, s_lg);
         const long long f_lo = best - 64 > d_lo ? best - 64 : d_lo, f_hi = best + 64 < d_hi ? best + 64 : d_hi;
-        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
+        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log, s_lg);
     } else {
         auto at = [obs_lo, obs_hi](int i) { return (long long)(obs_lo[i] + obs_hi[i]); };
-        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
+        best = ln_scan(ln, d_lo, 64, (d_hi - d_lo) / 64 + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log, s_lg);
         const long long f_lo = best - 64 > d_lo ? best - 64 : d_lo, f_hi = best + 64 < d_hi ? best + 64 : d_hi;
-        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log);
+        best = ln_scan(ln, f_lo, 1, f_hi - f_lo + 1, n, at, lpg, c_min, c_max, r, s_bv, s_bd, s_log, s_lg);
     }
     return (double)best;
 }
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, LogNo
     __shared__ unsigned char s_cmp[256];
     __shared__ double s_bracket[4];
     __shared__ LogTable s_log[kLogNormal ? 128 : 1];
+    __shared__ double s_lg[kLogNormal ? kScoreThreads : 1];
     const int e = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t row = a.row[e];
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(ScoreArgs a, LogNo
             if (long_enough) {
                 build_log_table(s_log);                          // (the barriers of lognormal_gap stand before its use)
                 gap = lognormal_gap(ln, a.obs_lo + off, a.obs_hi + off, n, a.read_len, (long long)a.len1[e],
-                                    (long long)a.len2[e], s_buf, 2 * CAP, s_bracket, s_red, s_max, s_log);
+                                    (long long)a.len2[e], s_buf, 2 * CAP, s_bracket, s_red, s_max, s_log, s_lg);
                 if (gap > (double)ln.max_gap) gap = (double)ln.max_gap;          // :527-528
             }
         } else {
