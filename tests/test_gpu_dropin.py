@@ -254,3 +254,44 @@ def test_linearize_the_graph_pe_returns(name):
     # every remaining node has at most one link edge: the graph is a set of paths
     for n in G.nodes():
         assert sum(1 for m in G.neighbors(n) if G[n][m]['nr_links'] is not None) <= 1
+
+
+def test_skewed_library_end_to_end_against_the_oracle():
+    """A skewed library fifteen times the `fr_lognormal` golden (insert sizes exp(N(ln 1500, 0.35)), 250 k pairs on 800
+    contigs: ~450 scored edges; with 450 k pairs on 1500 contigs - 900 edges - and with 1.2 M pairs on 4000 contigs - 2400 edges - the same assertions held, the oracle took
+    three minutes) through the two entry points: get_metrics must flag it
+    (param.lognormal, libmetrics.py:380-390) and PE must score it by the log-normal branch ON THE DEVICE
+    (CreateGraph.py:485-494, 522-531, 549-553) - against the Python oracle end to end (its estimator sums directly, no
+    prefix tables): library parameters and graph structure exactly, every gap exactly, every score within 1e-9."""
+    from besst_amd import device, synth
+    from oracle import py_oracle as O
+    from tests.test_oracle_golden import edge_rows as oracle_rows, run_oracle
+    asm = synth.make_assembly(800, 8000, 77)
+    batch = synth.simulate_library(asm, synth.LibrarySpec('fr', 1500.0, 150.0, lognormal_sigma=0.35), 250_000, 78)
+    doc = dict(overrides={}, layout=None, layout_threshold=None, fasta_names=list(batch.references))
+    p, st, out = run_oracle(doc, batch)
+    assert p.lognormal is True
+    param = make_param({})
+    info = param.information_file
+    device.CALL_SECONDS = {}
+    try:
+        libmetrics.get_metrics(batch, param, info)
+        assert param.lognormal is True
+        for k in ('mean_ins_size', 'std_dev_ins_size', 'read_len', 'lognormal_mean', 'lognormal_sigma', 'ins_size_threshold',
+                  'contig_threshold'):
+            assert getattr(param, k) == getattr(p, k), k
+        C_dict = {n: 'A' * int(l) for n, l in zip(batch.references, batch.lengths)}
+        Contigs, Scaffolds, small_contigs, small_scaffolds = {}, {}, {}, {}
+        G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, batch)
+        assert 'conditional_stddevs' in device.CALL_SECONDS          # the sigma table came from the device
+    finally:
+        device.CALL_SECONDS = None
+        session.close_session(batch)
+    want, got = oracle_rows(out['G']), edge_rows(G, True)
+    strip = lambda rows: [{k: e[k] for k in ('u', 'v', 'nr_links', 'obs', 'obs_sq')} for e in rows]
+    assert strip(got) == strip(want) and len(want) > 300
+    assert strip(edge_rows(G_prime, False)) == strip(oracle_rows(out['Gp'], keys=()))
+    assert [g['gap'] for g in got] == [w['gap'] for w in want]
+    worst = max(abs(g['score'] - w['score']) for g, w in zip(got, want))
+    assert worst <= 1e-9, worst
+    assert len({w['gap'] for w in want}) > 40 and sum(1 for w in want if w['score'] > 0) > 40
