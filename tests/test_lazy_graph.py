@@ -110,7 +110,7 @@ def test_random_reads_and_mutations_match_an_eager_graph(seed):
         if not nodes:
             break
         n = rnd.choice(nodes)
-        op = rnd.randrange(11)
+        op = rnd.randrange(16)
         if op == 0:
             assert a.neighbors(n) == b.neighbors(n)
         elif op == 1:
@@ -147,6 +147,24 @@ def test_random_reads_and_mutations_match_an_eager_graph(seed):
                 assert a[n][m]['observations'] == b[n][m]['observations']
         elif op == 10 and step % 50 == 0:
             assert a.edges(data=True) == b.edges(data=True)
+        elif op == 11:                                       # what MakeScaffolds does to G_prime: new nodes and edges in bulk
+            new = (1000 + step, 'L'), (1000 + step, 'R')
+            for g in (a, b):
+                g.add_node(new[0], length=step)
+                g.add_nodes_from([new[1]], length=step)
+                g.add_edges_from([(new[0], new[1]), (new[1], n)], nr_links=None)
+        elif op == 12:
+            gone = rnd.sample(nodes, min(len(nodes), 3))
+            a.remove_nodes_from(gone)
+            b.remove_nodes_from(gone)
+        elif op == 13 and b.neighbors(n):
+            pairs = [(n, m) for m in b.neighbors(n)[:2]] + [(n, ('nobody', 'L'))]
+            a.remove_edges_from(pairs)
+            b.remove_edges_from(pairs)
+        elif op == 14 and step % 40 == 0:
+            assert list(a.edges_iter()) == list(b.edges_iter()) and list(a.nodes_iter()) == list(b.nodes_iter())
+        elif op == 15:
+            assert a.nodes(data=True)[:5] == b.nodes(data=True)[:5] and len(a) == len(b) and a.number_of_nodes() == b.number_of_nodes()
     assert snapshot(a) == snapshot(b)
     assert a.number_of_edges() == b.number_of_edges() and a.degree() == b.degree()
 
