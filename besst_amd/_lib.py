@@ -36,7 +36,7 @@ ERR_NOMEM = 4           # include/besst_amd.h: BESST_ERR_NOMEM
 class LibParams(C.Structure):
     _fields_ = [('read_len', C.c_double), ('ins_size_threshold', C.c_double), ('min_mapq', C.c_int32),
                 ('orientation', C.c_int32), ('detect_duplicate', C.c_int32), ('extend_paths', C.c_int32),
-                ('no_score', C.c_int32), ('record_path', C.c_int32)]
+                ('no_score', C.c_int32), ('record_path', C.c_int32), ('mate_bits', C.c_void_p)]
 
 
 class Presort(C.Structure):          # include/besst_amd.h: besst_presort
@@ -184,6 +184,8 @@ _SIGNATURES = {
     'besst_chain_scaffolds': (C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'besst_dev_score_edges': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double,
                                         C.c_double, _P, _P, _P, _P, _P, C.c_size_t]),
+    'besst_dev_mate_bits_bytes': (C.c_size_t, [C.c_int64]),
+    'besst_dev_mate_bits': (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     'besst_dev_lognormal_tables_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'besst_dev_lognormal_tables': (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, _P, _P, _P, C.c_size_t]),
     'besst_dev_score_edges_lognormal': (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_double,
@@ -229,7 +231,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.besst_abi_version() != 2:
+    if lib.besst_abi_version() != 3:
         raise BesstDeviceError('libbesst_amd.so ABI version mismatch')
     _lib = lib
     return lib

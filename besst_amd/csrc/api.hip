@@ -213,6 +213,8 @@ struct besst_ctx {
     DevBuf<int32_t> tid, mtid, pos, mpos, tlen;
     DevBuf<uint16_t> flag, qlen;
     DevBuf<uint8_t> mapq;
+    DevBuf<uint8_t> mate_bits;       // one bit per record: tid != mtid (ClassifyArgs::mate_bits), valid for the first bits_upto records
+    int64_t bits_upto = 0;
     // tuple stream + edge table
     DevBuf<uint64_t> keys, payload, row_key;
     DevBuf<uint32_t> row_mask, row_n, row_first, row_offset;
@@ -361,7 +363,7 @@ void besst_ctx_destroy(besst_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->table.release(); c->aligned.release();
     c->tid.release(); c->mtid.release(); c->pos.release(); c->mpos.release(); c->tlen.release();
-    c->flag.release(); c->qlen.release(); c->mapq.release();
+    c->flag.release(); c->qlen.release(); c->mapq.release(); c->mate_bits.release();
     c->keys.release(); c->payload.release(); c->row_key.release();
     c->row_mask.release(); c->row_n.release(); c->row_first.release(); c->row_offset.release();
     c->row_sum.release(); c->row_sum_sq.release(); c->obs_lo.release(); c->obs_hi.release();
@@ -452,6 +454,7 @@ int besst_ctx_set_library(besst_ctx* c, const besst_lib_params* p) {
 int besst_ctx_clear_records(besst_ctx* c) {
     BESST_REQUIRE(c, "null context");
     c->n_records = 0;
+    c->bits_upto = 0;
     c->built = false;
     return BESST_OK;
 }
@@ -1497,6 +1500,7 @@ static int fill_classify_args(ClassifyArgs& a, int64_t n, const int32_t* tid, co
     a.extend_paths = p->extend_paths;
     a.no_score = p->no_score;
     a.record_path = p->record_path;
+    a.mate_bits = static_cast<const uint8_t*>(p->mate_bits);
     a.ps_table = nullptr; a.ps_rows = 0; a.ps_shift = 0; a.ps_base = 0;
     BESST_REQUIRE(p->record_path == 0 || p->record_path == 1, "classify: record_path must be 0 or 1");
     return BESST_OK;
@@ -1725,6 +1729,16 @@ int besst_dev_score_edges_lognormal(void* stream, int64_t n_edges, const uint32_
     return launch_score_lognormal(static_cast<hipStream_t>(stream), a, l, gap, sd0, ks_h, flags, workspace, workspace_bytes - head);
 }
 
+size_t besst_dev_mate_bits_bytes(int64_t n_records) { return (size_t)(((n_records > 0 ? n_records : 0) + 7) / 8) + 16; }
+
+int besst_dev_mate_bits(void* stream, int64_t n, const int32_t* tid, const int32_t* mtid, void* bits) {
+    BESST_REQUIRE(n >= 0, "dev_mate_bits: negative record count");
+    if (n == 0) return BESST_OK;
+    BESST_REQUIRE(tid && mtid && bits, "dev_mate_bits: null pointer");
+    BESST_REQUIRE(aligned16(tid) && aligned16(mtid), "dev_mate_bits: columns must be 16-byte aligned");
+    return launch_mate_bits(static_cast<hipStream_t>(stream), tid, mtid, 0, n, n, static_cast<uint8_t*>(bits));
+}
+
 size_t besst_dev_lognormal_tables_workspace_bytes(int64_t x_max) { return lognormal_tables_workspace_bytes(x_max); }
 
 int besst_dev_lognormal_tables(void* stream, double mu, double sigma, int64_t x_max, double* F0, double* F1, void* workspace,
@@ -1793,6 +1807,24 @@ int besst_ctx_build_graph(besst_ctx* c) {
         if (rc) return rc;
         const char* forced = getenv("BESST_RECORD_PATH");   // tests and experiments: "0" / "1"
         if (forced && (forced[0] == '0' || forced[0] == '1') && forced[1] == 0) lp.record_path = forced[0] - '0';
+    }
+    {   // the mate-elsewhere bits of the records that have none yet (everything pushed since the last build): 8 bytes read
+        // per record once, after which every pass over these records leaves `mtid` alone where tid == mtid.
+        // BESST_MATE_BITS=0 (tests): the loop compares the columns itself.
+        const char* off = getenv("BESST_MATE_BITS");
+        lp.mate_bits = nullptr;
+        if (!(off && off[0] == '0' && off[1] == 0) && n > 0) {
+            const size_t need = (size_t)((n + 7) / 8) + 16;
+            if (need > c->mate_bits.cap) {                   // (growing drops what was there)
+                if ((rc = c->mate_bits.ensure(need + need / 2))) return rc;
+                c->bits_upto = 0;
+            }
+            if (c->bits_upto < n) {
+                if ((rc = launch_mate_bits(c->stream, c->tid.p, c->mtid.p, c->bits_upto, n, n, c->mate_bits.p))) return rc;
+                c->bits_upto = n;
+            }
+            lp.mate_bits = c->mate_bits.p;
+        }
     }
     rc = besst_dev_classify(c->stream, n, c->tid.p, c->mtid.p, c->pos.p, c->mpos.p, c->flag.p, c->mapq.p, c->qlen.p,
                             c->n_contigs, c->table.p, &lp, c->node_bits, sb->carry, c->aligned.p, c->keys.p,

@@ -185,6 +185,9 @@ __device__ __forceinline__ void wave_add_runs(unsigned long long* dst, int32_t k
     if (tail && v) atomicAdd(&dst[key], (unsigned long long)v);
 }
 
+// kBits: the records' mate-elsewhere bits are there (ClassifyArgs::mate_bits) - a full tile then reads 7 1/8 bytes per
+// record instead of 11: `mtid` is not read at all here (ordered_kernel gathers the candidates' own).
+template <bool kBits>
 __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
                                                                 unsigned long long* __restrict__ aligned,
                                                                 unsigned long long* __restrict__ bitmask) {
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
     int4 v_tid[kStreamSubTiles], v_mtid[kStreamSubTiles];
     uchar4 v_mapq[kStreamSubTiles];
     ushort4 v_qlen[kStreamSubTiles];
-    if (block_base + kStreamTile <= a.n) {
+    uint32_t v_bits[kStreamSubTiles];                        // kBits: the lane's four bits (full tiles)
+    const bool full_tile = block_base + kStreamTile <= a.n;
+    if (full_tile) {
         // full tile: issue every load of the workgroup's 4096 records before touching any of them
 #pragma unroll
         for (int st = 0; st < kStreamSubTiles; ++st) {
@@ -203,7 +208,13 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 typedef unsigned short v4h __attribute__((ext_vector_type(4)));
                 const v4i t4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a.tid + i0));
-                const v4i m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a.mtid + i0));
+                v4i m4 = t4;
+                if constexpr (kBits) {
+                    // (i0 is a multiple of 4: the lane's four bits are one nibble of byte i0 / 8)
+                    v_bits[st] = ((uint32_t)a.mate_bits[i0 >> 3] >> (uint32_t)(i0 & 4)) & 15u;
+                } else {
+                    m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a.mtid + i0));
+                }
                 const uint32_t q1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.mapq + i0));
                 const v4h q4 = __builtin_nontemporal_load(reinterpret_cast<const v4h*>(a.qlen + i0));
                 v_tid[st] = make_int4(t4.x, t4.y, t4.z, t4.w);
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
             v_mtid[st] = *reinterpret_cast<const int4*>(a.mtid + i0);
             v_mapq[st] = *reinterpret_cast<const uchar4*>(a.mapq + i0);
             v_qlen[st] = *reinterpret_cast<const ushort4*>(a.qlen + i0);
+            if constexpr (kBits) v_bits[st] = ((uint32_t)a.mate_bits[i0 >> 3] >> (uint32_t)(i0 & 4)) & 15u;
 #endif
         }
     } else {
@@ -251,7 +263,8 @@ __global__ __launch_bounds__(kStreamThreads) void stream_kernel(ClassifyArgs a,
         bool cand[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            cand[k] = r_tid[k] != r_mtid[k];
+            if constexpr (kBits) cand[k] = full_tile ? ((v_bits[st] >> k) & 1u) != 0u : r_tid[k] != r_mtid[k];
+            else cand[k] = r_tid[k] != r_mtid[k];
             uni = uni && (r_tid[k] == ref);
             const bool cov = ((int32_t)r_mapq[k] >= a.min_mapq || r_mapq[k] == 0);
             if (!cand[k] && cov) mine += (int)r_qlen[k];
@@ -609,7 +622,9 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {     // the sum in every lan
 // tuple and one table entry per run.  Per evaluation round the distinct keys among the <= 64 emitted tuples (two or three in
 // a coordinate-sorted stream) are peeled off - first emitting lane's key, one compare + ballot for the round's tuples, one
 // for the open runs the lanes hold - so the cost is per distinct key and round, not per tuple; no LDS, three registers.
-template <bool kRuns>
+// kBits: ClassifyArgs::mate_bits is there - `mtid` moves from the columns every record is read from to the columns that only
+// the lanes with a candidate read (pos / mpos / flag): 4 of a record's 11 always-read bytes become 1/8.
+template <bool kRuns, bool kBits>
 __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
     ClassifyArgs a, unsigned long long* __restrict__ aligned, uint64_t* __restrict__ seg_keys,
     uint64_t* __restrict__ seg_payload, SummView summ, uint32_t* __restrict__ run_status) {
@@ -963,8 +978,8 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         // number of outstanding loads is the same on every path and the waits the compiler places are exact.
         // (the byte and halfword columns stay packed as they were loaded - one and two registers - until process() takes
         // them apart: three sub-tiles of columns are live at once)
-        struct ColsA { int4 tid, mtid; uint32_t mapq; uint2 qlen; };
-        struct ColsC { int4 pos, mpos; uint2 flag; };
+        struct ColsA { int4 tid, mtid; uint32_t mapq; uint2 qlen; uint32_t bits; };     // (kBits: mtid unused, else bits)
+        struct ColsC { int4 pos, mpos, mtid; uint2 flag; };                              // (mtid: kBits only)
         // Addresses: the block's first record of every column is a uniform pointer (a scalar register pair), a lane adds
         // a 32-bit offset to it (the saddr + voffset form of the load) - as 64-bit pointers per lane and column the seven
         // columns held fourteen vector registers through the loop, and the loop spilled.
@@ -975,6 +990,7 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
         const uint16_t* const b_flag = a.flag + block_base;
         const uint8_t* const b_mapq = a.mapq + block_base;
         const uint16_t* const b_qlen = a.qlen + block_base;
+        const uint8_t* const b_bits = kBits ? a.mate_bits + (block_base >> 3) : nullptr;
         typedef int v4i __attribute__((ext_vector_type(4)));
         auto load_a = [&](int st) {
             const uint32_t li = (uint32_t)st * (uint32_t)(kFwSub / 4) + (uint32_t)lane;   // the lane's group of four records
@@ -983,7 +999,14 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             // (non-temporal: every record is read once - marking these four streams so took 2.3 % off the kernel; the same
             // mark on the candidate columns, where idle lanes re-read one sector, or on the segment stores made it slower)
             const v4i t4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_tid) + li);
-            const v4i m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_mtid) + li);
+            v4i m4 = t4;
+            v.bits = 0u;
+            if constexpr (kBits) {
+                // (the lane's four records begin at block_base + 4 li: their bits are a nibble of byte li / 2 of the block's)
+                v.bits = ((uint32_t)b_bits[li >> 1] >> ((li & 1u) * 4u)) & 15u;
+            } else {
+                m4 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b_mtid) + li);
+            }
             const uint32_t q1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(b_mapq) + li);
             typedef unsigned int v2u __attribute__((ext_vector_type(2)));
             const v2u q4 = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(b_qlen) + li);
@@ -993,14 +1016,21 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             v.qlen = make_uint2(q4.x, q4.y);
 #else
             v.tid = reinterpret_cast<const int4*>(b_tid)[li];
-            v.mtid = reinterpret_cast<const int4*>(b_mtid)[li];
+            v.bits = 0u;
+            if constexpr (kBits) {
+                v.mtid = v.tid;
+                v.bits = ((uint32_t)b_bits[li >> 1] >> ((li & 1u) * 4u)) & 15u;
+            } else {
+                v.mtid = reinterpret_cast<const int4*>(b_mtid)[li];
+            }
             v.mapq = reinterpret_cast<const uint32_t*>(b_mapq)[li];
             v.qlen = reinterpret_cast<const uint2*>(b_qlen)[li];
 #endif
             return v;
         };
         auto load_c = [&](int st, const ColsA& v) {
-            const bool need = v.tid.x != v.mtid.x || v.tid.y != v.mtid.y || v.tid.z != v.mtid.z || v.tid.w != v.mtid.w;
+            const bool need = kBits ? v.bits != 0u
+                                    : (v.tid.x != v.mtid.x || v.tid.y != v.mtid.y || v.tid.z != v.mtid.z || v.tid.w != v.mtid.w);
             // (a lane without a candidate reads the first 16 bytes of the BLOCK's columns - one sector per column and block,
             // in cache after its first use - and not its sub-tile's first sector, which nobody else may want: 0.3 GB less
             // from HBM, -3 %)
@@ -1009,6 +1039,8 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             c.pos = reinterpret_cast<const int4*>(b_pos)[li];
             c.mpos = reinterpret_cast<const int4*>(b_mpos)[li];
             c.flag = reinterpret_cast<const uint2*>(b_flag)[li];
+            if constexpr (kBits) c.mtid = reinterpret_cast<const int4*>(b_mtid)[li];
+            else c.mtid = v.mtid;
             return c;
         };
         constexpr int kSubs = kClsTile / kFwSub;
@@ -1029,7 +1061,11 @@ __global__ __launch_bounds__(64, BESST_FW_MIN_WAVES) void fused_wave_kernel(
             pend = round_fetch(q_count >= 64 ? 64 : 0);      // (fewer than 64 are left queued: the ring holds the 256 to come)
             {
                 const int32_t r_tid[4] = {a0.tid.x, a0.tid.y, a0.tid.z, a0.tid.w};
-                const int32_t r_mtid[4] = {a0.mtid.x, a0.mtid.y, a0.mtid.z, a0.mtid.w};
+                // (kBits: a lane that holds a candidate has read the `mtid` of its four records with the candidate columns; for
+                // a lane that holds none they equal `tid`)
+                const bool own = kBits && a0.bits != 0u;
+                const int32_t r_mtid[4] = {own ? c0.mtid.x : a0.mtid.x, own ? c0.mtid.y : a0.mtid.y, own ? c0.mtid.z : a0.mtid.z,
+                                           own ? c0.mtid.w : a0.mtid.w};
                 const int32_t r_pos[4] = {c0.pos.x, c0.pos.y, c0.pos.z, c0.pos.w};
                 const int32_t r_mpos[4] = {c0.mpos.x, c0.mpos.y, c0.mpos.z, c0.mpos.w};
                 const uint32_t r_flag[4] = {c0.flag.x & 0xffffu, c0.flag.x >> 16, c0.flag.y & 0xffffu, c0.flag.y >> 16};
@@ -1665,19 +1701,26 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
     if (a.record_path == 1) {
         if (group_runs) BESST_HIP_TRY(hipMemsetAsync(w.run_status, 0, 4, s));
         ProfScope ps(s, kProfFusedWave);
-        if (group_runs)
-            hipLaunchKernelGGL(fused_wave_kernel<true>, dim3(nblocks), dim3(64), 0, s, a,
-                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
+        auto* al = reinterpret_cast<unsigned long long*>(aligned);
+        if (group_runs && a.mate_bits)
+            hipLaunchKernelGGL((fused_wave_kernel<true, true>), dim3(nblocks), dim3(64), 0, s, a, al, w.seg_keys, w.seg_payload, w.summ, w.run_status);
+        else if (group_runs)
+            hipLaunchKernelGGL((fused_wave_kernel<true, false>), dim3(nblocks), dim3(64), 0, s, a, al, w.seg_keys, w.seg_payload, w.summ, w.run_status);
+        else if (a.mate_bits)
+            hipLaunchKernelGGL((fused_wave_kernel<false, true>), dim3(nblocks), dim3(64), 0, s, a, al, w.seg_keys, w.seg_payload, w.summ, w.run_status);
         else
-            hipLaunchKernelGGL(fused_wave_kernel<false>, dim3(nblocks), dim3(64), 0, s, a,
-                               reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ, w.run_status);
+            hipLaunchKernelGGL((fused_wave_kernel<false, false>), dim3(nblocks), dim3(64), 0, s, a, al, w.seg_keys, w.seg_payload, w.summ, w.run_status);
         BESST_HIP_TRY(hipGetLastError());
         return BESST_OK;
     }
     {
         ProfScope ps(s, kProfStream);
-        hipLaunchKernelGGL(stream_kernel, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
-                           reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
+        if (a.mate_bits)
+            hipLaunchKernelGGL(stream_kernel<true>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
+        else
+            hipLaunchKernelGGL(stream_kernel<false>, dim3(stream_blocks), dim3(kStreamThreads), 0, s, a,
+                               reinterpret_cast<unsigned long long*>(aligned), w.bitmask);
     }
     {
         ProfScope ps(s, kProfOrdered);
@@ -1685,6 +1728,37 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
                            reinterpret_cast<unsigned long long*>(aligned), w.seg_keys, w.seg_payload, w.summ);
     }
     (void)counters;
+    BESST_HIP_TRY(hipGetLastError());
+    return BESST_OK;
+}
+
+namespace {
+// one thread per byte of the bit column: eight records' tid != mtid (records behind n: 0)
+__global__ __launch_bounds__(256) void mate_bits_kernel(const int32_t* __restrict__ tid, const int32_t* __restrict__ mtid,
+                                                        int64_t first_byte, int64_t n_bytes, int64_t n, uint8_t* __restrict__ bits) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_bytes) return;
+    const int64_t i0 = (first_byte + k) * 8;
+    uint32_t b = 0;
+    if (i0 + 8 <= n) {
+        const int4 t0 = *reinterpret_cast<const int4*>(tid + i0), t1 = *reinterpret_cast<const int4*>(tid + i0 + 4);
+        const int4 m0 = *reinterpret_cast<const int4*>(mtid + i0), m1 = *reinterpret_cast<const int4*>(mtid + i0 + 4);
+        b = (t0.x != m0.x ? 1u : 0u) | (t0.y != m0.y ? 2u : 0u) | (t0.z != m0.z ? 4u : 0u) | (t0.w != m0.w ? 8u : 0u) |
+            (t1.x != m1.x ? 16u : 0u) | (t1.y != m1.y ? 32u : 0u) | (t1.z != m1.z ? 64u : 0u) | (t1.w != m1.w ? 128u : 0u);
+    } else {
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j < n && tid[i0 + j] != mtid[i0 + j]) b |= 1u << j;
+    }
+    bits[first_byte + k] = (uint8_t)b;
+}
+}  // namespace
+
+int launch_mate_bits(hipStream_t s, const int32_t* tid, const int32_t* mtid, int64_t lo, int64_t hi, int64_t n, uint8_t* bits) {
+    if (hi > n) hi = n;
+    if (lo < 0) lo = 0;
+    if (hi <= lo) return BESST_OK;
+    const int64_t first_byte = lo >> 3, n_bytes = ((hi + 7) >> 3) - first_byte;
+    hipLaunchKernelGGL(mate_bits_kernel, dim3((uint32_t)((n_bytes + 255) / 256)), dim3(256), 0, s, tid, mtid, first_byte, n_bytes, n, bits);
     BESST_HIP_TRY(hipGetLastError());
     return BESST_OK;
 }

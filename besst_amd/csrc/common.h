@@ -159,6 +159,10 @@ struct ClassifyArgs {
     const uint16_t* qlen;
     const ContigRow* table;
     const uint8_t* cls8;    // class per tid (follows the rows in the packed table)
+    // one bit per record, bit i % 8 of byte i / 8: the record's mate lies on another reference (tid != mtid).  Made when the
+    // records become resident (besst_dev_mate_bits: the ingest's decode, push_records); with it the record loop reads
+    // `mtid` only for the lanes that hold such a record.  nullptr: the loop compares the two columns itself.
+    const uint8_t* mate_bits;
     int64_t n;
     int32_t n_contigs;
     int32_t node_bits;
@@ -333,6 +337,9 @@ int launch_classify_scan(hipStream_t s, const ClassifyArgs& a, int64_t* aligned,
 bool classify_can_group_runs(const ClassifyArgs& a);
 int launch_candidate_density(hipStream_t s, int64_t n, const int32_t* tid, const int32_t* mtid, int64_t sample_records,
                              unsigned long long* counts);
+// bits of records [lo, hi) (whole bytes: from lo rounded down to hi rounded up to a multiple of 8, clipped to n: the records in
+// front of lo that share lo's byte are read again)
+int launch_mate_bits(hipStream_t s, const int32_t* tid, const int32_t* mtid, int64_t lo, int64_t hi, int64_t n, uint8_t* bits);
 int launch_classify_tail(hipStream_t s, int64_t n, int32_t* tail, void* ws, size_t ws_bytes);
 int launch_resolve_carry(hipStream_t s, const int32_t* tails, int rank, int32_t* carry);
 int launch_classify_emit(hipStream_t s, int64_t n, int detect_dup, int32_t* carry, uint64_t* keys,

@@ -334,6 +334,7 @@ class HipBackend(object):
         g, r, p = self.gb, self.rec, self.pipeline._p
         if 'classify_scan' not in self._args:
             g.params.record_path = g.record_path(r)          # sampled once (synchronises), before the first step
+        g.params.mate_bits = getattr(r, 'mate_bits_ptr', None)
         self._call('classify_scan', self.lib.besst_dev_classify_scan, lambda: (
             r.n, p(r.tid), p(r.mtid), p(r.pos), p(r.mpos), p(r.flag), p(r.mapq), p(r.qlen),
             g.n_contigs, p(g.table), C.byref(g.params), g.node_bits, p(g.aligned), g._small(0), p(g.ws1),

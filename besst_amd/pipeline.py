@@ -47,6 +47,8 @@ class DeviceRecords(object):
         self.mapq = _from_np(batch.mapq, device)
         self.qlen = _from_np(batch.qlen, device)
 
+        self._make_bits()
+
     @classmethod
     def from_columns(cls, cols, copy=False):
         """Columns that already live on the device (synth.simulate_library_device)."""
@@ -54,7 +56,27 @@ class DeviceRecords(object):
         self.n = int(cols['tid'].shape[0])
         for k in ('tid', 'mtid', 'pos', 'mpos', 'tlen', 'flag', 'mapq', 'qlen'):
             setattr(self, k, cols[k].clone() if copy else cols[k])
+        self._make_bits()
         return self
+
+    def _make_bits(self):
+        """The ninth column of the resident layout: one bit per record, set where the mate lies on another reference
+        (tid != mtid) - made once, here, when the records become resident (besst_dev_mate_bits; 1/8 byte per record).  The
+        record loop then reads `mtid` only where a lane holds such a record (besst_lib_params.mate_bits).
+        BESST_MATE_BITS=0: no bit column, the loop compares tid and mtid itself (tests compare the two forms)."""
+        self.mate_bits = None
+        if self.n == 0 or not self.tid.is_cuda or os.environ.get('BESST_MATE_BITS') == '0':
+            return
+        lib = _lib.load()
+        dev = self.tid.device
+        bits = torch.empty(int(lib.besst_dev_mate_bits_bytes(self.n)), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.besst_dev_mate_bits(C.c_void_p(stream), self.n, _p(self.tid), _p(self.mtid), _p(bits)), 'dev_mate_bits')
+        self.mate_bits = bits
+
+    @property
+    def mate_bits_ptr(self):
+        return None if self.mate_bits is None else self.mate_bits.data_ptr()
 
     @property
     def graph_bytes(self):
@@ -188,6 +210,7 @@ class DeviceGraphBuilder(object):
         import weakref
         self._last_rec = weakref.ref(rec)
         self.params.record_path = self.record_path(rec)
+        self.params.mate_bits = rec.mate_bits_ptr            # (the struct the marshalled argument lists point to)
         # argument lists are marshalled once per record set (every buffer is allocated once)
         args = self._rec_args.get(rec)
         if args is None:

@@ -35,8 +35,9 @@ extern "C" {
 #endif
 
 /* 1: rounds 1-4.  2: + the sharded-scan and BAM-slice entry points of round 5 and the log-normal scoring entry points of
- * round 6 (additions only: a caller built against 1 keeps working). */
-#define BESST_ABI_VERSION 2
+ * round 6 (additions only: a caller built against 1 keeps working).  3: besst_lib_params grew by `mate_bits` (a caller
+ * built against 2 passes a shorter struct: recompile), + besst_dev_mate_bits. */
+#define BESST_ABI_VERSION 3
 
 /* status codes */
 #define BESST_OK 0
@@ -80,6 +81,12 @@ typedef struct besst_lib_params {
                                 * second over the tid != mtid records only (paired-end libraries: ~1 % of the
                                 * records); 1 = one fused pass (mate-pair libraries: ~20 %); pick it from
                                 * besst_dev_candidate_density() - the besst_ctx_* layer does that itself          */
+    const void* mate_bits;     /* besst_dev_* layer (the besst_ctx_* layer keeps its own): one bit per record of the stream
+                                * the call is given - bit i % 8 of byte i / 8 set iff tid[i] != mtid[i] -, made by
+                                * besst_dev_mate_bits when the records became resident; the record loop then reads `mtid`
+                                * only for the lanes that hold such a record (CreateGraph.py:141-169: everything but the
+                                * coverage sum asks for contig1 != contig2).  NULL: the loop compares the columns itself.
+                                * (ABI version 3: the struct grew by this member.)                                 */
 } besst_lib_params;
 
 /* Tallies of the record loop: Parameter.counters (Parameter.py:113-124) plus the fishy-read count
@@ -550,6 +557,12 @@ int besst_dev_score_edges(void* stream, int64_t n_edges, const uint32_t* row, co
                           const int64_t* row_sum, const uint32_t* row_offset, const int32_t* obs_lo,
                           const int32_t* obs_hi, double mean, double sigma, double read_len, double* gap,
                           double* sd0, int32_t* ks_h, uint8_t* flags, void* workspace, size_t workspace_bytes);
+
+/* The mate-elsewhere bit column of a resident record stream (part of the record layout, made once when the records arrive:
+ * by the ingest, by whoever uploads columns): bits[i / 8] bit i % 8 = (tid[i] != mtid[i]), besst_dev_mate_bits_bytes(n)
+ * bytes.  Passed to the record loop in besst_lib_params.mate_bits. */
+size_t besst_dev_mate_bits_bytes(int64_t n_records);
+int besst_dev_mate_bits(void* stream, int64_t n_records, const int32_t* tid, const int32_t* mtid, void* bits);
 
 /* The log-normal branch on caller-owned device buffers (device-pointer forms of besst_ctx_score_edges_lognormal and
  * besst_ctx_conditional_stddevs).

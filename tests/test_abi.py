@@ -20,7 +20,7 @@ def test_header_symbols_exported_and_bound():
     for name in names:
         assert hasattr(lib, name), name
     assert names == _lib.exported_symbols()
-    assert lib.besst_abi_version() == 2
+    assert lib.besst_abi_version() == 3
 
 
 def test_argument_errors_do_not_need_a_gpu():
