@@ -723,7 +723,7 @@ def InitializeObjects(bam_file, Contigs, Scaffolds, param, Information, G_prime,
     cont_names = bam_file.references
     contig_lengths = [len(c_seq) for c_seq in C_dict.values()]
     param.tot_assembly_length = sum(contig_lengths)
-    N50, L50 = CalculateStats(sorted(contig_lengths, reverse=True), [], param, Information)
+    N50, L50 = CalculateStats(np.sort(np.asarray(contig_lengths, dtype=np.int64))[::-1], [], param, Information)
     param.current_L50 = L50
     param.current_N50 = N50
     n = len(cont_names)
