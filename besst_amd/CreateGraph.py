@@ -669,6 +669,20 @@ class GraphColumns(object):
     def node_side(self):
         return _NodeAttributes(self.nodes, self.lengths)
 
+    def link_arrays(self):
+        """The link edges as G.edges() would list them - every edge from its first endpoint in node order, a node's edges in
+        adjacency (= link) order - without making a single container: (slot of the first endpoint, slot of the second, link
+        position).  A node's slot is its place in the node order: 2 k / 2 k + 1 for the k-th scaffold."""
+        su, sv = self.su, self.sv
+        lo, hi = np.minimum(su, sv), np.maximum(su, sv)
+        order = np.lexsort((np.arange(su.shape[0]), lo))
+        return lo[order], hi[order], order
+
+    def link_scores(self):
+        """score per link position, or None when the graph's links carry none."""
+        self._columns()
+        return self.vals
+
 
 class _NodeAttributes(object):
     """The node attribute dictionaries ({'length': scaffold length}, CreateGraph.py:713-716) behind a filled graph."""

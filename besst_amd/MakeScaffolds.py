@@ -67,6 +67,9 @@ class _GraphArrays(object):
     """Link edges of a graph as arrays.  Scaffold k = k-th distinct scaffold in node order."""
 
     def __init__(self, G, scored_only):
+        cols = G.link_columns() if hasattr(G, 'link_columns') else None
+        if cols is not None and self._from_columns(cols, scored_only):
+            return
         self.index = {}
         for s, _ in G.nodes():
             self.index.setdefault(s, len(self.index))
@@ -85,6 +88,33 @@ class _GraphArrays(object):
             score.append(d.get('score', 1.0))
             edges.append((u, v))
         self.a, self.b, self.score, self.edges, self.unscored = a, b, score, edges, unscored
+
+    def _from_columns(self, cols, scored_only):
+        """A graph straight from CreateGraph.PE, not read or changed since: its link edges are still columns
+        (CreateGraph.GraphColumns) - the arrays come from them, no neighbour or attribute dictionary is made.  A node's
+        code here (2 x scaffold index + side) IS its slot in the columns' node order."""
+        nodes = cols.nodes
+        self.scaffolds = [n[0] for n in nodes[0::2]]
+        self.index = dict(zip(self.scaffolds, range(len(self.scaffolds))))
+        if len(self.index) != len(self.scaffolds):
+            return False                                     # (a scaffold listed twice: the general way)
+        a, b, pos = cols.link_arrays()
+        vals = cols.link_scores()
+        if vals is None:
+            self.unscored = int(pos.shape[0])
+            if scored_only:
+                a, b, pos, score = a[:0], b[:0], pos[:0], []
+            else:
+                score = [1.0] * int(pos.shape[0])
+        else:
+            score_all = [vals[p] for p in pos.tolist()]
+            if any(v.__class__ is object for v in score_all):
+                return False                                 # (links without a score among scored ones: the general way)
+            self.unscored, score = 0, score_all
+        self.a, self.b, self.score = a.tolist(), b.tolist(), score
+        self.edges = [(nodes[i], nodes[j]) for i, j in zip(self.a, self.b)]
+        self.from_columns = True
+        return True
 
     def node(self, n):
         return 2 * self.index[n[0]] + (n[1] == 'R')

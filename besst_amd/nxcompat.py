@@ -27,23 +27,44 @@ class LazyDict(dict):
     An unmade value is stored as the ``int`` token the source wants back (a legitimate value is always a dict).
     ``source.one(token) -> value`` makes one, ``source.rest(lazy_dict)`` makes every value still unmade.  Keys, length,
     membership and iteration over keys never make anything; assignment and deletion are the dictionary's own."""
-    __slots__ = ('_source',)
+    __slots__ = ('_source', '_untouched')
 
     def __init__(self, tokens, source):
         dict.__init__(self, tokens)
         self._source = source
+        self._untouched = True                               # nothing made, set or deleted yet: the columns ARE the content
 
     def __getitem__(self, key):
         value = dict.__getitem__(self, key)
         if value.__class__ is int:
             value = self._source.one(value)
             dict.__setitem__(self, key, value)
+            self._untouched = False
         return value
+
+    def __setitem__(self, key, value):
+        self._untouched = False
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._untouched = False
+        dict.__delitem__(self, key)
+
+    def update(self, *args, **kw):
+        self._untouched = False
+        dict.update(self, *args, **kw)
+
+    @property
+    def columns(self):
+        """The source behind the dictionary while it still IS the dictionary's whole content (no value made, nothing set or
+        deleted), else None: a reader that wants every edge as arrays can take them from the columns and touch nothing."""
+        return self._source if self._untouched else None
 
     def _all(self):
         source = self._source
         if source is not None:
             self._source = None
+            self._untouched = False
             # (hundreds of thousands of small containers that reference nothing but numbers and each other: with the cyclic
             # collector running, every allocation burst re-walks the growing heap - 0.7 s instead of 0.15 for the two graphs
             # of a 100 k-contig assembly; CreateGraph.PE pauses it for the same reason)
@@ -73,6 +94,7 @@ class LazyDict(dict):
         return dict.values(self)
 
     def pop(self, key, *default):
+        self._untouched = False
         if dict.__contains__(self, key):
             self[key]
         return dict.pop(self, key, *default)
@@ -84,6 +106,7 @@ class LazyDict(dict):
     def setdefault(self, key, default=None):
         if dict.__contains__(self, key):
             return self[key]
+        self._untouched = False
         dict.__setitem__(self, key, default)
         return default
 
@@ -93,6 +116,7 @@ class LazyDict(dict):
 
     def clear(self):
         self._source = None
+        self._untouched = False
         dict.clear(self)
 
     def __eq__(self, other):
@@ -179,6 +203,15 @@ class Graph(_BaseGraph):
             raise _nx.NetworkXError('adopt: the graph is not empty')
         self._node = LazyDict(node_tokens, node_source)
         self._adj = LazyDict(adj_tokens, adj_source)
+
+    def link_columns(self):
+        """The column source of a graph that CreateGraph.PE has filled and nobody has read or changed since (see LazyDict),
+        else None."""
+        adj, node = self._adj, self._node
+        if isinstance(adj, LazyDict) and isinstance(node, LazyDict) and node._source is not None and \
+                dict.__len__(node) == dict.__len__(adj):
+            return adj.columns
+        return None
 
     def add_scaffold(self, scaffold, length):
         """The two end nodes of a scaffold with their 'length' attribute and the intra-scaffold edge (nr_links=None):

@@ -241,6 +241,8 @@ def test_linearize_the_graph_pe_returns(name):
     G, G_prime = CreateGraph.PE(Contigs, Scaffolds, info, C_dict, param, small_contigs, small_scaffolds, batch)
     session.close_session(batch)
     arr = MS._GraphArrays(G, scored_only=True)
+    # (a graph straight from PE: its edge arrays come from the columns behind it, no container has been made)
+    assert getattr(arr, 'from_columns', False) and G.link_columns() is not None
     assert len(arr.edges) > 20
     want = SO.linearize(arr.n_scaffolds, arr.a, arr.b, arr.score)
     keep_nodes = [n for n in G.nodes() if want['present'][arr.index[n[0]]]]

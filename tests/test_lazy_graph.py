@@ -185,3 +185,27 @@ def test_copies_and_pickles_are_plain_and_complete():
     assert dict(g3._adj) == dict(eager(plan, scores)._adj)   # a C-level copy goes through __getitem__, not the raw slots
     g3.clear()
     assert len(g3) == 0 and g3.edges() == []
+
+
+@pytest.mark.parametrize('scored', [False, True])
+@pytest.mark.parametrize('scored_only', [False, True])
+def test_link_arrays_come_from_the_columns_without_touching_the_graph(scored, scored_only):
+    """MakeScaffolds._GraphArrays (the edge list the device-side graph cleaning works on, MakeScaffolds.py:134-274) on a
+    graph straight from PE: taken from the columns - same arrays as from walking an eagerly filled graph, and the graph is
+    still untouched afterwards; after any read or change the general way is taken and gives the same."""
+    from besst_amd import MakeScaffolds as MS
+    plan, scores = make_plan(150, 500, 31, scored)
+    lazy = Graph()
+    plan.build(lazy, scores)
+    want = MS._GraphArrays(eager(plan, scores), scored_only)
+    got = MS._GraphArrays(lazy, scored_only)
+    assert getattr(got, 'from_columns', False) and not getattr(want, 'from_columns', False)
+    assert lazy.link_columns() is not None                   # nothing was made
+    for f in ('scaffolds', 'index', 'a', 'b', 'score', 'edges', 'unscored'):
+        assert getattr(got, f) == getattr(want, f), f
+    lazy.neighbors(lazy.nodes()[0])                          # one node read: the columns no longer speak for the graph
+    assert lazy.link_columns() is None
+    again = MS._GraphArrays(lazy, scored_only)
+    assert not getattr(again, 'from_columns', False)
+    for f in ('scaffolds', 'index', 'a', 'b', 'score', 'edges', 'unscored'):
+        assert getattr(again, f) == getattr(want, f), f
