@@ -710,6 +710,422 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
     if (lane == 0) status[b] = err;
 }
 
+// ---- the second form of the inflate (round 6): the symbols of a DEFLATE block decoded by the 64 lanes SIDE BY SIDE ------------
+// bgzf_inflate_kernel above finds a dozen symbols per turn of ~300 vector instructions: every lane decodes speculatively
+// at one BIT position and one lane in five holds a real symbol.  It is bound by vector issue alone (351 k instructions per
+// block x 4 cycles x 5 waves per SIMD = the 3.4 ms a chunk of 5120 blocks takes).  Here every lane decodes REAL symbols, one
+// after the other, in its own 1/64 of the block's bits:
+//   1. the block's bits are cut into 64 equal ranges; lane 0 begins where the block's symbols begin, the others at a guess
+//      (their range's first bit).  Every lane decodes until it leaves its range and hands the position where it did to its
+//      neighbour; a lane whose start changed decodes again - but only until it is in step with what it decoded before: a
+//      Huffman decoder that starts inside a symbol falls into step with the true chain after a few dozen symbols (~250 lie
+//      in a range), and a lane remembers where its chain stood at three CHECKPOINTS of its range and what it had counted
+//      until there.  The hand-overs are stable after two or three rounds - and exact after at most 64: lane k's start is
+//      final once the k lanes in front of it are;
+//   2. the symbols and bytes each lane's chain makes are known then: exclusive scans place the lanes' symbols in the
+//      block's symbol buffer (four bytes per symbol: bytes | literal or distance) and their bytes in the output;
+//   3. the lanes decode once more and store their symbols, four at a time;
+//   4. the symbols are read back 64 at a time, in order, and their bytes laid into output groups of 64 bytes - the flush of
+//      the first form: a scan of the lengths, a marker per symbol and a max-scan, one gather of the lanes that copy from
+//      finished output, six doubling steps of a lane permute for those that copy from the group itself, one store.
+// Same tables, same statuses, same CRC kernel behind it.  BESST_INFLATE=1 selects the first form.
+struct Inflate2Lds {
+    uint16_t lit_tab[kTabSize];
+    uint16_t dist_tab[kDistSize];
+    uint16_t cl_tab[1 << kClBits];
+    uint16_t lit_sub[kSubCap << kLaneLongBits];
+    uint16_t lit_sorted[288];
+    uint16_t dist_sorted[32];
+    uint16_t cl_sorted[32];
+    CanonLds lit_c, dist_c, cl_c;
+    uint8_t lens[288 + 32 + 16];
+    uint8_t cl_lens[32];
+    uint32_t mark[64];
+    uint32_t len_info[32], dist_info[32];      // RFC 1951's length / distance codes: base | extra bits << 9 (<< 16)
+};
+
+// what a lane reads its symbols from: three dwords of the payload from word `w` on (96 bits: a length with its distance and
+// all extra bits is at most 48)
+struct LaneBits {
+    const uint32_t* words;
+    uint32_t w, d0, d1, d2;
+    __device__ __forceinline__ void seek(uint32_t p) {
+        w = p >> 5;
+        d0 = words[w]; d1 = words[w + 1u]; d2 = words[w + 2u];
+    }
+    __device__ __forceinline__ void advance(uint32_t p) {    // p is at most two words on
+        if ((p >> 5) > w) { d0 = d1; d1 = d2; ++w; d2 = words[w + 2u]; }
+        if ((p >> 5) > w) { d0 = d1; d1 = d2; ++w; d2 = words[w + 2u]; }
+    }
+    // 32 bits from bit q of d0 on, q < 64
+    __device__ __forceinline__ uint32_t at(uint32_t q) const {
+        return q < 32u ? __builtin_amdgcn_alignbit(d1, d0, q) : __builtin_amdgcn_alignbit(d2, d1, q - 32u);
+    }
+};
+
+enum : uint32_t { kSymLit = 0, kSymMatch = 1, kSymEnd = 2, kSymBad = 3 };
+constexpr uint32_t kSymIsLit = 0x8000u;                  // a stored symbol: bytes (9 bits) | this | literal or distance << 16
+constexpr uint32_t kCountSym = 1u << 17;                 // a lane's count: bytes + symbols << 17 (modulo 2^32 while it speculates)
+constexpr uint32_t kGrid0 = 64u, kGrid1 = 192u, kGrid2 = 448u;   // the checkpoints: bits behind the first bit of the lane's range
+constexpr uint32_t kSymSlack = 256u;                     // symbol places a block has beyond one per byte (lanes are padded to 4)
+
+// one symbol at bit p of the lane's window: kind, bits it takes, literal / match length, distance
+__device__ __forceinline__ uint32_t decode_symbol(const Inflate2Lds& s, const LaneBits& lb, uint32_t p, uint32_t& bits, uint32_t& val,
+                                                  uint32_t& dist) {
+    const uint32_t q0 = p & 31u;
+    const uint32_t x = lb.at(q0);
+    uint32_t e = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
+    if ((e & kLinkMask) == kLinkFlag)
+        e = s.lit_sub[((e >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u))];
+    if ((e & 15u) == 0u) {
+        e = slow_code(&s.lit_c, s.lit_sorted, x & 0x7fffu, kTabBits);
+        if (e == 0u) { bits = 1u; return kSymBad; }
+    }
+    const uint32_t la = e & 15u, sa = e >> 4;
+    if (sa < 256u) { bits = la; val = sa; return kSymLit; }
+    if (sa == 256u) { bits = la; return kSymEnd; }
+    if (sa >= 286u) { bits = la; return kSymBad; }
+    const uint32_t li = s.len_info[sa - 257u];
+    const uint32_t xa = li >> 9;
+    val = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
+    const uint32_t xq = lb.at(q0 + la + xa);                 // (la + xa <= 20: inside the window)
+    uint32_t d = s.dist_tab[xq & (uint32_t)(kDistSize - 1)];
+    if ((d & 15u) == 0u) {
+        d = slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kDistBits);
+        if (d == 0u) { bits = la + xa; return kSymBad; }
+    }
+    const uint32_t lb_ = d & 15u, sb = d >> 4;
+    if (sb >= 30u) { bits = la + xa + lb_; return kSymBad; }
+    const uint32_t di = s.dist_info[sb];
+    const uint32_t xb = di >> 16;
+    dist = (di & 0xffffu) + ((xq >> lb_) & ((1u << xb) - 1u));
+    bits = la + xa + lb_ + xb;
+    return kSymMatch;
+}
+
+__global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+                                                                       uint32_t n_blocks, uint8_t* dst, uint32_t* sym_all,
+                                                                       uint32_t* __restrict__ status) {
+    __shared__ Inflate2Lds s;
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t src_off = uni(blocks[b].src_off), src_len = uni(blocks[b].src_len);
+    const uint32_t dst_len = uni(blocks[b].dst_len);
+    const size_t out_at = (size_t)uni(blocks[b].dst_off_lo) + ((size_t)uni(blocks[b].dst_off_hi) << 32);
+    uint8_t* out = dst + out_at;
+    // the block's symbols: dst_len + kSymSlack places (a symbol makes a byte at least; 64 lanes are padded to four symbols),
+    // 16-byte aligned, behind those of the blocks before
+    uint32_t* sym = sym_all + ((out_at + 3u) & ~(size_t)3u) + (size_t)kSymSlack * b;
+    if (dst_len == 0) {                                      // the EOF marker block
+        if (lane == 0) status[b] = kInfOk;
+        return;
+    }
+    BitReader br;
+    br.lane = lane;
+    br.words = reinterpret_cast<const uint32_t*>(src + (src_off & ~3u));
+    br.seek(src_off & 3u);
+    const uint32_t in_base = src_off & 3u;
+    const uint32_t end_bit = (in_base + src_len) * 8u;       // the payload's last bit + 1, counted like the lanes' positions
+    {
+        const uint32_t k = (uint32_t)lane;
+        uint32_t base, extra = 0;
+        if (k < 8u) base = 3u + k;
+        else if (k == 28u) base = 258u;
+        else {
+            extra = (k - 4u) >> 2;
+            base = 3u + ((4u + (k & 3u)) << extra);
+        }
+        if (lane < 32) s.len_info[lane] = k < 29u ? base | (extra << 9) : 0u;
+        extra = 0;
+        if (k < 4u) base = 1u + k;
+        else {
+            extra = (k - 2u) >> 1;
+            base = 1u + ((2u + (k & 1u)) << extra);
+        }
+        if (lane < 32) s.dist_info[lane] = k < 30u ? base | (extra << 16) : 0u;
+    }
+    uint32_t pos = 0;
+    uint32_t err = kInfOk;
+    // ---- output groups, as in the first form (see there): lane k of the group stands for the byte at pos + k
+    auto put_byte = [&](uint32_t at, uint32_t v) { out[at] = (uint8_t)v; };
+    auto get_byte = [&](uint32_t at) -> uint32_t { return __hip_atomic_load(out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    uint32_t g = 0, filled = 0, pend_n = 0, pend_pos = 0, pend_g = 0, pend_v = 0, pend_s = 0;
+    bool pend_res = false;
+    auto retire = [&]() {
+        if (pend_n != 0u) {                                  // uniform
+            uint32_t val = (pend_g & kGroupLit) ? pend_g : pend_v;
+            if (pend_res) val = (uint32_t)__shfl((int)val, (int)pend_s, 64);
+            if ((uint32_t)lane < pend_n) put_byte(pend_pos + (uint32_t)lane, val);
+            pend_n = 0;
+        }
+    };
+    auto flush_group = [&]() {
+        if (filled != 0u) {                                  // uniform
+            retire();
+            const bool copy = (uint32_t)lane < filled && !(g & kGroupLit);
+            const bool own = copy && g >= pos;
+            pend_v = get_byte((copy && !own) ? g : 0u);
+            uint32_t from = own ? g - pos : (uint32_t)lane;
+            pend_res = __ballot(own) != 0ull;
+            if (pend_res) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) from = (uint32_t)__shfl((int)from, (int)from, 64);
+            }
+            pend_s = from;
+            pend_g = g;
+            pend_pos = pos;
+            pend_n = filled;
+            pos = uni(pos + filled);
+            filled = 0;
+        }
+    };
+    for (;;) {
+        if (br.byte_pos() - in_base > src_len + 8u) { err = kInfInputOverrun; break; }
+        const uint32_t final_block = br.take(1);
+        const uint32_t type = br.take(2);
+        if (type == 0u) {
+            br.align_to_byte();
+            const uint32_t len = br.take(16), nlen = br.take(16);
+            if (len != (~nlen & 0xffffu)) { err = kInfBadStored; break; }
+            const uint32_t at = br.byte_pos();
+            if (at - in_base + len > src_len) { err = kInfInputOverrun; break; }
+            if (pos + len > dst_len) { err = kInfOutputOverrun; break; }
+            const uint8_t* from = reinterpret_cast<const uint8_t*>(br.words) + at;
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64u) out[pos + i] = from[i];
+            pos += len;
+            br.seek(at + len);
+        } else if (type == 1u || type == 2u) {
+            int n_lit = 288, n_dist = 30;
+            if (type == 1u) {
+                for (int i = lane; i < 288; i += 64) s.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+                if (lane < 32) s.lens[288 + lane] = 5;
+            } else {
+                const uint32_t hlit = br.take(5) + 257u, hdist = br.take(5) + 1u, hclen = br.take(4) + 4u;
+                if (hlit > 286u || hdist > 30u) { err = kInfBadLengths; break; }
+                if (lane < 32) s.cl_lens[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = 0; i < hclen; ++i) {
+                    const uint32_t v = br.take(3);
+                    const uint32_t order = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
+                    s.cl_lens[order] = (uint8_t)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!build_code(s.cl_lens, 19, kClBits, s.cl_tab, s.cl_sorted, &s.cl_c, lane)) { err = kInfOversubscribed; break; }
+                const uint32_t total = hlit + hdist;
+                uint32_t have = 0, prev = 0;
+                bool bad = false;
+                while (have < total) {
+                    const uint32_t e = uni(s.cl_tab[br.peek32() & ((1u << kClBits) - 1u)]);
+                    const uint32_t l = e & 15u, sym_ = e >> 4;
+                    if (l == 0u) { bad = true; break; }
+                    br.drop(l);
+                    if (sym_ < 16u) {
+                        s.lens[have++] = (uint8_t)sym_;
+                        prev = sym_;
+                        continue;
+                    }
+                    uint32_t rep, val = 0;
+                    if (sym_ == 16u) {
+                        if (have == 0u) { bad = true; break; }
+                        rep = 3u + br.take(2);
+                        val = prev;
+                    } else if (sym_ == 17u) {
+                        rep = 3u + br.take(3);
+                    } else {
+                        rep = 11u + br.take(7);
+                    }
+                    if (have + rep > total) { bad = true; break; }
+                    for (uint32_t i = (uint32_t)lane; i < rep; i += 64u) s.lens[have + i] = (uint8_t)val;
+                    have += rep;
+                    prev = val;
+                }
+                if (bad) { err = kInfBadLengths; break; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) {
+                    const uint8_t v = (uint32_t)lane < hdist ? s.lens[hlit + (uint32_t)lane] : (uint8_t)0;
+                    __builtin_amdgcn_wave_barrier();
+                    s.lens[288 + lane] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = hlit + (uint32_t)lane; i < 288u; i += 64u) s.lens[i] = 0;
+                n_lit = (int)hlit;
+                n_dist = (int)hdist;
+                if (uni(s.lens[256]) == 0u) { err = kInfBadLengths; break; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane, s.lit_sub, s.mark)) { err = kInfOversubscribed; break; }
+            if (!build_code(s.lens + 288, n_dist, kDistBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
+            __builtin_amdgcn_wave_barrier();
+            // ---- 1. the lanes' ranges and the rounds of hand-overs
+            const uint32_t p0 = br.wbase * 32u + br.bitpos;  // where the block's symbols begin (uniform)
+            if (p0 >= end_bit) { err = kInfInputOverrun; break; }
+            uint32_t range = (end_bit - p0 + 63u) >> 6;
+            if (range < 64u) range = 64u;                    // (longer than any symbol: a hand-over lies in the next lane's range)
+            const uint32_t lo = p0 + (uint32_t)lane * range; // the lane's first bit, and the first that is not its own
+            const uint32_t bound = lo + range;
+            const uint32_t lim = bound < end_bit ? bound : end_bit;
+            uint32_t start = lo;
+            bool live = start < end_bit;
+            uint32_t done_for = 0xffffffffu;                 // the start the lane's results below belong to
+            uint32_t r_end = 0, r_kind = kSymBad, tot = 0;   // of its chain: where it left the range, how, what it counted
+            uint32_t cp0 = 0xffffffffu, cp1 = 0xffffffffu, cp2 = 0xffffffffu, pre0 = 0, pre1 = 0, pre2 = 0;   // ... and where it stood at
+            LaneBits lb;                                     // the checkpoints, what it had counted until there
+            lb.words = br.words;
+            for (int round = 0; round < 130; ++round) {
+                const bool need = live && start != done_for;
+                if (need) {
+                    uint32_t p = start, cnt = 0, kind = kSymLit, j = 0, grid = lo + kGrid0;
+                    bool in_step = false;
+                    lb.seek(p);
+                    while (p < lim) {
+                        uint32_t bits, val = 0, dist = 0;
+                        kind = decode_symbol(s, lb, p, bits, val, dist);
+                        if (kind >= kSymEnd) {
+                            if (kind == kSymEnd) p += bits;
+                            break;
+                        }
+                        cnt += (kind == kSymLit ? 1u : val) + kCountSym;
+                        p += bits;
+                        lb.advance(p);
+                        if (p >= grid) {                     // the first symbol behind a checkpoint: in step with the chain before?
+                            const uint32_t was = j == 0u ? cp0 : j == 1u ? cp1 : cp2;
+                            if (p == was) { in_step = true; break; }
+                            if (j == 0u) { cp0 = p; pre0 = cnt; grid = lo + kGrid1; }
+                            else if (j == 1u) { cp1 = p; pre1 = cnt; grid = lo + kGrid2; }
+                            else { cp2 = p; pre2 = cnt; grid = 0xffffffffu; }
+                            ++j;
+                        }
+                    }
+                    if (in_step) {                           // the rest is what it was: only what lies in front of the checkpoint changed
+                        const uint32_t delta = cnt - (j == 0u ? pre0 : j == 1u ? pre1 : pre2);
+                        tot += delta;
+                        if (j == 0u) { pre0 = cnt; pre1 += delta; pre2 += delta; }
+                        else if (j == 1u) { pre1 = cnt; pre2 += delta; }
+                        else pre2 = cnt;
+                    } else {
+                        if (kind < (uint32_t)kSymEnd && p >= end_bit) kind = kSymBad;      // the payload ends inside the block
+                        tot = cnt;
+                        r_end = p;
+                        r_kind = kind >= (uint32_t)kSymEnd ? kind : (uint32_t)kSymLit;
+                        if (j <= 0u) cp0 = 0xffffffffu;      // (checkpoints this chain did not reach are no longer its own)
+                        if (j <= 1u) cp1 = 0xffffffffu;
+                        if (j <= 2u) cp2 = 0xffffffffu;
+                    }
+                    done_for = start;
+                }
+                // the hand-over: a lane lives when the lane before it lives and left its range in the middle of the stream
+                const uint32_t up_end = (uint32_t)__shfl_up((int)r_end, 1, 64);
+                const uint32_t up_kind = (uint32_t)__shfl_up((int)r_kind, 1, 64);
+                const int up_live = __shfl_up((int)live, 1, 64);
+                bool changed = false;
+                if (lane > 0) {
+                    const bool now = up_live != 0 && up_kind == (uint32_t)kSymLit && up_end < end_bit;
+                    changed = now != live || (now && up_end != start);
+                    live = now;
+                    if (live) start = up_end;
+                }
+                if (__ballot(changed) == 0ull) break;        // uniform: every hand-over is what it was, every lane has decoded its own
+            }
+            // the stream ends in the first lane whose symbols did not leave its range
+            const unsigned long long m_stop = __ballot(live && r_kind != (uint32_t)kSymLit);
+            if (m_stop == 0ull) { err = kInfInputOverrun; break; }          // no end-of-block code inside the payload
+            const int last = __ffsll((long long)m_stop) - 1;
+            if ((uint32_t)__builtin_amdgcn_readlane((int)r_kind, last) != (uint32_t)kSymEnd) { err = kInfBadCode; break; }
+            const bool mine = live && lane <= last;
+            // ---- 2. where the lanes' symbols and bytes go
+            const uint32_t nb = mine ? tot & (kCountSym - 1u) : 0u;
+            const uint32_t ns = mine ? tot >> 17 : 0u;
+            const uint32_t np = (ns + 3u) & ~3u;
+            const uint32_t incl_b = scan_add(nb), incl_s = scan_add(np);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63);
+            const uint32_t n_sym = (uint32_t)__builtin_amdgcn_readlane((int)incl_s, 63);
+            // (the counts are exact modulo 2^32 only: a corrupt stream may claim anything - the places are checked, not trusted)
+            if (__ballot(mine && (nb > dst_len || ns > dst_len)) != 0ull || pos + total > dst_len || n_sym > dst_len + kSymSlack - 4u) {
+                err = kInfOutputOverrun;
+                break;
+            }
+            // ---- 3. the symbols, four at a time
+            bool bad_dist = false;
+            if (mine) {
+                uint32_t o = pos + incl_b - nb, p = start, at = incl_s - np, have = 0;
+                uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                lb.seek(p);
+                while (p < r_end) {
+                    uint32_t bits, val = 0, dist = 0;
+                    const uint32_t kind = decode_symbol(s, lb, p, bits, val, dist);
+                    if (kind >= (uint32_t)kSymEnd) break;   // the end-of-block code (the last lane's last symbol)
+                    if (kind == (uint32_t)kSymMatch && dist > o) { bad_dist = true; break; }
+                    o += kind == (uint32_t)kSymLit ? 1u : val;
+                    q0 = q1; q1 = q2; q2 = q3;
+                    q3 = kind == (uint32_t)kSymLit ? 1u | kSymIsLit | (val << 16) : val | (dist << 16);
+                    if ((++have & 3u) == 0u) {
+                        *reinterpret_cast<uint4*>(sym + at) = make_uint4(q0, q1, q2, q3);
+                        at += 4u;
+                    }
+                    p += bits;
+                    lb.advance(p);
+                }
+                const uint32_t rest = have & 3u;             // (the padding: symbols of no bytes)
+                if (rest != 0u && !bad_dist)
+                    *reinterpret_cast<uint4*>(sym + at) = rest == 1u ? make_uint4(q3, 0u, 0u, 0u) : rest == 2u ? make_uint4(q2, q3, 0u, 0u)
+                                                                                                       : make_uint4(q1, q2, q3, 0u);
+            }
+            if (__ballot(bad_dist) != 0ull) { err = kInfBadDistance; break; }
+            // ---- 4. their bytes, 64 symbols at a time
+            for (uint32_t i = 0; i < n_sym; i += 64u) {      // uniform
+                const uint32_t sy = i + (uint32_t)lane < n_sym ? __hip_atomic_load(sym + i + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const uint32_t bytes = sy & 0x1ffu;
+                const bool on = bytes != 0u;
+                const uint32_t what = (sy & kSymIsLit) ? kGroupLit | ((sy >> 16) & 0xffu) : sy >> 16;
+                const uint32_t incl = scan_add(bytes);
+                const uint32_t begin = incl - bytes;         // the symbol's first byte, counted from the batch's first
+                const uint32_t n_bytes = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t done = 0;
+                while (done < n_bytes) {                     // uniform
+                    const uint32_t room = 64u - filled;
+                    const uint32_t take = n_bytes - done < room ? n_bytes - done : room;
+                    // group lane filled + j takes byte done + j of the batch; the symbol that byte belongs to is the last one
+                    // beginning at or before it
+                    const unsigned long long before = __ballot(on && begin <= done);
+                    const uint32_t first = 64u - (uint32_t)__clzll((long long)before);   // (that symbol's lane + 1: never 0)
+                    s.mark[lane] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (on && begin > done && begin < done + take) s.mark[filled + begin - done] = (uint32_t)lane + 1u;
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t m = s.mark[lane];
+                    if ((uint32_t)lane == filled) m = first;
+                    m = scan_max(m);
+                    const uint32_t from = (uint32_t)__shfl((int)what, (int)(m - 1u), 64);
+                    const bool in = (uint32_t)lane >= filled && (uint32_t)lane < filled + take;
+                    const uint32_t at = pos + (uint32_t)lane;
+                    g = in ? ((from & kGroupLit) ? from : at - from) : g;
+                    filled = uni(filled + take);
+                    done += take;
+                    if (filled == 64u) flush_group();
+                }
+            }
+            flush_group();                                   // (a stored block writes its bytes itself)
+            const uint32_t after = (uint32_t)__builtin_amdgcn_readlane((int)r_end, last);   // the bit behind the end-of-block code
+            br.seek(after >> 3);
+            br.bitpos += after & 7u;
+        } else {
+            err = kInfBadBlockType;
+            break;
+        }
+        if (final_block) break;
+    }
+    retire();
+    if (!err) {
+        if (pos != dst_len) err = kInfSizeMismatch;
+        else if (br.byte_pos() - in_base > src_len + 8u) err = kInfInputOverrun;
+    }
+    if (lane == 0) status[b] = err;
+}
+
+// symbol places (four bytes each) the second form needs for n_blocks blocks that inflate to inflated_bytes bytes
+size_t bgzf_inflate_symbol_places(size_t inflated_bytes, size_t n_blocks) { return inflated_bytes + 8 + (size_t)kSymSlack * (n_blocks + 1); }
+
 // ---- the blocks' CRC32 ---------------------------------------------------------------------------------------------------
 // BGZF stores the CRC-32 of every block's inflated bytes (the gzip trailer); htslib - what the reference reads its files
 // through - checks it, and so does this path: a damaged payload that still decodes, or a byte the window logic got wrong,
@@ -1177,9 +1593,14 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
 }
 
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
-                        uint32_t* status) {
+                        uint32_t* status, uint32_t* symbols) {
     if (n_blocks == 0) return BESST_OK;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
+    // symbols (bgzf_inflate_symbol_places() of four bytes): the second form of the kernel; nullptr or BESST_INFLATE=1: the first
+    static const bool first_form = [] { const char* e = getenv("BESST_INFLATE"); return e && e[0] == '1' && e[1] == 0; }();
+    if (symbols && !first_form)
+        hipLaunchKernelGGL(bgzf_inflate2_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, symbols, status);
+    else
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, status);
     {   // the CRC kernel's power tables, once per device (on this stream, in front of the first CRC launch; a second
         // thread's first launch on the same device waits for the one that fills them)
         static std::mutex mu;

@@ -57,7 +57,8 @@ struct BamColumns {
     uint16_t* head_qlen;
 };
 int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* dst,
-                        uint32_t* status);
+                        uint32_t* status, uint32_t* symbols = nullptr);
+size_t bgzf_inflate_symbol_places(size_t inflated_bytes, size_t n_blocks);
 // modes of a chunk's walk: the first start of the chunk is a guess nobody vouches for (the first chunk of a part of the
 // file whose entry is not known yet) / only the record in the tail slot counts (the blocks behind a part's end, inflated
 // for the bytes of the part's last record); summary: 12 words (bgzf_gpu.hip)
