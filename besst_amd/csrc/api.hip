@@ -1353,7 +1353,9 @@ int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void
     BESST_REQUIRE(bgzf && out_len && (out || out_cap == 0), "bgzf_inflate_device: null pointer");
     BESST_HIP_TRY(hipSetDevice(device));
     const uint8_t* map = static_cast<const uint8_t*>(bgzf);
-    const size_t nb = 4096, comp_cap = nb * 65536;
+    size_t nb = 4096;                                        // (BESST_INFLATE_HOOK_BLOCKS: blocks per launch, for timing runs)
+    if (const char* e = getenv("BESST_INFLATE_HOOK_BLOCKS"); e && atoi(e) > 0) nb = (size_t)atoi(e);
+    const size_t comp_cap = nb * 65536;
     std::vector<BgzfBlock> desc(nb);
     std::vector<uint32_t> status(nb);
     std::vector<uint8_t> host;

@@ -729,6 +729,9 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
 //      the first form: a scan of the lengths, a marker per symbol and a max-scan, one gather of the lanes that copy from
 //      finished output, six doubling steps of a lane permute for those that copy from the group itself, one store.
 // Same tables, same statuses, same CRC kernel behind it.  BESST_INFLATE=1 selects the first form.
+#ifndef BESST_INF2_WAVES
+#define BESST_INF2_WAVES 5
+#endif
 struct Inflate2Lds {
     uint16_t lit_tab[kTabSize];
     uint16_t dist_tab[kDistSize];
@@ -742,24 +745,30 @@ struct Inflate2Lds {
     uint8_t cl_lens[32];
     uint32_t mark[64];
     uint32_t len_info[32], dist_info[32];      // RFC 1951's length / distance codes: base | extra bits << 9 (<< 16)
+#ifdef BESST_INF2_PAD
+    uint32_t pad[BESST_INF2_PAD];
+#endif
 };
 
 // what a lane reads its symbols from: three dwords of the payload from word `w` on (96 bits: a length with its distance and
-// all extra bits is at most 48)
+// all extra bits is at most 48) - and the dword behind them, loaded when the window moved on last: a lane's stream is its
+// own (64 lanes, 64 cache lines; twenty waves' lines do not stay in a CU's L1), and a load whose dword the very next symbol
+// needs costs the way to the L2 and back once per symbol
 struct LaneBits {
     const uint32_t* words;
-    uint32_t w, d0, d1, d2;
+    uint32_t w, d0, d1, d2, d3;
     __device__ __forceinline__ void seek(uint32_t p) {
         w = p >> 5;
-        d0 = words[w]; d1 = words[w + 1u]; d2 = words[w + 2u];
+        d0 = words[w]; d1 = words[w + 1u]; d2 = words[w + 2u]; d3 = words[w + 3u];
     }
     __device__ __forceinline__ void advance(uint32_t p) {    // p is at most two words on
-        if ((p >> 5) > w) { d0 = d1; d1 = d2; ++w; d2 = words[w + 2u]; }
-        if ((p >> 5) > w) { d0 = d1; d1 = d2; ++w; d2 = words[w + 2u]; }
+        if ((p >> 5) > w) { d0 = d1; d1 = d2; d2 = d3; ++w; d3 = words[w + 3u]; }
+        if ((p >> 5) > w) { d0 = d1; d1 = d2; d2 = d3; ++w; d3 = words[w + 3u]; }
     }
     // 32 bits from bit q of d0 on, q < 64
     __device__ __forceinline__ uint32_t at(uint32_t q) const {
-        return q < 32u ? __builtin_amdgcn_alignbit(d1, d0, q) : __builtin_amdgcn_alignbit(d2, d1, q - 32u);
+        const bool far = q >= 32u;
+        return __builtin_amdgcn_alignbit(far ? d2 : d1, far ? d1 : d0, q & 31u);
     }
 };
 
@@ -769,41 +778,38 @@ constexpr uint32_t kCountSym = 1u << 17;                 // a lane's count: byte
 constexpr uint32_t kGrid0 = 64u, kGrid1 = 192u, kGrid2 = 448u;   // the checkpoints: bits behind the first bit of the lane's range
 constexpr uint32_t kSymSlack = 256u;                     // symbol places a block has beyond one per byte (lanes are padded to 4)
 
-// one symbol at bit p of the lane's window: kind, bits it takes, literal / match length, distance
-__device__ __forceinline__ uint32_t decode_symbol(const Inflate2Lds& s, const LaneBits& lb, uint32_t p, uint32_t& bits, uint32_t& val,
-                                                  uint32_t& dist) {
+// one symbol at bit p of the lane's window: kind, bits it takes, bytes it makes, literal / distance.  No branch but for codes
+// longer than the tables: the lanes of a wave sit in different symbols, and what is a branch to one lane is a detour for all
+// (by the counters the loop issued more scalar instructions - execution masks, jumps - than vector ones): a literal looks a
+// distance up like a length does and throws it away.
+__device__ __forceinline__ uint32_t decode_symbol(const Inflate2Lds& s, const LaneBits& lb, uint32_t p, uint32_t& bits, uint32_t& bytes,
+                                                  uint32_t& what) {
     const uint32_t q0 = p & 31u;
     const uint32_t x = lb.at(q0);
     uint32_t e = s.lit_tab[x & (uint32_t)(kTabSize - 1)];
-    if ((e & kLinkMask) == kLinkFlag)
-        e = s.lit_sub[((e >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u))];
-    if ((e & 15u) == 0u) {
-        e = slow_code(&s.lit_c, s.lit_sorted, x & 0x7fffu, kTabBits);
-        if (e == 0u) { bits = 1u; return kSymBad; }
-    }
+    const bool link = (e & kLinkMask) == kLinkFlag;
+    const uint32_t e2 = s.lit_sub[link ? ((e >> 4) & (uint32_t)((kSubCap << kLaneLongBits) - 1)) + ((x >> kTabBits) & ((1u << kLaneLongBits) - 1u)) : 0u];
+    e = link ? e2 : e;
+    if ((e & 15u) == 0u) e = slow_code(&s.lit_c, s.lit_sorted, x & 0x7fffu, kTabBits);   // (0: not a code)
     const uint32_t la = e & 15u, sa = e >> 4;
-    if (sa < 256u) { bits = la; val = sa; return kSymLit; }
-    if (sa == 256u) { bits = la; return kSymEnd; }
-    if (sa >= 286u) { bits = la; return kSymBad; }
-    const uint32_t li = s.len_info[sa - 257u];
-    const uint32_t xa = li >> 9;
-    val = (li & 0x1ffu) + ((x >> la) & ((1u << xa) - 1u));
+    const bool is_len = sa > 256u;
+    const uint32_t li = s.len_info[is_len ? (sa - 257u) & 31u : 0u];       // (codes 286, 287: no length - entries of zero)
+    const uint32_t xa = is_len ? li >> 9 : 0u;
     const uint32_t xq = lb.at(q0 + la + xa);                 // (la + xa <= 20: inside the window)
     uint32_t d = s.dist_tab[xq & (uint32_t)(kDistSize - 1)];
-    if ((d & 15u) == 0u) {
-        d = slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kDistBits);
-        if (d == 0u) { bits = la + xa; return kSymBad; }
-    }
+    if (is_len && (d & 15u) == 0u) d = slow_code(&s.dist_c, s.dist_sorted, xq & 0x7fffu, kDistBits);
     const uint32_t lb_ = d & 15u, sb = d >> 4;
-    if (sb >= 30u) { bits = la + xa + lb_; return kSymBad; }
-    const uint32_t di = s.dist_info[sb];
+    const uint32_t di = s.dist_info[sb & 31u];               // (codes 30, 31: no distance - entries of zero)
     const uint32_t xb = di >> 16;
-    dist = (di & 0xffffu) + ((xq >> lb_) & ((1u << xb) - 1u));
-    bits = la + xa + lb_ + xb;
-    return kSymMatch;
+    const uint32_t dist = (di & 0xffffu) + __builtin_amdgcn_ubfe(xq, lb_, xb);
+    bits = is_len ? la + xa + lb_ + xb : la;
+    bytes = is_len ? (li & 0x1ffu) + __builtin_amdgcn_ubfe(x, la, xa) : 1u;
+    what = is_len ? dist : sa;
+    const bool bad = la == 0u || (is_len && (li == 0u || lb_ == 0u || di == 0u));
+    return bad ? (uint32_t)kSymBad : sa < 256u ? (uint32_t)kSymLit : sa == 256u ? (uint32_t)kSymEnd : (uint32_t)kSymMatch;
 }
 
-__global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+__global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
                                                                        uint32_t n_blocks, uint8_t* dst, uint32_t* sym_all,
                                                                        uint32_t* __restrict__ status) {
     __shared__ Inflate2Lds s;
@@ -821,6 +827,9 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint
         if (lane == 0) status[b] = kInfOk;
         return;
     }
+#ifdef BESST_INF2_PAD
+    s.pad[lane] = 0;
+#endif
     BitReader br;
     br.lane = lane;
     br.words = reinterpret_cast<const uint32_t*>(src + (src_off & ~3u));
@@ -957,6 +966,10 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane, s.lit_sub, s.mark)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kDistBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
             __builtin_amdgcn_wave_barrier();
+#ifndef BESST_INF2_SKIP
+#define BESST_INF2_SKIP 0
+#endif
+            if (BESST_INF2_SKIP & 8) { err = kInfBadCode; break; }
             // ---- 1. the lanes' ranges and the rounds of hand-overs
             const uint32_t p0 = br.wbase * 32u + br.bitpos;  // where the block's symbols begin (uniform)
             if (p0 >= end_bit) { err = kInfInputOverrun; break; }
@@ -972,30 +985,31 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint
             uint32_t cp0 = 0xffffffffu, cp1 = 0xffffffffu, cp2 = 0xffffffffu, pre0 = 0, pre1 = 0, pre2 = 0;   // ... and where it stood at
             LaneBits lb;                                     // the checkpoints, what it had counted until there
             lb.words = br.words;
-            for (int round = 0; round < 130; ++round) {
+            for (int round = 0; round < ((BESST_INF2_SKIP & 16) ? 1 : 130); ++round) {
                 const bool need = live && start != done_for;
                 if (need) {
                     uint32_t p = start, cnt = 0, kind = kSymLit, j = 0, grid = lo + kGrid0;
                     bool in_step = false;
                     lb.seek(p);
-                    while (p < lim) {
-                        uint32_t bits, val = 0, dist = 0;
-                        kind = decode_symbol(s, lb, p, bits, val, dist);
-                        if (kind >= kSymEnd) {
-                            if (kind == kSymEnd) p += bits;
-                            break;
-                        }
-                        cnt += (kind == kSymLit ? 1u : val) + kCountSym;
-                        p += bits;
+                    bool go = p < lim;
+                    while (go) {                             // (one condition, computed: every `break` is a mask to keep per turn)
+                        uint32_t bits, bytes, what;
+                        kind = decode_symbol(s, lb, p, bits, bytes, what);
+                        const bool sym = kind < (uint32_t)kSymEnd;
+                        cnt += sym ? bytes + kCountSym : 0u;
+                        p += (sym || kind == (uint32_t)kSymEnd) ? bits : 0u;
                         lb.advance(p);
-                        if (p >= grid) {                     // the first symbol behind a checkpoint: in step with the chain before?
+                        if (sym && p >= grid) {              // the first symbol behind a checkpoint: in step with the chain before?
                             const uint32_t was = j == 0u ? cp0 : j == 1u ? cp1 : cp2;
-                            if (p == was) { in_step = true; break; }
-                            if (j == 0u) { cp0 = p; pre0 = cnt; grid = lo + kGrid1; }
-                            else if (j == 1u) { cp1 = p; pre1 = cnt; grid = lo + kGrid2; }
-                            else { cp2 = p; pre2 = cnt; grid = 0xffffffffu; }
-                            ++j;
+                            in_step = p == was;
+                            if (!in_step) {
+                                if (j == 0u) { cp0 = p; pre0 = cnt; grid = lo + kGrid1; }
+                                else if (j == 1u) { cp1 = p; pre1 = cnt; grid = lo + kGrid2; }
+                                else { cp2 = p; pre2 = cnt; grid = 0xffffffffu; }
+                                ++j;
+                            }
                         }
+                        go = sym && !in_step && p < lim;
                     }
                     if (in_step) {                           // the rest is what it was: only what lies in front of the checkpoint changed
                         const uint32_t delta = cnt - (j == 0u ? pre0 : j == 1u ? pre1 : pre2);
@@ -1047,24 +1061,32 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint
             }
             // ---- 3. the symbols, four at a time
             bool bad_dist = false;
-            if (mine) {
+#ifndef BESST_INF2_SKIP
+#define BESST_INF2_SKIP 0
+#endif
+            if (mine && !(BESST_INF2_SKIP & 4)) {
                 uint32_t o = pos + incl_b - nb, p = start, at = incl_s - np, have = 0;
                 uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                 lb.seek(p);
-                while (p < r_end) {
-                    uint32_t bits, val = 0, dist = 0;
-                    const uint32_t kind = decode_symbol(s, lb, p, bits, val, dist);
-                    if (kind >= (uint32_t)kSymEnd) break;   // the end-of-block code (the last lane's last symbol)
-                    if (kind == (uint32_t)kSymMatch && dist > o) { bad_dist = true; break; }
-                    o += kind == (uint32_t)kSymLit ? 1u : val;
-                    q0 = q1; q1 = q2; q2 = q3;
-                    q3 = kind == (uint32_t)kSymLit ? 1u | kSymIsLit | (val << 16) : val | (dist << 16);
-                    if ((++have & 3u) == 0u) {
-                        *reinterpret_cast<uint4*>(sym + at) = make_uint4(q0, q1, q2, q3);
-                        at += 4u;
+                bool go = p < r_end;
+                while (go) {
+                    uint32_t bits, bytes, what;
+                    const uint32_t kind = decode_symbol(s, lb, p, bits, bytes, what);
+                    const bool far = kind == (uint32_t)kSymMatch && what > o;
+                    const bool is_sym = kind < (uint32_t)kSymEnd && !far;      // (else: the end-of-block code - the last lane's last symbol)
+                    bad_dist = bad_dist || far;
+                    if (is_sym) {
+                        o += bytes;
+                        q0 = q1; q1 = q2; q2 = q3;
+                        q3 = bytes | (kind == (uint32_t)kSymLit ? kSymIsLit : 0u) | (what << 16);
+                        if ((++have & 3u) == 0u) {
+                            *reinterpret_cast<uint4*>(sym + at) = make_uint4(q0, q1, q2, q3);
+                            at += 4u;
+                        }
+                        p += bits;
+                        lb.advance(p);
                     }
-                    p += bits;
-                    lb.advance(p);
+                    go = is_sym && p < r_end;
                 }
                 const uint32_t rest = have & 3u;             // (the padding: symbols of no bytes)
                 if (rest != 0u && !bad_dist)
@@ -1073,8 +1095,11 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate2_kernel(const uint
             }
             if (__ballot(bad_dist) != 0ull) { err = kInfBadDistance; break; }
             // ---- 4. their bytes, 64 symbols at a time
-            for (uint32_t i = 0; i < n_sym; i += 64u) {      // uniform
-                const uint32_t sy = i + (uint32_t)lane < n_sym ? __hip_atomic_load(sym + i + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (BESST_INF2_SKIP & 2) pos += total;
+            uint32_t sy_next = (uint32_t)lane < n_sym ? __hip_atomic_load(sym + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            for (uint32_t i = 0; i < ((BESST_INF2_SKIP & 2) ? 0u : n_sym); i += 64u) {      // uniform
+                const uint32_t sy = sy_next;                 // (the batch behind this one is on its way while this one is laid out)
+                sy_next = i + 64u + (uint32_t)lane < n_sym ? __hip_atomic_load(sym + i + 64u + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 const uint32_t bytes = sy & 0x1ffu;
                 const bool on = bytes != 0u;
                 const uint32_t what = (sy & kSymIsLit) ? kGroupLit | ((sy >> 16) & 0xffu) : sy >> 16;

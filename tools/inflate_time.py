@@ -18,7 +18,11 @@ os.remove(path)
 cap = 8 * len(data)
 for _ in range(3):
     t0 = time.perf_counter()
-    got = bamio.inflate_bgzf_device(data, out_cap=cap)
+    try:
+        got = bamio.inflate_bgzf_device(data, out_cap=cap)
+    except Exception as e:                                   # (a variant that skips a phase: the first launch only)
+        print(str(e)[-80:])
+        got = b''
     dt = time.perf_counter() - t0
     print('%d -> %d bytes, %.3f s in the call' % (len(data), len(got), dt), flush=True)
 if check:

@@ -7,7 +7,7 @@ CMD="$1"; shift
 i=0
 for grp in "$@"; do
   O=/tmp/pmcc_$i; rm -rf $O
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O -- python $R/$CMD > /tmp/pmcc_$i.log 2>&1)
+  (cd /tmp && timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O -- python $R/$CMD > /tmp/pmcc_$i.log 2>&1)
   python - "$O" <<'PY'
 import csv, glob, os, re, sys
 from collections import defaultdict
