@@ -837,7 +837,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         char* pin = nullptr;         // pinned: descriptors, then the chunk's bytes as they lie in the file
         char* dev = nullptr;         // the same on the device
         uint8_t* inflated = nullptr;
-        uint32_t* map = nullptr;     // the inflate kernel's symbols: four bytes per byte of `inflated` (touched: per symbol)
+        uint32_t* symbols = nullptr; // the inflate kernel's symbol buffer: four bytes per byte of `inflated` (touched: per symbol)
         uint16_t* offs = nullptr;
         uint32_t* words = nullptr;   // status | count | exits | rec_base | guess | tail_at (nbw each), then 8 summary words
         hipStream_t work = nullptr;
@@ -876,7 +876,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
             const auto t0 = std::chrono::steady_clock::now();
             g_pinned.give_back(q.pin);
             unpin_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            for (void* m : {(void*)q.dev, (void*)q.inflated, (void*)q.map, (void*)q.offs, (void*)q.words})
+            for (void* m : {(void*)q.dev, (void*)q.inflated, (void*)q.symbols, (void*)q.offs, (void*)q.words})
                 if (m) dev_mem.push_back(m);
             if (!kit) {
                 for (hipEvent_t e : {q.h2d_done, q.slot_free, q.summ_done, q.tail_taken})
@@ -937,7 +937,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         const auto t0 = std::chrono::steady_clock::now();
         const bool got = (q.pin = static_cast<char*>(g_pinned.acquire(slot_bytes))) != nullptr &&
              hipMalloc((void**)&q.dev, slot_bytes) == hipSuccess && hipMalloc((void**)&q.inflated, inflated_cap) == hipSuccess &&
-             hipMalloc((void**)&q.map, 4 * bgzf_inflate_symbol_places(inflated_cap, nbw)) == hipSuccess &&
+             hipMalloc((void**)&q.symbols, 4 * bgzf_inflate_symbol_places(inflated_cap, nbw)) == hipSuccess &&
              hipMalloc((void**)&q.offs, nbw * (size_t)kBamBlockRecs * sizeof(uint16_t)) == hipSuccess &&
              hipMalloc((void**)&q.words, (nbw * 6 + 12) * sizeof(uint32_t)) == hipSuccess &&
              (q.work || hipStreamCreateWithPriority(&q.work, hipStreamNonBlocking, prio_low) == hipSuccess) &&
@@ -998,7 +998,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         alloc_join();
         release();
         set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
-                  (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap)) >> 20);
+                  (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap + 4 * bgzf_inflate_symbol_places(inflated_cap, nbw))) >> 20);
         return BESST_ERR_NOMEM;
     }
     double stage_s = 0.0, wait_s = 0.0;
@@ -1015,7 +1015,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         if (fpos >= map_len) { q.ck = Chunk(); return true; }   // (nothing left: the slot is not touched)
         if ((j > 0 && !alloc_join()) || !alloc_slot((int)(j % kSlots))) {
             set_error("push_bam_device: cannot allocate the staging / scratch buffers (%zu MB pinned, %zu MB of HBM)",
-                      (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap)) >> 20);
+                      (kSlots * slot_bytes) >> 20, (kSlots * (slot_bytes + inflated_cap + 4 * bgzf_inflate_symbol_places(inflated_cap, nbw))) >> 20);
             rc = BESST_ERR_NOMEM;
             return false;
         }
@@ -1085,7 +1085,7 @@ int push_bam_device_impl(besst_ctx* c, besst_bam* bam, int32_t part, int32_t par
         if (e == hipSuccess) e = hipStreamWaitEvent(q.work, q.tail_taken, 0);
         if (e != hipSuccess) { hip_fail(e); return false; }
         if (launch_bgzf_inflate(q.work, reinterpret_cast<const uint8_t*>(q.dev + desc_bytes), reinterpret_cast<const BgzfBlock*>(q.dev),
-                                q.ck.n_blocks + 1, q.inflated, q.words, q.map)) {
+                                q.ck.n_blocks + 1, q.inflated, q.words, q.symbols)) {
             rc = BESST_ERR_HIP;
             return false;
         }
@@ -1363,11 +1363,11 @@ int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void
     uint8_t* d_inf = nullptr;
     BgzfBlock* d_desc = nullptr;
     uint32_t* d_status = nullptr;
-    uint32_t* d_map = nullptr;
+    uint32_t* d_sym = nullptr;
     auto release = [&]() {
         if (d_comp) (void)hipFree(d_comp);
         if (d_inf) (void)hipFree(d_inf);
-        if (d_map) (void)hipFree(d_map);
+        if (d_sym) (void)hipFree(d_sym);
         if (d_desc) (void)hipFree(d_desc);
         if (d_status) (void)hipFree(d_status);
     };
@@ -1384,17 +1384,17 @@ int besst_bgzf_inflate_device(int device, const void* bgzf, size_t n_bytes, void
         }
         if (n == 0) break;
         release();
-        d_comp = nullptr; d_inf = nullptr; d_desc = nullptr; d_status = nullptr; d_map = nullptr;
+        d_comp = nullptr; d_inf = nullptr; d_desc = nullptr; d_status = nullptr; d_sym = nullptr;
         hipError_t e = hipMalloc((void**)&d_comp, comp + 4096);
         if (e == hipSuccess) e = hipMalloc((void**)&d_inf, inflated + 4096);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_map, 4 * bgzf_inflate_symbol_places(inflated + 4096, n));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_sym, 4 * bgzf_inflate_symbol_places(inflated + 4096, n));
         if (e == hipSuccess) e = hipMalloc((void**)&d_desc, (size_t)n * sizeof(BgzfBlock));
         if (e == hipSuccess) e = hipMalloc((void**)&d_status, (size_t)n * 4);
         if (e == hipSuccess) e = hipMemset(d_comp + comp, 0, 4096);
         if (e == hipSuccess) e = hipMemcpy(d_comp, map + begin, comp, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_desc, desc.data(), (size_t)n * sizeof(BgzfBlock), hipMemcpyHostToDevice);
         if (e != hipSuccess) { set_error("bgzf_inflate_device: %s", hipGetErrorString(e)); rc = BESST_ERR_HIP; break; }
-        if ((rc = launch_bgzf_inflate(nullptr, reinterpret_cast<const uint8_t*>(d_comp), d_desc, n, d_inf, d_status, d_map))) break;
+        if ((rc = launch_bgzf_inflate(nullptr, reinterpret_cast<const uint8_t*>(d_comp), d_desc, n, d_inf, d_status, d_sym))) break;
         host.resize(inflated);
         e = hipMemcpy(status.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && inflated) e = hipMemcpy(host.data(), d_inf, inflated, hipMemcpyDeviceToHost);

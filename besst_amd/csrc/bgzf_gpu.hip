@@ -729,9 +729,11 @@ __global__ __launch_bounds__(64, kInfWaves) void bgzf_inflate_kernel(const uint8
 //      the first form: a scan of the lengths, a marker per symbol and a max-scan, one gather of the lanes that copy from
 //      finished output, six doubling steps of a lane permute for those that copy from the group itself, one store.
 // Same tables, same statuses, same CRC kernel behind it.  BESST_INFLATE=1 selects the first form.
-#ifndef BESST_INF2_WAVES
-#define BESST_INF2_WAVES 5
-#endif
+// Measured (a sequencer-like file, 4096 blocks per launch, the kernel alone): 1.89 ms against 4.04 ms; by the counters
+// 121 k vector + 68 k scalar instructions per block against 351 k + 250 k.  A quarter of the time is the rounds of
+// hand-overs, a quarter the second decode, nearly half the flush (54 k + 25 k instructions per block: ~80 per output
+// group).  What it costs: four bytes of symbol buffer per inflated byte of a chunk (touched: ~56 KB of a block's 260 KB).
+constexpr int kInf2Waves = 5;                    // per SIMD (96 VGPRs; six at 80 spill and gain nothing, four lose 7 %)
 struct Inflate2Lds {
     uint16_t lit_tab[kTabSize];
     uint16_t dist_tab[kDistSize];
@@ -745,9 +747,6 @@ struct Inflate2Lds {
     uint8_t cl_lens[32];
     uint32_t mark[64];
     uint32_t len_info[32], dist_info[32];      // RFC 1951's length / distance codes: base | extra bits << 9 (<< 16)
-#ifdef BESST_INF2_PAD
-    uint32_t pad[BESST_INF2_PAD];
-#endif
 };
 
 // what a lane reads its symbols from: three dwords of the payload from word `w` on (96 bits: a length with its distance and
@@ -809,7 +808,7 @@ __device__ __forceinline__ uint32_t decode_symbol(const Inflate2Lds& s, const La
     return bad ? (uint32_t)kSymBad : sa < 256u ? (uint32_t)kSymLit : sa == 256u ? (uint32_t)kSymEnd : (uint32_t)kSymMatch;
 }
 
-__global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
+__global__ __launch_bounds__(64, kInf2Waves) void bgzf_inflate2_kernel(const uint8_t* __restrict__ src, const BgzfBlock* __restrict__ blocks,
                                                                        uint32_t n_blocks, uint8_t* dst, uint32_t* sym_all,
                                                                        uint32_t* __restrict__ status) {
     __shared__ Inflate2Lds s;
@@ -827,9 +826,6 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
         if (lane == 0) status[b] = kInfOk;
         return;
     }
-#ifdef BESST_INF2_PAD
-    s.pad[lane] = 0;
-#endif
     BitReader br;
     br.lane = lane;
     br.words = reinterpret_cast<const uint32_t*>(src + (src_off & ~3u));
@@ -966,10 +962,6 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
             if (!build_code(s.lens, n_lit, kTabBits, s.lit_tab, s.lit_sorted, &s.lit_c, lane, s.lit_sub, s.mark)) { err = kInfOversubscribed; break; }
             if (!build_code(s.lens + 288, n_dist, kDistBits, s.dist_tab, s.dist_sorted, &s.dist_c, lane)) { err = kInfOversubscribed; break; }
             __builtin_amdgcn_wave_barrier();
-#ifndef BESST_INF2_SKIP
-#define BESST_INF2_SKIP 0
-#endif
-            if (BESST_INF2_SKIP & 8) { err = kInfBadCode; break; }
             // ---- 1. the lanes' ranges and the rounds of hand-overs
             const uint32_t p0 = br.wbase * 32u + br.bitpos;  // where the block's symbols begin (uniform)
             if (p0 >= end_bit) { err = kInfInputOverrun; break; }
@@ -985,7 +977,7 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
             uint32_t cp0 = 0xffffffffu, cp1 = 0xffffffffu, cp2 = 0xffffffffu, pre0 = 0, pre1 = 0, pre2 = 0;   // ... and where it stood at
             LaneBits lb;                                     // the checkpoints, what it had counted until there
             lb.words = br.words;
-            for (int round = 0; round < ((BESST_INF2_SKIP & 16) ? 1 : 130); ++round) {
+            for (int round = 0; round < 130; ++round) {
                 const bool need = live && start != done_for;
                 if (need) {
                     uint32_t p = start, cnt = 0, kind = kSymLit, j = 0, grid = lo + kGrid0;
@@ -1060,12 +1052,10 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
                 break;
             }
             // ---- 3. the symbols, four at a time
-            bool bad_dist = false;
-#ifndef BESST_INF2_SKIP
-#define BESST_INF2_SKIP 0
-#endif
-            if (mine && !(BESST_INF2_SKIP & 4)) {
+            bool bad_dist = false, overrun = false;
+            if (mine) {
                 uint32_t o = pos + incl_b - nb, p = start, at = incl_s - np, have = 0;
+                const uint32_t o_end = pos + incl_b;
                 uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                 lb.seek(p);
                 bool go = p < r_end;
@@ -1073,8 +1063,12 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
                     uint32_t bits, bytes, what;
                     const uint32_t kind = decode_symbol(s, lb, p, bits, bytes, what);
                     const bool far = kind == (uint32_t)kSymMatch && what > o;
-                    const bool is_sym = kind < (uint32_t)kSymEnd && !far;      // (else: the end-of-block code - the last lane's last symbol)
+                    // (a lane's counts are exact modulo 2^32: a corrupt stream whose chain makes more than 2^17 bytes in one
+                    // range would write past the places its lanes were given - into other blocks' symbols and bytes)
+                    const bool over = kind < (uint32_t)kSymEnd && (have >= ns || o + bytes > o_end);
+                    const bool is_sym = kind < (uint32_t)kSymEnd && !far && !over;   // (else: the end-of-block code - the last lane's last symbol)
                     bad_dist = bad_dist || far;
+                    overrun = overrun || over;
                     if (is_sym) {
                         o += bytes;
                         q0 = q1; q1 = q2; q2 = q3;
@@ -1089,15 +1083,15 @@ __global__ __launch_bounds__(64, BESST_INF2_WAVES) void bgzf_inflate2_kernel(con
                     go = is_sym && p < r_end;
                 }
                 const uint32_t rest = have & 3u;             // (the padding: symbols of no bytes)
-                if (rest != 0u && !bad_dist)
+                if (rest != 0u && !bad_dist && !overrun)
                     *reinterpret_cast<uint4*>(sym + at) = rest == 1u ? make_uint4(q3, 0u, 0u, 0u) : rest == 2u ? make_uint4(q2, q3, 0u, 0u)
                                                                                                        : make_uint4(q1, q2, q3, 0u);
             }
             if (__ballot(bad_dist) != 0ull) { err = kInfBadDistance; break; }
+            if (__ballot(overrun) != 0ull) { err = kInfOutputOverrun; break; }
             // ---- 4. their bytes, 64 symbols at a time
-            if (BESST_INF2_SKIP & 2) pos += total;
             uint32_t sy_next = (uint32_t)lane < n_sym ? __hip_atomic_load(sym + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            for (uint32_t i = 0; i < ((BESST_INF2_SKIP & 2) ? 0u : n_sym); i += 64u) {      // uniform
+            for (uint32_t i = 0; i < n_sym; i += 64u) {      // uniform
                 const uint32_t sy = sy_next;                 // (the batch behind this one is on its way while this one is laid out)
                 sy_next = i + 64u + (uint32_t)lane < n_sym ? __hip_atomic_load(sym + i + 64u + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 const uint32_t bytes = sy & 0x1ffu;
@@ -1621,7 +1615,8 @@ int launch_bgzf_inflate(hipStream_t s, const uint8_t* src, const BgzfBlock* bloc
                         uint32_t* status, uint32_t* symbols) {
     if (n_blocks == 0) return BESST_OK;
     // symbols (bgzf_inflate_symbol_places() of four bytes): the second form of the kernel; nullptr or BESST_INFLATE=1: the first
-    static const bool first_form = [] { const char* e = getenv("BESST_INFLATE"); return e && e[0] == '1' && e[1] == 0; }();
+    const char* form = getenv("BESST_INFLATE");              // (read per call: the tests run both forms in one process)
+    const bool first_form = form && form[0] == '1' && form[1] == 0;
     if (symbols && !first_form)
         hipLaunchKernelGGL(bgzf_inflate2_kernel, dim3(n_blocks), dim3(64), 0, s, src, blocks, n_blocks, dst, symbols, status);
     else

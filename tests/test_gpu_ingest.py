@@ -27,6 +27,17 @@ def _bgzf(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra=b''):
     return head + extra + payload + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data))
 
 
+@pytest.fixture(params=['second', 'first'])
+def inflate_form(request, monkeypatch):
+    """Both forms of the inflate kernel (csrc/bgzf_gpu.hip): the second - the lanes decode a DEFLATE block's symbols side by
+    side, the default - and the first (BESST_INFLATE=1: every lane decodes at one bit position)."""
+    if request.param == 'first':
+        monkeypatch.setenv('BESST_INFLATE', '1')
+    else:
+        monkeypatch.delenv('BESST_INFLATE', raising=False)
+    return request.param
+
+
 def _payloads():
     rnd = random.Random(11)
     out = {'empty': b'', 'one': b'x', 'zeros': bytes(65280), 'random': os.urandom(40000),
@@ -46,7 +57,7 @@ def _payloads():
 @pytest.mark.parametrize('level,strategy', [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
                                             (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE),
                                             (9, zlib.Z_FILTERED)])
-def test_inflate_equals_zlib(level, strategy):
+def test_inflate_equals_zlib(level, strategy, inflate_form):
     """Stored, fixed and dynamic blocks, codes longer than the primary table, overlapping and far matches, the empty block,
     blocks at every payload alignment (extra subfields of 0..3 bytes shift the DEFLATE stream)."""
     pay = _payloads()
@@ -63,7 +74,7 @@ def test_inflate_equals_zlib(level, strategy):
     assert got == want
 
 
-def test_inflate_code_shapes_at_random():
+def test_inflate_code_shapes_at_random(inflate_form):
     """Payloads that push the symbol loop's batches to their ends - one- and two-bit codes (more symbols in a window of 64 bit
     positions than a batch lays into lanes), long skewed codes (the second-level table and the codes beyond it), long
     matches, runs - under every strategy and level, 3000 blocks against the bytes that were compressed."""
@@ -93,7 +104,77 @@ def test_inflate_code_shapes_at_random():
         assert got == b''.join(want)
 
 
-def test_inflate_many_blocks():
+def test_inflate_many_deflate_blocks_in_one_bgzf_block(inflate_form):
+    """A BGZF block is one DEFLATE stream of ANY number of blocks: flush points every few hundred bytes (dynamic blocks of a
+    dozen symbols - shorter than the 64 ranges the second form cuts a block's bits into -, each followed by an empty
+    stored block), full flushes (the window restarts), and levels that alternate stored and dynamic blocks."""
+    rnd = random.Random(5)
+    src = _payloads()
+    blocks, want = [], []
+    for i in range(120):
+        raw = src[rnd.choice(('bamlike', 'words', 'acgt', 'skewed', 'random'))][rnd.randint(0, 3000):][:rnd.randint(1, 40000)]
+        comp = zlib.compressobj(rnd.choice((1, 6, 9)), zlib.DEFLATED, -15, 8, rnd.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY)))
+        payload, at = b'', 0
+        while at < len(raw):
+            step = rnd.choice((1, 7, 40, 300, 2500, 20000))
+            payload += comp.compress(raw[at:at + step]) + comp.flush(rnd.choice((zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH)))
+            at += step
+        payload += comp.flush()
+        if len(payload) + 25 > 65535:
+            continue
+        head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, len(payload) + 25)
+        blocks.append(head + payload + struct.pack('<II', zlib.crc32(raw) & 0xffffffff, len(raw)))
+        want.append(raw)
+    assert len(blocks) > 60
+    got = bamio.inflate_bgzf_device(b''.join(blocks), out_cap=sum(map(len, want)) + 16)
+    assert got == b''.join(want)
+
+
+def test_inflate_blocks_of_the_largest_size_and_of_symbols_only(inflate_form):
+    """ISIZE = 65536 (the most a BGZF block holds) made of literals alone - as many symbols as bytes, the most the second
+    form's symbol buffer has to take for a block - and of one-bit codes (a range of the block's bits holds as many symbols
+    as bits); codes of one length, which a decoder that starts inside a symbol never falls into step with (the hand-overs
+    take their 64 rounds)."""
+    rnd = random.Random(9)
+    cases = [(bytes(rnd.choice(b'ACGT') for _ in range(65536)), 6, zlib.Z_HUFFMAN_ONLY),
+             (bytes(rnd.choice(b'AC') for _ in range(65536)), 6, zlib.Z_HUFFMAN_ONLY),
+             (bytes(rnd.choice(b'ACGTNacg') for _ in range(65536)), 6, zlib.Z_HUFFMAN_ONLY),     # eight codes of three bits
+             (bytes(rnd.choice(bytes(range(16))) for _ in range(65536)), 9, zlib.Z_HUFFMAN_ONLY),  # sixteen of four
+             (b'\x00' * 65536, 1, zlib.Z_DEFAULT_STRATEGY), (b'ab' * 32768, 9, zlib.Z_DEFAULT_STRATEGY),
+             (bytes(rnd.choice(b'ACGT') for _ in range(65536)), 1, zlib.Z_DEFAULT_STRATEGY)]
+    data = b''.join(_bgzf(raw, level, strategy) for raw, level, strategy in cases)
+    got = bamio.inflate_bgzf_device(data * 3, out_cap=3 * 65536 * len(cases) + 16)
+    assert got == b''.join(raw for raw, _, _ in cases) * 3
+
+
+def test_a_stream_that_claims_more_than_its_block_holds_is_refused(inflate_form):
+    """ISIZE smaller than what the DEFLATE stream makes (a valid stream under a wrong trailer): the block is refused, the
+    blocks around it - whose bytes and, in the second form, symbols lie next to its own - inflate to what they were."""
+    src = _payloads()
+    big, small = src['zeros'], src['bamlike'][:30000]
+    for raw, claim in ((big, 300), (big, 65000), (src['acgt'], 100), (src['bamlike'], 64), (src['words'], 4000)):
+        liar = bytearray(_bgzf(raw, 6))
+        liar[-4:] = struct.pack('<I', claim)
+        good = _bgzf(small, 6)
+        with pytest.raises(_lib.BesstDeviceError) as e:
+            bamio.inflate_bgzf_device(good + bytes(liar) + good, out_cap=3 * 65536)
+        assert 'block 1' in str(e.value)
+        assert bamio.inflate_bgzf_device(good * 2, out_cap=60016) == small * 2
+    # ... and far more: 40 MB of zeros in 40 KB of payload - one lane's range of the block's bits makes more bytes than the
+    # lanes' counters hold (2^17): the places the symbols and bytes go to are checked, not trusted
+    comp = zlib.compressobj(9, zlib.DEFLATED, -15)
+    payload = comp.compress(bytes(40 << 20)) + comp.flush()
+    assert 30000 < len(payload) < 65000
+    for claim in (65536, 1000):
+        bomb = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, len(payload) + 25) + payload + struct.pack('<II', 0, claim)
+        good = _bgzf(small, 6)
+        with pytest.raises(_lib.BesstDeviceError) as e:
+            bamio.inflate_bgzf_device(good + bomb + good, out_cap=4 * 65536)
+        assert 'block 1' in str(e.value)
+        assert bamio.inflate_bgzf_device(good * 2, out_cap=60016) == small * 2
+
+
+def test_inflate_many_blocks(inflate_form):
     """More blocks than waves fit the chip, in one call and across the hook's chunks."""
     rnd = random.Random(3)
     base = os.urandom(3000)
@@ -107,7 +188,7 @@ def test_inflate_many_blocks():
     assert got == b''.join(want)
 
 
-def test_inflate_reports_a_corrupt_block():
+def test_inflate_reports_a_corrupt_block(inflate_form):
     raw = os.urandom(500) * 20
     good = _bgzf(raw)
     bad = bytearray(_bgzf(raw))
@@ -598,7 +679,7 @@ def test_endless_empty_blocks_end_at_the_payload():
     assert 'block 1' in str(e.value)
 
 
-def test_corrupt_payloads_are_refused_not_followed():
+def test_corrupt_payloads_are_refused_not_followed(inflate_form):
     """Random damage to the DEFLATE payloads of 300 blocks (bytes flipped, payloads cut short with ISIZE kept): the call
     reports the first block that does not inflate - or, where the damage happens to decode, still returns ISIZE bytes per
     block - and the device is fine afterwards."""
