@@ -274,7 +274,7 @@ class GraphContext(object):
             elif rc not in (_lib.ERR_UNSUPPORTED, _lib.ERR_NOMEM) or mode == 'device':
                 _lib.check(rc, 'push_bam_device')
             else:
-                # (out of memory: the device form wants up to three slots of scratch - ~0.7 GB of HBM and 170 MB pinned each -, the host form 2 x 25 B x chunk_records of pinned staging; context and reader are untouched)
+                # (out of memory: the device form wants up to three slots of scratch - ~1.8 GB of HBM (1.35 of it the inflate kernel's symbol buffer) and 170 MB pinned each -, the host form 2 x 25 B x chunk_records of pinned staging; context and reader are untouched)
                 self.ingest_fallback = _lib.last_error()
         if not done:
             _lib.check(self._lib.besst_ctx_push_bam(self._ctx, handle, int(chunk_records), int(head_records), _lib.ptr(rlen),
