@@ -9,6 +9,25 @@ def test_model_equals_zlib(capsys):
     assert 'equal to zlib' in capsys.readouterr().out
 
 
+def test_ranges_model_equals_zlib(capsys):
+    """The second form of the kernel (bgzf_inflate2_kernel) restated lane by lane: ranges of the block's bits, hand-overs,
+    checkpoints, counts - equal to zlib, the hand-overs stable within 65 rounds even for codes of one length, and what the
+    rounds counted for a lane is what its second decode makes (asserted inside the model)."""
+    from oracle import inflate_model
+    inflate_model.main_ranges()
+    assert 'equal to zlib' in capsys.readouterr().out
+
+
+def test_ranges_model_refuses_a_block_without_its_end_code():
+    import zlib
+    import pytest
+    from oracle import inflate_model
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(b'abcdefgh' * 500 + bytes(range(256))) + c.flush()
+    with pytest.raises((ValueError, AssertionError)):
+        inflate_model.inflate_ranges(comp[:len(comp) // 2])
+
+
 def test_length_and_distance_codes_in_closed_form():
     """RFC 1951's tables against the shifts the kernel computes them with."""
     lb = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
