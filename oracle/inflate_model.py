@@ -358,6 +358,8 @@ def _ranges_block(bits, lc, dc, p0, end_bit, out, stats):
             kind, n, bytes_, what = _symbol(bits, lc, dc, p)
             if kind >= END:
                 break
+            if 'symbols' in stats:                           # (for a look at the matches: place, bytes, distance - 0: a literal)
+                stats['symbols'].append((len(out), bytes_, 0 if kind == LIT else what))
             if kind == LIT:
                 out.append(what)
             else:
