@@ -405,7 +405,8 @@ def bam_to_graph_timing(device, config, pairs=None, realistic=False):
                         'constant bases and qualities') + ', %.1f B/record compressed' % (size / n_rec),
                'reader_threads': threads, 'usable_cpus': cores, 'machine_cpus': os.cpu_count(),
                'write_bam_s_untimed': round(write_s, 2),
-               'ingest_form': 'device: BGZF inflate + record decode on the GPU (besst_ctx_push_bam_device)' if st.on_device else
+               'ingest_form': ('device: BGZF inflate + record decode on the GPU (besst_ctx_push_bam_device; inflate kernel: %s form)'
+                               % ('first' if os.environ.get('BESST_INFLATE') == '1' else 'second')) if st.on_device else
                               'host: reader threads + pinned staging (besst_ctx_push_bam)',
                'ingest_s': round(t1 - t0, 3), 'ingest_records_per_s': n_rec / (t1 - t0),
                'ingest_compressed_GBps': round(size / (t1 - t0) / 1e9, 2),
