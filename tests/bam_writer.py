@@ -5,9 +5,16 @@ import zlib
 import numpy as np
 
 
+LIBDEFLATE_LEVEL = None              # set (0-12): the blocks are compressed by libdeflate - what htslib writes them with - instead of zlib
+
+
 def _bgzf_block(data):
-    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
-    payload = comp.compress(data) + comp.flush()
+    if LIBDEFLATE_LEVEL is not None:
+        from tests import libdeflate_util
+        payload = libdeflate_util.deflate(data, LIBDEFLATE_LEVEL)
+    else:
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = comp.compress(data) + comp.flush()
     bsize = len(payload) + 25
     head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, bsize)
     return head + payload + struct.pack('<II', zlib.crc32(data) & 0xffffffff, len(data))

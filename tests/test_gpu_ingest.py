@@ -174,6 +174,35 @@ def test_a_stream_that_claims_more_than_its_block_holds_is_refused(inflate_form)
         assert bamio.inflate_bgzf_device(good * 2, out_cap=60016) == small * 2
 
 
+def test_inflate_streams_of_libdeflate(inflate_form):
+    """BGZF blocks compressed by libdeflate - the compressor htslib (pysam, samtools, the aligners' writers) uses for them:
+    another block splitting, other length-limited codes, near-optimal parsing at level 12 - levels 1 to 12, every payload."""
+    from tests import libdeflate_util as LD
+    if not LD.available():
+        pytest.skip('no libdeflate in this image')
+    rnd = random.Random(12)
+    pay = _payloads()
+    blocks, want = [], []
+    for level in (1, 3, 6, 9, 12):
+        for name, raw in sorted(pay.items()):
+            raw = raw[:65000]
+            payload = LD.deflate(raw, level)
+            if len(payload) + 25 > 65535:
+                continue                                     # (incompressible at this size: not a BGZF block)
+            head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, len(payload) + 25)
+            blocks.append(head + payload + struct.pack('<II', zlib.crc32(raw) & 0xffffffff, len(raw)))
+            want.append(raw)
+    for _ in range(300):                                     # ... and slices of the BAM-like payload at any length
+        raw = pay['bamlike'][rnd.randint(0, 5000):][:rnd.randint(1, 60000)]
+        payload = LD.deflate(raw, rnd.choice((1, 6, 6, 12)))
+        head = struct.pack('<BBBBIBBHBBHH', 31, 139, 8, 4, 0, 0, 255, 6, ord('B'), ord('C'), 2, len(payload) + 25)
+        blocks.append(head + payload + struct.pack('<II', zlib.crc32(raw) & 0xffffffff, len(raw)))
+        want.append(raw)
+    assert len(blocks) > 340
+    got = bamio.inflate_bgzf_device(b''.join(blocks), out_cap=sum(map(len, want)) + 16)
+    assert got == b''.join(want)
+
+
 def test_inflate_many_blocks(inflate_form):
     """More blocks than waves fit the chip, in one call and across the hook's chunks."""
     rnd = random.Random(3)
@@ -234,6 +263,30 @@ def test_device_ingest_equals_host_reader(writer, level, block_bytes, chunk_bloc
         try:
             assert bam.ingest.on_device == 1 and bam.ingest.blocks > 0 and bam.ingest.starts_repaired == 0
             assert bam.ingest.bytes_h2d <= os.path.getsize(path)
+            _check_against_host(path, bam, host)
+        finally:
+            bam.close()
+    for col in COLS:
+        assert np.array_equal(getattr(host, col), getattr(batch, col)), col
+
+
+@pytest.mark.parametrize('level,align', [(6, True), (1, True), (12, True), (6, False)])
+def test_a_file_whose_blocks_libdeflate_compressed(level, align, inflate_form, monkeypatch):
+    """A BAM as htslib writes it where it is built with libdeflate (pysam, samtools, the aligners): blocks of 0xff00 bytes
+    that begin with a record, compressed by libdeflate - and the same compressor under blocks cut at arbitrary bytes.  The
+    device form's records equal the host reader's (zlib's inflate) and the batch the file was written from."""
+    from tests import libdeflate_util as LD
+    if not LD.available():
+        pytest.skip('no libdeflate in this image')
+    monkeypatch.setattr(bam_writer, 'LIBDEFLATE_LEVEL', level)
+    batch = _library(12000)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'x.bam')
+        bam_writer.write_bam(path, batch, block_bytes=0xff00, align_records=align)
+        host = bamio.read_bam(path, threads=2)
+        bam = bamio.ResidentBam(path, threads=3, mode='device', chunk_blocks=16)
+        try:
+            assert bam.ingest.on_device == 1 and bam.ingest.blocks > 30
             _check_against_host(path, bam, host)
         finally:
             bam.close()

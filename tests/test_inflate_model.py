@@ -18,6 +18,32 @@ def test_ranges_model_equals_zlib(capsys):
     assert 'equal to zlib' in capsys.readouterr().out
 
 
+def test_models_on_streams_of_libdeflate():
+    """Streams of another compressor - libdeflate, what htslib writes BGZF blocks with: its own block splitting and
+    length-limited codes, near-optimal parsing at level 12 - through both models (the tables; the ranges and hand-overs)."""
+    import os
+    import random
+    import zlib
+    import pytest
+    from oracle import inflate_model
+    from tests import libdeflate_util as LD
+    if not LD.available():
+        pytest.skip('no libdeflate in this image')
+    rnd = random.Random(8)
+    bam = b''.join(b'read%05d\0' % i + bytes([0x12, 0x48] * 20) + bytes(rnd.choice(b'FFFFF:,#') for _ in range(80)) for i in range(300))
+    cases = [bam, bytes(rnd.choice(b'ACGT') for _ in range(12000)), bytes(30000), b'abcde' * 4000, os.urandom(2000) + bam[:8000],
+             bytes(int(rnd.expovariate(0.03)) & 255 for _ in range(12000))]
+    n = 0
+    for raw in cases:
+        for level in (1, 6, 12):
+            comp = LD.deflate(raw, level)
+            assert zlib.decompress(comp, -15) == raw
+            assert inflate_model.inflate(comp) == raw
+            assert inflate_model.inflate_ranges(comp) == raw
+            n += 1
+    assert n == 18
+
+
 def test_ranges_model_refuses_a_block_without_its_end_code():
     import zlib
     import pytest
